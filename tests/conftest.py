@@ -1,0 +1,72 @@
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+GOLDEN = Path(__file__).resolve().parent / 'golden'
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run through gpurun)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests must never silently pass on a box without a GPU: they are skipped there only when
+    the run did not ask for them (``-m gpu`` on a GPU-less box fails loudly in the test body)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    selected = config.getoption('-m') or ''
+    if 'gpu' in selected and 'not gpu' not in selected:
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container (use gpurun)')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope='session')
+def g1():
+    return json.loads((GOLDEN / 'g1_known_answers.json').read_text())
+
+
+def _npz(name):
+    return dict(np.load(GOLDEN / name, allow_pickle=False))
+
+
+@pytest.fixture(scope='session')
+def g2():
+    d = _npz('g2_stft.npz')
+    d['cases'] = json.loads(str(d['cases']))
+    return d
+
+
+@pytest.fixture(scope='session')
+def g3():
+    return _npz('g3_features.npz')
+
+
+@pytest.fixture(scope='session')
+def g4():
+    d = _npz('g4_pit.npz')
+    d['names'] = json.loads(str(d['names']))
+    return d
+
+
+@pytest.fixture(scope='session')
+def g5():
+    return _npz('g5_dc.npz')
+
+
+@pytest.fixture(scope='session')
+def g6():
+    d = _npz('g6_models.npz')
+    d['train_example_indices'] = json.loads(str(d['train_example_indices']))
+    return d

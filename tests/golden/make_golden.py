@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures of tests/golden/ by importing the REAL reference.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference (pure Python) is imported from /root/reference with the stand-ins of
+tests/golden/ref_shim/ for its absent third-party deps (README there).  The outputs are data only
+(inputs + expected outputs); neither the reference nor the shim travels to the GPU box.
+
+Fixtures:
+  g1_known_answers.json   literal answers held by the reference's own tests/doctests
+  g2_stft.npz             pt.ops.STFT option grid: forward + inverse + frame/sample helpers
+  g3_features.npz         pit/data.py pre_batch_transform on a seeded 2-speaker mixture
+  g4_pit.npz              pit_loss / compute_pairwise_losses / pit_loss_from_loss_matrix
+  g5_dc.npz               deep_clustering_loss
+  g6_models.npz           tiny PIT + DC model: state_dict, inputs, outputs, losses, grads,
+                          3 reference-Trainer optimizer steps (virtual_minibatch_size=2)
+"""
+import itertools
+import json
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+sys.path[:0] = [str(HERE / 'ref_shim'), str(REPO), '/root/reference']
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import padertorch as pt  # noqa: E402  (the reference)
+from padertorch.ops.losses.source_separation import (  # noqa: E402
+    compute_pairwise_losses, pit_loss_from_loss_matrix)
+from padertorch.contrib.examples.source_separation.pit.model import (  # noqa: E402
+    PermutationInvariantTrainingModel)
+from padertorch.contrib.examples.source_separation.pit.data import pre_batch_transform  # noqa: E402
+from padertorch.contrib.tcl.dc import DeepClusteringModel  # noqa: E402
+
+torch.set_num_threads(1)
+torch.use_deterministic_algorithms(True)
+
+
+def g1():
+    """Literal known answers copied as DATA from the reference's tests/doctests."""
+    d = {
+        # padertorch/contrib/cb/transform.py:219-232 (hann, size 4, shift 2, arange(8), fading full)
+        'cb_stft': {
+            'kwargs': dict(size=4, shift=2, window='hann', fading='full'),
+            'input': list(range(8)),
+            'real': [[0.5, 0., -0.5], [4., -2., 0.], [8., -4., 0.], [12., -6., 0.], [3.5, 0., -3.5]],
+            'imag': [[0., 0.5, 0.], [0., 1., 0.], [0., 1., 0.], [0., 1., 0.], [0., -3.5, 0.]],
+        },
+        # tests/test_ops/test_stft.py:44-70 and :139-165 (samples -> frames)
+        'frame_counts': [
+            dict(size=1024, shift=256, window_length=1024, fading=False, samples=[1023, 1024, 1025], frames=[1, 1, 2]),
+            dict(size=1024, shift=256, window_length=1024, fading=True, samples=[1023, 1024, 1025], frames=[7, 7, 8]),
+            dict(size=512, shift=20, window_length=40, fading=False, samples=[1019, 1020, 1021], frames=[50, 50, 51]),
+            dict(size=512, shift=20, window_length=40, fading=True, samples=[1019, 1020, 1021], frames=[52, 52, 53]),
+        ],
+        # padertorch/ops/_stft.py:113-114,124-125,194-195 doctest shapes
+        'doctest_shapes': [
+            dict(size=512, shift=20, window_length=40, rep='concat', inp=[2, 6, 203], out=[2, 6, 12, 514]),
+            dict(size=512, shift=20, window_length=40, rep='complex', inp=[2, 6, 203], out=[2, 6, 12, 257]),
+            dict(size=512, shift=20, window_length=40, rep='concat', inverse_inp=[2, 4, 10, 514], inverse_out=[2, 4, 180]),
+        ],
+        # tests/test_ops/test_losses.py:137-150
+        'pit_toys': [
+            dict(estimate=[[[0], [2]]], target=[[[0], [2]]], loss=0.),
+            dict(estimate=[[[0], [2]]], target=[[[2], [0]]], loss=0.),
+            dict(estimate=[[[0], [2]]], target=[[[-1], [0]]], loss=2.5),
+            dict(estimate=[[[0], [1]]], target=[[[0], [1]]], loss=0.),
+        ],
+        # tests/test_ops/test_losses.py:61-84,105-116
+        'dc_toys': [
+            dict(embedding=[[1, 0], [0, 1], [0, 1]], target=[[1, 0], [0, 1], [0, 1]], loss=0.),
+            dict(embedding=[[1, 0], [0, 1], [0, 1]], target=[[1, 0], [0, 1], [1, 0]], loss=4 / 9),
+        ],
+        # padertorch/ops/losses/source_separation.py:63-93 doctests (mse variants)
+        'pit_doctests': [
+            dict(est_shape=[4, 2, 5], axis=1, loss=1.),
+            dict(est_shape=[2, 5, 4], axis=0, loss=1.),
+            dict(est_shape=[5], axis=0, loss=1.),
+            dict(est_shape=[4, 5, 3, 100, 128], axis=-3, loss=1.),
+        ],
+        # source_separation.py:262-270: -score matrix, Hungarian 'sum' -> -26
+        'hungarian': dict(score=[[11., 10, 0], [4, 5, 10], [6, 0, 5]], loss_sum=-26.),
+    }
+    # replay them against the imported reference so a typo here cannot become "truth"
+    for toy in d['pit_toys']:
+        got = pt.ops.losses.pit_loss(torch.tensor(toy['estimate'], dtype=torch.float32),
+                                     torch.tensor(toy['target'], dtype=torch.float32), axis=-2)
+        np.testing.assert_allclose(got, toy['loss'], rtol=1e-4)
+    for toy in d['dc_toys']:
+        got = pt.ops.losses.deep_clustering_loss(torch.tensor(toy['embedding'], dtype=torch.float64),
+                                                 torch.tensor(toy['target'], dtype=torch.float64))
+        np.testing.assert_allclose(got, toy['loss'], atol=1e-12)
+    for fc in d['frame_counts']:
+        s = pt.ops.STFT(fc['size'], fc['shift'], window_length=fc['window_length'],
+                        fading=fc['fading'], complex_representation='concat')
+        for n, fr in zip(fc['samples'], fc['frames']):
+            assert s(torch.rand(n)).shape[0] == fr, (fc, n)
+            assert s.samples_to_frames(n) == fr, (fc, n)
+    got = pit_loss_from_loss_matrix(-torch.tensor(d['hungarian']['score']), reduction='sum')
+    assert float(got) == d['hungarian']['loss_sum']
+    (HERE / 'g1_known_answers.json').write_text(json.dumps(d, indent=1))
+
+
+STFT_GRID = [
+    # size, shift, window_length, window
+    (512, 128, 512, 'blackman'),
+    (1024, 256, 1024, 'blackman'),
+    (512, 20, 40, 'hamming'),
+    (256, 10, 20, 'hann'),
+    (64, 24, 50, 'hann'),          # window_length % shift != 0
+    (128, 48, 100, 'blackman'),
+]
+
+
+def g2():
+    rng = np.random.RandomState(2)
+    out = {}
+    cases = []
+    for (size, shift, wl, win) in STFT_GRID:
+        # long enough for fading=False/pad=False (the reference's conv1d needs T >= window_length)
+        shape = (2, 400) if size <= 256 else (1, wl + 3 * shift + 5)
+        out[f'x_s{size}_h{shift}'] = rng.standard_normal(shape)
+    for (size, shift, wl, win), fading, pad in itertools.product(
+            STFT_GRID, ['full', 'half', False], [True, False]):
+        name = f's{size}_h{shift}_l{wl}_{win}_{fading}_{int(pad)}'
+        x = out[f'x_s{size}_h{shift}']
+        s = pt.ops.STFT(size, shift, window=win, window_length=wl, fading=fading, pad=pad,
+                        complex_representation='complex')
+        X = s(torch.from_numpy(x))
+        xi = s.inverse(X)
+        out[name + '_X'] = X.numpy()
+        out[name + '_xi'] = xi.numpy()
+        cases.append(dict(name=name, x=f'x_s{size}_h{shift}', size=size, shift=shift, window_length=wl, window=win,
+                          fading=fading, pad=pad,
+                          frames=int(s.samples_to_frames(x.shape[-1])),
+                          samples_back=int(s.frames_to_samples(X.shape[-2]))))
+        assert cases[-1]['frames'] == X.shape[-2]
+        assert cases[-1]['samples_back'] == xi.shape[-1]
+    # the other two representations once (concat, stacked), fp32 input like the doctests
+    x32 = torch.from_numpy(out['x_s512_h128'].astype(np.float32))
+    for rep in ['concat', 'stacked']:
+        s = pt.ops.STFT(512, 128, complex_representation=rep)
+        X = s(x32)
+        out[f'rep_{rep}_X'] = X.numpy()
+        out[f'rep_{rep}_xi'] = s.inverse(X).numpy()
+    out['cases'] = np.array(json.dumps(cases))
+    np.savez(HERE / 'g2_stft.npz', **out)
+
+
+def g3():
+    rng = np.random.RandomState(3)
+    s = (0.1 * rng.standard_normal((2, 1500))).astype(np.float32)
+    y = s.sum(0)
+    f = pre_batch_transform(dict(audio_data=dict(speech_source=s, observation=y), example_id='g3'))
+    np.savez(HERE / 'g3_features.npz', s=s, y=y, Y=f['Y'], X_abs=f['X_abs'], Y_abs=f['Y_abs'],
+             cos_phase_difference=f['cos_phase_difference'], num_frames=f['num_frames'])
+
+
+def g4():
+    rng = np.random.RandomState(4)
+    out = {}
+    names = []
+    for name, shape, axis in [('a', (7, 2, 5), -2), ('b', (5, 3, 4), -2), ('c', (3, 6, 4), 0),
+                              ('d', (6, 4, 3), 1)]:
+        est = rng.standard_normal(shape).astype(np.float32)
+        tgt = rng.standard_normal(shape).astype(np.float32)
+        loss, perm = pt.ops.losses.pit_loss(torch.from_numpy(est), torch.from_numpy(tgt), axis=axis,
+                                            return_permutation=True)
+        pw = compute_pairwise_losses(torch.from_numpy(est), torch.from_numpy(tgt), axis=axis)
+        hl, col = pit_loss_from_loss_matrix(pw, return_permutation=True)
+        out.update({f'{name}_est': est, f'{name}_tgt': tgt, f'{name}_loss': loss.numpy(),
+                    f'{name}_perm': np.array(perm), f'{name}_axis': axis,
+                    f'{name}_pairwise': pw.numpy(), f'{name}_hungarian_loss': hl.numpy(),
+                    f'{name}_hungarian_col': np.asarray(col)})
+        names.append(name)
+    # tie: identical estimates -> every permutation has the same loss -> first (identity) wins
+    est = np.repeat(rng.standard_normal((4, 1, 3)).astype(np.float32), 3, axis=1)
+    tgt = rng.standard_normal((4, 3, 3)).astype(np.float32)
+    loss, perm = pt.ops.losses.pit_loss(torch.from_numpy(est), torch.from_numpy(tgt), axis=1,
+                                        return_permutation=True)
+    out.update(tie_est=est, tie_tgt=tgt, tie_loss=loss.numpy(), tie_perm=np.array(perm), tie_axis=1)
+    names.append('tie')
+    # gradient of the PIT loss wrt the estimate (autograd of the reference)
+    est = torch.from_numpy(out['b_est']).clone().requires_grad_(True)
+    pt.ops.losses.pit_loss(est, torch.from_numpy(out['b_tgt']), axis=-2).backward()
+    out['b_grad'] = est.grad.numpy()
+    out['names'] = np.array(json.dumps(names))
+    np.savez(HERE / 'g4_pit.npz', **out)
+
+
+def g5():
+    rng = np.random.RandomState(5)
+    x = rng.standard_normal((100, 20)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    t = np.eye(3, dtype=np.float32)[rng.randint(0, 3, size=100)]
+    xt = torch.from_numpy(x).clone().requires_grad_(True)
+    loss = pt.ops.losses.deep_clustering_loss(xt, torch.from_numpy(t))
+    loss.backward()
+    loss64 = pt.ops.losses.deep_clustering_loss(torch.from_numpy(x).double(), torch.from_numpy(t).double())
+    np.savez(HERE / 'g5_dc.npz', x=x, t=t, loss=loss.detach().numpy(), loss64=loss64.numpy(),
+             grad=xt.grad.numpy())
+
+
+def _sd_to_np(sd, prefix):
+    return {prefix + k: v.detach().numpy().copy() for k, v in sd.items()}
+
+
+def g6():
+    out = {}
+    rng = np.random.RandomState(6)
+    Ts = [6, 5, 3]
+    F, K, E = 9, 2, 3
+    batch = dict(
+        Y_abs=[np.abs(rng.standard_normal((T, F))).astype(np.float32) for T in Ts],
+        X_abs=[np.abs(rng.standard_normal((T, K, F))).astype(np.float32) for T in Ts],
+        cos_phase_difference=[np.cos(rng.uniform(-3, 3, (T, K, F))).astype(np.float32) for T in Ts],
+        target_mask=[np.eye(K, dtype=np.float32)[rng.randint(0, K, (T, F))].transpose(0, 2, 1).copy()
+                     for T in Ts],
+        num_frames=Ts,
+    )
+    for k in ['Y_abs', 'X_abs', 'cos_phase_difference', 'target_mask']:
+        for b, a in enumerate(batch[k]):
+            out[f'in_{k}_{b}'] = a
+    out['Ts'] = np.array(Ts)
+
+    # ---- PIT model
+    torch.manual_seed(60)
+    model = PermutationInvariantTrainingModel(F=F, recurrent_layers=2, units=4, K=K)
+    out.update(_sd_to_np(model.state_dict(), 'pit_sd_'))
+    ex = model.example_to_device(batch, 'cpu')
+    masks = model(ex)
+    review = model.review(ex, masks)
+    for b, m in enumerate(masks):
+        out[f'pit_mask_{b}'] = m.detach().numpy()
+    out['pit_mse_loss'] = review['losses']['pit_mse_loss'].detach().numpy()
+    out['pit_ips_loss'] = review['losses']['pit_ips_loss'].detach().numpy()
+    # per-example single losses: "batch loss == mean of single-example losses" (test_bss.py:153-192)
+    singles = []
+    for b in range(len(Ts)):
+        exb = {k: [v[b]] for k, v in ex.items()}
+        rb = model.review(exb, model(exb))
+        singles.append([float(rb['losses']['pit_mse_loss']), float(rb['losses']['pit_ips_loss'])])
+    out['pit_single_losses'] = np.array(singles)
+    (1.0 * review['losses']['pit_ips_loss']).backward()
+    for n, p in model.named_parameters():
+        out[f'pit_grad_{n}'] = p.grad.numpy().copy()
+
+    # ---- 3 optimizer steps under the reference Trainer (virtual_minibatch_size=2, clip=1)
+    torch.manual_seed(60)
+    model = PermutationInvariantTrainingModel(F=F, recurrent_layers=2, units=4, K=K)
+    with tempfile.TemporaryDirectory() as tmp:
+        trainer = pt.Trainer(model, tmp, pt.optimizer.Adam(gradient_clipping=1.),
+                             loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.),
+                             summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1000, 'iteration'),
+                             stop_trigger=(3, 'iteration'), virtual_minibatch_size=2)
+        # 6 examples = 3 optimizer steps x 2 accumulated micro-steps; examples = sub-batches
+        exs = [{k: [v[b] for b in idx] for k, v in batch.items()}
+               for idx in [(0, 1, 2), (0, 1), (1, 2), (0, 2), (0,), (1,)]]
+        trainer.train(exs, device='cpu')
+        assert trainer.iteration == 3, trainer.iteration
+    out.update(_sd_to_np(model.state_dict(), 'pit_sd3_'))
+    out['train_example_indices'] = np.array(json.dumps([(0, 1, 2), (0, 1), (1, 2), (0, 2), (0,), (1,)]))
+
+    # ---- DC model
+    torch.manual_seed(61)
+    dc = DeepClusteringModel(F=F, recurrent_layers=1, units=4, E=E)
+    out.update(_sd_to_np(dc.state_dict(), 'dc_sd_'))
+    ex = dc.example_to_device(batch, 'cpu')
+    emb = dc(ex)
+    review = dc.review(ex, emb)
+    for b, m in enumerate(emb):
+        out[f'dc_emb_{b}'] = m.detach().numpy()
+    out['dc_loss'] = review['losses']['dc_loss'].detach().numpy()
+    review['losses']['dc_loss'].backward()
+    for n, p in dc.named_parameters():
+        out[f'dc_grad_{n}'] = p.grad.numpy().copy()
+    np.savez(HERE / 'g6_models.npz', **out)
+
+
+if __name__ == '__main__':
+    assert os.path.isdir('/root/reference'), 'run in the build container'
+    for fn in (g1, g2, g3, g4, g5, g6):
+        fn()
+        print('wrote', fn.__name__)
+    for p in sorted(HERE.glob('g*.*')):
+        print(f'{p.name:28s} {p.stat().st_size / 1024:8.1f} KiB')
