@@ -1,0 +1,144 @@
+/*
+ * ptmi.h - C ABI of libptmi.so: the MI355X (gfx950) kernels behind the padertorch PIT hot path.
+ *
+ * Plain pointers and sizes only (no torch types).  Every pointer marked "device" is a HIP device
+ * pointer owned by the caller; kernels are enqueued on `stream` (a hipStream_t passed as void*)
+ * and borrow the buffers until that work has run.  Every entry point returns 0 on success, a
+ * negative PTMI_E_* code for argument errors, or a positive hipError_t from the launch.
+ *
+ * Each function cites the reference interface (file:line below /root/reference) it replaces.
+ */
+#ifndef PTMI_H_
+#define PTMI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTMI_OK 0
+#define PTMI_E_INVALID (-1)     /* bad argument (null pointer, odd size, ...)            */
+#define PTMI_E_UNSUPPORTED (-2) /* configuration the kernels do not cover                 */
+
+typedef void* ptmi_stream_t; /* hipStream_t */
+
+const char* ptmi_version(void);
+const char* ptmi_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * STFT geometry: the framing of padertorch/ops/_stft.py:131-158 (STFT.__call__).
+ *   pad_left / pad_right : fading zeros (L-shift each for 'full'; (L-shift)//2, ceil((L-shift)/2)
+ *                          for 'half'; 0 for None/False)                       (_stft.py:137-146)
+ *   pad                  : 1 = right-pad to a whole frame (ceil), 0 = cut (floor) (_stft.py:148-154)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ptmi_stft_geom {
+    int32_t size;          /* FFT size (even)                                   */
+    int32_t shift;         /* hop                                               */
+    int32_t window_length; /* L <= size                                         */
+    int32_t pad_left;
+    int32_t pad_right;
+    int32_t pad;
+} ptmi_stft_geom;
+
+/* Frame / sample bookkeeping (integer, bit-exact).
+ * Replaces STFT.samples_to_frames / frames_to_samples (_stft.py:265-307 -> paderbox
+ * _samples_to_stft_frames / _stft_frames_to_samples) and the conv1d output length of _stft.py:158. */
+int64_t ptmi_stft_num_frames(const ptmi_stft_geom* g, int64_t num_samples);
+int64_t ptmi_istft_num_samples(const ptmi_stft_geom* g, int64_t num_frames);
+
+/* Output layouts of ptmi_stft_forward / input layouts of ptmi_istft_forward (_stft.py:162-174). */
+#define PTMI_LAYOUT_INTERLEAVED 0 /* [..., frames, F, 2] == complex64 == 'stacked' */
+#define PTMI_LAYOUT_CONCAT 1      /* [..., frames, 2F]  (re | im)                  */
+
+/* Forward STFT: framing + window + real FFT in one kernel.
+ * Replaces STFT.__call__ (_stft.py:103-174: F.pad, F.pad, kernel.to(x), F.conv1d, rearrange, chunk).
+ *   x            device [batch, x_row_stride] float32, row b valid for row_samples[b] (or num_samples)
+ *   row_samples  device int32[batch] or NULL (all rows num_samples long)
+ *   window       device float32[window_length]
+ *   twiddle      device float32[(size/2+1)*2]: (cos, -sin)(2*pi*j/size), j = 0..size/2
+ *   out          device float32 [batch, out_frames, F, 2] or [batch, out_frames, 2F]; rows past a
+ *                row's own frame count are zero-filled
+ *   edge_scale   1.0 for the plain transform; 0.5 when used as the adjoint of ptmi_istft_forward
+ *                (scales the DC/Nyquist bins and zeroes their imaginary part)
+ */
+int ptmi_stft_forward(const float* x, int64_t batch, int64_t x_row_stride, int64_t num_samples,
+                      const int32_t* row_samples, const float* window, const float* twiddle,
+                      const ptmi_stft_geom* g, int64_t out_frames, int32_t layout, float edge_scale,
+                      float* out, ptmi_stream_t stream);
+
+/* Inverse STFT: hermitian inverse real FFT + synthesis window + overlap-add + fading cut.
+ * Replaces STFT.inverse (_stft.py:176-263: two conv_transpose1d over the hermitian-extended
+ * spectrum, sum, cut).
+ *   spec         device float32, layout as above, [batch, num_frames, ...]
+ *   row_frames   device int32[batch] or NULL (all rows num_frames)
+ *   syn_window   device float32[window_length]: biorthogonal window / size   (_stft.py:27-28)
+ *   out          device float32 [batch, out_row_stride]; out_samples per row are written
+ *   cut_left     samples dropped in front (int(pad_width), _stft.py:257-262)
+ *   edge_scale   1.0 for the plain inverse; 2.0 when used as the adjoint of ptmi_stft_forward
+ */
+int ptmi_istft_forward(const float* spec, int64_t batch, int64_t num_frames, const int32_t* row_frames,
+                       const float* syn_window, const float* twiddle, const ptmi_stft_geom* g,
+                       int32_t layout, float edge_scale, int64_t cut_left, int64_t out_samples,
+                       int64_t out_row_stride, float* out, ptmi_stream_t stream);
+
+/* Fused PIT feature front-end: STFT of the mixture and of K sources + |.| + cos(phase difference).
+ * Replaces pre_batch_transform (padertorch/contrib/examples/source_separation/pit/data.py:49-77).
+ *   y            device [batch, row_stride]           mixture waveforms
+ *   s            device [batch, K, row_stride]        source waveforms (may be NULL: only Y_abs)
+ *   row_samples  device int32[batch] or NULL
+ *   Y_abs        device [batch, out_frames, F]
+ *   X_abs, cos_pd device [batch, out_frames, K, F]    (NULL when s is NULL)
+ */
+int ptmi_pit_features(const float* y, const float* s, int64_t batch, int32_t K, int64_t row_stride,
+                      int64_t num_samples, const int32_t* row_samples, const float* window,
+                      const float* twiddle, const ptmi_stft_geom* g, int64_t out_frames, float* Y_abs,
+                      float* X_abs, float* cos_pd, ptmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Permutation-invariant training loss.
+ * Replaces pit_loss (padertorch/ops/losses/source_separation.py:34-124) with loss_fn = mse_loss
+ * and the review loop of pit/model.py:117-140.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Pairwise sums of squared errors for `batch` ragged examples stored in padded buffers.
+ *   est      device, element (b, t, i, f) at b*strides[0] + t*strides[1] + i*F + f: estimates
+ *            (or masks when obs != NULL: est = mask * obs); batch- or time-major padded storage
+ *   obs      device or NULL, element (b, t, f) at b*strides[2] + t*strides[3] + f
+ *   tgt      device, element (b, t, j, f) at b*strides[4] + t*strides[5] + j*F + f
+ *   tgt_scale device like tgt or NULL; second target = tgt * tgt_scale (cos phase difference)
+ *   strides  HOST int64[6] (element strides, see above)
+ *   row_frames device int32[batch] or NULL (all t_len)
+ *   sse      device float64 [batch, nvar, K, K]: sse[b, v, i, j] = sum_{t,f} (est_i - tgt^v_j)^2
+ *            nvar = 1 (tgt) or 2 (tgt, tgt*tgt_scale)
+ *   workspace device float64 [ptmi_pit_workspace_elems(...)]
+ */
+int64_t ptmi_pit_workspace_elems(int64_t batch, int64_t t_len, int32_t K, int32_t F);
+int ptmi_pit_pairwise_sse(const float* est, const float* obs, const float* tgt, const float* tgt_scale,
+                          int64_t batch, int64_t t_len, const int64_t* strides, int32_t K, int32_t F,
+                          const int32_t* row_frames, double* workspace, double* sse,
+                          ptmi_stream_t stream);
+
+/* Permutation search on the pairwise matrix + batch mean (first minimum wins, torch.min).
+ *   loss     device float32 [nvar]         mean_b min_perm (1/(T_b K F)) sum_j sse[b,v,perm[j],j]
+ *   perm     device int32 [batch, nvar, K] estimate index per target (pit_loss's convention)
+ *   ex_loss  device float32 [batch, nvar]  per-example losses (may be NULL)
+ */
+int ptmi_pit_assign(const double* sse, int64_t batch, int32_t nvar, int32_t K, int32_t F,
+                    int64_t t_len, const int32_t* row_frames, float* loss, int32_t* perm,
+                    float* ex_loss, ptmi_stream_t stream);
+
+/* Gradient wrt est (or wrt the mask when obs != NULL):
+ *   grad[b,t,i,f] = sum_v gscale[v] * 2/(B T_b K F) * (est_i - tgt^v_{j: perm[b,v,j]=i}) [* obs]
+ *   gscale   device float32 [nvar] (upstream gradients of the two batch-mean losses)
+ *   grad     device, same addressing as est (strides[0], strides[1]); frames t >= T_b get 0
+ */
+int ptmi_pit_backward(const float* est, const float* obs, const float* tgt, const float* tgt_scale,
+                      const int32_t* perm, const float* gscale, int64_t batch, int64_t t_len,
+                      const int64_t* strides, int32_t K, int32_t F, int32_t nvar, const int32_t* row_frames,
+                      float* grad, ptmi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTMI_H_ */

@@ -1,0 +1,91 @@
+"""ctypes binding of libptmi.so (C ABI declared in include/ptmi.h).
+
+The product path has NO CPU fallback: if the library is missing, or a tensor is not on an
+MI355X device, the ops raise instead of silently computing something else.
+"""
+import ctypes
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / 'libptmi.so'
+
+
+class StftGeom(ctypes.Structure):
+    """``ptmi_stft_geom`` (include/ptmi.h)."""
+    _fields_ = [('size', c_int32), ('shift', c_int32), ('window_length', c_int32),
+                ('pad_left', c_int32), ('pad_right', c_int32), ('pad', c_int32)]
+
+
+_P = c_void_p   # device pointers travel as integers
+_G = POINTER(StftGeom)
+_I64P = POINTER(c_int64)
+
+#: name -> (restype, argtypes); must list every symbol include/ptmi.h declares
+SIGNATURES = {
+    'ptmi_version': (c_char_p, []),
+    'ptmi_error_string': (c_char_p, [c_int]),
+    'ptmi_stft_num_frames': (c_int64, [_G, c_int64]),
+    'ptmi_istft_num_samples': (c_int64, [_G, c_int64]),
+    'ptmi_stft_forward': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _G, c_int64, c_int32,
+                                  c_float, _P, _P]),
+    'ptmi_istft_forward': (c_int, [_P, c_int64, c_int64, _P, _P, _P, _G, c_int32, c_float, c_int64,
+                                   c_int64, c_int64, _P, _P]),
+    'ptmi_pit_features': (c_int, [_P, _P, c_int64, c_int32, c_int64, c_int64, _P, _P, _P, _G, c_int64,
+                                  _P, _P, _P, _P]),
+    'ptmi_pit_workspace_elems': (c_int64, [c_int64, c_int64, c_int32, c_int32]),
+    'ptmi_pit_pairwise_sse': (c_int, [_P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, _P,
+                                      _P, _P, _P]),
+    'ptmi_pit_assign': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P]),
+    'ptmi_pit_backward': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32,
+                                  c_int32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libptmi.so (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise ImportError(
+                f'{LIB_PATH} is missing: build the HIP kernels first '
+                f'(python -m padertorch_amd.build, or __graft_entry__.build()). '
+                f'padertorch_amd has no CPU fallback.')
+        lib = ctypes.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().ptmi_error_string(int(rc)).decode()
+        raise RuntimeError(f'{what}: {msg} (code {rc})')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'padertorch_amd ops run on an MI355X (HIP) device only and have no CPU fallback; '
+                f'got a tensor on {t.device}. Move the example to the GPU first.')
+
+
+def stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def strides6(*vals):
+    return (c_int64 * 6)(*vals)

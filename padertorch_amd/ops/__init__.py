@@ -1,0 +1,9 @@
+from .losses import *  # noqa: F401,F403
+from . import losses
+from . import sequence
+from . import mappings
+
+from ._stft import STFT  # noqa: F401
+from .einsum import *  # noqa: F401,F403
+from .sequence import *  # noqa: F401,F403
+from .features import pit_features  # noqa: F401

@@ -1,0 +1,287 @@
+"""``padertorch_amd.ops.STFT``: drop-in for ``padertorch.ops.STFT`` on MI355X.
+
+Same constructor / ``__call__`` / ``inverse`` / helper signatures and assertion behaviour as
+``padertorch/ops/_stft.py:46-307``; the arithmetic runs in hand-written HIP kernels
+(``csrc/stft.hip``) through the C ABI of ``include/ptmi.h``:
+
+* ``__call__``  -> ``ptmi_stft_forward``  (reference: F.pad + F.pad + kernel.to(x) + F.conv1d with a
+  dense ``[2F,1,L]`` DFT matrix, ``_stft.py:131-174``)
+* ``inverse``   -> ``ptmi_istft_forward`` (reference: two ``conv_transpose1d``, ``_stft.py:226-262``)
+* both are differentiable; each op's backward is the other kernel (adjoint), see DESIGN.md.
+
+Like the reference it is a plain class (no parameters, not in ``state_dict``).  The window /
+synthesis-window / twiddle tables are built once on the host in float64 (window semantics of
+paderbox ``_get_window`` / ``_biorthogonal_window_fastest``: periodic unless
+``symmetric_window``; synthesis window ``w[n] / sum_m w[n+m*shift]**2``) and cached per device.
+"""
+import typing
+from math import ceil
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+__all__ = ['STFT']
+
+
+def _get_window(window, symmetric_window, window_length):
+    """paderbox ``_get_window`` semantics (reference call site ``_stft.py:91-95``)."""
+    import scipy.signal
+    fn = window if callable(window) else getattr(scipy.signal.windows, window)
+    if symmetric_window:
+        return np.asarray(fn(window_length), dtype=np.float64)
+    return np.asarray(fn(window_length + 1)[:-1], dtype=np.float64)
+
+
+def _biorthogonal_window(window, shift):
+    """paderbox ``_biorthogonal_window_fastest`` semantics (reference call site ``_stft.py:27-28``)."""
+    w = np.asarray(window, dtype=np.float64)
+    sq = w * w
+    denom = np.empty_like(w)
+    for r in range(min(shift, len(w))):
+        denom[r::shift] = sq[r::shift].sum()
+    return w / denom
+
+
+def _fading_pads(window_length, shift, fading):
+    """``_stft.py:137-146``."""
+    if fading in (None, False):
+        return 0, 0
+    if fading == 'half':
+        return (window_length - shift) // 2, ceil((window_length - shift) / 2)
+    return window_length - shift, window_length - shift
+
+
+class _Tables:
+    """Per-device float32 tables derived from float64 host arrays."""
+
+    def __init__(self, window, shift, size):
+        self.host = dict(
+            window=window,
+            syn=_biorthogonal_window(window, shift) / size,          # _stft.py:27-28
+            # adjoint windows (DESIGN.md "adjoints"): d stft -> istft with w/2; d istft -> stft with 2*syn
+            window_adj=window / 2,
+            syn_adj=2 * _biorthogonal_window(window, shift) / size,
+        )
+        j = np.arange(size // 2 + 1)
+        ang = 2 * np.pi * j / size
+        self.host['twiddle'] = np.stack([np.cos(ang), -np.sin(ang)], axis=-1).reshape(-1)
+        self._dev = {}
+
+    def get(self, device):
+        key = (device.type, device.index)
+        if key not in self._dev:
+            self._dev[key] = {k: torch.as_tensor(v, dtype=torch.float32).to(device)
+                              for k, v in self.host.items()}
+        return self._dev[key]
+
+
+def _to_f32(x):
+    if x.dtype != torch.float32:
+        x = x.to(torch.float32)       # arithmetic is fp32 (documented deviation for f64 inputs)
+    return x.contiguous()
+
+
+class _StftFn(torch.autograd.Function):
+    """[rows, T] float32 -> [rows, frames, F, 2] (interleaved) or [rows, frames, 2F] (concat)."""
+
+    @staticmethod
+    def forward(ctx, x, st, layout, row_samples):
+        _lib.require_gpu(x)
+        lib = _lib.load()
+        tb = st._tables.get(x.device)
+        rows, T = x.shape
+        frames = st._frames_for(T)
+        F = st.size // 2 + 1
+        shape = (rows, frames, F, 2) if layout == 0 else (rows, frames, 2 * F)
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+        _lib.check(lib.ptmi_stft_forward(
+            x.data_ptr(), rows, x.stride(0), T, _lib.ptr(row_samples), tb['window'].data_ptr(),
+            tb['twiddle'].data_ptr(), st._geom, frames, layout, 1.0, out.data_ptr(),
+            _lib.stream(x.device)), 'ptmi_stft_forward')
+        ctx.st, ctx.layout, ctx.T = st, layout, T
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        st, T = ctx.st, ctx.T
+        g = g.contiguous()
+        lib = _lib.load()
+        tb = st._tables.get(g.device)
+        rows, frames = g.shape[0], g.shape[1]
+        dx = torch.empty((rows, T), dtype=torch.float32, device=g.device)
+        # adjoint of (frame, window, one-sided DFT) = hermitian inverse with doubled DC/Nyquist,
+        # window w/2, overlap-add, cut the fading pad and anything right of the row.
+        _lib.check(lib.ptmi_istft_forward(
+            g.data_ptr(), rows, frames, None, tb['window_adj'].data_ptr(), tb['twiddle'].data_ptr(),
+            st._geom, ctx.layout, 2.0, st._geom.pad_left, T, T, dx.data_ptr(),
+            _lib.stream(g.device)), 'ptmi_istft_forward(adjoint)')
+        return dx, None, None, None
+
+
+class _IstftFn(torch.autograd.Function):
+    """[rows, frames, F, 2] or [rows, frames, 2F] float32 -> [rows, samples]."""
+
+    @staticmethod
+    def forward(ctx, spec, st, layout):
+        _lib.require_gpu(spec)
+        lib = _lib.load()
+        tb = st._tables.get(spec.device)
+        rows, frames = spec.shape[0], spec.shape[1]
+        n = int(lib.ptmi_istft_num_samples(st._geom, frames))
+        out = torch.empty((rows, max(n, 0)), dtype=torch.float32, device=spec.device)
+        if n > 0:
+            _lib.check(lib.ptmi_istft_forward(
+                spec.data_ptr(), rows, frames, None, tb['syn'].data_ptr(), tb['twiddle'].data_ptr(),
+                st._geom, layout, 1.0, st._geom.pad_left, n, n, out.data_ptr(),
+                _lib.stream(spec.device)), 'ptmi_istft_forward')
+        ctx.st, ctx.layout, ctx.frames = st, layout, frames
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        st, frames = ctx.st, ctx.frames
+        g = g.contiguous()
+        lib = _lib.load()
+        tb = st._tables.get(g.device)
+        rows, n = g.shape
+        F = st.size // 2 + 1
+        shape = (rows, frames, F, 2) if ctx.layout == 0 else (rows, frames, 2 * F)
+        ds = torch.empty(shape, dtype=torch.float32, device=g.device)
+        # adjoint of (hermitian inverse, window, overlap-add, cut) = forward STFT of the gradient
+        # with window 2*syn and halved, real-only DC/Nyquist bins.
+        _lib.check(lib.ptmi_stft_forward(
+            g.data_ptr(), rows, g.stride(0), n, None, tb['syn_adj'].data_ptr(),
+            tb['twiddle'].data_ptr(), st._geom, frames, ctx.layout, 0.5, ds.data_ptr(),
+            _lib.stream(g.device)), 'ptmi_stft_forward(adjoint)')
+        return ds, None, None
+
+
+class STFT:
+    def __init__(
+            self,
+            size: int = 1024,
+            shift: int = 256,
+            *,
+            window: typing.Union[str, typing.Callable] = 'blackman',
+            window_length: int = None,
+            fading: typing.Optional[typing.Union[bool, str]] = 'full',
+            pad: bool = True,
+            symmetric_window: bool = False,
+            complex_representation: str = 'complex'
+    ):
+        """Arguments as ``padertorch.ops.STFT`` (``_stft.py:47-58``)."""
+        self.possible_out_types = ['concat', 'stacked', 'complex']
+        assert complex_representation in self.possible_out_types, (
+            f'Please choose one of the predefined output_types'
+            f' {self.possible_out_types}, not {complex_representation}'
+        )
+        self.complex_representation = complex_representation
+        assert size % 2 == 0, 'At the moment we only support even FFT sizes'
+        self.size = size
+        self.shift = shift
+        self.window_length = window_length if window_length is not None else size
+        assert self.window_length <= size, (self.window_length, size)
+        assert fading in [None, True, False, 'full', 'half'], fading
+        self._fading = fading
+        self._pad = pad
+        self.window = _get_window(window, symmetric_window, self.window_length)
+        self._tables = _Tables(self.window, shift, size)
+        self._update_geom()
+
+    # ``fading`` / ``pad`` may be reassigned after construction (tests/test_ops/test_stft.py:45-58)
+    @property
+    def fading(self):
+        return self._fading
+
+    @fading.setter
+    def fading(self, value):
+        assert value in [None, True, False, 'full', 'half'], value
+        self._fading = value
+        self._update_geom()
+
+    @property
+    def pad(self):
+        return self._pad
+
+    @pad.setter
+    def pad(self, value):
+        self._pad = value
+        self._update_geom()
+
+    def _update_geom(self):
+        left, right = _fading_pads(self.window_length, self.shift, self._fading)
+        self._geom = _lib.StftGeom(self.size, self.shift, self.window_length, left, right,
+                                   1 if self._pad else 0)
+
+    def _frames_for(self, samples):
+        """Exact frame count of the strided conv in ``_stft.py:158`` (integer arithmetic)."""
+        n = int(_lib.load().ptmi_stft_num_frames(self._geom, int(samples)))
+        if n <= 0:
+            raise RuntimeError(
+                f'STFT: input of {samples} samples is shorter than the window '
+                f'({self.window_length}) and pad=False')
+        return n
+
+    def __call__(self, inputs, num_samples=None):
+        """``inputs``: ``[..., T]`` -> ``[..., frames, F]`` complex64 (or concat / stacked).
+
+        ``num_samples`` (extension, optional int32 tensor with one entry per flattened row): rows
+        are zero-padded to ``T``; frames past a row's own count are zero.
+        """
+        org_shape = inputs.shape
+        x = _to_f32(inputs.reshape(-1, org_shape[-1]))
+        layout = 1 if self.complex_representation == 'concat' else 0
+        out = _StftFn.apply(x, self, layout, num_samples)
+        out = out.reshape(*org_shape[:-1], *out.shape[1:])
+        if self.complex_representation == 'complex':
+            out = torch.view_as_complex(out)
+        if inputs.dtype == torch.float64:
+            out = out.to(torch.complex128 if out.is_complex() else torch.float64)
+        return out
+
+    def inverse(self, stft_signal):
+        """``[..., frames, F]`` complex / ``[..., frames, 2F]`` / ``[..., frames, F, 2]`` -> ``[..., T]``."""
+        if self.complex_representation == 'complex':
+            assert stft_signal.is_complex(), stft_signal.dtype
+            dbl = stft_signal.dtype == torch.complex128
+            spec = torch.view_as_real(stft_signal.to(torch.complex64).contiguous())
+            lead, layout = stft_signal.shape[:-2], 0
+        elif self.complex_representation == 'stacked':
+            dbl = stft_signal.dtype == torch.float64
+            spec, lead, layout = _to_f32(stft_signal), stft_signal.shape[:-3], 0
+        elif self.complex_representation == 'concat':
+            dbl = stft_signal.dtype == torch.float64
+            spec, lead, layout = _to_f32(stft_signal), stft_signal.shape[:-2], 1
+        else:
+            raise ValueError(
+                f'Please choose one of the predefined output_types'
+                f'{self.possible_out_types} not {self.complex_representation}')
+        F = self.size // 2 + 1
+        frames = spec.shape[len(lead)]
+        spec = spec.reshape(-1, frames, *((F, 2) if layout == 0 else (2 * F,)))
+        out = _IstftFn.apply(spec, self, layout)
+        out = out.reshape(*lead, out.shape[-1])
+        return out.to(torch.float64) if dbl else out
+
+    def samples_to_frames(self, samples):
+        """paderbox ``_samples_to_stft_frames(samples, window_length, shift, pad, fading)``."""
+        if self._fading not in (None, False):
+            samples = samples + (1 + (self._fading != 'half')) * (self.window_length - self.shift)
+        frames = (samples - self.window_length + self.shift) / self.shift
+        if isinstance(frames, np.ndarray):
+            return (np.ceil(frames) if self._pad else np.floor(frames)).astype(np.int64)
+        return ceil(frames) if self._pad else int(np.floor(frames))
+
+    def sample_index_to_frame_index(self, sample_index):
+        raise NotImplementedError(
+            'paderbox.sample_index_to_stft_frame_index is third-party, absent from the reference '
+            'tree and not pinned by any reference test (SURVEY.md section 8c: parity unpinned).')
+
+    def frames_to_samples(self, frames):
+        """paderbox ``_stft_frames_to_samples(frames, window_length, shift, fading)``."""
+        samples = frames * self.shift + self.window_length - self.shift
+        if self._fading not in (None, False):
+            samples = samples - (1 + (self._fading != 'half')) * (self.window_length - self.shift)
+        return samples

@@ -1,0 +1,3 @@
+from . import source_separation
+from .source_separation import *  # noqa: F401,F403
+from .source_separation import pit_mse_ips_losses  # noqa: F401

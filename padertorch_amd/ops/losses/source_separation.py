@@ -1,0 +1,180 @@
+"""Source-separation losses on MI355X: drop-in for ``padertorch.ops.losses.source_separation``.
+
+* :func:`pit_loss` keeps the reference signature (``source_separation.py:34-40``).  For the
+  default ``loss_fn=mse_loss`` the K! python loop (``:110-119``) is replaced by one HIP pass that
+  builds the K x K pairwise squared-error matrix (``ptmi_pit_pairwise_sse``), an on-device walk
+  over the permutations in ``itertools`` order (``ptmi_pit_assign``, first minimum wins like
+  ``torch.min``) and a HIP backward (``ptmi_pit_backward``).  Any other ``loss_fn`` runs the
+  reference's own brute-force loop with torch ops on the device (no kernel claims made for it).
+* :func:`pit_mse_ips_losses` fuses the review loop of ``pit/model.py:117-140`` over a whole ragged
+  batch (both losses, all examples, one pass over mask / observation / target / cos).
+* :func:`deep_clustering_loss` (``source_separation.py:13-31``).
+"""
+import itertools
+
+import torch
+import torch.nn.functional
+
+from ... import _lib
+
+__all__ = [
+    'deep_clustering_loss',
+    'pit_loss',
+]
+
+
+def deep_clustering_loss(x, t):
+    """Deep clustering loss as in Hershey 2016 (``source_separation.py:13-31``).
+
+    Args:
+        x: Shape (N, E), unit-norm embeddings.
+        t: Target mask with shape (N, K).
+    """
+    _lib.require_gpu(x, t)
+    N = x.size()[0]
+    # (E+K)^2 Gram entries of an (N, E+K) matrix: three skinny GEMMs on the device BLAS for now;
+    # the fused single-pass HIP Gram kernel is SURVEY section 8 row f / config 5 ("next").
+    return (
+        torch.sum((x.t() @ x) ** 2)
+        - 2 * torch.sum((x.t() @ t) ** 2)
+        + torch.sum((t.t() @ t) ** 2)
+    ) / N ** 2
+
+
+class _PitFn(torch.autograd.Function):
+    """losses[nvar] = batch mean of min-permutation MSE for nvar in {mse, mse vs tgt*scale}.
+
+    All tensors are addressed through (batch stride, time stride) so batch-major front-end buffers
+    and the time-major padded output of the packed BLSTM are consumed in place.
+    """
+
+    @staticmethod
+    def forward(ctx, est, obs, tgt, scale, row_frames, geom):
+        B, T, K, F, es, os_, ts = geom
+        lib = _lib.load()
+        dev = est.device
+        nvar = 2 if scale is not None else 1
+        nws = int(lib.ptmi_pit_workspace_elems(B, T, K, F))
+        ws = torch.empty(nws, dtype=torch.float64, device=dev)
+        sse = torch.empty((B, nvar, K, K), dtype=torch.float64, device=dev)
+        strides = _lib.strides6(es[0], es[1], os_[0], os_[1], ts[0], ts[1])
+        st = _lib.stream(dev)
+        _lib.check(lib.ptmi_pit_pairwise_sse(
+            est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), B, T, strides, K, F,
+            _lib.ptr(row_frames), ws.data_ptr(), sse.data_ptr(), st), 'ptmi_pit_pairwise_sse')
+        loss = torch.empty(nvar, dtype=torch.float32, device=dev)
+        perm = torch.empty((B, nvar, K), dtype=torch.int32, device=dev)
+        ex_loss = torch.empty((B, nvar), dtype=torch.float32, device=dev)
+        _lib.check(lib.ptmi_pit_assign(
+            sse.data_ptr(), B, nvar, K, F, T, _lib.ptr(row_frames), loss.data_ptr(), perm.data_ptr(),
+            ex_loss.data_ptr(), st), 'ptmi_pit_assign')
+        ctx.save_for_backward(est, obs, tgt, scale, row_frames, perm)
+        ctx.geom = geom
+        ctx.mark_non_differentiable(perm, ex_loss, sse)
+        return loss, perm, ex_loss, sse
+
+    @staticmethod
+    def backward(ctx, g_loss, _gp, _ge, _gs):
+        est, obs, tgt, scale, row_frames, perm = ctx.saved_tensors
+        B, T, K, F, es, os_, ts = ctx.geom
+        lib = _lib.load()
+        nvar = 2 if scale is not None else 1
+        # the kernel writes every (b, t < T) row, zero for the padded frames t >= T_b
+        grad = torch.empty_strided(est.shape, est.stride(), dtype=est.dtype, device=est.device)
+        strides = _lib.strides6(es[0], es[1], os_[0], os_[1], ts[0], ts[1])
+        gs = g_loss.to(torch.float32).contiguous()
+        _lib.check(lib.ptmi_pit_backward(
+            est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), perm.data_ptr(),
+            gs.data_ptr(), B, T, strides, K, F, nvar, _lib.ptr(row_frames), grad.data_ptr(),
+            _lib.stream(est.device)), 'ptmi_pit_backward')
+        return grad, None, None, None, None, None
+
+
+def _bt_strides(t, batch_first, inner):
+    """(batch stride, time stride) in elements of a padded [B,T,...] / [T,B,...] tensor whose
+    trailing ``inner`` dims are contiguous."""
+    return (t.stride(0), t.stride(1)) if batch_first else (t.stride(1), t.stride(0))
+
+
+def pit_mse_ips_losses(mask, observation, target, cos_phase_difference=None, lengths=None, *,
+                       mask_batch_first=True, data_batch_first=True):
+    """Fused review of ``pit/model.py:117-140`` for a whole ragged batch.
+
+    mask ``[B,T,K,F]`` (or ``[T,B,K,F]`` with ``mask_batch_first=False``), observation ``[B,T,F]``,
+    target / cos_phase_difference ``[B,T,K,F]``; ``lengths``: int32 device tensor ``[B]`` or None.
+    Returns ``(losses[nvar], perm[B,nvar,K], per_example[B,nvar])`` where ``losses[0]`` is
+    ``pit_mse_loss`` and ``losses[1]`` ``pit_ips_loss`` (batch means); differentiable wrt ``mask``.
+    """
+    _lib.require_gpu(mask, observation, target, cos_phase_difference, lengths)
+    for t in (mask, observation, target, cos_phase_difference):
+        assert t is None or t.dtype == torch.float32, t.dtype
+    if mask_batch_first:
+        B, T, K, F = mask.shape
+    else:
+        T, B, K, F = mask.shape
+    assert mask.stride(-1) == 1 and mask.stride(-2) == F, mask.stride()
+    assert target.stride(-1) == 1 and target.stride(-2) == F, target.stride()
+    assert observation.stride(-1) == 1
+    if cos_phase_difference is not None:
+        assert cos_phase_difference.stride() == target.stride()
+    geom = (B, T, K, F, _bt_strides(mask, mask_batch_first, K * F),
+            _bt_strides(observation, data_batch_first, F), _bt_strides(target, data_batch_first, K * F))
+    loss, perm, ex_loss, _ = _PitFn.apply(mask, observation, target, cos_phase_difference, lengths, geom)
+    return loss, perm, ex_loss
+
+
+def pit_loss(
+        estimate: torch.Tensor,
+        target: torch.Tensor,
+        axis: int,
+        loss_fn=torch.nn.functional.mse_loss,
+        return_permutation: bool = False
+):
+    """Permutation invariant loss (signature and semantics of ``source_separation.py:34-124``).
+
+    Does not support batch dimension. Does not support PackedSequence.
+    The returned permutation lists the *estimate* index for every target index.
+    """
+    sources = estimate.size()[axis]
+    assert sources < 30, f'Are you sure? sources={sources}, estimate.shape={estimate.shape}, target.shape={target.shape}'
+    _lib.require_gpu(estimate, target)
+
+    if loss_fn in [torch.nn.functional.cross_entropy]:
+        assert axis % estimate.ndimension() == 1, axis
+        estimate_shape = list(estimate.shape)
+        del estimate_shape[axis]
+        assert estimate_shape == list(target.shape), (
+            f'{estimate.shape} (N, K, ...) does not match {target.shape} (N, ...)'
+        )
+    else:
+        assert estimate.size() == target.size(), (
+            f'{estimate.size()} != {target.size()}'
+        )
+
+    if loss_fn is torch.nn.functional.mse_loss and sources <= 8 \
+            and estimate.dtype == torch.float32 and target.dtype == torch.float32:
+        axis = axis % estimate.ndim
+        outer = 1
+        for d in estimate.shape[:axis]:
+            outer *= d
+        inner = estimate.numel() // max(outer * sources, 1)
+        est = estimate.contiguous().view(1, outer, sources, inner)
+        tgt = target.contiguous().view(1, outer, sources, inner)
+        geom = (1, outer, sources, inner, (0, sources * inner), (0, 0), (0, sources * inner))
+        loss, perm, _, _ = _PitFn.apply(est, None, tgt, None, None, geom)
+        min_loss = loss[0]
+        if return_permutation:
+            return min_loss, tuple(int(p) for p in perm[0, 0].tolist())
+        return min_loss
+
+    # generic loss_fn: the reference's brute-force algorithm, evaluated with torch ops on the device
+    candidates = []
+    indexer = [slice(None), ] * estimate.ndim
+    permutations = list(itertools.permutations(range(sources)))
+    for permutation in permutations:
+        indexer[axis] = permutation
+        candidates.append(loss_fn(estimate[tuple(indexer)], target))
+    min_loss, idx = torch.min(torch.stack(candidates), dim=0)
+    if return_permutation:
+        return min_loss, permutations[int(idx)]
+    return min_loss

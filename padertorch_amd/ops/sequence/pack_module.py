@@ -1,0 +1,83 @@
+"""Switch between packed / padded / list-of-tensor sequences.
+
+Same public names as ``padertorch/ops/sequence/pack_module.py:17-34`` (pure data movement: the
+torch ``rnn`` utilities are the implementation in the reference too), plus :class:`PaddedList`,
+the container this package uses to hand a ragged batch to the HIP kernels without re-padding.
+"""
+import torch
+from torch.nn.utils.rnn import PackedSequence  # noqa: F401
+from torch.nn.utils.rnn import pad_packed_sequence
+from torch.nn.utils.rnn import pack_padded_sequence
+from torch.nn.utils.rnn import pack_sequence as _torch_pack_sequence
+from torch.nn.utils.rnn import pad_sequence
+
+__all__ = [
+    'pack_sequence',
+    'unpack_sequence',
+    'pad_sequence',
+    'unpad_sequence',
+    'pad_packed_sequence',
+    'pack_padded_sequence',
+    'PaddedList',
+]
+
+
+class PaddedList(list):
+    """A python list of per-example tensors that are views into ONE padded buffer.
+
+    Behaves exactly like the ``list`` the reference's data contract asks for
+    (``pit/model.py:81-82,110``: ``list[(T_b, ...)]``, sorted by descending length), but keeps
+    the padded storage and the lengths so that kernels can consume the batch in place.
+
+    Attributes:
+        padded: ``[B, T, ...]`` (``batch_first``) or ``[T, B, ...]`` tensor
+        lengths: python list of ints (descending)
+        lengths_dev: int32 device tensor ``[B]``
+    """
+
+    def __init__(self, padded, lengths, batch_first=True, lengths_dev=None):
+        lengths = [int(l) for l in lengths]
+        if batch_first:
+            super().__init__(padded[b, :l] for b, l in enumerate(lengths))
+        else:
+            super().__init__(padded[:l, b] for b, l in enumerate(lengths))
+        self.padded = padded
+        self.lengths = lengths
+        self.batch_first = batch_first
+        if lengths_dev is None:
+            lengths_dev = torch.tensor(lengths, dtype=torch.int32, device=padded.device)
+        self.lengths_dev = lengths_dev
+
+    def to(self, device):
+        return PaddedList(self.padded.to(device), self.lengths, self.batch_first,
+                          self.lengths_dev.to(device))
+
+
+def as_padded(seq, batch_first=True):
+    """list of tensors (descending length) or :class:`PaddedList` -> (padded, lengths, lengths_dev)."""
+    if isinstance(seq, PaddedList) and seq.batch_first == batch_first:
+        return seq.padded, seq.lengths, seq.lengths_dev
+    if isinstance(seq, PaddedList):
+        return seq.padded.transpose(0, 1).contiguous(), seq.lengths, seq.lengths_dev
+    lengths = [int(t.shape[0]) for t in seq]
+    padded = pad_sequence(list(seq), batch_first=batch_first)
+    return padded, lengths, torch.tensor(lengths, dtype=torch.int32, device=padded.device)
+
+
+def pack_sequence(sequences, enforce_sorted=True):
+    """``torch.nn.utils.rnn.pack_sequence`` (``pack_module.py:14``); PaddedList skips the re-pad."""
+    if isinstance(sequences, PaddedList):
+        return pack_padded_sequence(sequences.padded, torch.tensor(sequences.lengths),
+                                    batch_first=sequences.batch_first, enforce_sorted=enforce_sorted)
+    return _torch_pack_sequence(sequences, enforce_sorted=enforce_sorted)
+
+
+def unpack_sequence(packed_sequence: PackedSequence) -> list:
+    """``pack_module.py:29-30``; returns a :class:`PaddedList` (time-major storage)."""
+    padded, lengths = pad_packed_sequence(packed_sequence)
+    return PaddedList(padded, lengths.tolist(), batch_first=False)
+
+
+def unpad_sequence(padded_sequence: torch.Tensor, lengths: list):
+    """``pack_module.py:33-34``."""
+    return [padded_sequence[:l, b, ...] for b, l in enumerate(lengths)]

@@ -1,0 +1,206 @@
+"""HIP STFT / iSTFT / feature front-end vs the oracle and the reference goldens (GPU, via the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import features_np, stft_np
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _stft(c, **kw):
+    from padertorch_amd.ops import STFT
+    return STFT(c['size'], c['shift'], window=c['window'], window_length=c['window_length'],
+                fading=c['fading'], pad=c['pad'], **kw)
+
+
+def test_option_grid_vs_reference(g2):
+    """Every golden case: forward within 1e-4*max|X| (fp32 FFT vs fp64 reference), inverse 1e-5."""
+    for c in g2['cases']:
+        x = torch.from_numpy(g2[c['x']].astype(np.float32)).to(DEV)
+        st = _stft(c)
+        X = st(x)
+        ref = g2[c['name'] + '_X']
+        assert tuple(X.shape) == ref.shape, c           # framing: exact
+        tol = 1e-4 * np.abs(ref).max()
+        np.testing.assert_allclose(X.cpu().numpy(), ref, atol=tol, err_msg=str(c))
+        xi = st.inverse(torch.from_numpy(ref.astype(np.complex64)).to(DEV))
+        refi = g2[c['name'] + '_xi']
+        assert tuple(xi.shape) == refi.shape, c
+        np.testing.assert_allclose(xi.cpu().numpy(), refi, atol=1e-4 * max(1., np.abs(refi).max()),
+                                   err_msg=str(c))
+
+
+def test_known_answer_generic_path(g1):
+    """size=4 (not a fast-path size) through the generic kernel: cb/transform.py:219-232."""
+    from padertorch_amd.ops import STFT
+    c = g1['cb_stft']
+    st = STFT(c['kwargs']['size'], c['kwargs']['shift'], window=c['kwargs']['window'],
+              fading=c['kwargs']['fading'])
+    X = st(torch.tensor(c['input'], dtype=torch.float32, device=DEV)).cpu().numpy()
+    np.testing.assert_allclose(X.real, c['real'], atol=1e-5)
+    np.testing.assert_allclose(X.imag, c['imag'], atol=1e-5)
+
+
+@pytest.mark.parametrize('size,shift,wl', [(100, 40, None), (150, 64, 90), (4096, 1024, None)])
+def test_generic_sizes_vs_oracle(size, shift, wl):
+    from padertorch_amd.ops import STFT
+    rng = np.random.RandomState(size)
+    x = rng.standard_normal((3, 5 * size + 17)).astype(np.float32)
+    st = STFT(size, shift, window='hann', window_length=wl)
+    X = st(torch.from_numpy(x).to(DEV))
+    ref = stft_np.stft(x, size, shift, window='hann', window_length=wl)
+    assert tuple(X.shape) == ref.shape
+    np.testing.assert_allclose(X.cpu().numpy(), ref, atol=2e-4 * np.abs(ref).max())
+    xi = st.inverse(X)
+    np.testing.assert_allclose(xi.cpu().numpy()[..., :x.shape[-1]], x, atol=2e-4)
+
+
+def test_representations(g2):
+    from padertorch_amd.ops import STFT
+    x = torch.from_numpy(g2['x_s512_h128'].astype(np.float32)).to(DEV)
+    for rep in ['concat', 'stacked']:
+        st = STFT(512, 128, complex_representation=rep)
+        X = st(x)
+        ref = g2[f'rep_{rep}_X']
+        assert tuple(X.shape) == ref.shape
+        np.testing.assert_allclose(X.cpu().numpy(), ref, atol=2e-4)
+        xi = st.inverse(X)
+        np.testing.assert_allclose(xi.cpu().numpy(), g2[f'rep_{rep}_xi'], atol=1e-4)
+
+
+def test_doctest_shapes_and_frame_counts(g1):
+    from padertorch_amd.ops import STFT
+    for d in g1['doctest_shapes']:
+        st = STFT(d['size'], d['shift'], window_length=d['window_length'], complex_representation=d['rep'])
+        if 'inp' in d:
+            assert list(st(torch.rand(d['inp'], device=DEV)).shape) == d['out']
+        else:
+            assert list(st.inverse(torch.rand(d['inverse_inp'], device=DEV)).shape) == d['inverse_out']
+    for fc in g1['frame_counts']:
+        st = STFT(fc['size'], fc['shift'], window_length=fc['window_length'], fading=fc['fading'],
+                  complex_representation='concat')
+        for n, fr in zip(fc['samples'], fc['frames']):
+            assert st(torch.rand(n, device=DEV)).shape == (fr, fc['size'] + 2)
+
+
+@pytest.mark.parametrize('B,N', [(4, 32000), (64, 64000)])
+def test_full_size_roundtrip_and_linearity(B, N):
+    """BASELINE sizes through size-independent properties: stft->istft identity, linearity, and a
+    strided sample of bins against the fp64 oracle."""
+    from padertorch_amd.ops import STFT
+    g = torch.Generator(device='cpu').manual_seed(0)
+    x = (0.1 * torch.randn(B, N, generator=g)).to(DEV)
+    z = (0.1 * torch.randn(B, N, generator=g)).to(DEV)
+    st = STFT(512, 128)
+    X = st(x)
+    T = (N + 384 + 127) // 128
+    assert X.shape == (B, T, 257)
+    np.testing.assert_allclose(st.inverse(X)[..., :N].cpu().numpy(), x.cpu().numpy(), atol=2e-6)
+    lin = st(2 * x - 3 * z) - (2 * X - 3 * st(z))
+    assert lin.abs().max().item() < 2e-4
+    rows = [0, B // 2, B - 1]
+    ref = stft_np.stft(x[rows].cpu().numpy(), 512, 128)
+    np.testing.assert_allclose(X[rows].cpu().numpy(), ref, atol=1e-4 * np.abs(ref).max())
+
+
+def test_ragged_rows_and_edge_lengths():
+    """Empty-ish, shorter-than-window and ragged rows (zero padded rows + num_samples)."""
+    from padertorch_amd.ops import STFT
+    st = STFT(512, 128)
+    rng = np.random.RandomState(1)
+    lens = [1500, 1000, 513, 512, 511, 130, 1]
+    x = np.zeros((len(lens), max(lens)), np.float32)
+    for b, n in enumerate(lens):
+        x[b, :n] = rng.standard_normal(n)
+    ns = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    X = st(torch.from_numpy(x).to(DEV), num_samples=ns).cpu().numpy()
+    for b, n in enumerate(lens):
+        ref = stft_np.stft(x[b, :n], 512, 128)
+        np.testing.assert_allclose(X[b, :ref.shape[0]], ref, atol=1e-4 * np.abs(ref).max())
+        assert np.all(X[b, ref.shape[0]:] == 0)
+    for n in [1, 127, 128, 129, 511, 512, 513]:
+        xs = rng.standard_normal(n).astype(np.float32)
+        ref = stft_np.stft(xs, 512, 128)
+        got = st(torch.from_numpy(xs).to(DEV)).cpu().numpy()
+        assert got.shape == ref.shape
+        np.testing.assert_allclose(got, ref, atol=1e-4 * max(np.abs(ref).max(), 1e-3))
+
+
+def test_autograd_adjoints():
+    """backward(stft) and backward(istft) against autograd through the dense fp64 oracle maths."""
+    from padertorch_amd.ops import STFT
+    from oracle.torch_ref import ConvSTFT
+    for kw in [dict(size=512, shift=128), dict(size=256, shift=10, window_length=20, window='hann'),
+               dict(size=64, shift=24, window_length=50, window='hann', fading='half')]:
+        st = STFT(**kw)
+        ref = ConvSTFT(kw['size'], kw['shift'], window=kw.get('window', 'blackman'),
+                       window_length=kw.get('window_length'), fading=kw.get('fading', 'full'))
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 1300, generator=g)
+        xd = x.to(DEV).requires_grad_(True)
+        X = st(xd)
+        gw = torch.randn(X.shape, dtype=torch.complex64, generator=g)
+        (X * gw.to(DEV).conj()).real.sum().backward()
+        xr = x.double().requires_grad_(True)
+        Xr = ref(xr)
+        (Xr * gw.to(torch.complex128).conj()).real.sum().backward()
+        np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(),
+                                   atol=2e-4 * xr.grad.abs().max().item(), err_msg=str(kw))
+        # inverse: compare with autograd through irfft + overlap-add
+        S = torch.randn(2, 9, kw['size'] // 2 + 1, dtype=torch.complex64, generator=g)
+        Sd = S.to(DEV).requires_grad_(True)
+        y = st.inverse(Sd)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy.to(DEV)).sum().backward()
+        L = kw.get('window_length') or kw['size']
+        ws = torch.from_numpy(stft_np.biorthogonal_window(
+            stft_np.get_window(kw.get('window', 'blackman'), False, L), kw['shift']))
+        Sr = S.to(torch.complex128).requires_grad_(True)
+        fr = torch.fft.irfft(Sr, n=kw['size'])[..., :L] * ws
+        n = (9 - 1) * kw['shift'] + L
+        out = torch.zeros(2, n, dtype=torch.float64)
+        for t in range(9):
+            out[:, t * kw['shift']:t * kw['shift'] + L] = out[:, t * kw['shift']:t * kw['shift'] + L] + fr[:, t]
+        left, right = stft_np.fading_pad_width(L, kw['shift'], kw.get('fading', 'full'))
+        out = out[:, left:n - right]
+        np.testing.assert_allclose(y.detach().cpu().numpy(), out.detach().numpy(), atol=1e-5)
+        (out * gy.double()).sum().backward()
+        # torch's irfft backward treats DC/Nyquist imaginary parts like ours: zero gradient
+        np.testing.assert_allclose(Sd.grad.cpu().numpy(), Sr.grad.numpy(),
+                                   atol=2e-4 * Sr.grad.abs().max().item(), err_msg=str(kw))
+
+
+def test_pit_features_vs_reference(g3):
+    from padertorch_amd.ops import pit_features
+    s = torch.from_numpy(g3['s']).to(DEV)
+    y = torch.from_numpy(g3['y']).to(DEV)
+    f = pit_features([y], [s])
+    assert f['num_frames'] == [int(g3['num_frames'])]
+    np.testing.assert_allclose(f['Y_abs'][0].cpu().numpy(), g3['Y_abs'], atol=2e-5)
+    np.testing.assert_allclose(f['X_abs'][0].cpu().numpy(), g3['X_abs'], atol=2e-5)
+    # cos(phase difference) is ill-conditioned where |Y| or |X| is ~0: weight the error by magnitude
+    w = np.minimum(g3['Y_abs'][:, None, :], g3['X_abs'])
+    err = np.abs(f['cos_phase_difference'][0].cpu().numpy() - g3['cos_phase_difference']) * w
+    assert err.max() < 2e-5, err.max()
+
+
+def test_pit_features_ragged_batch_vs_oracle():
+    from padertorch_amd.ops import pit_features
+    rng = np.random.RandomState(7)
+    lens = [4000, 3500, 3499, 900]
+    exs = [features_np.synthetic_mixture(rng, n) for n in lens]
+    ref = [features_np.pre_batch_transform(s, y) for s, y in exs]
+    f = pit_features([torch.from_numpy(y).to(DEV) for _, y in exs],
+                     [torch.from_numpy(s).to(DEV) for s, _ in exs])
+    assert f['num_frames'] == [r['num_frames'] for r in ref]
+    for b, r in enumerate(ref):
+        assert f['Y_abs'][b].shape == r['Y_abs'].shape and f['X_abs'][b].shape == r['X_abs'].shape
+        np.testing.assert_allclose(f['Y_abs'][b].cpu().numpy(), r['Y_abs'], atol=2e-5)
+        np.testing.assert_allclose(f['X_abs'][b].cpu().numpy(), r['X_abs'], atol=2e-5)
+        w = np.minimum(r['Y_abs'][:, None, :], r['X_abs'])
+        err = np.abs(f['cos_phase_difference'][b].cpu().numpy() - r['cos_phase_difference']) * w
+        assert err.max() < 2e-5
+    # padded frames are exactly zero
+    assert f['Y_abs'].padded[3, f['num_frames'][3]:].abs().max().item() == 0
