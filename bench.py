@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the PIT mask-estimation training step on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torchrun)
+
+Metric (BASELINE.json): training frames/s = mixture STFT frames through ONE full optimizer step
+(on-device STFT feature front-end from HBM-resident waveforms -> BLSTM mask estimator forward ->
+PIT review -> backward -> [RCCL all-reduce(sum)] -> global-norm clip -> Adam), whole job.
+Workload = BASELINE.json configs[1]: 2-speaker synthetic 8 kHz mixtures, batch 32 per GPU,
+4 s each (T = 253 frames/example, 8096 frames/step/GPU), PIT model defaults (3xBLSTM-600, K=2,
+23 480 914 parameters), STFT 512/128.  One micro-step per rank per optimizer step (weak scaling).
+
+The JSON line also carries
+  roofline     : the HBM-bound STFT feature kernel (pit_features_kernel), algorithmic bytes
+                 (6676 B per mixture frame at K=2) / HIP-event time of its
+                 launches inside the timed steps, against the 8 TB/s HBM3E peak;
+  cpu_baseline : the oracle's torch-CPU port of the reference step (oracle/torch_ref.py) timed on
+                 this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FS = 8000
+SECONDS = 4
+BATCH = 32
+K = 2
+SIZE, SHIFT = 512, 128
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FEATURE_BYTES_PER_FRAME = 3 * SHIFT * 4 + (1 + 2 * K) * (SIZE // 2 + 1) * 4   # 6676 B at K=2
+LOSS_WEIGHTS = dict(pit_ips_loss=1., pit_mse_loss=0.)      # pit/train.py:68-71
+
+
+def synthetic_batch(seed, batch, n, device):
+    """K sources 0.1*N(0,1) fp32, mixture = sum (seeded, on device)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    s = 0.1 * torch.randn(batch, K, n, generator=g)
+    return dict(y=s.sum(1).to(device), s=s.to(device), num_samples=[n] * batch)
+
+
+def cpu_baseline(max_seconds=25.):
+    """Reference algorithm (oracle/torch_ref.py: conv1d STFT, nn.LSTM on PackedSequence, python-loop
+    pit_loss, clip + Adam) on the host cores, bounded sample: batch 4 x 4 s (1012 frames / step)."""
+    from oracle import torch_ref
+    torch.manual_seed(0)
+    model = torch_ref.PITModelRef()
+    opt = torch.optim.Adam(model.parameters())
+    stft = torch_ref.ConvSTFT(SIZE, SHIFT)
+    b = 4
+    g = torch.Generator().manual_seed(1)
+    s = [0.1 * torch.randn(K, FS * SECONDS, generator=g) for _ in range(b)]
+    y = [x.sum(0) for x in s]
+
+    def step():
+        with torch.no_grad():
+            feats = torch_ref.features_from_waveforms(stft, s, y)
+        torch_ref.train_step(model, opt, [feats], LOSS_WEIGHTS, 1.)
+        return sum(feats['num_frames'])
+
+    frames = step()          # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_all) < max_seconds:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return dict(value=frames / med, unit='frames/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'batch {b} x {SECONDS} s @ {FS} Hz ({frames} frames/step), PIT defaults fp32, '
+                       f'{len(times)} timed steps after 1 warm-up, median {med:.3f} s/step, '
+                       f'os.cpu_count()={os.cpu_count()}')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 through torchrun)'
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=device)
+
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import \
+        PermutationInvariantTrainingModel
+
+    torch.manual_seed(0)
+    model = PermutationInvariantTrainingModel()          # defaults: F=257, 3 x BLSTM-600, K=2
+    trainer = pt.Trainer(model, f'/tmp/ptmi_bench_{rank}', pt.optimizer.Adam(gradient_clipping=1.),
+                         loss_weights=LOSS_WEIGHTS, virtual_minibatch_size=world)
+    trainer.to(device)
+    trainer._flat = trainer.optimizer.use_flat_grads()
+    if world > 1:
+        trainer._broadcast_parameters()
+    model.train()
+
+    n = FS * SECONDS
+    data = synthetic_batch(1000 + rank, BATCH, n, device)
+    frames_per_step = None
+    ev = []
+
+    def step(timed):
+        nonlocal frames_per_step
+        # the STFT feature front-end is part of the step; its launch is bracketed by HIP events on
+        # the stream it runs on (torch's current stream) for the roofline figure
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        feats = pt.ops.pit_features(data['y'], data['s'], data['num_samples'])
+        e1.record()
+        if timed:
+            ev.append((e0, e1))
+        frames_per_step = sum(feats['num_frames'])
+        loss, _, _, _ = trainer.train_step(model, feats, device)
+        loss.backward()
+        trainer.optimizer_step()
+
+    for _ in range(args.warmup):
+        step(False)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        alg_bytes = FEATURE_BYTES_PER_FRAME * frames_per_step
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        out = {
+            'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)',
+            'value': frames_per_step * world * args.steps / elapsed,
+            'unit': 'frames/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'BASELINE configs[1]: PIT mask estimator (3xBLSTM-600, K=2, 23.5M params), '
+                            f'{BATCH} x {SECONDS} s 2-spk {FS} Hz mixtures per GPU '
+                            f'({frames_per_step} frames/step/GPU), STFT {SIZE}/{SHIFT} on device, '
+                            f'full optimizer step (Adam, clip 1)',
+                'global_batch': BATCH * world,
+                'frames_per_step': frames_per_step * world,
+                'parallelism': f'dp{world}',
+                'blstm': 'torch.nn.LSTM (MIOpen)',
+            },
+            'roofline': {
+                'kernel': 'pit_features_kernel<Plan<16,16>> (fused STFT front-end)',
+                'bound': 'hbm',
+                'achieved': achieved,
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK_GBS,
+                'traffic': None,
+                'algorithmic_bytes_per_launch': alg_bytes,
+                'avg_launch_ms': kern_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

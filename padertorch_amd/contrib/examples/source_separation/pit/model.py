@@ -1,0 +1,138 @@
+"""BLSTM mask estimator trained with permutation-invariant training, MI355X-native.
+
+Drop-in for ``padertorch/contrib/examples/source_separation/pit/model.py:11-151``
+(``PermutationInvariantTrainingModel``): identical constructor kwargs, identical ``state_dict``
+keys/shapes (``blstm.*``, ``linear1.*``, ``linear2.*``; gate order i,f,g,o, two bias vectors), the
+same ``forward(batch) -> list[(T_b, K, F)]`` / ``review(batch, out) -> dict`` contract.
+
+What changed underneath:
+  * ``review`` (reference ``:112-140``: python loop over examples x 2 losses x K! permutations)
+    is ONE fused HIP pass over the whole ragged batch (``pit_mse_ips_losses``);
+  * the model output stays in the time-major padded buffer the packed BLSTM produced; the list
+    handed back is a :class:`PaddedList` of views, so nothing is re-padded or copied;
+  * the summary images (``:142-147``) are only rendered when ``self.create_snapshot`` is set
+    (allowed by ``base.py:300-306``), which removes a device->host sync from every step;
+  * ``batch`` may carry raw waveforms (``y``, ``s``, the keys of ``pit/data.py:66-68``) instead of
+    precomputed features; they are turned into ``Y_abs`` / ``X_abs`` / ``cos_phase_difference`` on
+    the device by the fused STFT front-end (``ops.pit_features``).
+"""
+import torch
+from torch.nn.utils.rnn import PackedSequence
+
+from padertorch_amd import base
+from padertorch_amd import ops
+from padertorch_amd.ops.mappings import ACTIVATION_FN_MAP
+from padertorch_amd.ops.sequence.pack_module import PaddedList, as_padded
+from padertorch_amd.summary import mask_to_image, stft_to_image
+
+
+class PermutationInvariantTrainingModel(base.Model):
+    """Implements a variant of Permutation Invariant Training [1].
+
+    [1] Kolbaek 2017, https://arxiv.org/pdf/1703.06284.pdf
+    """
+
+    def __init__(
+            self,
+            F=257,
+            recurrent_layers=3,
+            units=600,
+            K=2,
+            dropout_input=0.,
+            dropout_hidden=0.,
+            dropout_linear=0.,
+            output_activation='relu'
+    ):
+        """
+        Args:
+            F: Number of frequency bins, fft_size / 2 + 1
+            recurrent_layers:
+            units: results in `units` forward and `units` backward units
+            K: Number of output streams/ speakers
+            dropout_input: Dropout forget ratio before first recurrent layer
+            dropout_hidden: Vertical forget ratio dropout between each recurrent layer
+            dropout_linear: Dropout forget ratio before first linear layer
+            output_activation: Different activations. Default is 'ReLU'.
+        """
+        super().__init__()
+        self.K = K
+        self.F = F
+
+        assert dropout_input <= 0.5, dropout_input
+        self.dropout_input = torch.nn.Dropout(dropout_input)
+        assert dropout_hidden <= 0.5, dropout_hidden
+        self.blstm = torch.nn.LSTM(F, units, recurrent_layers, bidirectional=True,
+                                   dropout=dropout_hidden)
+        assert dropout_linear <= 0.5, dropout_linear
+        self.dropout_linear = torch.nn.Dropout(dropout_linear)
+        self.relu = torch.nn.ReLU()
+        self.linear1 = torch.nn.Linear(2 * units, 2 * units)
+        self.linear2 = torch.nn.Linear(2 * units, F * K)
+        self.output_activation = ACTIVATION_FN_MAP[output_activation]()
+
+    def prepare_batch(self, batch):
+        """Waveforms -> features on the device when the batch does not carry them yet."""
+        if 'Y_abs' in batch:
+            return batch
+        feats = ops.pit_features(batch['y'], batch.get('s'), batch.get('num_samples'))
+        out = dict(batch)
+        out.update(feats)
+        return out
+
+    def example_to_device(self, example, device=None, memo=None):
+        return self.prepare_batch(super().example_to_device(example, device, memo))
+
+    def forward(self, batch):
+        """
+        Args:
+            batch: Dictionary with lists of tensors (``Y_abs[b]: (T_b, F)``, descending ``T_b``)
+
+        Returns: List of mask tensors, each list element has shape (T, K, F)
+        """
+        batch = self.prepare_batch(batch)
+        h = ops.pack_sequence(batch['Y_abs'])
+
+        _, F = h.data.size()
+        assert F == self.F, f'self.F = {self.F} != F = {F}'
+
+        h_data = self.dropout_input(h.data)
+        h_data = ops.sequence.log1p(h_data)
+        h = PackedSequence(h_data, h.batch_sizes)
+
+        # Returns tensor with shape (t, b, num_directions * hidden_size)
+        h, _ = self.blstm(h)
+
+        h_data = self.dropout_linear(h.data)
+        h_data = self.linear1(h_data)
+        h_data = self.relu(h_data)
+        h_data = self.linear2(h_data)
+        h_data = self.output_activation(h_data)
+
+        mask = PackedSequence(h_data.view(-1, self.K, self.F), h.batch_sizes)  # 'tb (k f) -> tb k f'
+        return ops.unpack_sequence(mask)
+
+    def review(self, batch, model_out):
+        batch = self.prepare_batch(batch)
+        if isinstance(model_out, PaddedList):
+            mask, mask_bf = model_out.padded, model_out.batch_first
+            lengths_dev = model_out.lengths_dev
+        else:
+            mask, _, lengths_dev = as_padded(model_out, batch_first=True)
+            mask_bf = True
+        Y, _, _ = as_padded(batch['Y_abs'])
+        X, _, _ = as_padded(batch['X_abs'])
+        C, _, _ = as_padded(batch['cos_phase_difference'])
+        # MSE loss and ideal-phase-sensitive loss of every example, batch means (reference :117-140)
+        loss, _, _ = ops.losses.pit_mse_ips_losses(
+            mask, Y, X, C, lengths_dev.to(mask.device), mask_batch_first=mask_bf)
+        review = dict(losses={'pit_mse_loss': loss[0], 'pit_ips_loss': loss[1]})
+
+        if self.create_snapshot:
+            b = 0   # only print image of first example in a batch
+            images = dict()
+            images['observation'] = stft_to_image(batch['Y_abs'][b])
+            for i in range(model_out[b].shape[1]):
+                images[f'mask_{i}'] = mask_to_image(model_out[b][:, i, :])
+                images[f'estimation_{i}'] = stft_to_image(batch['X_abs'][b][:, 0, :])
+            review['images'] = images
+        return review

@@ -1,0 +1,64 @@
+"""Deep-clustering embedding model, drop-in for ``padertorch/contrib/tcl/dc.py:8-84``
+(identical constructor kwargs and ``state_dict`` layout ``blstm.*`` + ``linear.*``)."""
+import torch
+from torch.nn.utils.rnn import PackedSequence
+
+from padertorch_amd import base
+from padertorch_amd import ops
+
+
+class DeepClusteringModel(base.Model):
+    def __init__(
+            self,
+            F=257,
+            recurrent_layers=2,
+            units=600,
+            E=20,
+            input_feature_transform='identity'
+    ):
+        """
+        Args:
+            F: Number of frequency bins, fft_size / 2 + 1
+            recurrent_layers:
+            units: results in `units` forward and `units` backward units
+            E: Dimensionality of the embedding
+        """
+        super().__init__()
+        self.E = E
+        self.F = F
+        self.input_feature_transform = input_feature_transform
+        self.blstm = torch.nn.LSTM(F, units, recurrent_layers, bidirectional=True)
+        self.linear = torch.nn.Linear(2 * units, F * E)
+
+    def forward(self, batch):
+        """batch: dictionary with lists of tensors -> list of embeddings ``(T_b, E, F)``."""
+        h = ops.pack_sequence(batch['Y_abs'])
+
+        if self.input_feature_transform == 'identity':
+            pass
+        elif self.input_feature_transform == 'log1p':
+            h = ops.sequence.log1p(h)
+        elif self.input_feature_transform == 'log':
+            h = PackedSequence(h.data + 1e-10, h.batch_sizes)
+            h = ops.sequence.log(h)
+        else:
+            raise NotImplementedError(self.input_feature_transform)
+
+        _, F = h.data.size()
+        assert F == self.F, f'self.F = {self.F} != F = {F}'
+
+        h, _ = self.blstm(h)
+        h_data = self.linear(h.data).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
+        # Hershey 2016 page 2 top right paragraph: Unit norm
+        h_data = torch.nn.functional.normalize(h_data, dim=-2)
+        return ops.unpack_sequence(PackedSequence(h_data, h.batch_sizes))
+
+    def review(self, batch, model_out):
+        dc_loss = list()
+        for embedding, target_mask in zip(model_out, batch['target_mask']):
+            E, K = embedding.shape[1], target_mask.shape[1]
+            dc_loss.append(ops.losses.deep_clustering_loss(
+                embedding.permute(0, 2, 1).reshape(-1, E),        # 't e f -> (t f) e'
+                target_mask.permute(0, 2, 1).reshape(-1, K),      # 't k f -> (t f) k'
+            ))
+        return {'losses': {'dc_loss': torch.mean(torch.stack(dc_loss))}}

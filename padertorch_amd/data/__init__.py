@@ -1,0 +1,3 @@
+from . import batch, utils  # noqa: F401
+from .batch import example_to_device, Sorter  # noqa: F401
+from .utils import collate_fn  # noqa: F401

@@ -1,0 +1,477 @@
+"""Trainer with the loop semantics of ``padertorch/train/trainer.py`` and an RCCL data-parallel path.
+
+Mirrors (reference file:line)
+  * constructor / attributes                      trainer.py:42-148
+  * ``train`` main loop, virtual minibatch        trainer.py:205-465  (gradients are ACCUMULATED, :87)
+  * ``step`` / ``train_step`` / ``validation_step`` trainer.py:534-565
+  * ``_review_to_loss_and_summary``               trainer.py:567-638  (weighted loss sum, finiteness)
+  * ``optimizer_step`` / ``clip_grad``            trainer.py:512-532, 740-780
+  * ``validate``                                  trainer.py:467-510
+  * ``state_dict`` / checkpoints                  trainer.py:789-886
+  * ``test_run`` invariants                       train/runtime_tests.py:74-410 (section 3.1 of SURVEY.md)
+
+Data parallelism.  The reference's multi-GPU branch (trainer.py:396-442) is single-process:
+``replicate`` broadcasts all 93.9 MB of parameters to every GPU and ``ReduceAddCoalesced`` reduces all
+gradients into GPU 0 on EVERY micro-step, driven by GIL-bound python threads.  Here one process
+owns one MI355X (``torch.distributed``, backend "nccl" = RCCL over xGMI): of every group of W
+consecutive examples rank j takes the j-th (as trainer.py:357-359,413-419 hands example j to
+device j), gradients accumulate locally in one flat fp32 bucket over ``virtual_minibatch_size // W``
+micro-steps and are exchanged by ONE ``all_reduce(SUM)`` per optimizer step - a sum, not a mean,
+like the reference's ``gather(...).sum()`` (:426-428).  Every rank then applies the identical
+clip + Adam, so replicas stay bit-identical without any parameter broadcast after step 0.  A rank
+without an example in the last partial group contributes zeros (:408).
+"""
+import itertools
+import json
+import os
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .optimizer import Optimizer
+from .trigger import EndTrigger, IntervalTrigger
+
+__all__ = ['Trainer', 'StopTraining']
+
+ALLOWED_REVIEW_KEYS = {'loss', 'losses', 'scalars', 'histograms', 'audios', 'images', 'texts',
+                       'figures', 'buffers', 'snapshots', 'timings'}
+
+
+class StopTraining(Exception):
+    pass
+
+
+class _Summary:
+    """In-memory stand-in for the SummaryHook: accumulates scalars, emits means (hooks.py:153-405)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.data = dict(scalars={}, histograms={}, audios={}, images={}, texts={}, figures={},
+                         buffers={}, snapshots={})
+
+    def update(self, review):
+        for key, value in review.get('scalars', {}).items():
+            self.data['scalars'].setdefault(key, []).append(
+                float(value.item() if torch.is_tensor(value) else value))
+        for kind in ('images', 'audios', 'texts', 'figures', 'histograms'):
+            self.data[kind].update(review.get(kind, {}))
+
+
+class Trainer:
+    def __init__(
+            self,
+            model,
+            storage_dir,
+            optimizer,
+            loss_weights=None,
+            summary_trigger=(1, 'epoch'),
+            checkpoint_trigger=(1, 'epoch'),
+            stop_trigger=(1, 'epoch'),
+            virtual_minibatch_size=1,
+    ):
+        if not isinstance(model, torch.nn.Module):
+            raise TypeError('Expect that the model is a subclass from padertorch.Module.\n'
+                            f'Got: type: {type(model)}\n{model}')
+        self.model = model
+        assert isinstance(optimizer, Optimizer), optimizer
+        optimizer.set_parameters(model.parameters())
+        self.optimizer = optimizer
+        self.device = None
+        self.storage_dir = Path(storage_dir).expanduser().resolve()
+        self.iteration = -1
+        self.epoch = -1
+        self.loss_weights = loss_weights
+        self.virtual_minibatch_size = virtual_minibatch_size
+        self.summary_trigger = IntervalTrigger.new(summary_trigger)
+        self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)
+        self.stop_trigger = EndTrigger.new(stop_trigger)
+        self.validation_iterator = None
+        self.validation_metric = 'loss'
+        self.train_summary = _Summary()
+        self.summaries = []          # list of (iteration, prefix, dict of mean scalars)
+        self.timer = {}
+        self._flat = None
+
+    # ------------------------------------------------------------------ distributed helpers
+    @property
+    def world_size(self):
+        return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+    @property
+    def rank(self):
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+    def _time(self, key, t0):
+        self.timer[key] = self.timer.get(key, 0.) + time.perf_counter() - t0
+
+    # ------------------------------------------------------------------ public API
+    def register_validation_hook(self, validation_iterator, metric='loss', maximize=False):
+        """Validate at every checkpoint trigger and track the best checkpoint (trainer.py:699-738)."""
+        self.validation_iterator = validation_iterator
+        self.validation_metric = metric
+        self.validation_maximize = maximize
+        self._best = None
+
+    def to(self, device):
+        self.model.to(device)
+        self.optimizer.to(device)
+        self.device = device
+        return self
+
+    def train(self, train_dataset, *, resume=False, device=None):
+        """Same contract as ``pt.Trainer.train`` (trainer.py:205-465); ``device`` is ONE device per
+        process (``int`` / ``str`` / ``torch.device``); multi-GPU = launch one process per GPU."""
+        if isinstance(device, (list, tuple)):
+            assert len(device) == 1, (
+                'padertorch_amd runs one process per GPU (torchrun); a device list is the '
+                "reference's single-process mode", device)
+            device = device[0]
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else 'cpu'
+        if resume:
+            assert self.checkpoint_dir.exists(), self.checkpoint_dir
+            self.load_checkpoint()
+        else:
+            assert not self.checkpoint_dir.exists() or not any(self.checkpoint_dir.iterdir()), \
+                f'A checkpoint directory already exists ({self.checkpoint_dir}); use resume=True'
+            self.iteration, self.epoch = 0, 0
+        self.model.train()
+        self.to(device)
+        W = self.world_size
+        assert self.virtual_minibatch_size % W == 0, (self.virtual_minibatch_size, W)
+        self._flat = self.optimizer.use_flat_grads()
+        if W > 1:
+            self._broadcast_parameters()
+        self.optimizer.zero_grad()
+
+        try:
+            train_iterable = None
+            while True:
+                new_epoch = False
+                if train_iterable is None:
+                    new_epoch = True
+                    self._pre_step()            # hooks run between the epochs (trainer.py:348-353)
+                    train_iterable = iter(train_dataset)
+                optimize = True
+                for minibatch_index in range(self.virtual_minibatch_size // W):
+                    t0 = time.perf_counter()
+                    group = list(itertools.islice(train_iterable, W))
+                    self._time('time_per_data_loading', t0)
+                    if len(group) == 0:
+                        train_iterable = None
+                        self.epoch += 1
+                        if minibatch_index == 0:
+                            optimize = False
+                        break
+                    if new_epoch:
+                        new_epoch = False
+                    elif minibatch_index == 0:
+                        self._pre_step()
+                    if self.rank < len(group):
+                        loss, example, model_output, review = self.train_step(
+                            self.model, group[self.rank], device)
+                        self.train_summary.update(review)
+                        del example, model_output, review
+                        t0 = time.perf_counter()
+                        loss.backward(retain_graph=False)
+                        self._time('time_per_backward', t0)
+                        del loss
+                    # else: idle rank of a partial last group: contributes zero gradient (:408)
+                if optimize:
+                    t0 = time.perf_counter()
+                    summary = self.optimizer_step()
+                    self.train_summary.update(summary)
+                    self._time('time_per_optimize', t0)
+                    self.iteration += 1
+        except StopTraining:
+            pass
+        finally:
+            self._close()
+
+    # ------------------------------------------------------------------ hooks (fixed set)
+    def _pre_step(self):
+        """Summary(50) > Validation(20) > Checkpoint(11) > Stop(10) priority order (hooks.py:43-62)."""
+        it, ep = self.iteration, self.epoch
+        if self.summary_trigger(it, ep) and it > 0:
+            self._dump_summary('training')
+        if self.checkpoint_trigger(it, ep):
+            if self.validation_iterator is not None:
+                self._run_validation()
+            if self.rank == 0:
+                self.save_checkpoint()
+        if self.stop_trigger(it, ep):
+            raise StopTraining
+
+    def _close(self):
+        self._dump_summary('training')
+        if self.rank == 0 and self.iteration >= 0:
+            if self.validation_iterator is not None and not self.default_checkpoint_path().exists():
+                self._run_validation()
+            if not self.default_checkpoint_path().exists():
+                self.save_checkpoint()
+
+    def _dump_summary(self, prefix, summary=None):
+        summary = summary or self.train_summary
+        data = summary.data
+        if not data['scalars']:
+            summary.reset()
+            return None
+        data = self.model.modify_summary(data) if hasattr(self.model, 'modify_summary') else data
+        scalars = {k: float(np.mean(v)) for k, v in data['scalars'].items()}
+        self.summaries.append((self.iteration, prefix, scalars))
+        if self.rank == 0:
+            self.storage_dir.mkdir(parents=True, exist_ok=True)
+            with open(self.storage_dir / 'summary.jsonl', 'a') as f:
+                f.write(json.dumps(dict(iteration=self.iteration, epoch=self.epoch, prefix=prefix,
+                                        scalars=scalars)) + '\n')
+        summary.reset()
+        return scalars
+
+    def _run_validation(self):
+        val = _Summary()
+        for _, _, review in self.validate(self.validation_iterator):
+            val.update(review)
+        scalars = self._dump_summary('validation', val) or {}
+        metric = scalars.get(self.validation_metric)
+        if metric is not None and self.rank == 0:
+            better = self._best is None or (metric > self._best[0] if self.validation_maximize
+                                            else metric < self._best[0])
+            if better:
+                self._best = (metric, self.iteration)
+        return scalars
+
+    # ------------------------------------------------------------------ step path
+    def validate(self, validation_iterator):
+        """trainer.py:467-510: eval mode, no_grad, yields (example, model_out, review)."""
+        train_end_time = self.model.training
+        self.model.eval()
+        try:
+            with torch.no_grad():
+                for example in validation_iterator:
+                    yield self.validation_step(self.model, example, self.device)
+        finally:
+            self.model.train(train_end_time)
+
+    def optimizer_step(self):
+        """clip (global norm) -> lr summary -> optimizer.step -> zero_grad (trainer.py:512-532).
+        With W > 1 the flat gradient bucket is summed over all ranks first (one collective)."""
+        if self.world_size > 1:
+            t0 = time.perf_counter()
+            dist.all_reduce(self._flat.flat, op=dist.ReduceOp.SUM)
+            self._time('time_per_all_reduce', t0)
+        summary = self.clip_grad({})
+        for i, param_group in enumerate(self.optimizer.optimizer.param_groups):
+            summary['scalars'][f'lr/param_group_{i}'] = param_group['lr']
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return summary
+
+    def clip_grad(self, summary: dict):
+        """trainer.py:740-780 incl. the non-finite check (one host sync per optimizer step)."""
+        summary.setdefault('scalars', {})
+        summary.setdefault('histograms', {})
+        grad_norm = float(self.optimizer.clip_grad())
+        if not np.isfinite(grad_norm):
+            path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': summary})
+            raise RuntimeError(f'The grad_norm ({grad_norm}) is not finite.\n'
+                               f'See error states (model, example, model_out and review) in {path}.')
+        summary['scalars']['grad_norm'] = grad_norm
+        summary['histograms']['grad_norm_'] = torch.Tensor([grad_norm])
+        return summary
+
+    def train_step(self, model, example, device):
+        return self.step(model, example, device, 'train')
+
+    def validation_step(self, model, example, device):
+        # [1:] -> ignore the loss. Is already in scalars.
+        return self.step(model, example, device, 'validate')[1:]
+
+    def step(self, model, example, device, mode='train'):
+        """to_device -> forward -> review -> loss (trainer.py:541-565); dumps an error state and
+        re-raises on any exception."""
+        try:
+            t0 = time.perf_counter()
+            example = model.example_to_device(example, device)
+            self._time('time_per_to_device', t0)
+            t0 = time.perf_counter()
+            model_out = model(example)
+            self._time('time_per_forward', t0)
+            t0 = time.perf_counter()
+            review = model.review(example, model_out)
+            loss, summary = self._review_to_loss_and_summary(review)
+            self._time('time_per_review', t0)
+            return loss, example, model_out, summary
+        except Exception:
+            data = {'state_dict': self.state_dict(), 'example': example}
+            if 'model_out' in locals():
+                data['model_out'] = model_out
+            if 'review' in locals():
+                data['review'] = review
+            path = self.log_error_state(data)
+            print(f'Wrote\n{path}\nfor debugging.')
+            raise
+
+    def _review_to_loss_and_summary(self, review):
+        """trainer.py:567-638.  ``loss = sum_k loss_weights[k] * losses[k]`` over non-zero weights;
+        every loss is logged.  All scalars of the step cross to the host in ONE transfer (the
+        reference does one ``.item()`` per loss, i.e. one device sync each)."""
+        assert set(review) <= ALLOWED_REVIEW_KEYS, set(review) - ALLOWED_REVIEW_KEYS
+        review.setdefault('scalars', {})
+        if 'losses' in review:
+            assert 'loss' not in review, review
+            losses = review['losses']
+            loss_weights = self.loss_weights
+            if len(losses) != 1:
+                if loss_weights is None:
+                    raise Exception('You can not have multiple losses without specifying '
+                                    f'loss_weights. losses: {losses}')
+                if set(loss_weights.keys()) != set(losses.keys()):
+                    raise Exception('You can not have multiple losses without specifying '
+                                    f'a loss_weight for each loss.\nlosses: {losses}\n'
+                                    f'loss_weights: {loss_weights}')
+            loss = 0.
+            for key, value in losses.items():
+                weight = loss_weights[key] if loss_weights is not None else 1.
+                if weight != 0:
+                    loss = loss + (weight * value)
+                review['scalars'][f'{key}_loss_weight'] = weight
+            keys = list(losses)
+            host = torch.stack([losses[k].detach().reshape(()) for k in keys]
+                               + [loss.detach().reshape(())]).tolist()
+            for k, v in zip(keys, host[:-1]):
+                review['scalars'][k] = v
+            loss_value = host[-1]
+            del review['losses']
+        else:
+            assert 'loss' in review, review
+            loss = review.pop('loss')
+            loss_value = loss.item()
+        review['scalars']['loss'] = loss_value
+        assert loss.dim() == 0, loss
+        if not np.isfinite(loss_value):
+            path = self.log_error_state({'state_dict': self.state_dict(), 'review': review})
+            raise RuntimeError(f'The loss ({loss_value}) is not finite.\n'
+                               f'See error states (model, example, model_out and review) in {path}.')
+        return loss, review
+
+    def log_error_state(self, data_dict, folder='log'):
+        """trainer.py:640-690: one file per object so a non-picklable one does not lose the rest."""
+        log_dir = self.storage_dir / folder
+        log_dir.mkdir(parents=True, exist_ok=True)
+        for k, v in data_dict.items():
+            path = log_dir / f'error_state_{k}.pth'
+            try:
+                torch.save(v, str(path))
+            except Exception as e:  # noqa
+                path.with_suffix('.txt').write_text(f'could not be saved: {e!r}')
+        return str(log_dir / 'error_state_*.pth')
+
+    # ------------------------------------------------------------------ data parallel
+    def _broadcast_parameters(self):
+        """Step-0 sync: every rank starts from rank 0's weights and buffers."""
+        with torch.no_grad():
+            for t in itertools.chain(self.model.parameters(), self.model.buffers()):
+                dist.broadcast(t, src=0)
+
+    # ------------------------------------------------------------------ checkpoints
+    @property
+    def checkpoint_dir(self):
+        return self.storage_dir / 'checkpoints'
+
+    def default_checkpoint_path(self) -> Path:
+        return self.checkpoint_dir / f'ckpt_{self.iteration}.pth'
+
+    def state_dict(self):
+        """trainer.py:789-810."""
+        return dict(model=self.model.state_dict(), iteration=self.iteration, epoch=self.epoch,
+                    optimizer=self.optimizer.state_dict() if self.optimizer.optimizer else None)
+
+    def load_state_dict(self, state_dict):
+        self.model.load_state_dict(state_dict['model'])
+        if state_dict.get('optimizer') is not None:
+            self.optimizer.load_state_dict(state_dict['optimizer'])
+        self.iteration, self.epoch = state_dict['iteration'], state_dict['epoch']
+
+    def save_checkpoint(self, checkpoint_path=None):
+        """``ckpt_{iteration}.pth`` + relative symlink ``ckpt_latest.pth`` (trainer.py:812-828)."""
+        path = Path(checkpoint_path or self.default_checkpoint_path())
+        path.parent.mkdir(parents=True, exist_ok=True)
+        torch.save(self.state_dict(), str(path))
+        latest = path.parent / 'ckpt_latest.pth'
+        if latest.is_symlink() or latest.exists():
+            latest.unlink()
+        latest.symlink_to(path.name)
+        best = getattr(self, '_best', None)
+        if best is not None and best[1] == self.iteration:
+            link = path.parent / f'ckpt_best_{self.validation_metric}.pth'
+            if link.is_symlink() or link.exists():
+                link.unlink()
+            link.symlink_to(path.name)
+        return path
+
+    def load_checkpoint(self, map_location='cpu'):
+        path = self.checkpoint_dir / 'ckpt_latest.pth'
+        assert path.exists(), path
+        self.load_state_dict(torch.load(str(path), map_location=map_location, weights_only=False))
+
+    # ------------------------------------------------------------------ runtime test
+    def test_run(self, train_iterator, validation_iterator, device=None, deterministic_atol=1e-5,
+                 deterministic_rtol=1e-5):
+        """Short double training with the invariants of ``runtime_tests.test_run`` (:74-410):
+        2 optimizer steps x 2 runs from the same state; validation outputs of both runs agree
+        (atol/rtol 1e-5), the first losses agree, training changes the loss and every parameter,
+        the review keys are allowed, and the trainer/model state is restored bit-exactly."""
+        import copy
+        import tempfile
+        vmb = self.virtual_minibatch_size
+        sub_train = list(itertools.islice(iter(train_iterator), 2 * vmb))
+        sub_val = list(itertools.islice(iter(validation_iterator), 2))
+        backup = copy.deepcopy(self.state_dict())
+        saved = (self.storage_dir, self.iteration, self.epoch, self.stop_trigger, self.checkpoint_trigger,
+                 self.summary_trigger, self.validation_iterator, self.summaries)
+        records = []
+        try:
+            for run in range(2):
+                with tempfile.TemporaryDirectory() as tmp:
+                    self.load_state_dict(copy.deepcopy(backup))
+                    self.optimizer.set_parameters(self.model.parameters())
+                    self.storage_dir = Path(tmp)
+                    self.stop_trigger = EndTrigger(2, 'iteration')
+                    self.checkpoint_trigger = IntervalTrigger(2, 'iteration')
+                    self.summary_trigger = IntervalTrigger(1, 'iteration')
+                    self.summaries = []
+                    self.register_validation_hook(sub_val)
+                    self.train(sub_train, device=device)
+                    files = sorted(p.name for p in (Path(tmp) / 'checkpoints').iterdir())
+                    assert files == ['ckpt_0.pth', 'ckpt_2.pth', 'ckpt_best_loss.pth', 'ckpt_latest.pth'], files
+                    val = [(out, rv) for _, out, rv in self.validate(sub_val)]
+                    records.append(dict(summaries=self.summaries, val=val,
+                                        params={k: v.detach().clone() for k, v in self.model.named_parameters()}))
+            a, b = records
+            for (oa, ra), (ob, rb) in zip(a['val'], b['val']):
+                for ta, tb_ in zip(oa, ob):
+                    torch.testing.assert_close(ta, tb_, atol=deterministic_atol, rtol=deterministic_rtol)
+                for k in ra['scalars']:
+                    np.testing.assert_allclose(ra['scalars'][k], rb['scalars'][k],
+                                               atol=deterministic_atol, rtol=deterministic_rtol)
+            first = [[s for s in r['summaries'] if s[1] == 'validation'][0][2]['loss'] for r in records]
+            last = [[s for s in r['summaries'] if s[1] == 'validation'][-1][2]['loss'] for r in records]
+            np.testing.assert_allclose(first[0], first[1], atol=1e-6)
+            assert first[0] != last[0], 'the loss did not change during training'
+            self.load_state_dict(copy.deepcopy(backup))
+            for k, v in self.model.named_parameters():
+                assert not torch.equal(v.detach().cpu(), a['params'][k].cpu()), \
+                    f'parameter {k} did not change (zero gradient?)'
+        finally:
+            self.load_state_dict(backup)
+            self.optimizer.set_parameters(self.model.parameters())
+            (self.storage_dir, self.iteration, self.epoch, self.stop_trigger, self.checkpoint_trigger,
+             self.summary_trigger, self.validation_iterator, self.summaries) = saved
+        for k, v in self.model.state_dict().items():
+            assert torch.equal(v.cpu(), backup['model'][k].cpu()), k
+        print('Successfully finished test run')

@@ -1,0 +1,108 @@
+"""PIT / DC models + Trainer on the GPU vs the reference goldens (G6) and the torch-CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _batch(g6, keys):
+    Ts = [int(t) for t in g6['Ts']]
+    b = {k: [g6[f'in_{k}_{i}'] for i in range(len(Ts))] for k in keys}
+    b['num_frames'] = Ts
+    return b
+
+
+def _load(model, g6, prefix):
+    model.load_state_dict({k[len(prefix):]: torch.from_numpy(v) for k, v in g6.items()
+                           if isinstance(v, np.ndarray) and k.startswith(prefix)}, strict=True)
+    return model
+
+
+def test_pit_model_vs_reference(g6):
+    """Reference state_dict loads (identical keys/shapes); masks, both losses and all gradients match;
+    minibatch loss == mean of single-example losses (tests/test_models/test_bss.py:153-192)."""
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_').to(DEV)
+    batch = model.example_to_device(_batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference']), DEV)
+    masks = model(batch)
+    assert isinstance(masks, list) and len(masks) == 3
+    for b, m in enumerate(masks):
+        assert m.shape == g6[f'pit_mask_{b}'].shape
+        np.testing.assert_allclose(m.detach().cpu().numpy(), g6[f'pit_mask_{b}'], atol=1e-5)
+    rv = model.review(batch, masks)
+    assert set(rv) == {'losses'} and set(rv['losses']) == {'pit_mse_loss', 'pit_ips_loss'}
+    np.testing.assert_allclose(rv['losses']['pit_mse_loss'].item(), g6['pit_mse_loss'], atol=1e-5)
+    np.testing.assert_allclose(rv['losses']['pit_ips_loss'].item(), g6['pit_ips_loss'], atol=1e-5)
+    rv['losses']['pit_ips_loss'].backward()
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g6[f'pit_grad_{n}'], atol=1e-5, err_msg=n)
+    singles = []
+    for b in range(3):
+        ex = {k: [v[b]] for k, v in batch.items()}
+        r = model.review(ex, model(ex))['losses']
+        singles.append([r['pit_mse_loss'].item(), r['pit_ips_loss'].item()])
+    np.testing.assert_allclose(np.mean(singles, 0), [g6['pit_mse_loss'], g6['pit_ips_loss']], atol=1e-5)
+    np.testing.assert_allclose(singles, g6['pit_single_losses'], atol=1e-5)
+    # snapshot images only on request
+    model.create_snapshot = True
+    rv = model.review(batch, model(batch))
+    assert set(rv['images']) == {'observation', 'mask_0', 'mask_1', 'estimation_0', 'estimation_1'}
+
+
+def test_trainer_three_steps_vs_reference(g6, tmp_path):
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+    batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
+    exs = [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+    t = pt.Trainer(model, tmp_path, pt.optimizer.Adam(gradient_clipping=1.),
+                   loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), summary_trigger=(1000, 'iteration'),
+                   checkpoint_trigger=(1000, 'iteration'), stop_trigger=(3, 'iteration'), virtual_minibatch_size=2)
+    t.train(exs, device=DEV)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g6['pit_sd3_' + k], atol=2e-5, err_msg=k)
+
+
+def test_trainer_test_run_on_gpu(g6, tmp_path):
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+    batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
+    exs = [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+    t = pt.Trainer(model, tmp_path, pt.optimizer.Adam(gradient_clipping=1.),
+                   loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), virtual_minibatch_size=2)
+    t.test_run(exs, exs[:2], device=DEV)
+
+
+def test_dc_model_vs_reference(g6):
+    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
+    model = _load(DeepClusteringModel(F=9, recurrent_layers=1, units=4, E=3), g6, 'dc_sd_').to(DEV)
+    batch = model.example_to_device(_batch(g6, ['Y_abs', 'target_mask']), DEV)
+    emb = model(batch)
+    for b, m in enumerate(emb):
+        np.testing.assert_allclose(m.detach().cpu().numpy(), g6[f'dc_emb_{b}'], atol=1e-5)
+    rv = model.review(batch, emb)
+    np.testing.assert_allclose(rv['losses']['dc_loss'].item(), g6['dc_loss'], atol=1e-5)
+    rv['losses']['dc_loss'].backward()
+    for n, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g6[f'dc_grad_{n}'], atol=1e-5, err_msg=n)
+
+
+def test_dc_loss_vs_reference(g1, g5):
+    from padertorch_amd.ops import deep_clustering_loss
+    for toy in g1['dc_toys']:
+        got = deep_clustering_loss(torch.tensor(toy['embedding'], dtype=torch.float32, device=DEV),
+                                   torch.tensor(toy['target'], dtype=torch.float32, device=DEV))
+        np.testing.assert_allclose(got.item(), toy['loss'], atol=1e-6)
+    x = torch.from_numpy(g5['x']).to(DEV).requires_grad_(True)
+    loss = deep_clustering_loss(x, torch.from_numpy(g5['t']).to(DEV))
+    np.testing.assert_allclose(loss.item(), g5['loss'], atol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g5['grad'], atol=1e-6)
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()

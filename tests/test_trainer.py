@@ -1,0 +1,159 @@
+"""Host logic of padertorch_amd.Trainer on CPU: loop semantics vs the reference Trainer (G6),
+checkpoints/resume, error handling, and the data-parallel path with gloo (world_size 2)."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+import padertorch_amd as pt
+from oracle import torch_ref
+
+
+class RefModel(torch_ref.PITModelRef):
+    """The oracle's torch-CPU model behind the Model API the Trainer touches."""
+    create_snapshot = False
+
+    def example_to_device(self, example, device=None, memo=None):
+        return pt.data.example_to_device(example, device, memo)
+
+    def modify_summary(self, summary):
+        return summary
+
+
+def _batch(g6):
+    Ts = [int(t) for t in g6['Ts']]
+    b = {k: [g6[f'in_{k}_{i}'] for i in range(len(Ts))]          # numpy: example_to_device converts
+         for k in ['Y_abs', 'X_abs', 'cos_phase_difference']}
+    b['num_frames'] = Ts
+    return b
+
+
+def _model(g6):
+    m = RefModel(F=9, recurrent_layers=2, units=4, K=2)
+    m.load_state_dict({k[len('pit_sd_'):]: torch.from_numpy(v) for k, v in g6.items()
+                       if isinstance(v, np.ndarray) and k.startswith('pit_sd_')})
+    return m
+
+
+def _examples(g6):
+    batch = _batch(g6)
+    return [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+
+
+LW = dict(pit_ips_loss=1., pit_mse_loss=0.)
+
+
+def test_three_steps_match_reference_trainer(g6, tmp_path):
+    """Adam(clip=1), virtual_minibatch_size=2, 6 examples -> the reference Trainer's parameters."""
+    model = _model(g6)
+    trainer = pt.Trainer(model, tmp_path, pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW,
+                         summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1000, 'iteration'),
+                         stop_trigger=(3, 'iteration'), virtual_minibatch_size=2)
+    trainer.train(_examples(g6), device='cpu')
+    assert trainer.iteration == 3
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.numpy(), g6['pit_sd3_' + k], atol=1e-6, err_msg=k)
+    # storage layout: ckpt_0 (first pre_step), ckpt_3 (close), ckpt_latest -> ckpt_3
+    files = sorted(p.name for p in (tmp_path / 'checkpoints').iterdir())
+    assert files == ['ckpt_0.pth', 'ckpt_3.pth', 'ckpt_latest.pth'], files
+    assert os.readlink(tmp_path / 'checkpoints' / 'ckpt_latest.pth') == 'ckpt_3.pth'
+    # zero-weight losses are logged but not part of the objective (trainer.py:608-613)
+    sc = trainer.summaries[-1][2]
+    assert {'pit_mse_loss', 'pit_ips_loss', 'loss', 'grad_norm', 'lr/param_group_0'} <= set(sc)
+
+
+def test_resume_continues_bit_exact(g6, tmp_path):
+    exs = _examples(g6)
+    kw = dict(loss_weights=LW, summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1, 'iteration'),
+              virtual_minibatch_size=1)
+    a = pt.Trainer(_model(g6), tmp_path / 'a', pt.optimizer.Adam(1.), stop_trigger=(4, 'iteration'), **kw)
+    a.train(exs, device='cpu')
+    b = pt.Trainer(_model(g6), tmp_path / 'b', pt.optimizer.Adam(1.), stop_trigger=(2, 'iteration'), **kw)
+    b.train(exs, device='cpu')
+    b2 = pt.Trainer(_model(g6), tmp_path / 'b', pt.optimizer.Adam(1.), stop_trigger=(4, 'iteration'), **kw)
+    b2.train(exs[2:], resume=True, device='cpu')
+    assert b2.iteration == 4
+    for (k, va), vb in zip(a.model.state_dict().items(), b2.model.state_dict().values()):
+        assert torch.equal(va, vb), k
+
+
+def test_non_finite_loss_raises_and_dumps(g6, tmp_path):
+    exs = _examples(g6)
+    exs[0]['Y_abs'][0] = exs[0]['Y_abs'][0].copy()      # the fixture is session scoped
+    exs[0]['Y_abs'][0][0, 0] = np.nan
+    t = pt.Trainer(_model(g6), tmp_path, pt.optimizer.Adam(1.), loss_weights=LW)
+    with pytest.raises(RuntimeError, match='not finite'):
+        t.train(exs, device='cpu')
+    assert list((tmp_path / 'log').glob('error_state_*'))
+
+
+def test_review_key_and_loss_weight_checks(g6, tmp_path):
+    t = pt.Trainer(_model(g6), tmp_path, pt.optimizer.Adam(1.), loss_weights=None)
+    with pytest.raises(Exception, match='multiple losses'):
+        t.train(_examples(g6), device='cpu')
+
+
+def test_test_run_invariants(g6, tmp_path):
+    model = _model(g6)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    t = pt.Trainer(model, tmp_path, pt.optimizer.Adam(1.), loss_weights=LW, virtual_minibatch_size=2)
+    t.test_run(_examples(g6), _examples(g6)[:2], device='cpu')
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k            # parameters restored bit-exact
+    assert not (tmp_path / 'checkpoints').exists()     # the run happened in temp dirs
+
+
+# ------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, g6_path, n_examples, out_dir):
+    import json
+    torch.set_num_threads(1)
+    g6 = dict(np.load(g6_path, allow_pickle=False))
+    g6['train_example_indices'] = json.loads(str(g6['train_example_indices']))
+    torch.distributed.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}',
+                                         rank=rank, world_size=world)
+    model = _model(g6)
+    if rank == 1:                         # ranks start different: step-0 broadcast must fix it
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.)
+    exs = (_examples(g6) * 2)[:n_examples]
+    t = pt.Trainer(model, os.path.join(out_dir, f'r{rank}'), pt.optimizer.Adam(gradient_clipping=1.),
+                   loss_weights=LW, summary_trigger=(1000, 'iteration'),
+                   checkpoint_trigger=(1000, 'iteration'), stop_trigger=(1, 'epoch'),
+                   virtual_minibatch_size=2)
+    t.train(exs, device='cpu')
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f'sd{rank}.pth'))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_examples', [8, 7])
+def test_data_parallel_gloo_matches_single_process(g6, tmp_path, n_examples):
+    """W=2 ranks x 1 micro-step == 1 process x virtual_minibatch_size=2: gradients are SUMMED (no
+    averaging), replicas end bit-identical, and a partial last group (7 examples) works."""
+    import torch.multiprocessing as mp
+    from conftest import GOLDEN
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(GOLDEN / 'g6_models.npz'), n_examples, str(tmp_path)),
+             nprocs=2, join=True)
+    sd0 = torch.load(tmp_path / 'sd0.pth')
+    sd1 = torch.load(tmp_path / 'sd1.pth')
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k           # replicas identical
+    model = _model(g6)
+    exs = (_examples(g6) * 2)[:n_examples]
+    t = pt.Trainer(model, tmp_path / 'single', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW,
+                   summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1000, 'iteration'),
+                   stop_trigger=(1, 'epoch'), virtual_minibatch_size=2)
+    t.train(exs, device='cpu')
+    assert t.iteration == 4
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(sd0[k].numpy(), v.numpy(), atol=2e-6, err_msg=k)
