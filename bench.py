@@ -39,6 +39,7 @@ K = 2
 SIZE, SHIFT = 512, 128
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FEATURE_BYTES_PER_FRAME = 3 * SHIFT * 4 + (1 + 2 * K) * (SIZE // 2 + 1) * 4   # 6676 B at K=2
+PIT_LOSS_BYTES_PER_FRAME = (1 + 3 * K) * (SIZE // 2 + 1) * 4                  # 7196 B at K=2
 LOSS_WEIGHTS = dict(pit_ips_loss=1., pit_mse_loss=0.)      # pit/train.py:68-71
 
 
@@ -53,6 +54,9 @@ def cpu_baseline(max_seconds=25.):
     """Reference algorithm (oracle/torch_ref.py: conv1d STFT, nn.LSTM on PackedSequence, python-loop
     pit_loss, clip + Adam) on the host cores, bounded sample: batch 4 x 4 s (1012 frames / step)."""
     from oracle import torch_ref
+    # many-core hosts: the small LSTM GEMMs of this model run fastest on a few cores (the reference
+    # README even recommends OMP_NUM_THREADS=1, pit/README.md:15); use 16 threads, state it.
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     torch.manual_seed(0)
     model = torch_ref.PITModelRef()
     opt = torch.optim.Adam(model.parameters())
@@ -118,24 +122,20 @@ def main():
     n = FS * SECONDS
     data = synthetic_batch(1000 + rank, BATCH, n, device)
     frames_per_step = None
-    ev = []
+    from padertorch_amd import _lib
 
     def step(timed):
         nonlocal frames_per_step
-        # the STFT feature front-end is part of the step; its launch is bracketed by HIP events on
-        # the stream it runs on (torch's current stream) for the roofline figure
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        # the STFT feature front-end is part of the step; inside the timed region every launch of
+        # a ptmi kernel is bracketed by HIP events on the stream it runs on (torch's current stream)
+        _lib.KERNEL_TIMERS = timers if timed else None
         feats = pt.ops.pit_features(data['y'], data['s'], data['num_samples'])
-        e1.record()
-        if timed:
-            ev.append((e0, e1))
         frames_per_step = sum(feats['num_frames'])
         loss, _, _, _ = trainer.train_step(model, feats, device)
         loss.backward()
         trainer.optimizer_step()
 
+    timers = []
     for _ in range(args.warmup):
         step(False)
     if world > 1:
@@ -153,10 +153,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    _lib.KERNEL_TIMERS = None
     if rank == 0:
-        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        by_name = {}
+        for name, a, b in timers:
+            by_name.setdefault(name, []).append(a.elapsed_time(b))
+        kern_ms = float(np.mean(by_name['pit_features']))
         alg_bytes = FEATURE_BYTES_PER_FRAME * frames_per_step
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        pit_bytes = {'pit_pairwise_sse': PIT_LOSS_BYTES_PER_FRAME * frames_per_step,
+                     'pit_backward': (PIT_LOSS_BYTES_PER_FRAME + K * (SIZE // 2 + 1) * 4) * frames_per_step}
+        other = [dict(kernel=n, avg_launch_ms=float(np.mean(v)), bound='hbm',
+                      achieved=pit_bytes[n] / (float(np.mean(v)) * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
+                      unit='GB/s', frac=pit_bytes[n] / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                 for n, v in by_name.items() if n in pit_bytes]
         out = {
             'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)',
             'value': frames_per_step * world * args.steps / elapsed,
@@ -191,6 +201,7 @@ def main():
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': kern_ms,
             },
+            'other_kernels': other,
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -87,5 +87,23 @@ def stream(device):
     return torch.cuda.current_stream(device).cuda_stream
 
 
+#: when a list, ``timed`` brackets every kernel launch with HIP events recorded on the launch stream
+#: and appends ``(name, start_event, end_event)`` (bench.py's roofline figure); None = off
+KERNEL_TIMERS = None
+
+
+def timed(name, fn, *args):
+    """Call a C-ABI launcher; optionally bracket it with events on torch's current stream."""
+    if KERNEL_TIMERS is None:
+        return fn(*args)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    KERNEL_TIMERS.append((name, e0, e1))
+    return rc
+
+
 def strides6(*vals):
     return (c_int64 * 6)(*vals)

@@ -124,7 +124,7 @@ class PermutationInvariantTrainingModel(base.Model):
         C, _, _ = as_padded(batch['cos_phase_difference'])
         # MSE loss and ideal-phase-sensitive loss of every example, batch means (reference :117-140)
         loss, _, _ = ops.losses.pit_mse_ips_losses(
-            mask, Y, X, C, lengths_dev.to(mask.device), mask_batch_first=mask_bf)
+            mask, Y, X, C, lengths_dev, mask_batch_first=mask_bf)
         review = dict(losses={'pit_mse_loss': loss[0], 'pit_ips_loss': loss[1]})
 
         if self.create_snapshot:

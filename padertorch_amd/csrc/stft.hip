@@ -67,17 +67,57 @@ __device__ __forceinline__ cpx tw_full(const cpx* tw, int j) {
     return tw[j];
 }
 
+// LDS carve-up shared by the forward kernels (all offsets multiples of 16 bytes):
+//   buf  [FPB][FS] cpx   per-frame transposition / natural-order spectrum
+//   tws  [F+1]     cpx   split twiddles W_size^k, k = 0..M
+//   tw1t [R1][LPF] cpx   inter-stage twiddles W_M^(l*k1), lane-contiguous
+//   win  [SIZE]    float analysis window, zero beyond window_length
+//   sig  [...]     float staged samples of the FPB frames, zero-filled tail up to SIZE
+template <class PL>
+struct FwdLds {
+    cpx* buf;
+    cpx* tws;
+    cpx* tw1t;
+    float* win;
+    float* sig;
+    __device__ __forceinline__ explicit FwdLds(char* smem) {
+        buf = reinterpret_cast<cpx*>(smem);
+        tws = buf + PL::FPB * PL::FS;
+        tw1t = tws + PL::F + 1;
+        win = reinterpret_cast<float*>(tw1t + PL::R1 * PL::LPF);
+        sig = win + PL::SIZE;
+    }
+    static size_t bytes(int shift) {
+        const size_t chunk = (size_t)(PL::FPB - 1) * shift + PL::SIZE;
+        return sizeof(cpx) * ((size_t)PL::FPB * PL::FS + PL::F + 1 + PL::R1 * PL::LPF) +
+               sizeof(float) * (PL::SIZE + chunk + 2 * PL::LPF + 8);
+    }
+};
+
+// Fill the constant tables (once per workgroup, coalesced; the tables are L2 resident).
+template <class PL>
+__device__ __forceinline__ void load_tables(const FwdLds<PL>& S, const float* __restrict__ window,
+                                            const cpx* __restrict__ twiddle, int L, int tid) {
+    for (int i = tid; i <= PL::M; i += 256) S.tws[i] = twiddle[i];
+    for (int i = tid; i < PL::SIZE; i += 256) S.win[i] = (i < L) ? window[i] : 0.f;
+    for (int i = tid; i < PL::R1 * PL::LPF; i += 256) {
+        const int k1 = i / PL::LPF, l = i - k1 * PL::LPF;
+        S.tw1t[i] = tw_full<PL::M>(twiddle, (2 * l * k1) % PL::SIZE);   // W_M^(l*k1) = W_size^(2*l*k1)
+    }
+}
+
 // Two-step complex FFT of one frame.  On entry lane l (< R2) holds a[i1] = in[R2*i1 + l].
 // On exit fbuf[k], k < M, holds the transform in natural order.  Contains block-wide barriers.
 template <class PL, bool INV>
-__device__ __forceinline__ void fft_to_lds(cpx (&a)[PL::R1], cpx* fbuf, int l, const cpx (&tw1)[PL::R1]) {
+__device__ __forceinline__ void fft_to_lds(cpx (&a)[PL::R1], cpx* fbuf, int l, const cpx* tw1t) {
     constexpr int R1 = PL::R1, R2 = PL::R2, P = PL::P;
     if (l < R2) {
         fft_dif<R1, INV>(a);
 #pragma unroll
         for (int k1 = 0; k1 < R1; ++k1) {
             const cpx v = a[bitrev<R1>(k1)];
-            fbuf[k1 * P + l] = INV ? cmulc(v, tw1[k1]) : cmul(v, tw1[k1]);
+            const cpx w = tw1t[k1 * PL::LPF + l];
+            fbuf[k1 * P + l] = INV ? cmulc(v, w) : cmul(v, w);
         }
     }
     __syncthreads();
@@ -95,28 +135,30 @@ __device__ __forceinline__ void fft_to_lds(cpx (&a)[PL::R1], cpx* fbuf, int l, c
     __syncthreads();
 }
 
-// Stage the samples of frames [t0, t0+FPB) of one row into LDS (zero outside [0, n_b)).
+// Stage the samples of frames [t0, t0+FPB) of one row into LDS: zero outside [0, n_b) (fading and
+// frame padding) and zero up to SIZE past the last frame start (so the unpredicated window loads
+// below never see uninitialised LDS).  Row offsets fit in 32 bits (checked on the host).
 template <class PL>
-__device__ __forceinline__ void stage_signal(float* sig, const float* __restrict__ xrow, long long n_b,
+__device__ __forceinline__ void stage_signal(float* sig, const float* __restrict__ xrow, int n_b,
                                              int t0, const Geo& g, int tid) {
-    const int chunk = (PL::FPB - 1) * g.shift + g.L;
-    const long long v0 = (long long)t0 * g.shift - g.pad_left;
+    const int chunk = (PL::FPB - 1) * g.shift + PL::SIZE;
+    const int v0 = t0 * g.shift - g.pad_left;
     for (int i = tid; i < chunk; i += 256) {
-        const long long xi = v0 + i;
-        sig[i] = (xi >= 0 && xi < n_b) ? xrow[xi] : 0.f;
+        const int xi = v0 + i;
+        float v = 0.f;
+        if (xi >= 0 && xi < n_b) v = xrow[xi];
+        sig[i] = v;
     }
 }
 
-// Load the windowed, even/odd packed samples of this lane's frame into registers.
+// Load the windowed, even/odd packed samples of this lane's frame into registers
+// (a[n1] = x_w[2 (R2 n1 + l)] + i x_w[2 (R2 n1 + l) + 1]).  No predicates: win is 0 beyond L.
 template <class PL>
-__device__ __forceinline__ void load_windowed(cpx (&a)[PL::R1], const float* sf, int l, int L,
-                                              const float (&w0)[PL::R1], const float (&w1)[PL::R1]) {
+__device__ __forceinline__ void load_windowed(cpx (&a)[PL::R1], const float* sf, const float* win, int l) {
 #pragma unroll
     for (int n1 = 0; n1 < PL::R1; ++n1) {
         const int k = 2 * (PL::R2 * n1 + l);
-        const float e = (k < L) ? sf[k] : 0.f;
-        const float o = (k + 1 < L) ? sf[k + 1] : 0.f;
-        a[n1] = cpx{e * w0[n1], o * w1[n1]};
+        a[n1] = cpx{sf[k] * win[k], sf[k + 1] * win[k + 1]};
     }
 }
 
@@ -133,127 +175,110 @@ __device__ __forceinline__ cpx split_bin(const cpx* zb, const cpx* tws, int k) {
     return cpx{ex + dy * w.x + dx * w.y, ey + dy * w.y - dx * w.x};
 }
 
-template <class PL>
-__device__ __forceinline__ void load_lane_constants(const FwdArgs& A, int l, float (&w0)[PL::R1],
-                                                    float (&w1)[PL::R1], cpx (&tw1)[PL::R1]) {
-#pragma unroll
-    for (int n1 = 0; n1 < PL::R1; ++n1) {
-        const int k = 2 * (PL::R2 * n1 + l);
-        w0[n1] = (l < PL::R2 && k < A.g.L) ? A.window[k] : 0.f;
-        w1[n1] = (l < PL::R2 && k + 1 < A.g.L) ? A.window[k + 1] : 0.f;
-        tw1[n1] = tw_full<PL::M>(A.twiddle, (2 * l * n1) % PL::SIZE);  // W_M^(l*k1)
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 template <class PL>
-__global__ __launch_bounds__(256) void stft_fwd_kernel(const FwdArgs A) {
+__global__ __launch_bounds__(256, 3) void stft_fwd_kernel(const FwdArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cpx* buf = reinterpret_cast<cpx*>(smem);
-    cpx* tws = buf + FPB * FS;
-    float* sig = reinterpret_cast<float*>(tws + F + 1);
+    const FwdLds<PL> S(smem);
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x / A.nchunks;
     const int t0 = (blockIdx.x - b * A.nchunks) * FPB;
-    const long long n_b = A.row_samples ? (long long)A.row_samples[b] : A.num_samples;
-    const long long frames_b = row_frames_of(A.g, n_b);
+    const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
+    const int frames_b = (int)row_frames_of(A.g, n_b);
     const int lane = tid & 63, wave = tid >> 6;
     const int fl = lane / LPF, l = lane - fl * LPF;
     const int fb = wave * FPW + fl;
 
-    stage_signal<PL>(sig, A.x + (long long)b * A.x_row_stride, n_b, t0, A.g, tid);
-    for (int i = tid; i <= M; i += 256) tws[i] = A.twiddle[i];
-    float w0[PL::R1], w1[PL::R1];
-    cpx tw1[PL::R1];
-    load_lane_constants<PL>(A, l, w0, w1, tw1);
+    stage_signal<PL>(S.sig, A.x + (long long)b * A.x_row_stride, n_b, t0, A.g, tid);
+    load_tables<PL>(S, A.window, A.twiddle, A.g.L, tid);
     __syncthreads();
 
     cpx a[PL::R1];
-    load_windowed<PL>(a, sig + fb * A.g.shift, l, A.g.L, w0, w1);
-    fft_to_lds<PL, false>(a, buf + fb * FS, l, tw1);
+    load_windowed<PL>(a, S.sig + fb * A.g.shift, S.win, l);
+    fft_to_lds<PL, false>(a, S.buf + fb * FS, l, S.tw1t);
 
-    // epilogue: this wavefront's FPW frames are FPW*F consecutive output rows-elements
-    const long long tw0 = (long long)t0 + wave * FPW;
-    float* orow = A.out + ((long long)b * A.out_frames + tw0) * (2 * F);
-    for (int idx = lane; idx < FPW * F; idx += 64) {
+    // epilogue: this wavefront's FPW frames are FPW*F consecutive complex outputs of one row
+    const int tw0 = t0 + wave * FPW;
+    const int nvalid = min(FPW, (int)A.out_frames - tw0) * F;     // outputs inside [0, out_frames)
+    float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * (2 * F);
+    const cpx* zw = S.buf + wave * FPW * FS;
+    const float es = A.edge_scale;
+    for (int idx = lane; idx < nvalid; idx += 64) {
         const int f = idx / F, k = idx - f * F;
-        const long long t = tw0 + f;
-        if (t >= A.out_frames) break;
-        cpx X = cpx{0.f, 0.f};
-        if (t < frames_b) {
-            X = split_bin<PL>(buf + (wave * FPW + f) * FS, tws, k);
-            if (k == 0 || k == M) X = cpx{X.x * A.edge_scale, A.edge_scale == 1.f ? X.y : 0.f};
-        }
+        cpx X = split_bin<PL>(zw + f * FS, S.tws, k);
+        if (k == 0 || k == M) X = cpx{X.x * es, es == 1.f ? X.y : 0.f};
+        if (tw0 + f >= frames_b) X = cpx{0.f, 0.f};
         if (A.layout == PTMI_LAYOUT_INTERLEAVED) {
-            *reinterpret_cast<float2*>(orow + 2 * (long long)idx) = make_float2(X.x, X.y);
+            reinterpret_cast<float2*>(orow)[idx] = make_float2(X.x, X.y);
         } else {
-            orow[(long long)f * 2 * F + k] = X.x;
-            orow[(long long)f * 2 * F + F + k] = X.y;
+            orow[f * 2 * F + k] = X.x;
+            orow[f * 2 * F + F + k] = X.y;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Fused PIT front-end: Y_abs [B,T,F], X_abs / cos_phase_difference [B,T,K,F].
+// cos(angle(Y) - angle(X)) = Re(Y conj X) / (|Y| |X|), with angle(0) := 0 like np.angle.
 template <class PL>
-__global__ __launch_bounds__(256) void pit_features_kernel(const FwdArgs A) {
-    constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
+__global__ __launch_bounds__(256, 3) void pit_features_kernel(const FwdArgs A) {
+    constexpr int F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
     constexpr int NIT = PL::NIT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cpx* buf = reinterpret_cast<cpx*>(smem);
-    cpx* tws = buf + FPB * FS;
-    float* sig = reinterpret_cast<float*>(tws + F + 1);
+    const FwdLds<PL> S(smem);
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x / A.nchunks;
     const int t0 = (blockIdx.x - b * A.nchunks) * FPB;
-    const long long n_b = A.row_samples ? (long long)A.row_samples[b] : A.num_samples;
-    const long long frames_b = row_frames_of(A.g, n_b);
+    const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
+    const int frames_b = (int)row_frames_of(A.g, n_b);
     const int lane = tid & 63, wave = tid >> 6;
     const int fl = lane / LPF, l = lane - fl * LPF;
     const int fb = wave * FPW + fl;
-    const long long tw0 = (long long)t0 + wave * FPW;
+    const int tw0 = t0 + wave * FPW;
+    const int nvalid = min(FPW, (int)A.out_frames - tw0) * F;
+    const cpx* zw = S.buf + wave * FPW * FS;
 
-    for (int i = tid; i <= M; i += 256) tws[i] = A.twiddle[i];
-    float w0[PL::R1], w1[PL::R1];
-    cpx tw1[PL::R1];
-    load_lane_constants<PL>(A, l, w0, w1, tw1);
+    load_tables<PL>(S, A.window, A.twiddle, A.g.L, tid);
 
-    float yr[NIT], yi[NIT], ya[NIT];  // mixture spectrum of this lane's epilogue items
+    float yr[NIT], yi[NIT];  // mixture spectrum of this lane's epilogue items
     const int nsig = A.s ? A.K + 1 : 1;
     for (int q = 0; q < nsig; ++q) {
         const float* row = (q == 0) ? A.x + (long long)b * A.x_row_stride
                                     : A.s + ((long long)b * A.K + (q - 1)) * A.x_row_stride;
-        stage_signal<PL>(sig, row, n_b, t0, A.g, tid);
+        stage_signal<PL>(S.sig, row, n_b, t0, A.g, tid);
         __syncthreads();
         cpx a[PL::R1];
-        load_windowed<PL>(a, sig + fb * A.g.shift, l, A.g.L, w0, w1);
-        fft_to_lds<PL, false>(a, buf + fb * FS, l, tw1);
+        load_windowed<PL>(a, S.sig + fb * A.g.shift, S.win, l);
+        fft_to_lds<PL, false>(a, S.buf + fb * FS, l, S.tw1t);
+        // output rows of this wavefront: Y_abs (tw0.., F) contiguous; X_abs/cos (t, q-1, F) rows
+        float* __restrict__ yo = A.out + ((long long)b * A.out_frames + tw0) * F;
+        const long long xo = (((long long)b * A.out_frames + tw0) * A.K + (q - 1)) * F;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int idx = lane + 64 * it;
-            const int f = idx / F, k = idx - f * F;
-            const long long t = tw0 + f;
-            if (idx < FPW * F && t < A.out_frames) {
-                cpx X = cpx{0.f, 0.f};
-                if (t < frames_b) X = split_bin<PL>(buf + (wave * FPW + f) * FS, tws, k);
-                const float mag = sqrtf(X.x * X.x + X.y * X.y);
+            if (idx < nvalid) {
+                const int f = idx / F, k = idx - f * F;
+                cpx X = split_bin<PL>(zw + f * FS, S.tws, k);
+                if (tw0 + f >= frames_b) X = cpx{0.f, 0.f};
+                const float p = X.x * X.x + X.y * X.y;
+                const float r = __builtin_amdgcn_rsqf(p);          // 1/|X| (inf at 0, handled below)
+                const float mag = p > 0.f ? p * r : 0.f;
                 if (q == 0) {
                     yr[it] = X.x;
                     yi[it] = X.y;
-                    ya[it] = mag;
-                    A.out[((long long)b * A.out_frames + t) * F + k] = mag;
+                    yo[idx] = mag;
                 } else {
-                    // cos(angle(Y) - angle(X)) with angle(0) := 0  (np.angle(0) == 0)
-                    const float cy = ya[it] > 0.f ? yr[it] / ya[it] : 1.f;
-                    const float sy = ya[it] > 0.f ? yi[it] / ya[it] : 0.f;
-                    const float cx = mag > 0.f ? X.x / mag : 1.f;
-                    const float sx = mag > 0.f ? X.y / mag : 0.f;
-                    const long long o = (((long long)b * A.out_frames + t) * A.K + (q - 1)) * F + k;
-                    A.X_abs[o] = mag;
-                    A.cos_pd[o] = (t < frames_b) ? cy * cx + sy * sx : 0.f;
+                    const float py = yr[it] * yr[it] + yi[it] * yi[it];
+                    const float ry = __builtin_amdgcn_rsqf(py);
+                    // unit phasors (1, 0) for zero magnitudes
+                    const float cy = py > 0.f ? yr[it] * ry : 1.f, sy = py > 0.f ? yi[it] * ry : 0.f;
+                    const float cx = p > 0.f ? X.x * r : 1.f, sx = p > 0.f ? X.y * r : 0.f;
+                    const int o = f * A.K * F + k;
+                    A.X_abs[xo + o] = mag;
+                    A.cos_pd[xo + o] = (tw0 + f < frames_b) ? cy * cx + sy * sx : 0.f;
                 }
             }
         }
@@ -280,12 +305,13 @@ struct InvArgs {
 };
 
 template <class PL>
-__global__ __launch_bounds__(256) void istft_kernel(const InvArgs A) {
+__global__ __launch_bounds__(256, 3) void istft_kernel(const InvArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cpx* buf = reinterpret_cast<cpx*>(smem);
     cpx* tws = buf + FPB * FS;
-    float* wsyn = reinterpret_cast<float*>(tws + F + 1);
+    cpx* tw1t = tws + F + 1;
+    float* wsyn = reinterpret_cast<float*>(tw1t + PL::R1 * LPF);
 
     const int tid = threadIdx.x;
     const int b = blockIdx.x / A.nchunks;
@@ -299,9 +325,10 @@ __global__ __launch_bounds__(256) void istft_kernel(const InvArgs A) {
 
     for (int i = tid; i <= M; i += 256) tws[i] = A.twiddle[i];
     for (int i = tid; i < A.g.L; i += 256) wsyn[i] = A.syn_window[i];
-    cpx tw1[PL::R1];
-#pragma unroll
-    for (int n1 = 0; n1 < PL::R1; ++n1) tw1[n1] = tw_full<M>(A.twiddle, (2 * l * n1) % PL::SIZE);
+    for (int i = tid; i < PL::R1 * LPF; i += 256) {
+        const int k1 = i / LPF, ll = i - k1 * LPF;
+        tw1t[i] = tw_full<M>(A.twiddle, (2 * ll * k1) % PL::SIZE);
+    }
 
     // (a) raw one-sided spectra of this wavefront's frames -> LDS (coalesced row reads)
     for (int idx = lane; idx < FPW * F; idx += 64) {
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(256) void istft_kernel(const InvArgs A) {
         }
     }
     __syncthreads();  // every lane has consumed raw before the transposition overwrites it
-    fft_to_lds<PL, true>(a, buf + fb * FS, l, tw1);
+    fft_to_lds<PL, true>(a, buf + fb * FS, l, tw1t);
 
     // (c) overlap-add from LDS: buf viewed as floats holds frame samples x[0..size)
     const long long o0 = (long long)c * nout * A.g.shift;
@@ -457,12 +484,12 @@ __global__ __launch_bounds__(256) void istft_generic_kernel(const InvArgs A) {
 // ------------------------------------------------------------------------------------------------
 template <class PL>
 static size_t fwd_smem_bytes(const Geo& g) {
-    const size_t chunk = (size_t)(PL::FPB - 1) * g.shift + g.L;
-    return sizeof(cpx) * ((size_t)PL::FPB * PL::FS + PL::F + 1) + sizeof(float) * (chunk + 2);
+    return FwdLds<PL>::bytes(g.shift);
 }
 template <class PL>
 static size_t inv_smem_bytes(const Geo& g) {
-    return sizeof(cpx) * ((size_t)PL::FPB * PL::FS + PL::F + 1) + sizeof(float) * (g.L + 2);
+    return sizeof(cpx) * ((size_t)PL::FPB * PL::FS + PL::F + 1 + PL::R1 * PL::LPF) +
+           sizeof(float) * (g.L + 4);
 }
 
 constexpr size_t kMaxSmem = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB LDS)
@@ -552,6 +579,7 @@ int ptmi_stft_forward(const float* x, int64_t batch, int64_t x_row_stride, int64
     PTMI_RETURN_IF(!geom_ok(g) || !x || !window || !twiddle || !out, PTMI_E_INVALID);
     PTMI_RETURN_IF(batch < 0 || out_frames < 0 || (layout != 0 && layout != 1), PTMI_E_INVALID);
     PTMI_RETURN_IF(g->window_length > g->size, PTMI_E_INVALID);
+    PTMI_RETURN_IF(num_samples > 0x7ff00000LL || out_frames > 0x7ff00000LL / (g->size + 2), PTMI_E_UNSUPPORTED);
     if (batch == 0 || out_frames == 0) return PTMI_OK;
     FwdArgs A{};
     A.x = x;
@@ -614,6 +642,7 @@ int ptmi_pit_features(const float* y, const float* s, int64_t batch, int32_t K, 
     PTMI_RETURN_IF(!geom_ok(g) || !y || !window || !twiddle || !Y_abs, PTMI_E_INVALID);
     PTMI_RETURN_IF(s && (!X_abs || !cos_pd || K < 1), PTMI_E_INVALID);
     PTMI_RETURN_IF(batch < 0 || out_frames < 0, PTMI_E_INVALID);
+    PTMI_RETURN_IF(num_samples > 0x7ff00000LL || out_frames > 0x7ff00000LL / (g->size + 2), PTMI_E_UNSUPPORTED);
     if (batch == 0 || out_frames == 0) return PTMI_OK;
     FwdArgs A{};
     A.x = y;

@@ -96,8 +96,8 @@ class _StftFn(torch.autograd.Function):
         F = st.size // 2 + 1
         shape = (rows, frames, F, 2) if layout == 0 else (rows, frames, 2 * F)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
-        _lib.check(lib.ptmi_stft_forward(
-            x.data_ptr(), rows, x.stride(0), T, _lib.ptr(row_samples), tb['window'].data_ptr(),
+        _lib.check(_lib.timed(
+            'stft_forward', lib.ptmi_stft_forward, x.data_ptr(), rows, x.stride(0), T, _lib.ptr(row_samples), tb['window'].data_ptr(),
             tb['twiddle'].data_ptr(), st._geom, frames, layout, 1.0, out.data_ptr(),
             _lib.stream(x.device)), 'ptmi_stft_forward')
         ctx.st, ctx.layout, ctx.T = st, layout, T
@@ -132,8 +132,8 @@ class _IstftFn(torch.autograd.Function):
         n = int(lib.ptmi_istft_num_samples(st._geom, frames))
         out = torch.empty((rows, max(n, 0)), dtype=torch.float32, device=spec.device)
         if n > 0:
-            _lib.check(lib.ptmi_istft_forward(
-                spec.data_ptr(), rows, frames, None, tb['syn'].data_ptr(), tb['twiddle'].data_ptr(),
+            _lib.check(_lib.timed(
+                'istft_forward', lib.ptmi_istft_forward, spec.data_ptr(), rows, frames, None, tb['syn'].data_ptr(), tb['twiddle'].data_ptr(),
                 st._geom, layout, 1.0, st._geom.pad_left, n, n, out.data_ptr(),
                 _lib.stream(spec.device)), 'ptmi_istft_forward')
         ctx.st, ctx.layout, ctx.frames = st, layout, frames

@@ -58,7 +58,8 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None):
     if num_samples is None:
         num_samples = [N] * B
     lib = _lib.load()
-    frames = [int(lib.ptmi_stft_num_frames(stft._geom, n)) for n in num_samples]
+    per_len = {n: int(lib.ptmi_stft_num_frames(stft._geom, n)) for n in set(num_samples)}
+    frames = [per_len[n] for n in num_samples]
     T = max(frames)
     F = stft.size // 2 + 1
     dev = y.device
@@ -70,15 +71,15 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None):
     if K:
         X_abs = torch.empty((B, T, K, F), dtype=torch.float32, device=dev)
         cos_pd = torch.empty((B, T, K, F), dtype=torch.float32, device=dev)
-    rc = lib.ptmi_pit_features(
-        y.data_ptr(), _lib.ptr(s), B, K, N, N, _lib.ptr(ns_dev), tb['window'].data_ptr(),
+    rc = _lib.timed(
+        'pit_features', lib.ptmi_pit_features, y.data_ptr(), _lib.ptr(s), B, K, N, N, _lib.ptr(ns_dev), tb['window'].data_ptr(),
         tb['twiddle'].data_ptr(), stft._geom, T, Y_abs.data_ptr(), _lib.ptr(X_abs), _lib.ptr(cos_pd),
         _lib.stream(dev))
     if rc == -2:
         raise NotImplementedError(
             f'pit_features needs a power-of-two STFT size in 64..2048 (got {stft.size})')
     _lib.check(rc, 'ptmi_pit_features')
-    fl = torch.tensor(frames, dtype=torch.int32, device=dev)
+    fl = torch.tensor(frames, dtype=torch.int32, device=dev) if ragged else None
     out = dict(Y_abs=PaddedList(Y_abs, frames, True, fl), num_frames=frames)
     if K:
         out['X_abs'] = PaddedList(X_abs, frames, True, fl)

@@ -59,8 +59,8 @@ class _PitFn(torch.autograd.Function):
         sse = torch.empty((B, nvar, K, K), dtype=torch.float64, device=dev)
         strides = _lib.strides6(es[0], es[1], os_[0], os_[1], ts[0], ts[1])
         st = _lib.stream(dev)
-        _lib.check(lib.ptmi_pit_pairwise_sse(
-            est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), B, T, strides, K, F,
+        _lib.check(_lib.timed(
+            'pit_pairwise_sse', lib.ptmi_pit_pairwise_sse, est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), B, T, strides, K, F,
             _lib.ptr(row_frames), ws.data_ptr(), sse.data_ptr(), st), 'ptmi_pit_pairwise_sse')
         loss = torch.empty(nvar, dtype=torch.float32, device=dev)
         perm = torch.empty((B, nvar, K), dtype=torch.int32, device=dev)
@@ -83,8 +83,8 @@ class _PitFn(torch.autograd.Function):
         grad = torch.empty_strided(est.shape, est.stride(), dtype=est.dtype, device=est.device)
         strides = _lib.strides6(es[0], es[1], os_[0], os_[1], ts[0], ts[1])
         gs = g_loss.to(torch.float32).contiguous()
-        _lib.check(lib.ptmi_pit_backward(
-            est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), perm.data_ptr(),
+        _lib.check(_lib.timed(
+            'pit_backward', lib.ptmi_pit_backward, est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), perm.data_ptr(),
             gs.data_ptr(), B, T, strides, K, F, nvar, _lib.ptr(row_frames), grad.data_ptr(),
             _lib.stream(est.device)), 'ptmi_pit_backward')
         return grad, None, None, None, None, None

@@ -37,20 +37,21 @@ class PaddedList(list):
 
     def __init__(self, padded, lengths, batch_first=True, lengths_dev=None):
         lengths = [int(l) for l in lengths]
-        if batch_first:
-            super().__init__(padded[b, :l] for b, l in enumerate(lengths))
-        else:
-            super().__init__(padded[:l, b] for b, l in enumerate(lengths))
+        T = padded.shape[1 if batch_first else 0]
+        rows = padded.unbind(0 if batch_first else 1)        # one call, B views
+        super().__init__(r if l == T else r[:l] for r, l in zip(rows, lengths))
         self.padded = padded
         self.lengths = lengths
         self.batch_first = batch_first
-        if lengths_dev is None:
+        self.ragged = any(l != T for l in lengths)
+        if lengths_dev is None and self.ragged:
             lengths_dev = torch.tensor(lengths, dtype=torch.int32, device=padded.device)
+        #: int32 device tensor [B], or None when every example fills the padded length
         self.lengths_dev = lengths_dev
 
     def to(self, device):
-        return PaddedList(self.padded.to(device), self.lengths, self.batch_first,
-                          self.lengths_dev.to(device))
+        ld = None if self.lengths_dev is None else self.lengths_dev.to(device)
+        return PaddedList(self.padded.to(device), self.lengths, self.batch_first, ld)
 
 
 def as_padded(seq, batch_first=True):
@@ -61,7 +62,9 @@ def as_padded(seq, batch_first=True):
         return seq.padded.transpose(0, 1).contiguous(), seq.lengths, seq.lengths_dev
     lengths = [int(t.shape[0]) for t in seq]
     padded = pad_sequence(list(seq), batch_first=batch_first)
-    return padded, lengths, torch.tensor(lengths, dtype=torch.int32, device=padded.device)
+    ragged = any(l != lengths[0] for l in lengths)
+    return padded, lengths, (torch.tensor(lengths, dtype=torch.int32, device=padded.device)
+                             if ragged else None)
 
 
 def pack_sequence(sequences, enforce_sorted=True):
