@@ -138,6 +138,35 @@ int ptmi_pit_backward(const float* est, const float* obs, const float* tgt, cons
                       const int64_t* strides, int32_t K, int32_t F, int32_t nvar, const int32_t* row_frames,
                       float* grad, ptmi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Packed-sequence (B)LSTM recurrence (time loop of torch.nn.LSTM on a PackedSequence:
+ * pit/model.py:60-66,97, contrib/tcl/dc.py:32-34,61; gate order i,f,g,o; zero initial state).
+ * rows = packed time-major rows, row(t, b) = offsets[t] + b, b < batch_sizes[t] (descending).
+ * One launch per timestep covers both directions (direction 1 walks time backwards).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Forward through time.
+ *   gates      device [rows, ndir, 4, H]  in: x W_ih^T + b_ih + b_hh; out: activated i,f,g,o (in place)
+ *   hy, c      device [rows, ndir, H]     out: hidden / cell state of every step
+ *   w_hh_pad   device [ndir, 4H, KP]      recurrent weights, K zero-padded to KP = roundup(H, 16)
+ *   batch_sizes device int32 [T], offsets device int64 [T] (PackedSequence bookkeeping)
+ *   H % 4 == 0 is required (16-byte aligned operand rows), else PTMI_E_UNSUPPORTED.
+ */
+int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, const int32_t* batch_sizes,
+                      const int64_t* offsets, int32_t T, int32_t max_batch, int32_t H, int32_t KP,
+                      int32_t ndir, ptmi_stream_t stream);
+
+/* Backward through time.
+ *   gates, c   saved by ptmi_lstm_forward;  dhy device [rows, ndir, H] gradient wrt hy
+ *   w_hh_t     device [ndir, H, 4H]  (transposed recurrent weights)
+ *   dgates     device [rows, ndir, 4, H]  out: gradient wrt the gate pre-activations
+ *   dc_state   device [max_batch, ndir, H] scratch (zeroed by the call)
+ * dW_ih, dW_hh, db and dx follow from dgates by dense GEMMs on the caller's side.
+ */
+int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
+                       float* dc_state, const int32_t* batch_sizes, const int64_t* offsets, int32_t T,
+                       int32_t max_batch, int32_t H, int32_t ndir, ptmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,8 @@ SIGNATURES = {
     'ptmi_pit_assign': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P]),
     'ptmi_pit_backward': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32,
                                   c_int32, _P, _P, _P]),
+    'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
 }
 
 _lib = None

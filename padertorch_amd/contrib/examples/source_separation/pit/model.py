@@ -31,6 +31,8 @@ class PermutationInvariantTrainingModel(base.Model):
 
     [1] Kolbaek 2017, https://arxiv.org/pdf/1703.06284.pdf
     """
+    #: run the BLSTM time recurrence in the hand-written HIP kernels (False: torch.nn.LSTM / MIOpen)
+    hip_blstm = True
 
     def __init__(
             self,
@@ -100,7 +102,10 @@ class PermutationInvariantTrainingModel(base.Model):
         h = PackedSequence(h_data, h.batch_sizes)
 
         # Returns tensor with shape (t, b, num_directions * hidden_size)
-        h, _ = self.blstm(h)
+        if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
+            h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
+        else:
+            h, _ = self.blstm(h)                      # library LSTM (MIOpen)
 
         h_data = self.dropout_linear(h.data)
         h_data = self.linear1(h_data)

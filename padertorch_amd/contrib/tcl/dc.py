@@ -8,6 +8,9 @@ from padertorch_amd import ops
 
 
 class DeepClusteringModel(base.Model):
+    #: run the BLSTM time recurrence in the hand-written HIP kernels (False: torch.nn.LSTM / MIOpen)
+    hip_blstm = True
+
     def __init__(
             self,
             F=257,
@@ -47,7 +50,10 @@ class DeepClusteringModel(base.Model):
         _, F = h.data.size()
         assert F == self.F, f'self.F = {self.F} != F = {F}'
 
-        h, _ = self.blstm(h)
+        if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
+            h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
+        else:
+            h, _ = self.blstm(h)
         h_data = self.linear(h.data).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
         # Hershey 2016 page 2 top right paragraph: Unit norm
         h_data = torch.nn.functional.normalize(h_data, dim=-2)

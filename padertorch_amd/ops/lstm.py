@@ -1,0 +1,128 @@
+"""Packed-sequence (B)LSTM on MI355X: drop-in compute path for ``torch.nn.LSTM(PackedSequence)``.
+
+``packed_lstm(lstm, packed)`` evaluates a ``torch.nn.LSTM`` module (its own parameters - the
+``state_dict`` layout of the reference models is untouched) on a
+``PackedSequence`` exactly like ``lstm(packed)[0]`` as used at
+``padertorch/contrib/examples/source_separation/pit/model.py:97`` and ``contrib/tcl/dc.py:61``:
+
+* per layer ONE dense GEMM ``X [W_ih_fwd; W_ih_rev]^T + (b_ih + b_hh)`` for both directions (BLAS);
+* the time recurrence runs in the HIP kernels of ``csrc/lstm.hip`` (``ptmi_lstm_forward`` /
+  ``ptmi_lstm_backward``): one launch per timestep for both directions, exact fp32 on the matrix
+  cores, fused gate non-linearities, activations saved in place for the backward pass;
+* weight / input gradients are dense GEMMs on the saved gate gradients.
+"""
+import functools
+
+import numpy as np
+import torch
+from torch.nn.utils.rnn import PackedSequence
+
+from .. import _lib
+
+__all__ = ['packed_lstm']
+
+
+class _PackMeta:
+    """Device-side bookkeeping of one ``batch_sizes`` vector (cached: batches repeat shapes)."""
+
+    def __init__(self, batch_sizes, device):
+        bs = np.asarray(batch_sizes, dtype=np.int64)
+        assert np.all(bs[:-1] >= bs[1:]), 'batch_sizes must be non-increasing (sorted sequences)'
+        self.T = int(len(bs))
+        self.max_batch = int(bs[0]) if self.T else 0
+        offs = np.concatenate([[0], np.cumsum(bs)])
+        self.rows = int(offs[-1])
+        self.bs_dev = torch.tensor(bs, dtype=torch.int32, device=device)
+        self.offs_dev = torch.tensor(offs[:-1], dtype=torch.int64, device=device)
+        # index of the predecessor row (forward sense) per direction; `rows` = "no predecessor"
+        prev = np.full((2, self.rows), self.rows, dtype=np.int64)
+        for t in range(self.T):
+            if t > 0:
+                prev[0, offs[t]:offs[t] + bs[t]] = offs[t - 1] + np.arange(bs[t])
+            if t + 1 < self.T:
+                prev[1, offs[t]:offs[t] + bs[t + 1]] = offs[t + 1] + np.arange(bs[t + 1])
+        self.prev_dev = torch.tensor(prev, device=device)
+
+
+@functools.lru_cache(maxsize=64)
+def _meta(batch_sizes_key, device_key):
+    return _PackMeta(batch_sizes_key, torch.device(*device_key))
+
+
+def pack_meta(batch_sizes, device):
+    return _meta(tuple(int(b) for b in batch_sizes.tolist()), (device.type, device.index))
+
+
+class _LstmLayerFn(torch.autograd.Function):
+    """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, bias, w_hh, meta):
+        lib = _lib.load()
+        ndir, G, H = w_hh.shape
+        assert G == 4 * H
+        KP = (H + 15) // 16 * 16
+        gates = torch.addmm(bias, x, w_ih.t())                       # [rows, ndir*4H]
+        w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
+        hy = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
+        c = torch.empty_like(hy)
+        _lib.check(_lib.timed(
+            'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
+            w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(), meta.T, meta.max_batch,
+            H, KP, ndir, _lib.stream(x.device)), 'ptmi_lstm_forward')
+        ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy)
+        ctx.meta = meta
+        return hy
+
+    @staticmethod
+    def backward(ctx, dhy):
+        x, w_ih, w_hh, gates, c, hy = ctx.saved_tensors
+        meta = ctx.meta
+        lib = _lib.load()
+        ndir, G, H = w_hh.shape
+        dhy = dhy.contiguous()
+        w_t = w_hh.transpose(1, 2).contiguous()                       # [ndir, H, 4H]
+        dg = torch.empty_like(gates)
+        dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.timed(
+            'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
+            w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_dev.data_ptr(),
+            meta.offs_dev.data_ptr(), meta.T, meta.max_batch, H, ndir, _lib.stream(x.device)),
+            'ptmi_lstm_backward')
+        dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
+        dw_ih = dg.t() @ x                                            # [ndir*4H, I]
+        db = dg.sum(0)
+        hy_pad = torch.cat([hy.view(meta.rows, ndir, H),
+                            hy.new_zeros(1, ndir, H)], 0)             # row `rows` = zero state
+        dgv = dg.view(meta.rows, ndir, G)
+        dw_hh = torch.stack([dgv[:, d].t() @ hy_pad[:, d].index_select(0, meta.prev_dev[d])
+                             for d in range(ndir)])
+        return dx, dw_ih, db, dw_hh, None
+
+
+def supported(lstm, data):
+    return (isinstance(lstm, torch.nn.LSTM) and lstm.hidden_size % 4 == 0 and lstm.proj_size == 0
+            and lstm.bias and data.is_cuda and data.dtype == torch.float32)
+
+
+def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None):
+    """``lstm(packed)[0]`` through the HIP recurrence (zero initial state)."""
+    data = packed.data
+    _lib.require_gpu(data)
+    if not supported(lstm, data):
+        raise NotImplementedError(
+            'packed_lstm needs an fp32 torch.nn.LSTM with bias, proj_size=0 and hidden_size % 4 == 0')
+    assert packed.sorted_indices is None, 'sequences must be sorted by length (enforce_sorted=True)'
+    training = lstm.training if training is None else training
+    meta = pack_meta(packed.batch_sizes, data.device)
+    sfx = ['', '_reverse'] if lstm.bidirectional else ['']
+    h = data.contiguous()
+    for layer in range(lstm.num_layers):
+        w_ih = torch.cat([getattr(lstm, f'weight_ih_l{layer}{s}') for s in sfx], 0)
+        bias = torch.cat([getattr(lstm, f'bias_ih_l{layer}{s}') + getattr(lstm, f'bias_hh_l{layer}{s}')
+                          for s in sfx], 0)
+        w_hh = torch.stack([getattr(lstm, f'weight_hh_l{layer}{s}') for s in sfx], 0)
+        h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta)
+        if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
+            h = torch.nn.functional.dropout(h, lstm.dropout, True)
+    return PackedSequence(h, packed.batch_sizes)
