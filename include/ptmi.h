@@ -149,7 +149,8 @@ int ptmi_pit_backward(const float* est, const float* obs, const float* tgt, cons
  *   gates      device [rows, ndir, 4, H]  in: x W_ih^T + b_ih + b_hh; out: activated i,f,g,o (in place)
  *   hy, c      device [rows, ndir, H]     out: hidden / cell state of every step
  *   w_hh_pad   device [ndir, 4H, KP]      recurrent weights, K zero-padded to KP = roundup(H, 16)
- *   batch_sizes device int32 [T], offsets device int64 [T] (PackedSequence bookkeeping)
+ *   batch_sizes HOST int32 [T], offsets HOST int64 [T] (PackedSequence bookkeeping; per-step row
+ *              ranges travel as kernel arguments)
  *   H % 4 == 0 is required (16-byte aligned operand rows), else PTMI_E_UNSUPPORTED.
  */
 int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, const int32_t* batch_sizes,

@@ -21,56 +21,66 @@
 //   hy, c, dhy           [rows][ndir][H]
 //   w_hh_pad             [ndir][4H][KP]       KP = H rounded up to 16, zero padded
 //   w_hh_t               [ndir][H][4H]
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ptmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Per-direction bookkeeping of ONE timestep, computed on the host and passed as kernel arguments
+// (a scalar load of batch_sizes[t] / offsets[t] from memory costs a cold round trip per launch).
+struct StepMeta {
+    long long row0[2];   // first packed row of this step's time index
+    long long prow0[2];  // first packed row of the neighbouring time index (see kernels)
+    long long qrow0[2];  // backward only: first row of the forward-sense predecessor
+    int nb[2];           // active sequences at this time index
+    int nprev[2];        // of those, how many are also active at the neighbouring time index
+    int npv[2];          // backward only: how many have a forward-sense predecessor
+};
+
 struct LstmArgs {
     float* gx;
     float* hy;
     float* c;
     const float* w;
-    const int32_t* bs;
-    const int64_t* offs;
-    int T, H, KP, ndir, step;
+    int H, KP, ndir, dbg;
+    StepMeta m;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-// One forward timestep.  grid = (H / JT, ndir, ceil(maxB / 32)), 256 threads.
-// Workgroup tile: 32 batch rows x (4 gates x JT hidden units) = 32 x 32 outputs (JT = 8).
-template <int JT>
-__global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs A) {
-    constexpr int NC = 4 * JT;          // gate columns per workgroup (32)
-    static_assert(NC == 32, "tile is 2 x 2 MFMA tiles");
+// One forward timestep.  grid = (ceil(H / JT), ndir, ceil(maxB / 32)), NW * 64 threads.
+// Workgroup tile: 32 batch rows x (4 gates x JT hidden units) = 32 x NC outputs, NC = 4 JT (16 or 32).
+// K (= H, padded to KP) is split over the NW wavefronts; every wavefront issues the float4 loads of
+// its whole K slice (CH 16-wide blocks) up front so that the L2 latency is paid once, not per block.
+template <int JT, int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(const LstmArgs A) {
+    constexpr int NC = 4 * JT;          // gate columns per workgroup
+    constexpr int NT = NC / 16;         // MFMA tiles along the gate columns
+    static_assert(NC % 16 == 0, "gate columns must fill MFMA tiles");
     const int dir = blockIdx.y;
     const int j0 = blockIdx.x * JT;
     const int m0 = blockIdx.z * 32;
-    const int t = dir == 0 ? A.step : A.T - 1 - A.step;
-    const int nb = A.bs[t];
+    const int nb = A.m.nb[dir];
     if (m0 >= nb) return;
-    const long long row0 = A.offs[t];
-    const int tp = dir == 0 ? t - 1 : t + 1;
-    int nprev = 0;
-    long long prow0 = 0;
-    if (tp >= 0 && tp < A.T) {
-        nprev = min(A.bs[tp], nb);
-        prow0 = A.offs[tp];
-    }
+    const long long row0 = A.m.row0[dir];
+    const int nprev = A.m.nprev[dir];
+    const long long prow0 = A.m.prow0[dir];
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, r = lane & 15;
 
-    __shared__ float red[4][32][NC + 1];
-    const bool has_rec = nprev > m0;
+    __shared__ float red[NW][32][NC + 1];
+    const bool has_rec = nprev > m0 && !(A.dbg & 1);
+    const int mtiles = (min(nprev, m0 + 32) - m0 + 15) >> 4;   // 1 or 2 live row tiles
 
     // epilogue operands first: their latency hides behind the GEMM
     const int bl = tid / JT, u = tid - bl * JT;
     const int b = m0 + bl;
-    const bool act = b < nb && j0 + u < H;
+    const bool act = tid < 32 * JT && b < nb && j0 + u < H;
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     float cprev = 0.f;
     float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
@@ -81,19 +91,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs A) {
     }
 
     if (has_rec) {
-        f32x4 acc[2][2];
+        f32x4 acc[2][NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nblk = A.KP >> 4;
-        const int per = (nblk + 3) >> 2;
+        const int per = (nblk + NW - 1) / NW;
         const int kb0 = wave * per;
         const int kb1 = min(nblk, kb0 + per);
         const float* ap[2];
         bool av[2];
-        const float* bp[2];
-        bool bv[2];
+        const float* bp[NT];
+        bool bv[NT];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int i = m0 + mt * 16 + r;
@@ -101,36 +111,39 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs A) {
             ap[mt] = A.hy + (prow0 + (av[mt] ? i : 0)) * ld_h + dir * H + 4 * g4;
         }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             const int cidx = nt * 16 + r;
             const int gate = cidx / JT, uu = cidx - gate * JT;
             bv[nt] = j0 + uu < H;
             bp[nt] = A.w + ((long long)dir * G + gate * H + (bv[nt] ? j0 + uu : 0)) * A.KP + 4 * g4;
         }
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto load_a = [&](int mt, int kb) -> f32x4 {
-            const bool ok = av[mt] && (kb * 16 + 4 * g4 < H);
-            return ok ? *reinterpret_cast<const f32x4*>(ap[mt] + kb * 16) : zero;
-        };
-        auto load_b = [&](int nt, int kb) -> f32x4 {
-            return bv[nt] ? *reinterpret_cast<const f32x4*>(bp[nt] + kb * 16) : zero;
-        };
-        if (kb0 < kb1) {
-            f32x4 a_n[2], b_n[2];
-            a_n[0] = load_a(0, kb0); a_n[1] = load_a(1, kb0);
-            b_n[0] = load_b(0, kb0); b_n[1] = load_b(1, kb0);
-            for (int kb = kb0; kb < kb1; ++kb) {
-                const f32x4 a0 = a_n[0], a1 = a_n[1], b0 = b_n[0], b1 = b_n[1];
-                if (kb + 1 < kb1) {
-                    a_n[0] = load_a(0, kb + 1); a_n[1] = load_a(1, kb + 1);
-                    b_n[0] = load_b(0, kb + 1); b_n[1] = load_b(1, kb + 1);
-                }
+        for (int kc = kb0; kc < kb1; kc += CH) {
+            f32x4 a[CH][2], bq[CH][NT];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b0[q], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], b1[q], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b0[q], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], b1[q], acc[1][1], 0, 0, 0);
+            for (int i = 0; i < CH; ++i) {
+                const int kb = kc + i;
+                const bool in = kb < kb1;
+                const bool kin = in && (kb * 16 + 4 * g4 < H);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    a[i][mt] = (kin && av[mt]) ? *reinterpret_cast<const f32x4*>(ap[mt] + kb * 16) : zero;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bq[i][nt] = (in && bv[nt]) ? *reinterpret_cast<const f32x4*>(bp[nt] + kb * 16) : zero;
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (kc + i < kb1 && !(A.dbg & 2)) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0][q], bq[i][nt][q], acc[0][nt], 0, 0, 0);
+                            if (mtiles > 1 || (A.dbg & 8))
+                                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1][q], bq[i][nt][q], acc[1][nt], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
@@ -138,14 +151,19 @@ __global__ __launch_bounds__(256) void lstm_fwd_step_kernel(const LstmArgs A) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
         __syncthreads();
+        if (tid < 32 * JT) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cidx = q * JT + u;
-            pre[q] += (red[0][bl][cidx] + red[1][bl][cidx]) + (red[2][bl][cidx] + red[3][bl][cidx]);
+            for (int q = 0; q < 4; ++q) {
+                const int cidx = q * JT + u;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += red[w][bl][cidx];
+                pre[q] += s;
+            }
         }
     }
     if (act) {
@@ -172,43 +190,35 @@ struct LstmBwdArgs {
     const float* wt;
     float* dg;
     float* dcs;
-    const int32_t* bs;
-    const int64_t* offs;
-    int T, H, ndir, step;
+    int H, ndir;
+    StepMeta m;
 };
 
-// One backward timestep.  grid = (ceil(H / 16), ceil(maxB / 16), ndir), 256 threads.
-// Workgroup tile: 16 batch rows x 16 hidden units of dh_rec = dgates_{next} W_hh, K = 4H.
-__global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmBwdArgs A) {
+// One backward timestep.  grid = (ceil(H / 16), ceil(maxB / 16), ndir), NW * 64 threads.
+// Workgroup tile: 16 batch rows x 16 hidden units of dh_rec = dgates_{next} W_hh, K = 4H split
+// over NW wavefronts (each issues its whole K slice of float4 loads up front).
+template <int NW, int CH>
+__global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(const LstmBwdArgs A) {
     const int dir = blockIdx.z;
     const int n0 = blockIdx.x * 16;
     const int m0 = blockIdx.y * 16;
-    const int t = dir == 0 ? A.T - 1 - A.step : A.step;
-    const int nb = A.bs[t];
+    const int nb = A.m.nb[dir];
     if (m0 >= nb) return;
-    const long long row0 = A.offs[t];
-    const int tn = dir == 0 ? t + 1 : t - 1;      // processed by the previous launch
-    const int tp = dir == 0 ? t - 1 : t + 1;      // the forward pass' predecessor (for c_{t-1})
-    int nnext = 0, npv = 0;
-    long long nrow0 = 0, prow0 = 0;
-    if (tn >= 0 && tn < A.T) {
-        nnext = min(A.bs[tn], nb);
-        nrow0 = A.offs[tn];
-    }
-    if (tp >= 0 && tp < A.T) {
-        npv = min(A.bs[tp], nb);
-        prow0 = A.offs[tp];
-    }
+    const long long row0 = A.m.row0[dir];
+    // "next" = the time index the previous launch processed (its dgates feed dh_rec);
+    // "pv"   = the forward pass' predecessor (for c_{t-1})
+    const int nnext = A.m.nprev[dir], npv = A.m.npv[dir];
+    const long long nrow0 = A.m.prow0[dir], prow0 = A.m.qrow0[dir];
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, r = lane & 15;
 
-    __shared__ float red[4][16][17];
+    __shared__ float red[NW][16][17];
     const bool has_rec = nnext > m0;
-    const int bl = tid >> 4, jl = tid & 15;
+    const int bl = (tid >> 4) & 15, jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
-    const bool act = b < nb && j < H;
+    const bool act = tid < 256 && b < nb && j < H;
 
     // epilogue operands first
     float dh = 0.f, dc = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cprev = 0.f;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmBwdArgs A)
     if (has_rec) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const int nblk = G >> 4;
-        const int per = (nblk + 3) >> 2;
+        const int per = (nblk + NW - 1) / NW;
         const int kb0 = wave * per;
         const int kb1 = min(nblk, kb0 + per);
         const bool av = m0 + r < nnext;
@@ -237,23 +247,29 @@ __global__ __launch_bounds__(256) void lstm_bwd_step_kernel(const LstmBwdArgs A)
         const float* ap = A.dg + (nrow0 + (av ? m0 + r : 0)) * ld_g + (long long)dir * G + 4 * g4;
         const float* bp = A.wt + ((long long)dir * H + (bv ? n0 + r : 0)) * G + 4 * g4;
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (kb0 < kb1) {
-            f32x4 a_n = av ? *reinterpret_cast<const f32x4*>(ap + kb0 * 16) : zero;
-            f32x4 b_n = bv ? *reinterpret_cast<const f32x4*>(bp + kb0 * 16) : zero;
-            for (int kb = kb0; kb < kb1; ++kb) {
-                const f32x4 a = a_n, bb = b_n;
-                if (kb + 1 < kb1) {
-                    a_n = av ? *reinterpret_cast<const f32x4*>(ap + (kb + 1) * 16) : zero;
-                    b_n = bv ? *reinterpret_cast<const f32x4*>(bp + (kb + 1) * 16) : zero;
-                }
+        for (int kc = kb0; kc < kb1; kc += CH) {
+            f32x4 a[CH], bq[CH];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], bb[q], acc, 0, 0, 0);
+            for (int i = 0; i < CH; ++i) {
+                const bool in = kc + i < kb1;
+                a[i] = (in && av) ? *reinterpret_cast<const f32x4*>(ap + (kc + i) * 16) : zero;
+                bq[i] = (in && bv) ? *reinterpret_cast<const f32x4*>(bp + (kc + i) * 16) : zero;
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) red[wave][g4 * 4 + q][r] = acc[q];
         __syncthreads();
-        if (b < nnext) dh += (red[0][bl][jl] + red[1][bl][jl]) + (red[2][bl][jl] + red[3][bl][jl]);
+        if (tid < 256 && b < nnext) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red[w][bl][jl];
+            dh += s;
+        }
     }
     if (act) {
         const float tc = tanhf(cn);
@@ -277,6 +293,15 @@ using namespace ptmi;
 
 extern "C" {
 
+static void neighbour(const int32_t* bs, const int64_t* offs, int T, int t, int tn, int* n, long long* row) {
+    *n = 0;
+    *row = 0;
+    if (tn >= 0 && tn < T) {
+        *n = bs[tn] < bs[t] ? bs[tn] : bs[t];
+        *row = offs[tn];
+    }
+}
+
 int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, const int32_t* batch_sizes,
                       const int64_t* offsets, int32_t T, int32_t max_batch, int32_t H, int32_t KP,
                       int32_t ndir, ptmi_stream_t stream) {
@@ -284,11 +309,28 @@ int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, 
     PTMI_RETURN_IF(T < 0 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2), PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LstmArgs A{gates, hy, c, w_hh_pad, batch_sizes, offsets, T, H, KP, ndir, 0};
-    const dim3 grid((unsigned)((H + 7) / 8), (unsigned)ndir, (unsigned)((max_batch + 31) / 32));
+    const char* dbg_env = getenv("PTMI_LSTM_DBG");
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+    LstmArgs A{gates, hy, c, w_hh_pad, H, KP, ndir, dbg, {}};
+    // JT = 8 (32 gate columns per workgroup) reads h_{t-1} from half as many workgroups as JT = 4;
+    // measured faster at H = 600 (9.4 vs 10.3 us per step, B = 32) because the step is bound by
+    // operand traffic, not by the matrix cores.  JT = 4 only when H is too small to fill the chip.
+    const unsigned mz = (unsigned)((max_batch + 31) / 32);
+    bool small_tiles = (long long)((H + 7) / 8) * ndir * mz < 64;
+    if (dbg & 4) small_tiles = !small_tiles;
     for (int s = 0; s < T; ++s) {
-        A.step = s;
-        hipLaunchKernelGGL(lstm_fwd_step_kernel<8>, grid, dim3(256), 0, st, A);
+        for (int d = 0; d < ndir; ++d) {
+            const int t = d == 0 ? s : T - 1 - s;          // direction 1 walks time backwards
+            A.m.nb[d] = batch_sizes[t];
+            A.m.row0[d] = offsets[t];
+            neighbour(batch_sizes, offsets, T, t, d == 0 ? t - 1 : t + 1, &A.m.nprev[d], &A.m.prow0[d]);
+        }
+        if (small_tiles)
+            hipLaunchKernelGGL((lstm_fwd_step_kernel<4, 8, 5>), dim3((unsigned)((H + 3) / 4), (unsigned)ndir, mz),
+                               dim3(512), 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_fwd_step_kernel<8, 8, 5>), dim3((unsigned)((H + 7) / 8), (unsigned)ndir, mz),
+                               dim3(512), 0, st, A);
     }
     return launch_status();
 }
@@ -303,11 +345,17 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(dc_state, 0, sizeof(float) * (size_t)max_batch * ndir * H, st);
     if (e != hipSuccess) return (int)e;
-    LstmBwdArgs A{gates, c, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, H, ndir, 0};
+    LstmBwdArgs A{gates, c, dhy, w_hh_t, dgates, dc_state, H, ndir, {}};
     const dim3 grid((unsigned)((H + 15) / 16), (unsigned)((max_batch + 15) / 16), (unsigned)ndir);
     for (int s = 0; s < T; ++s) {
-        A.step = s;
-        hipLaunchKernelGGL(lstm_bwd_step_kernel, grid, dim3(256), 0, st, A);
+        for (int d = 0; d < ndir; ++d) {
+            const int t = d == 0 ? T - 1 - s : s;          // reverse of the forward order
+            A.m.nb[d] = batch_sizes[t];
+            A.m.row0[d] = offsets[t];
+            neighbour(batch_sizes, offsets, T, t, d == 0 ? t + 1 : t - 1, &A.m.nprev[d], &A.m.prow0[d]);
+            neighbour(batch_sizes, offsets, T, t, d == 0 ? t - 1 : t + 1, &A.m.npv[d], &A.m.qrow0[d]);
+        }
+        hipLaunchKernelGGL((lstm_bwd_step_kernel<16, 10>), grid, dim3(1024), 0, st, A);
     }
     return launch_status();
 }

@@ -32,8 +32,9 @@ class _PackMeta:
         self.max_batch = int(bs[0]) if self.T else 0
         offs = np.concatenate([[0], np.cumsum(bs)])
         self.rows = int(offs[-1])
-        self.bs_dev = torch.tensor(bs, dtype=torch.int32, device=device)
-        self.offs_dev = torch.tensor(offs[:-1], dtype=torch.int64, device=device)
+        # host-side copies: the C ABI turns them into per-launch kernel arguments
+        self.bs_host = np.ascontiguousarray(bs, dtype=np.int32)
+        self.offs_host = np.ascontiguousarray(offs[:-1], dtype=np.int64)
         # index of the predecessor row (forward sense) per direction; `rows` = "no predecessor"
         prev = np.full((2, self.rows), self.rows, dtype=np.int64)
         for t in range(self.T):
@@ -68,7 +69,7 @@ class _LstmLayerFn(torch.autograd.Function):
         c = torch.empty_like(hy)
         _lib.check(_lib.timed(
             'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
-            w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(), meta.T, meta.max_batch,
+            w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T, meta.max_batch,
             H, KP, ndir, _lib.stream(x.device)), 'ptmi_lstm_forward')
         ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy)
         ctx.meta = meta
@@ -86,8 +87,8 @@ class _LstmLayerFn(torch.autograd.Function):
         dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
         _lib.check(_lib.timed(
             'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
-            w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_dev.data_ptr(),
-            meta.offs_dev.data_ptr(), meta.T, meta.max_batch, H, ndir, _lib.stream(x.device)),
+            w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
+            meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, _lib.stream(x.device)),
             'ptmi_lstm_backward')
         dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
