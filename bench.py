@@ -86,6 +86,16 @@ def cpu_baseline(max_seconds=25.):
                        f'os.cpu_count()={os.cpu_count()}')
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_traffic.json: rocprofv3
+    FETCH_SIZE / WRITE_SIZE in separate passes of this same command, FETCH_SIZE doubled as the
+    MI355X guide prescribes for gfx950).  None when no measurement is committed."""
+    f = REPO / 'profiles' / 'pmc_traffic.json'
+    if not f.exists():
+        return None
+    return json.loads(f.read_text()).get(kernel, {}).get('hbm_bytes_per_launch')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -188,7 +198,7 @@ def main():
                 'global_batch': BATCH * world,
                 'frames_per_step': frames_per_step * world,
                 'parallelism': f'dp{world}',
-                'blstm': 'torch.nn.LSTM (MIOpen)',
+                'blstm': 'HIP recurrence (csrc/lstm.hip)' if model.hip_blstm else 'torch.nn.LSTM (MIOpen)',
             },
             'roofline': {
                 'kernel': 'pit_features_kernel<Plan<16,16>> (fused STFT front-end)',
@@ -197,7 +207,7 @@ def main():
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK_GBS,
-                'traffic': None,
+                'traffic': measured_traffic('pit_features'),
                 'algorithmic_bytes_per_launch': alg_bytes,
                 'avg_launch_ms': kern_ms,
             },
