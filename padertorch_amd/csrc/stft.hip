@@ -17,6 +17,10 @@
 //  * the inverse runs the same machinery backwards and overlap-adds from LDS; halo frames are
 //    recomputed (ceil(L/shift)-1 per workgroup) so the result is deterministic (no atomics).
 // The kernels are HBM-bound (2568 algorithmic bytes per frame at size 512 / shift 128).
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.h"
 #include "fft_regs.h"
 
@@ -50,9 +54,13 @@ struct FwdArgs {
     long long x_row_stride;
     long long num_samples;
     long long out_frames;
+    long long batch;
     int nchunks;
     int layout;
     int K;
+    int ngroups;     // features: frame groups per workgroup
+    int dbg;         // PTMI_STFT_DBG ablation bits (1: no stores, 2: no FFT, 4: no loads)
+    bool aligned2;   // every frame start is 8-byte aligned -> float2 sample loads
     float edge_scale;
     Geo g;
 };
@@ -176,113 +184,356 @@ __device__ __forceinline__ cpx split_bin(const cpx* zb, const cpx* tws, int k) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward kernels, wave-private pipelines: every wavefront owns FPW frames of ONE signal from the
+// global loads to the stores (no workgroup barrier on the way), so the wavefronts of a CU drift
+// apart and overlap each other's load / FFT / store phases.
+__device__ __forceinline__ void wave_sync() {
+    // LDS hand-off between lanes of ONE wavefront: DS operations of a wavefront execute in order,
+    // so only the compiler must be kept from reordering across this point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// tables shared by the workgroup + per-wavefront spectrum buffers (+ features: phasors of Y)
 template <class PL>
-__global__ __launch_bounds__(256, 3) void stft_fwd_kernel(const FwdArgs A) {
-    constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
+struct WaveLds {
+    cpx* tws;    // [F+1]      split twiddles W_size^k
+    cpx* tw1t;   // [R1][LPF]  inter-stage twiddles
+    float* win;  // [SIZE]     window, zero beyond window_length
+    cpx* buf;    // [nwaves][FPW][FS]
+    cpx* yph;    // [ngroups][FPW][YS]  unit phasors of the mixture spectrum (features only)
+    static constexpr int YS = (PL::F + 1) & ~1;
+    __device__ __forceinline__ WaveLds(char* smem, int nwaves) {
+        tws = reinterpret_cast<cpx*>(smem);
+        tw1t = tws + PL::F + 1;
+        win = reinterpret_cast<float*>(tw1t + PL::R1 * PL::LPF);
+        buf = reinterpret_cast<cpx*>(win + PL::SIZE);
+        yph = buf + nwaves * PL::FPW * PL::FS;
+    }
+    static size_t bytes(int nwaves, int ngroups) {
+        return sizeof(cpx) * (PL::F + 1 + PL::R1 * PL::LPF + (size_t)nwaves * PL::FPW * PL::FS +
+                              (size_t)ngroups * PL::FPW * YS) + sizeof(float) * PL::SIZE;
+    }
+};
+
+template <class PL>
+__device__ __forceinline__ void load_tables_w(const WaveLds<PL>& S, const float* __restrict__ window,
+                                              const cpx* __restrict__ twiddle, int L, int tid, int nthr) {
+    for (int i = tid; i <= PL::M; i += nthr) S.tws[i] = twiddle[i];
+    for (int i = tid; i < PL::SIZE; i += nthr) S.win[i] = (i < L) ? window[i] : 0.f;
+    for (int i = tid; i < PL::R1 * PL::LPF; i += nthr) {
+        const int k1 = i / PL::LPF, l = i - k1 * PL::LPF;
+        S.tw1t[i] = tw_full<PL::M>(twiddle, (2 * l * k1) % PL::SIZE);
+    }
+}
+
+// Windowed even/odd packed samples of one frame straight from global memory (L1/L2 absorb the
+// size/shift-fold overlap between the frames of a wavefront).  Fading / frame padding is a SELECT
+// on unconditionally issued loads from clamped addresses: a branch around each load would make the
+// compiler wait for every load separately (16 dependent round trips instead of one).
+template <class PL>
+__device__ __forceinline__ void load_windowed_global(cpx (&a)[PL::R1], const float* __restrict__ xrow, int n_b,
+                                                     int x0, int L, bool aligned, const float* win, int l) {
+    const int last = n_b > 0 ? n_b - 1 : 0;
+    if (aligned && n_b >= 2) {
+        // x0 and k are even, so (xi, xi+1) is an 8-byte aligned pair; only the pair that straddles
+        // the end of an odd-length row needs the separately loaded last sample.
+        const int cmax = (n_b - 2) & ~1;
+        const float xl = xrow[last];
+        float2 v[PL::R1];
+#pragma unroll
+        for (int n1 = 0; n1 < PL::R1; ++n1) {
+            const int xi = x0 + 2 * (PL::R2 * n1 + l);
+            const int c = min(max(xi, 0), cmax);
+            v[n1] = *reinterpret_cast<const float2*>(xrow + c);
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < PL::R1; ++n1) {
+            const int k = 2 * (PL::R2 * n1 + l);
+            const int xi = x0 + k;
+            float e = (xi >= 0 && xi < n_b) ? v[n1].x : 0.f;
+            const float o = (xi + 1 >= 0 && xi + 1 < n_b) ? v[n1].y : 0.f;
+            if (xi == last && xi > cmax) e = xl;
+            a[n1] = cpx{e * win[k], o * win[k + 1]};
+        }
+    } else {
+        float ve[PL::R1], vo[PL::R1];
+#pragma unroll
+        for (int n1 = 0; n1 < PL::R1; ++n1) {
+            const int xi = x0 + 2 * (PL::R2 * n1 + l);
+            ve[n1] = xrow[min(max(xi, 0), last)];
+            vo[n1] = xrow[min(max(xi + 1, 0), last)];
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < PL::R1; ++n1) {
+            const int k = 2 * (PL::R2 * n1 + l);
+            const int xi = x0 + k;
+            const float e = (n_b > 0 && xi >= 0 && xi < n_b) ? ve[n1] : 0.f;
+            const float o = (n_b > 0 && xi + 1 >= 0 && xi + 1 < n_b) ? vo[n1] : 0.f;
+            a[n1] = cpx{e * win[k], o * win[k + 1]};
+        }
+    }
+}
+
+// Interior frames (every sample of the wavefront's frames lies inside the row, 8-byte aligned):
+// immediate-offset float2 loads and float2 window reads, no clamps / selects.
+template <class PL>
+__device__ __forceinline__ void load_windowed_interior(cpx (&a)[PL::R1], const float* __restrict__ xf,
+                                                       const float* win, int l) {
+    const float2* __restrict__ px = reinterpret_cast<const float2*>(xf) + l;
+    const float2* pw = reinterpret_cast<const float2*>(win) + l;
+    float2 v[PL::R1];
+#pragma unroll
+    for (int n1 = 0; n1 < PL::R1; ++n1) v[n1] = px[PL::R2 * n1];
+#pragma unroll
+    for (int n1 = 0; n1 < PL::R1; ++n1) {
+        const float2 w = pw[PL::R2 * n1];
+        a[n1] = cpx{v[n1].x * w.x, v[n1].y * w.y};
+    }
+}
+
+template <class PL>
+__device__ __forceinline__ void load_frames(cpx (&a)[PL::R1], const float* __restrict__ xrow, int n_b, int tw0,
+                                            int fl, int l, const Geo& g, bool aligned, const float* win) {
+    const int x_first = tw0 * g.shift - g.pad_left;
+    const int x_last = (tw0 + PL::FPW - 1) * g.shift - g.pad_left + PL::SIZE;
+    if (aligned && x_first >= 0 && x_last <= n_b) {          // wave-uniform
+        if (l < PL::R2) load_windowed_interior<PL>(a, xrow + x_first + fl * g.shift, win, l);
+    } else {
+        load_windowed_global<PL>(a, xrow, n_b, x_first + fl * g.shift, g.L, aligned, win, l);
+    }
+}
+
+// Two-step complex FFT of the FPW frames of ONE wavefront (wave-level hand-offs only).
+template <class PL, bool INV>
+__device__ __forceinline__ void fft_to_lds_wave(cpx (&a)[PL::R1], cpx* fbuf, int l, const cpx* tw1t) {
+    constexpr int R1 = PL::R1, R2 = PL::R2, P = PL::P;
+    if (l < R2) {
+        fft_dif<R1, INV>(a);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) {
+            const cpx v = a[bitrev<R1>(k1)];
+            const cpx w = tw1t[k1 * PL::LPF + l];
+            fbuf[k1 * P + l] = INV ? cmulc(v, w) : cmul(v, w);
+        }
+    }
+    wave_sync();
+    cpx c[R2];
+    if (l < R1) {
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) c[n2] = fbuf[l * P + n2];
+    }
+    wave_sync();
+    if (l < R1) {
+        fft_dif<R2, INV>(c);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) fbuf[l + R1 * k2] = c[bitrev<R2>(k2)];
+    }
+    wave_sync();
+}
+
+// Hermitian split of the bin pair (k, M-k) from Z[k], Z[M-k]:  with E = (Z[k] + conj Z[M-k])/2 and
+// Q = W^k (Z[k] - conj Z[M-k]) / (2i):  X[k] = E + Q,  X[M-k] = conj(E - Q).
+template <class PL>
+__device__ __forceinline__ void split_pair(const cpx* zb, const cpx* tws, int k, cpx& Xk, cpx& Xm) {
+    constexpr int M = PL::M;
+    const cpx z1 = zb[k & (M - 1)];
+    const cpx z2 = zb[(M - k) & (M - 1)];
+    const cpx w = tws[k];
+    const float ex = 0.5f * (z1.x + z2.x), ey = 0.5f * (z1.y - z2.y);
+    const float dx = 0.5f * (z1.x - z2.x), dy = 0.5f * (z1.y + z2.y);
+    const float qx = dy * w.x + dx * w.y, qy = dy * w.y - dx * w.x;   // (-i D) * w
+    Xk = cpx{ex + qx, ey + qy};
+    Xm = cpx{ex - qx, qy - ey};
+}
+
+template <class PL>
+__global__ __launch_bounds__(256) void stft_fwd_kernel(const FwdArgs A) {
+    constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
+    constexpr int NP = M / 2 + 1;   // bin pairs (k, M-k) per frame
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FwdLds<PL> S(smem);
+    const WaveLds<PL> S(smem, 4);
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / A.nchunks;
-    const int t0 = (blockIdx.x - b * A.nchunks) * FPB;
-    const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
-    const int frames_b = (int)row_frames_of(A.g, n_b);
     const int lane = tid & 63, wave = tid >> 6;
     const int fl = lane / LPF, l = lane - fl * LPF;
-    const int fb = wave * FPW + fl;
+    cpx* wbuf = S.buf + wave * FPW * FS;
+    const float es = A.edge_scale;
 
-    stage_signal<PL>(S.sig, A.x + (long long)b * A.x_row_stride, n_b, t0, A.g, tid);
-    load_tables<PL>(S, A.window, A.twiddle, A.g.L, tid);
+    load_tables_w<PL>(S, A.window, A.twiddle, A.g.L, tid, 256);
     __syncthreads();
 
-    cpx a[PL::R1];
-    load_windowed<PL>(a, S.sig + fb * A.g.shift, S.win, l);
-    fft_to_lds<PL, false>(a, S.buf + fb * FS, l, S.tw1t);
+    // persistent wavefronts: work item = FPW consecutive frames of one row; nchunks items per row
+    const unsigned items = (unsigned)(A.batch * A.nchunks);
+    for (unsigned item = blockIdx.x * 4 + wave; item < items; item += gridDim.x * 4) {
+        const int b = (int)(item / (unsigned)A.nchunks);
+        const int tw0 = (int)(item - (unsigned)b * (unsigned)A.nchunks) * FPW;
+        const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
+        const int frames_b = (int)row_frames_of(A.g, n_b);
+        const float* xrow = A.x + (long long)b * A.x_row_stride;
+        cpx a[PL::R1];
+        if (!(A.dbg & 4))
+            load_frames<PL>(a, xrow, n_b, tw0, fl, l, A.g, A.aligned2, S.win);
+        else
+            for (int i = 0; i < PL::R1; ++i) a[i] = cpx{(float)(lane + i), 1.f};
+        if (!(A.dbg & 2))
+            fft_to_lds_wave<PL, false>(a, wbuf + fl * FS, l, S.tw1t);
+        else
+            for (int i = 0; i < PL::R1; ++i) wbuf[fl * FS + i * LPF + l] = a[i];
 
-    // epilogue: this wavefront's FPW frames are FPW*F consecutive complex outputs of one row
-    const int tw0 = t0 + wave * FPW;
-    const int nvalid = min(FPW, (int)A.out_frames - tw0) * F;     // outputs inside [0, out_frames)
-    float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * (2 * F);
-    const cpx* zw = S.buf + wave * FPW * FS;
-    const float es = A.edge_scale;
-    for (int idx = lane; idx < nvalid; idx += 64) {
-        const int f = idx / F, k = idx - f * F;
-        cpx X = split_bin<PL>(zw + f * FS, S.tws, k);
-        if (k == 0 || k == M) X = cpx{X.x * es, es == 1.f ? X.y : 0.f};
-        if (tw0 + f >= frames_b) X = cpx{0.f, 0.f};
-        if (A.layout == PTMI_LAYOUT_INTERLEAVED) {
-            reinterpret_cast<float2*>(orow)[idx] = make_float2(X.x, X.y);
+        float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * (2 * F);
+        const int nfr = min(FPW, (int)A.out_frames - tw0);
+        const bool fast = nfr == FPW && tw0 + FPW <= frames_b && es == 1.f &&
+                          A.layout == PTMI_LAYOUT_INTERLEAVED && !(A.dbg & 1);
+        if (fast) {
+            // all frames live: pairs (k, M-k), k = 0..M/2-1, then the self-paired middle bins
+            float2* __restrict__ o2 = reinterpret_cast<float2*>(orow);
+#pragma unroll
+            for (int f = 0; f < FPW; ++f) {
+#pragma unroll
+                for (int k0 = 0; k0 < M / 2; k0 += 64) {
+                    const int k = k0 + lane;
+                    if (M / 2 >= 64 || k < M / 2) {
+                        cpx Xk, Xm;
+                        split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
+                        o2[f * F + k] = make_float2(Xk.x, Xk.y);
+                        o2[f * F + M - k] = make_float2(Xm.x, Xm.y);
+                    }
+                }
+            }
+            if (lane < FPW) {
+                cpx Xk, Xm;
+                split_pair<PL>(wbuf + lane * FS, S.tws, M / 2, Xk, Xm);
+                o2[lane * F + M / 2] = make_float2(Xk.x, Xk.y);
+            }
         } else {
-            orow[f * 2 * F + k] = X.x;
-            orow[f * 2 * F + F + k] = X.y;
+            for (int p = lane; p < nfr * NP; p += 64) {
+                const int f = p / NP, k = p - f * NP;
+                cpx Xk, Xm;
+                split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
+                if (k == 0) {   // DC and Nyquist
+                    Xk = cpx{Xk.x * es, es == 1.f ? Xk.y : 0.f};
+                    Xm = cpx{Xm.x * es, es == 1.f ? Xm.y : 0.f};
+                }
+                if (tw0 + f >= frames_b) Xk = Xm = cpx{0.f, 0.f};
+                const int km = M - k;
+                if ((A.dbg & 1) && Xk.x != 123456.f) continue;
+                if (A.layout == PTMI_LAYOUT_INTERLEAVED) {
+                    float2* o2 = reinterpret_cast<float2*>(orow) + f * F;
+                    o2[k] = make_float2(Xk.x, Xk.y);
+                    if (km != k) o2[km] = make_float2(Xm.x, Xm.y);
+                } else {
+                    float* o1 = orow + f * 2 * F;
+                    o1[k] = Xk.x;
+                    o1[F + k] = Xk.y;
+                    if (km != k) {
+                        o1[km] = Xm.x;
+                        o1[F + km] = Xm.y;
+                    }
+                }
+            }
         }
+        wave_sync();   // the next item's transposition reuses wbuf
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // Fused PIT front-end: Y_abs [B,T,F], X_abs / cos_phase_difference [B,T,K,F].
-// cos(angle(Y) - angle(X)) = Re(Y conj X) / (|Y| |X|), with angle(0) := 0 like np.angle.
+// Workgroup = NG frame groups x (K+1) wavefronts; wavefront (g, q) transforms signal q (0 = mixture,
+// q >= 1 = source q-1) of frame group g.  The mixture wavefront leaves the unit phasors of Y in LDS;
+// after ONE workgroup barrier the source wavefronts form cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)
+// (angle(0) := 0 like np.angle).
+__device__ __forceinline__ void mag_phasor(cpx X, float& mag, cpx& ph) {
+    const float p = X.x * X.x + X.y * X.y;
+    const float r = __builtin_amdgcn_rsqf(p);            // 1/|X|; inf at 0, selected away below
+    mag = p > 0.f ? p * r : 0.f;
+    ph = p > 0.f ? cpx{X.x * r, X.y * r} : cpx{1.f, 0.f};
+}
+
 template <class PL>
-__global__ __launch_bounds__(256, 3) void pit_features_kernel(const FwdArgs A) {
-    constexpr int F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
-    constexpr int NIT = PL::NIT;
+__global__ __launch_bounds__(1024) void pit_features_kernel(const FwdArgs A) {
+    constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
+    constexpr int NP = M / 2 + 1, YS = WaveLds<PL>::YS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const FwdLds<PL> S(smem);
+    const int nsig = A.s ? A.K + 1 : 1;
+    const int nwaves = blockDim.x >> 6;
+    const WaveLds<PL> S(smem, nwaves);
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.x / A.nchunks;
-    const int t0 = (blockIdx.x - b * A.nchunks) * FPB;
-    const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
-    const int frames_b = (int)row_frames_of(A.g, n_b);
     const int lane = tid & 63, wave = tid >> 6;
+    const int grp = wave / nsig, q = wave - grp * nsig;
     const int fl = lane / LPF, l = lane - fl * LPF;
-    const int fb = wave * FPW + fl;
-    const int tw0 = t0 + wave * FPW;
-    const int nvalid = min(FPW, (int)A.out_frames - tw0) * F;
-    const cpx* zw = S.buf + wave * FPW * FS;
+    cpx* wbuf = S.buf + wave * FPW * FS;
+    cpx* yph = S.yph + grp * FPW * YS;
 
-    load_tables<PL>(S, A.window, A.twiddle, A.g.L, tid);
+    load_tables_w<PL>(S, A.window, A.twiddle, A.g.L, tid, blockDim.x);
+    __syncthreads();
 
-    float yr[NIT], yi[NIT];  // mixture spectrum of this lane's epilogue items
-    const int nsig = A.s ? A.K + 1 : 1;
-    for (int q = 0; q < nsig; ++q) {
-        const float* row = (q == 0) ? A.x + (long long)b * A.x_row_stride
-                                    : A.s + ((long long)b * A.K + (q - 1)) * A.x_row_stride;
-        stage_signal<PL>(S.sig, row, n_b, t0, A.g, tid);
-        __syncthreads();
-        cpx a[PL::R1];
-        load_windowed<PL>(a, S.sig + fb * A.g.shift, S.win, l);
-        fft_to_lds<PL, false>(a, S.buf + fb * FS, l, S.tw1t);
-        // output rows of this wavefront: Y_abs (tw0.., F) contiguous; X_abs/cos (t, q-1, F) rows
-        float* __restrict__ yo = A.out + ((long long)b * A.out_frames + tw0) * F;
-        const long long xo = (((long long)b * A.out_frames + tw0) * A.K + (q - 1)) * F;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = lane + 64 * it;
-            if (idx < nvalid) {
-                const int f = idx / F, k = idx - f * F;
-                cpx X = split_bin<PL>(zw + f * FS, S.tws, k);
-                if (tw0 + f >= frames_b) X = cpx{0.f, 0.f};
-                const float p = X.x * X.x + X.y * X.y;
-                const float r = __builtin_amdgcn_rsqf(p);          // 1/|X| (inf at 0, handled below)
-                const float mag = p > 0.f ? p * r : 0.f;
-                if (q == 0) {
-                    yr[it] = X.x;
-                    yi[it] = X.y;
-                    yo[idx] = mag;
-                } else {
-                    const float py = yr[it] * yr[it] + yi[it] * yi[it];
-                    const float ry = __builtin_amdgcn_rsqf(py);
-                    // unit phasors (1, 0) for zero magnitudes
-                    const float cy = py > 0.f ? yr[it] * ry : 1.f, sy = py > 0.f ? yi[it] * ry : 0.f;
-                    const float cx = p > 0.f ? X.x * r : 1.f, sx = p > 0.f ? X.y * r : 0.f;
-                    const int o = f * A.K * F + k;
-                    A.X_abs[xo + o] = mag;
-                    A.cos_pd[xo + o] = (tw0 + f < frames_b) ? cy * cx + sy * sx : 0.f;
+    // persistent workgroups: work item = FPW frames of one example, handled by the nsig wavefronts
+    // of one group (wavefront q transforms signal q); every wavefront runs the same number of
+    // iterations (two barriers each: phasors of Y ready / consumed).
+    const unsigned items = (unsigned)(A.batch * A.nchunks);
+    const unsigned stride = gridDim.x * (unsigned)A.ngroups;
+    const unsigned iters = (items + stride - 1) / stride;
+    for (unsigned it = 0; it < iters; ++it) {
+        const unsigned item = it * stride + blockIdx.x * (unsigned)A.ngroups + grp;
+        const bool live = item < items;
+        const int b = live ? (int)(item / (unsigned)A.nchunks) : 0;
+        const int tw0 = live ? (int)(item - (unsigned)b * (unsigned)A.nchunks) * FPW : 0;
+        const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
+        const int frames_b = (int)row_frames_of(A.g, n_b);
+        const int nfr = live ? min(FPW, (int)A.out_frames - tw0) : 0;
+        if (live) {
+            const float* xrow = (q == 0) ? A.x + (long long)b * A.x_row_stride
+                                         : A.s + ((long long)b * A.K + (q - 1)) * A.x_row_stride;
+            cpx a[PL::R1];
+            load_frames<PL>(a, xrow, n_b, tw0, fl, l, A.g, A.aligned2, S.win);
+            fft_to_lds_wave<PL, false>(a, wbuf + fl * FS, l, S.tw1t);
+            if (q == 0) {
+                float* __restrict__ yo = A.out + ((long long)b * A.out_frames + tw0) * F;
+                for (int p = lane; p < nfr * NP; p += 64) {
+                    const int f = p / NP, k = p - f * NP, km = M - k;
+                    cpx Xk, Xm, pk, pm;
+                    float mk, mm;
+                    split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
+                    if (tw0 + f >= frames_b) Xk = Xm = cpx{0.f, 0.f};
+                    mag_phasor(Xk, mk, pk);
+                    mag_phasor(Xm, mm, pm);
+                    yo[f * F + k] = mk;
+                    yph[f * YS + k] = pk;
+                    if (km != k) {
+                        yo[f * F + km] = mm;
+                        yph[f * YS + km] = pm;
+                    }
                 }
             }
         }
-        __syncthreads();  // buf / sig are reused by the next signal
+        __syncthreads();   // phasors of Y are in LDS
+        if (live && q > 0) {
+            const long long xo = (((long long)b * A.out_frames + tw0) * A.K + (q - 1)) * F;
+            float* __restrict__ xa = A.X_abs + xo;
+            float* __restrict__ cp = A.cos_pd + xo;
+            const int fstride = A.K * F;
+            for (int p = lane; p < nfr * NP; p += 64) {
+                const int f = p / NP, k = p - f * NP, km = M - k;
+                cpx Xk, Xm, pk, pm;
+                float mk, mm;
+                split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
+                const bool valid = tw0 + f < frames_b;
+                if (!valid) Xk = Xm = cpx{0.f, 0.f};
+                mag_phasor(Xk, mk, pk);
+                mag_phasor(Xm, mm, pm);
+                const cpx yk = yph[f * YS + k], ym = yph[f * YS + km];
+                xa[f * fstride + k] = mk;
+                cp[f * fstride + k] = valid ? yk.x * pk.x + yk.y * pk.y : 0.f;
+                if (km != k) {
+                    xa[f * fstride + km] = mm;
+                    cp[f * fstride + km] = valid ? ym.x * pm.x + ym.y * pm.y : 0.f;
+                }
+            }
+        }
+        __syncthreads();   // yph / wbuf are rewritten by the next iteration
     }
 }
 
@@ -483,10 +734,6 @@ __global__ __launch_bounds__(256) void istft_generic_kernel(const InvArgs A) {
 
 // ------------------------------------------------------------------------------------------------
 template <class PL>
-static size_t fwd_smem_bytes(const Geo& g) {
-    return FwdLds<PL>::bytes(g.shift);
-}
-template <class PL>
 static size_t inv_smem_bytes(const Geo& g) {
     return sizeof(cpx) * ((size_t)PL::FPB * PL::FS + PL::F + 1 + PL::R1 * PL::LPF) +
            sizeof(float) * (g.L + 4);
@@ -496,16 +743,44 @@ constexpr size_t kMaxSmem = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB 
 
 template <class PL>
 static int launch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t st) {
-    const size_t smem = fwd_smem_bytes<PL>(A.g);
-    if (smem > kMaxSmem) return PTMI_E_UNSUPPORTED;
-    A.nchunks = (int)((A.out_frames + PL::FPB - 1) / PL::FPB);
-    const long long blocks = batch * A.nchunks;
-    if (blocks <= 0) return PTMI_OK;
-    if (blocks > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
-    if (features)
-        hipLaunchKernelGGL(pit_features_kernel<PL>, dim3((unsigned)blocks), dim3(256), smem, st, A);
-    else
+    const char* dbg_env = getenv("PTMI_STFT_DBG");
+    A.dbg = dbg_env ? atoi(dbg_env) : 0;
+    A.aligned2 = (A.x_row_stride % 2 == 0) && (A.g.shift % 2 == 0) && (A.g.pad_left % 2 == 0) &&
+                 (reinterpret_cast<uintptr_t>(A.x) % 8 == 0) &&
+                 (!A.s || reinterpret_cast<uintptr_t>(A.s) % 8 == 0);
+    if (!features) {
+        const size_t smem = WaveLds<PL>::bytes(4, 0);
+        if (smem > kMaxSmem) return PTMI_E_UNSUPPORTED;
+        A.batch = batch;
+        A.nchunks = (int)((A.out_frames + PL::FPW - 1) / PL::FPW);      // work items per row
+        const long long items = batch * A.nchunks;
+        if (items <= 0) return PTMI_OK;
+        if (items > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
+        // persistent grid: as many workgroups as stay resident (LDS bound), never more than needed
+        const long long resident = 256LL * (long long)((160 * 1024) / smem);
+        const long long blocks = std::min((items + 3) / 4, resident);
         hipLaunchKernelGGL(stft_fwd_kernel<PL>, dim3((unsigned)blocks), dim3(256), smem, st, A);
+        return launch_status();
+    }
+    const int nsig = A.s ? A.K + 1 : 1;
+    if (nsig > 16) return PTMI_E_UNSUPPORTED;
+    A.ngroups = nsig <= 4 ? 2 : 1;
+    const int nwaves = A.ngroups * nsig;
+    const size_t smem = WaveLds<PL>::bytes(nwaves, A.ngroups);
+    if (smem > 2 * kMaxSmem) return PTMI_E_UNSUPPORTED;
+    A.batch = batch;
+    A.nchunks = (int)((A.out_frames + PL::FPW - 1) / PL::FPW);          // work items per example
+    const long long items = batch * A.nchunks;
+    if (items <= 0) return PTMI_OK;
+    if (items > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
+    const long long resident = 256LL * (long long)((160 * 1024) / smem);
+    const long long blocks = std::min((items + A.ngroups - 1) / A.ngroups, resident);
+    if (smem > kMaxSmem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pit_features_kernel<PL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(pit_features_kernel<PL>, dim3((unsigned)blocks), dim3((unsigned)(64 * nwaves)), smem, st, A);
     return launch_status();
 }
 
