@@ -139,6 +139,27 @@ int ptmi_pit_backward(const float* est, const float* obs, const float* tgt, cons
                       float* grad, ptmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Deep-clustering loss.  Replaces deep_clustering_loss (padertorch/ops/losses/source_separation.py:
+ * 13-31) and the per-example review loop + re-layout of contrib/tcl/dc.py:73-84.
+ *   x  embeddings, element (b, t, e, f) at b*strides[0] + t*strides[1] + e*strides[2] + f*strides[3]
+ *   t  targets,    element (b, t, k, f) at b*strides[4] + t*strides[5] + k*strides[6] + f*strides[7]
+ *      rows of example b: n = (t, f), t < T_b (row_frames[b] or T), f < F;  N_b = T_b * F
+ *      (plain (N, E) / (N, K) matrices: T = N, F = 1, strides = {0, E, 1, 0, 0, K, 1, 0})
+ *   strides HOST int64[8];  E + K <= 32
+ *   gram    device float64 [batch, 32, 32]: V'V with V = [x | t] (zero padded)
+ *   ex_loss device float32 [batch]: (|X'X|^2 - 2|X'T|^2 + |T'T|^2) / N_b^2;  loss [1]: batch mean
+ *   workspace device float32 [ptmi_dc_workspace_elems(batch, T, F)]
+ * ------------------------------------------------------------------------------------------- */
+int64_t ptmi_dc_workspace_elems(int64_t batch, int64_t T, int32_t F);
+int ptmi_dc_loss_forward(const float* x, const float* t, int64_t batch, int64_t T, const int64_t* strides,
+                         int32_t E, int32_t K, int32_t F, const int32_t* row_frames, float* workspace,
+                         double* gram, float* ex_loss, float* loss, ptmi_stream_t stream);
+/* dx = gscale[0] / batch * 4 / N_b^2 * (x (X'X) - t (T'X)), same addressing as x. */
+int ptmi_dc_loss_backward(const float* x, const float* t, const double* gram, const float* gscale,
+                          int64_t batch, int64_t T, const int64_t* strides, int32_t E, int32_t K, int32_t F,
+                          const int32_t* row_frames, float* dx, ptmi_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Packed-sequence (B)LSTM recurrence (time loop of torch.nn.LSTM on a PackedSequence:
  * pit/model.py:60-66,97, contrib/tcl/dc.py:32-34,61; gate order i,f,g,o; zero initial state).
  * rows = packed time-major rows, row(t, b) = offsets[t] + b, b < batch_sizes[t] (descending).

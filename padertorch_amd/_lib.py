@@ -41,6 +41,9 @@ SIGNATURES = {
     'ptmi_pit_assign': (c_int, [_P, c_int64, c_int32, c_int32, c_int32, c_int64, _P, _P, _P, _P, _P]),
     'ptmi_pit_backward': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32,
                                   c_int32, _P, _P, _P]),
+    'ptmi_dc_workspace_elems': (c_int64, [c_int64, c_int64, c_int32]),
+    'ptmi_dc_loss_forward': (c_int, [_P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
+    'ptmi_dc_loss_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P]),
     'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
 }
@@ -109,3 +112,7 @@ def timed(name, fn, *args):
 
 def strides6(*vals):
     return (c_int64 * 6)(*vals)
+
+
+def strides8(*vals):
+    return (c_int64 * 8)(*vals)

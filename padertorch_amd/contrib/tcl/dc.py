@@ -5,6 +5,7 @@ from torch.nn.utils.rnn import PackedSequence
 
 from padertorch_amd import base
 from padertorch_amd import ops
+from padertorch_amd.ops.sequence.pack_module import PaddedList, as_padded
 
 
 class DeepClusteringModel(base.Model):
@@ -60,6 +61,15 @@ class DeepClusteringModel(base.Model):
         return ops.unpack_sequence(PackedSequence(h_data, h.batch_sizes))
 
     def review(self, batch, model_out):
+        """Mean deep-clustering loss of the batch (reference ``dc.py:73-84``: per-example loop over
+        re-laid-out copies).  A :class:`PaddedList` output is consumed in place by ONE fused HIP
+        pass; anything else follows the reference loop through ``deep_clustering_loss``."""
+        if isinstance(model_out, PaddedList):
+            tm, _, _ = as_padded(batch['target_mask'])
+            loss, _ = ops.losses.dc_loss_batched(
+                model_out.padded, tm, model_out.lengths_dev,
+                embedding_batch_first=model_out.batch_first)
+            return {'losses': {'dc_loss': loss}}
         dc_loss = list()
         for embedding, target_mask in zip(model_out, batch['target_mask']):
             E, K = embedding.shape[1], target_mask.shape[1]

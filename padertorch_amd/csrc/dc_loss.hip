@@ -1,0 +1,269 @@
+// Deep-clustering loss (Hershey 2016) for gfx950: single-pass Gram matrix on the matrix cores.
+//
+// Replaces padertorch/ops/losses/source_separation.py:13-31 (three einsum GEMMs over an (N, E) and an
+// (N, K) matrix that the caller first re-lays-out with 't e f -> (t f) e', contrib/tcl/dc.py:73-84):
+//     loss = (|X'X|_F^2 - 2 |X'T|_F^2 + |T'T|_F^2) / N^2,   N = T * F rows per example.
+// With V = [X | T] (N x D, D = E + K) all three products are blocks of the ONE Gram matrix V'V.
+// The kernel streams V once (HBM bound: D * 4 B per row), in whatever layout the caller has
+// (strided (t, c, f) addressing: the model's (T, E, F) embedding is consumed in place), stages one
+// tile of rows in LDS and accumulates V'V with v_mfma_f32_32x32x2_f32 (exact fp32; both operands of
+// the symmetric product are the SAME register).  Per-workgroup partial Grams are reduced in fp64 in a
+// fixed order (bitwise reproducible).  Backward: dX = 4/N^2 (X (X'X) - T (T'X)) as a streaming kernel.
+#include "common.h"
+
+namespace ptmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kDcMaxD = 32;      // E + K <= 32 (one 32x32 MFMA tile)
+constexpr int kDcTile = 256;     // rows (n) per LDS tile
+constexpr int kDcPitch = 258;    // LDS pitch (floats): even, conflict-free ds_read_b64 by 32 columns
+constexpr int kDcTilesPerWg = 8;
+
+struct DcArgs {
+    const float* x;
+    const float* t;
+    const int32_t* row_frames;
+    long long T;                 // time steps (padded length)
+    long long xs[4];             // x element (b, t, e, f) at b*xs[0] + t*xs[1] + e*xs[2] + f*xs[3]
+    long long ts[4];             // t element (b, t, k, f) likewise
+    int E, K, F;                 // F = inner extent per time step (rows n = t*F + f)
+    int nchunks;                 // workgroups per example
+};
+
+// Stage rows [n0, n0 + kDcTile) of example b (row n = (t, f) = (n / F, n % F)) of V^T into LDS:
+// lds[c][i] = V[n0 + i][c]; rows past N_b and columns past D are zero.
+__device__ __forceinline__ void dc_stage(float* lds, const DcArgs& A, int b, long long n0, long long N_b,
+                                         int tid) {
+    const int D = A.E + A.K;
+    const float* xb = A.x + b * A.xs[0];
+    const float* tb = A.t + b * A.ts[0];
+    const bool along_rows = A.xs[3] == 1;     // inner index contiguous: threads run along the rows
+    for (int idx = tid; idx < D * kDcTile; idx += 256) {
+        int c, i;
+        if (along_rows) {
+            c = idx / kDcTile;
+            i = idx - c * kDcTile;
+        } else {                              // column index contiguous (plain (N, E) rows)
+            i = idx / D;
+            c = idx - i * D;
+        }
+        const long long n = n0 + i;
+        float v = 0.f;
+        if (n < N_b) {
+            const long long tt = n / A.F;
+            const long long f = n - tt * A.F;
+            v = c < A.E ? xb[tt * A.xs[1] + c * A.xs[2] + f * A.xs[3]]
+                        : tb[tt * A.ts[1] + (c - A.E) * A.ts[2] + f * A.ts[3]];
+        }
+        lds[c * kDcPitch + i] = v;
+    }
+    for (int idx = tid; idx < (kDcMaxD - D) * kDcTile; idx += 256) {
+        const int c = D + idx / kDcTile, i = idx % kDcTile;
+        lds[c * kDcPitch + i] = 0.f;
+    }
+}
+
+// partial[b, chunk, 32, 32] (fp32) = V'V over the chunk's tiles
+__global__ __launch_bounds__(256) void dc_gram_kernel(const DcArgs A, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[kDcMaxD * kDcPitch];
+    __shared__ float red[4][32][33];
+    const int b = blockIdx.x / A.nchunks;
+    const int chunk = blockIdx.x - b * A.nchunks;
+    const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.T;
+    const long long N_b = T_b * A.F;
+    const long long ntiles = (N_b + kDcTile - 1) / kDcTile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int it = 0; it < kDcTilesPerWg; ++it) {
+        const long long tile = (long long)chunk * kDcTilesPerWg + it;
+        if (tile >= ntiles) break;                      // uniform
+        __syncthreads();                                // previous tile consumed
+        dc_stage(lds, A, b, tile * kDcTile, N_b, tid);
+        __syncthreads();
+        // wave w takes rows [64 w, 64 w + 64) of the tile; lane (c, h) rows 64 w + 32 h + 2 j + {0, 1}
+        const float* col = lds + c * kDcPitch + 64 * wave + 32 * h;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float2 v = *reinterpret_cast<const float2*>(col + 2 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
+        }
+    }
+    // C layout of mfma_f32_32x32x2: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int i = idx >> 5, j = idx & 31;
+        partial[((long long)blockIdx.x << 10) + idx] = (red[0][i][j] + red[1][i][j]) + (red[2][i][j] + red[3][i][j]);
+    }
+}
+
+// gram[b, 32, 32] (fp64) = sum over the example's chunks in order; ex_loss[b]; loss = batch mean
+__global__ void dc_reduce_kernel(const float* __restrict__ partial, double* __restrict__ gram,
+                                 float* __restrict__ ex_loss, int nchunks, int E, int K, int F,
+                                 const int32_t* row_frames, long long T) {
+    const int b = blockIdx.x;
+    const long long T_b = row_frames ? (long long)row_frames[b] : T;
+    const long long used = ((T_b * F + kDcTile - 1) / kDcTile + kDcTilesPerWg - 1) / kDcTilesPerWg;
+    __shared__ double part[256];
+    double mine = 0.0;
+    for (int idx = threadIdx.x; idx < 1024; idx += blockDim.x) {
+        double s = 0.0;
+        for (long long c = 0; c < used && c < nchunks; ++c) s += (double)partial[(((long long)b * nchunks + c) << 10) + idx];
+        gram[((long long)b << 10) + idx] = s;
+        const int i = idx >> 5, j = idx & 31;
+        const int D = E + K;
+        if (i < D && j < D) {
+            const double w = (i < E) == (j < E) ? 1.0 : -1.0;     // xx and tt blocks +, xt and tx blocks -
+            mine += w * s * s;
+        }
+    }
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < (int)blockDim.x; ++i) s += part[i];
+        const double N = (double)T_b * F;
+        ex_loss[b] = (float)(s / (N * N));
+    }
+}
+
+__global__ void dc_mean_kernel(const float* __restrict__ ex_loss, float* __restrict__ loss, int batch) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < batch; ++b) s += (double)ex_loss[b];
+        loss[0] = (float)(s / batch);
+    }
+}
+
+struct DcBwdArgs {
+    DcArgs a;
+    const double* gram;
+    const float* gscale;
+    float* dx;
+    long long batch;
+};
+
+// dx[b, t, e, f] = gscale / batch * 4 / N_b^2 * sum_i V[n, i] C[i, e],  C = [X'X ; -T'X]
+__global__ __launch_bounds__(256) void dc_backward_kernel(const DcBwdArgs B) {
+    const DcArgs& A = B.a;
+    __shared__ __attribute__((aligned(16))) float lds[kDcMaxD * kDcPitch];
+    __shared__ float Cm[kDcMaxD][kDcMaxD + 1];
+    const int b = blockIdx.x / A.nchunks;
+    const int chunk = blockIdx.x - b * A.nchunks;
+    const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.T;
+    const long long N_b = T_b * A.F;
+    const long long ntiles = (N_b + kDcTile - 1) / kDcTile;
+    const int tid = threadIdx.x;
+    const int D = A.E + A.K;
+    const double N = (double)T_b * A.F;
+    const float coef = T_b > 0 ? B.gscale[0] * (float)(4.0 / (N * N * (double)B.batch)) : 0.f;
+    for (int idx = tid; idx < D * A.E; idx += 256) {
+        const int i = idx / A.E, e = idx - i * A.E;
+        const double g = B.gram[((long long)b << 10) + i * 32 + e];
+        Cm[i][e] = (float)(i < A.E ? g : -g) * coef;
+    }
+    for (int it = 0; it < kDcTilesPerWg; ++it) {
+        const long long tile = (long long)chunk * kDcTilesPerWg + it;
+        if (tile >= ntiles) break;
+        const long long n0 = tile * kDcTile;
+        const int nf = (int)min((long long)kDcTile, N_b - n0);
+        __syncthreads();
+        dc_stage(lds, A, b, n0, N_b, tid);
+        __syncthreads();
+        float* dxb = B.dx + b * A.xs[0];
+        const bool along_rows = A.xs[3] == 1;
+        for (int idx = tid; idx < A.E * nf; idx += 256) {
+            int e, i;
+            if (along_rows) {
+                e = idx / nf;
+                i = idx - e * nf;
+            } else {
+                i = idx / A.E;
+                e = idx - i * A.E;
+            }
+            float s = 0.f;
+            for (int q = 0; q < D; ++q) s += lds[q * kDcPitch + i] * Cm[q][e];
+            const long long n = n0 + i;
+            const long long tt = n / A.F;
+            const long long f = n - tt * A.F;
+            dxb[tt * A.xs[1] + e * A.xs[2] + f * A.xs[3]] = s;
+        }
+    }
+}
+
+static int dc_fill(DcArgs& A, const float* x, const float* t, int64_t T, const int64_t* strides, int32_t E,
+                   int32_t K, int32_t F, const int32_t* row_frames) {
+    if (!x || !t || !strides || E < 1 || K < 1 || F < 1 || T < 0) return PTMI_E_INVALID;
+    if (E + K > kDcMaxD) return PTMI_E_UNSUPPORTED;
+    A.x = x;
+    A.t = t;
+    A.row_frames = row_frames;
+    A.T = T;
+    for (int i = 0; i < 4; ++i) {
+        A.xs[i] = strides[i];
+        A.ts[i] = strides[4 + i];
+    }
+    A.E = E;
+    A.K = K;
+    A.F = F;
+    A.nchunks = (int)(((T * F + kDcTile - 1) / kDcTile + kDcTilesPerWg - 1) / kDcTilesPerWg);
+    if (A.nchunks < 1) A.nchunks = 1;
+    return PTMI_OK;
+}
+
+}  // namespace ptmi
+
+using namespace ptmi;
+
+extern "C" {
+
+int64_t ptmi_dc_workspace_elems(int64_t batch, int64_t T, int32_t F) {
+    int64_t nchunks = ((T * F + kDcTile - 1) / kDcTile + kDcTilesPerWg - 1) / kDcTilesPerWg;
+    if (nchunks < 1) nchunks = 1;
+    return batch * nchunks * 1024;      // float32 elements
+}
+
+int ptmi_dc_loss_forward(const float* x, const float* t, int64_t batch, int64_t T, const int64_t* strides,
+                         int32_t E, int32_t K, int32_t F, const int32_t* row_frames, float* workspace,
+                         double* gram, float* ex_loss, float* loss, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!workspace || !gram || !ex_loss || !loss || batch < 1, PTMI_E_INVALID);
+    DcArgs A{};
+    int rc = dc_fill(A, x, t, T, strides, E, K, F, row_frames);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long blocks = (long long)batch * A.nchunks;
+    PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, workspace);
+    rc = launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(dc_reduce_kernel, dim3((unsigned)batch), dim3(256), 0, st, workspace, gram, ex_loss,
+                       A.nchunks, (int)E, (int)K, (int)F, row_frames, (long long)T);
+    hipLaunchKernelGGL(dc_mean_kernel, dim3(1), dim3(64), 0, st, ex_loss, loss, (int)batch);
+    return launch_status();
+}
+
+int ptmi_dc_loss_backward(const float* x, const float* t, const double* gram, const float* gscale,
+                          int64_t batch, int64_t T, const int64_t* strides, int32_t E, int32_t K, int32_t F,
+                          const int32_t* row_frames, float* dx, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!gram || !gscale || !dx || batch < 1, PTMI_E_INVALID);
+    DcBwdArgs B{};
+    int rc = dc_fill(B.a, x, t, T, strides, E, K, F, row_frames);
+    if (rc) return rc;
+    B.gram = gram;
+    B.gscale = gscale;
+    B.dx = dx;
+    B.batch = batch;
+    const long long blocks = (long long)batch * B.a.nchunks;
+    PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    hipLaunchKernelGGL(dc_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), B);
+    return launch_status();
+}
+
+}  // extern "C"

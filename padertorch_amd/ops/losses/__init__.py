@@ -1,3 +1,3 @@
 from . import source_separation
 from .source_separation import *  # noqa: F401,F403
-from .source_separation import pit_mse_ips_losses  # noqa: F401
+from .source_separation import pit_mse_ips_losses, dc_loss_batched  # noqa: F401

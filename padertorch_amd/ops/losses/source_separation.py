@@ -21,24 +21,94 @@ __all__ = [
     'deep_clustering_loss',
     'pit_loss',
 ]
+# like the reference (source_separation.py:7-10) the pairwise / Hungarian variants are importable
+# from this module but not part of ``__all__``: compute_pairwise_losses, pit_loss_from_loss_matrix
+
+
+class _DcFn(torch.autograd.Function):
+    """Batch-mean deep-clustering loss from ONE streaming Gram pass (``ptmi_dc_loss_forward``)."""
+
+    @staticmethod
+    def forward(ctx, x, t, row_frames, geom):
+        B, T, E, K, F, xs, ts = geom
+        lib = _lib.load()
+        dev = x.device
+        ws = torch.empty(int(lib.ptmi_dc_workspace_elems(B, T, F)), dtype=torch.float32, device=dev)
+        gram = torch.empty((B, 32, 32), dtype=torch.float64, device=dev)
+        ex_loss = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        strides = _lib.strides8(*xs, *ts)
+        _lib.check(_lib.timed(
+            'dc_loss_forward', lib.ptmi_dc_loss_forward, x.data_ptr(), t.data_ptr(), B, T, strides, E, K, F,
+            _lib.ptr(row_frames), ws.data_ptr(), gram.data_ptr(), ex_loss.data_ptr(), loss.data_ptr(),
+            _lib.stream(dev)), 'ptmi_dc_loss_forward')
+        ctx.save_for_backward(x, t, row_frames, gram)
+        ctx.geom = geom
+        ctx.mark_non_differentiable(ex_loss)
+        return loss[0], ex_loss
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_ex):
+        x, t, row_frames, gram = ctx.saved_tensors
+        B, T, E, K, F, xs, ts = ctx.geom
+        lib = _lib.load()
+        # rows past an example's length are never touched by the kernel -> zeros
+        dx = torch.zeros_like(x, memory_format=torch.preserve_format) if row_frames is not None \
+            else torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+        gs = g_loss.to(torch.float32).reshape(1).contiguous()
+        _lib.check(_lib.timed(
+            'dc_loss_backward', lib.ptmi_dc_loss_backward, x.data_ptr(), t.data_ptr(), gram.data_ptr(),
+            gs.data_ptr(), B, T, _lib.strides8(*xs, *ts), E, K, F, _lib.ptr(row_frames), dx.data_ptr(),
+            _lib.stream(x.device)), 'ptmi_dc_loss_backward')
+        return dx, None, None, None
 
 
 def deep_clustering_loss(x, t):
     """Deep clustering loss as in Hershey 2016 (``source_separation.py:13-31``).
 
+    yields losses in the range 0.01 to 1 due to the normalization with N^2.
+
     Args:
-        x: Shape (N, E), unit-norm embeddings.
+        x: Shape (N, E), where it is assumed that each embedding vector is normalized to unit norm.
         t: Target mask with shape (N, K).
     """
     _lib.require_gpu(x, t)
-    N = x.size()[0]
-    # (E+K)^2 Gram entries of an (N, E+K) matrix: three skinny GEMMs on the device BLAS for now;
-    # the fused single-pass HIP Gram kernel is SURVEY section 8 row f / config 5 ("next").
-    return (
-        torch.sum((x.t() @ x) ** 2)
-        - 2 * torch.sum((x.t() @ t) ** 2)
-        + torch.sum((t.t() @ t) ** 2)
-    ) / N ** 2
+    N, E = x.shape
+    K = t.shape[1]
+    assert t.shape[0] == N, (x.shape, t.shape)
+    if E + K > 32 or x.dtype != torch.float32:
+        # wider than one 32x32 matrix-core tile: the reference's three products on the device BLAS
+        t = t.to(x.dtype)
+        return (torch.sum((x.t() @ x) ** 2) - 2 * torch.sum((x.t() @ t) ** 2)
+                + torch.sum((t.t() @ t) ** 2)) / N ** 2
+    x = x.contiguous()
+    t = t.to(torch.float32).contiguous()
+    geom = (1, N, E, K, 1, (0, E, 1, 0), (0, K, 1, 0))
+    return _DcFn.apply(x, t, None, geom)[0]
+
+
+def dc_loss_batched(embedding, target_mask, lengths=None, *, embedding_batch_first=False,
+                    target_batch_first=True):
+    """Fused review of ``contrib/tcl/dc.py:73-84`` for a whole ragged batch: mean over examples of
+    ``deep_clustering_loss('t e f -> (t f) e', 't k f -> (t f) k')`` without the re-layout copies.
+
+    embedding ``[T,B,E,F]`` (or ``[B,T,E,F]``), target_mask ``[B,T,K,F]`` (or ``[T,B,K,F]``),
+    ``lengths``: int32 device tensor ``[B]`` or None.  Returns ``(loss, per_example[B])``.
+    """
+    _lib.require_gpu(embedding, target_mask, lengths)
+    assert embedding.dtype == torch.float32, embedding.dtype
+    target_mask = target_mask.to(torch.float32)
+    if embedding_batch_first:
+        B, T, E, F = embedding.shape
+    else:
+        T, B, E, F = embedding.shape
+    K = target_mask.shape[2]
+    assert E + K <= 32, 'dc_loss_batched handles E + K <= 32'
+    assert embedding.stride(-1) == 1 and target_mask.stride(-1) == 1
+    xb, xt = _bt_strides(embedding, embedding_batch_first, E * F)
+    tb, tt = _bt_strides(target_mask, target_batch_first, K * F)
+    geom = (B, T, E, K, F, (xb, xt, embedding.stride(2), 1), (tb, tt, target_mask.stride(2), 1))
+    return _DcFn.apply(embedding, target_mask, lengths, geom)
 
 
 class _PitFn(torch.autograd.Function):
@@ -177,4 +247,96 @@ def pit_loss(
     min_loss, idx = torch.min(torch.stack(candidates), dim=0)
     if return_permutation:
         return min_loss, permutations[int(idx)]
+    return min_loss
+
+
+def compute_pairwise_losses(
+        estimate: torch.Tensor,
+        target: torch.Tensor,
+        axis: int,
+        loss_fn=torch.nn.functional.mse_loss,
+):
+    """``L[i, j] = loss_fn(estimate_i, target_j)`` (``source_separation.py:127-241``).
+
+    For ``mse_loss`` the K x K matrix comes from the same single-pass HIP kernel as :func:`pit_loss`
+    (``ptmi_pit_pairwise_sse``; forward only - use :func:`pit_loss` for training); the
+    cross-entropy and generic branches follow the reference with torch ops on the device.
+    """
+    sources = estimate.size()[axis]
+    assert sources < 30, f'Are you sure? sources={sources}'
+    _lib.require_gpu(estimate, target)
+    if loss_fn in [torch.nn.functional.cross_entropy]:
+        assert axis % estimate.ndimension() == 1, axis
+        estimate_shape = list(estimate.shape)
+        del estimate_shape[1]
+        assert estimate_shape == list(target.shape), (
+            f'{estimate.shape} (N, K, ...) does not match {target.shape} (N, ...)'
+        )
+        logp = -torch.nn.functional.log_softmax(estimate, dim=1)                    # n c ...
+        onehot = torch.nn.functional.one_hot(target, num_classes=sources).to(estimate.dtype)  # n ... k
+        onehot = onehot.movedim(-1, 1)                                                  # n k ...
+        n = logp.numel() // sources
+        return torch.einsum('nc...,nk...->ck', logp, onehot) / n
+    assert estimate.size() == target.size(), f'{estimate.size()} != {target.size()}'
+    if loss_fn is torch.nn.functional.mse_loss and estimate.dtype == torch.float32 \
+            and target.dtype == torch.float32 and not (estimate.requires_grad or target.requires_grad):
+        axis = axis % estimate.ndim
+        outer = 1
+        for d in estimate.shape[:axis]:
+            outer *= d
+        inner = estimate.numel() // max(outer * sources, 1)
+        est = estimate.contiguous().view(1, outer, sources, inner)
+        tgt = target.contiguous().view(1, outer, sources, inner)
+        lib = _lib.load()
+        ws = torch.empty(int(lib.ptmi_pit_workspace_elems(1, outer, sources, inner)),
+                         dtype=torch.float64, device=est.device)
+        sse = torch.empty((1, 1, sources, sources), dtype=torch.float64, device=est.device)
+        _lib.check(lib.ptmi_pit_pairwise_sse(
+            est.data_ptr(), None, tgt.data_ptr(), None, 1, outer, _lib.strides6(
+                0, sources * inner, 0, 0, 0, sources * inner), sources, inner, None,
+            ws.data_ptr(), sse.data_ptr(), _lib.stream(est.device)), 'ptmi_pit_pairwise_sse')
+        return (sse[0, 0] / (outer * inner)).to(torch.float32)
+    indexer_e = [slice(None), ] * estimate.ndim
+    indexer_t = [slice(None), ] * target.ndim
+    pair_wise_loss_matrix = []
+    for i in range(sources):
+        indexer_e[axis] = i
+        for j in range(0, sources):
+            indexer_t[axis] = j
+            pair_wise_loss_matrix.append(loss_fn(estimate[tuple(indexer_e)], target[tuple(indexer_t)]))
+    return torch.stack(pair_wise_loss_matrix, 0).reshape(sources, sources)
+
+
+def pit_loss_from_loss_matrix(
+        pair_wise_loss_matrix,
+        *,
+        reduction='mean',
+        algorithm='optimal',
+        return_permutation=False,
+):
+    """PIT loss from a K x K pairwise loss matrix (``source_separation.py:244-312``).
+
+    The assignment runs on the host with ``scipy.optimize.linear_sum_assignment`` exactly like the
+    reference (one small D2H copy); returns scipy's ``col_ind`` (target index per estimate - the
+    inverse convention of :func:`pit_loss`).  ``algorithm='greedy'`` needs the third-party ``pb_bss``
+    package in the reference and is not provided here.
+    """
+    import scipy.optimize
+    assert len(pair_wise_loss_matrix.shape) == 2, pair_wise_loss_matrix.shape
+    assert pair_wise_loss_matrix.shape[-2] == pair_wise_loss_matrix.shape[-1], pair_wise_loss_matrix.shape
+    pair_wise_loss_np = pair_wise_loss_matrix.detach().cpu().numpy()
+    if algorithm in ('optimal', 'hungarian'):
+        row_ind, col_ind = scipy.optimize.linear_sum_assignment(pair_wise_loss_np)
+    else:
+        raise ValueError(algorithm)
+    if reduction is None:
+        min_loss = pair_wise_loss_matrix[row_ind, col_ind]
+    elif reduction == 'mean':
+        min_loss = pair_wise_loss_matrix[row_ind, col_ind].mean()
+    elif reduction == 'sum':
+        min_loss = pair_wise_loss_matrix[row_ind, col_ind].sum()
+    else:
+        raise ValueError(reduction)
+    if return_permutation:
+        return min_loss, col_ind
     return min_loss

@@ -103,6 +103,36 @@ def test_dc_loss_vs_reference(g1, g5):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g5['grad'], atol=1e-6)
 
 
+def test_dc_loss_batched_full_size_vs_oracle():
+    """Config-5 shape (K=3, E=20, F=257): fused batched kernel on the model's (T,B,E,F) layout vs the
+    fp64 oracle per example, value and gradient; ragged lengths."""
+    from oracle import losses_np
+    from padertorch_amd.ops.losses import dc_loss_batched
+    rng = np.random.RandomState(5)
+    lens, E, K, F = [37, 30, 30, 11], 20, 3, 257
+    B, T = len(lens), max(lens)
+    emb = rng.standard_normal((T, B, E, F)).astype(np.float32)
+    emb /= np.linalg.norm(emb, axis=2, keepdims=True)
+    tm = np.eye(K, dtype=np.float32)[rng.randint(0, K, (B, T, F))].transpose(0, 1, 3, 2).copy()
+    ref = [losses_np.deep_clustering_loss(emb[:l, b].transpose(0, 2, 1).reshape(-1, E),
+                                          tm[b, :l].transpose(0, 2, 1).reshape(-1, K)) for b, l in enumerate(lens)]
+    x = torch.from_numpy(emb).to(DEV).requires_grad_(True)
+    ld = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    loss, ex = dc_loss_batched(x, torch.from_numpy(tm).to(DEV), ld)
+    np.testing.assert_allclose(ex.cpu().numpy(), ref, rtol=2e-5)
+    np.testing.assert_allclose(loss.item(), np.mean(ref), rtol=2e-5)
+    loss.backward()
+    xt = torch.from_numpy(emb).double().requires_grad_(True)
+    tot = 0
+    for b, l in enumerate(lens):
+        X = xt[:l, b].permute(0, 2, 1).reshape(-1, E)
+        Tm = torch.from_numpy(tm[b, :l]).double().permute(0, 2, 1).reshape(-1, K)
+        N = X.shape[0]
+        tot = tot + (((X.t() @ X) ** 2).sum() - 2 * ((X.t() @ Tm) ** 2).sum() + ((Tm.t() @ Tm) ** 2).sum()) / N ** 2 / B
+    tot.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), xt.grad.numpy(), atol=1e-9, rtol=2e-4)
+
+
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()

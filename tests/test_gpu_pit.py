@@ -103,3 +103,25 @@ def test_full_size_property():
     assert l0.abs().max().item() == 0.
     # runs are bitwise reproducible (fixed reduction order)
     assert torch.equal(pit_mse_ips_losses(mask, Y, X, C)[2], ex)
+
+
+def test_pairwise_and_hungarian_vs_reference(g1, g4):
+    """compute_pairwise_losses + pit_loss_from_loss_matrix (source_separation.py:127-312)."""
+    from padertorch_amd.ops.losses.source_separation import compute_pairwise_losses, pit_loss_from_loss_matrix
+    for name in g4['names']:
+        if f'{name}_pairwise' not in g4:
+            continue
+        axis = int(g4[f'{name}_axis'])
+        pw = compute_pairwise_losses(torch.from_numpy(g4[f'{name}_est']).to(DEV),
+                                     torch.from_numpy(g4[f'{name}_tgt']).to(DEV), axis)
+        np.testing.assert_allclose(pw.cpu().numpy(), g4[f'{name}_pairwise'], rtol=1e-5)
+        loss, col = pit_loss_from_loss_matrix(pw, return_permutation=True)
+        np.testing.assert_allclose(loss.item(), g4[f'{name}_hungarian_loss'], rtol=1e-5)
+        assert list(col) == list(g4[f'{name}_hungarian_col'])
+    h = g1['hungarian']
+    got = pit_loss_from_loss_matrix(-torch.tensor(h['score'], device=DEV), reduction='sum')
+    assert got.item() == h['loss_sum']
+    # cross-entropy pairwise branch (source_separation.py:172-175 doctest: 0.6931 with 'sum')
+    est, tgt = torch.ones(4, 2, 5, device=DEV), torch.zeros(4, 5, dtype=torch.int64, device=DEV)
+    pw = compute_pairwise_losses(est, tgt, 1, loss_fn=torch.nn.functional.cross_entropy)
+    np.testing.assert_allclose(pit_loss_from_loss_matrix(pw, reduction='sum').item(), 0.6931, atol=1e-4)
