@@ -182,12 +182,25 @@ int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, 
  *   gates, c   saved by ptmi_lstm_forward;  dhy device [rows, ndir, H] gradient wrt hy
  *   w_hh_t     device [ndir, H, 4H]  (transposed recurrent weights)
  *   dgates     device [rows, ndir, 4, H]  out: gradient wrt the gate pre-activations
- *   dc_state   device [max_batch, ndir, H] scratch (zeroed by the call)
+ *   dc_state   device [max_batch, ndir, H] scratch (need not be initialised)
  * dW_ih, dW_hh, db and dx follow from dgates by dense GEMMs on the caller's side.
  */
 int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
                        float* dc_state, const int32_t* batch_sizes, const int64_t* offsets, int32_t T,
                        int32_t max_batch, int32_t H, int32_t ndir, ptmi_stream_t stream);
+
+/* Plans: the two time loops over FIXED buffers captured once as hipGraphs and replayed with one
+ * host call each (same buffers / bookkeeping arguments as ptmi_lstm_forward / ptmi_lstm_backward;
+ * dhy, w_hh_t, dgates, dc_state may be NULL for an inference-only plan).  The caller owns the
+ * buffers and must keep them alive and at the same addresses for the lifetime of the plan. */
+typedef struct ptmi_lstm_plan ptmi_lstm_plan;
+int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float* c, const float* w_hh_pad,
+                          const float* dhy, const float* w_hh_t, float* dgates, float* dc_state,
+                          const int32_t* batch_sizes, const int64_t* offsets, int32_t T, int32_t max_batch,
+                          int32_t H, int32_t KP, int32_t ndir);
+int ptmi_lstm_plan_forward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
+int ptmi_lstm_plan_backward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
+void ptmi_lstm_plan_destroy(ptmi_lstm_plan* plan);
 
 #ifdef __cplusplus
 }

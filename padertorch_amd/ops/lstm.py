@@ -11,6 +11,7 @@
   cores, fused gate non-linearities, activations saved in place for the backward pass;
 * weight / input gradients are dense GEMMs on the saved gate gradients.
 """
+import ctypes
 import functools
 
 import numpy as np
@@ -26,6 +27,7 @@ class _PackMeta:
     """Device-side bookkeeping of one ``batch_sizes`` vector (cached: batches repeat shapes)."""
 
     def __init__(self, batch_sizes, device):
+        self.key = tuple(batch_sizes)
         bs = np.asarray(batch_sizes, dtype=np.int64)
         assert np.all(bs[:-1] >= bs[1:]), 'batch_sizes must be non-increasing (sorted sequences)'
         self.T = int(len(bs))
@@ -54,6 +56,91 @@ def pack_meta(batch_sizes, device):
     return _meta(tuple(int(b) for b in batch_sizes.tolist()), (device.type, device.index))
 
 
+class _Workspace:
+    """Fixed device buffers of one (layer-call, packing pattern) + the hipGraph plan over them."""
+
+    def __init__(self, meta, ndir, H, device):
+        lib = _lib.load()
+        G, KP = 4 * H, (H + 15) // 16 * 16
+        f32 = dict(dtype=torch.float32, device=device)
+        self.gates = torch.empty((meta.rows, ndir * G), **f32)
+        self.hy = torch.empty((meta.rows, ndir * H), **f32)
+        self.c = torch.empty((meta.rows, ndir * H), **f32)
+        self.dhy = torch.empty((meta.rows, ndir * H), **f32)
+        self.dg = torch.empty((meta.rows, ndir * G), **f32)
+        self.dcs = torch.empty((meta.max_batch, ndir, H), **f32)
+        self.w_pad = torch.zeros((ndir, G, KP), **f32)
+        self.w_t = torch.empty((ndir, H, G), **f32)
+        self.busy = False
+        self.generation = 0
+        self.plan = ctypes.c_void_p()
+        _lib.check(lib.ptmi_lstm_plan_create(
+            ctypes.byref(self.plan), self.gates.data_ptr(), self.hy.data_ptr(), self.c.data_ptr(),
+            self.w_pad.data_ptr(), self.dhy.data_ptr(), self.w_t.data_ptr(), self.dg.data_ptr(),
+            self.dcs.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T,
+            meta.max_batch, H, KP, ndir), 'ptmi_lstm_plan_create')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'plan', None):
+                _lib.load().ptmi_lstm_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:       # interpreter shutdown
+            pass
+
+
+class _Lease:
+    """Exclusive use of a workspace from a forward call until its backward (or until dropped)."""
+
+    def __init__(self, ws):
+        self.ws = ws
+        ws.busy = True
+        ws.generation += 1
+        self.generation = ws.generation
+
+    def valid(self):
+        return self.ws is not None and self.ws.generation == self.generation
+
+    def release(self):
+        if self.ws is not None and self.ws.generation == self.generation:
+            self.ws.busy = False
+        self.ws = None
+
+    def __del__(self):
+        self.release()
+
+
+#: key -> [seen count, [workspaces]]; a plan is only built when a packing pattern repeats
+_POOL = {}
+_MAX_WS_PER_KEY = 8
+_MAX_KEYS = 16
+#: replay captured hipGraphs over pooled workspaces (saves host launches; the GPU time per step is
+#: the same as eager launches, so it only pays when the host is the bottleneck)
+USE_GRAPHS = False
+
+
+def _acquire(meta, ndir, H, device):
+    """A free workspace for this packing pattern, or None (-> eager launches)."""
+    if not USE_GRAPHS or meta.T < 8:
+        return None
+    key = (device.type, device.index, meta.key, ndir, H)
+    entry = _POOL.get(key)
+    if entry is None:
+        if len(_POOL) >= _MAX_KEYS:
+            _POOL.pop(next(iter(_POOL)))        # oldest pattern; its workspaces die with their leases
+        _POOL[key] = [1, []]
+        return None                             # first sighting: eager
+    entry[0] += 1
+    for ws in entry[1]:
+        if not ws.busy:
+            return _Lease(ws)
+    if len(entry[1]) >= _MAX_WS_PER_KEY:
+        return None
+    ws = _Workspace(meta, ndir, H, device)
+    entry[1].append(ws)
+    return _Lease(ws)
+
+
 class _LstmLayerFn(torch.autograd.Function):
     """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
 
@@ -63,33 +150,62 @@ class _LstmLayerFn(torch.autograd.Function):
         ndir, G, H = w_hh.shape
         assert G == 4 * H
         KP = (H + 15) // 16 * 16
-        gates = torch.addmm(bias, x, w_ih.t())                       # [rows, ndir*4H]
-        w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
-        hy = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
-        c = torch.empty_like(hy)
-        _lib.check(_lib.timed(
-            'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
-            w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T, meta.max_batch,
-            H, KP, ndir, _lib.stream(x.device)), 'ptmi_lstm_forward')
-        ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy)
+        lease = _acquire(meta, ndir, H, x.device)
+        st = _lib.stream(x.device)
+        if lease is not None:
+            ws = lease.ws
+            torch.addmm(bias, x, w_ih.t(), out=ws.gates)              # [rows, ndir*4H]
+            ws.w_pad[:, :, :H].copy_(w_hh)
+            _lib.check(_lib.timed('lstm_forward', lib.ptmi_lstm_plan_forward, ws.plan, st),
+                       'ptmi_lstm_plan_forward')
+            hy = ws.hy.clone()                                        # outputs never alias the workspace
+            ctx.save_for_backward(x, w_ih, w_hh)
+            ctx.lease = lease
+            if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
+                lease.release()
+        else:
+            gates = torch.addmm(bias, x, w_ih.t())
+            w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
+            hy = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
+            c = torch.empty_like(hy)
+            _lib.check(_lib.timed(
+                'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
+                w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T, meta.max_batch,
+                H, KP, ndir, st), 'ptmi_lstm_forward')
+            ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy)
+            ctx.lease = None
         ctx.meta = meta
         return hy
 
     @staticmethod
     def backward(ctx, dhy):
-        x, w_ih, w_hh, gates, c, hy = ctx.saved_tensors
-        meta = ctx.meta
+        meta, lease = ctx.meta, ctx.lease
         lib = _lib.load()
-        ndir, G, H = w_hh.shape
-        dhy = dhy.contiguous()
-        w_t = w_hh.transpose(1, 2).contiguous()                       # [ndir, H, 4H]
-        dg = torch.empty_like(gates)
-        dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.timed(
-            'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
-            w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
-            meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, _lib.stream(x.device)),
-            'ptmi_lstm_backward')
+        st = _lib.stream(dhy.device)
+        if lease is not None:
+            x, w_ih, w_hh = ctx.saved_tensors
+            if not lease.valid():
+                raise RuntimeError(
+                    'packed_lstm: the workspace of this forward pass has been released or reused (backward '
+                    'twice / retain_graph?). Set padertorch_amd.ops.lstm.USE_GRAPHS = False for that use.')
+            ws = lease.ws
+            ndir, G, H = w_hh.shape
+            ws.dhy.copy_(dhy)
+            ws.w_t.copy_(w_hh.transpose(1, 2))
+            _lib.check(_lib.timed('lstm_backward', lib.ptmi_lstm_plan_backward, ws.plan, st),
+                       'ptmi_lstm_plan_backward')
+            dg, hy = ws.dg, ws.hy
+        else:
+            x, w_ih, w_hh, gates, c, hy = ctx.saved_tensors
+            ndir, G, H = w_hh.shape
+            dhy = dhy.contiguous()
+            w_t = w_hh.transpose(1, 2).contiguous()                   # [ndir, H, 4H]
+            dg = torch.empty_like(gates)
+            dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
+            _lib.check(_lib.timed(
+                'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
+                w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
+                meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
         dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
         db = dg.sum(0)
@@ -98,6 +214,8 @@ class _LstmLayerFn(torch.autograd.Function):
         dgv = dg.view(meta.rows, ndir, G)
         dw_hh = torch.stack([dgv[:, d].t() @ hy_pad[:, d].index_select(0, meta.prev_dev[d])
                              for d in range(ndir)])
+        if lease is not None:
+            lease.release()
         return dx, dw_ih, db, dw_hh, None
 
 
