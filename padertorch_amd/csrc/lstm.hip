@@ -288,6 +288,324 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(const LstmBwdArg
     }
 }
 
+// ================================================================================================
+// Persistent forward recurrence: ONE launch per layer.  Every workgroup keeps its slice of W_hh in
+// registers for all T steps (the step-per-launch variant re-streams W_hh, 11.7 MB at H = 600, from
+// Infinity Cache on every step because L2 is invalidated at each kernel boundary) and the steps
+// are chained inside the launch:
+//   producer  h_t / c_t stores are write-through (sc1), drained (s_waitcnt vmcnt(0)) by every
+//             wavefront, then ONE lane adds 1 to the step's arrival counter (8 shards per
+//             direction and step, relaxed agent-scope atomics);
+//   consumer  wavefront 0 polls the 8 shards of step s-1 of ITS direction (relaxed loads +
+//             s_sleep), the workgroup barrier releases the other wavefronts, h_{t-1} / c_{t-1}
+//             are read with sc1 loads (never served from this CU's L1).
+// All rows of hy / c are written exactly once and never read before their producer's counter was
+// observed, so no stale copy can exist in any cache.  The two directions use separate counters and
+// drift freely.  Every workgroup must be resident (checked on the host against 256 CUs x 2);
+// every spin is bounded and reports through an error word instead of hanging.
+struct LstmPersistArgs {
+    float* gx;
+    float* hy;
+    float* c;
+    const float* w;
+    const int32_t* bs;       // device [T]
+    const int64_t* offs;     // device [T]
+    unsigned* flags;         // device [ndir][T][8] arrival counters + 1 error word, zeroed per call
+    int T, H, KP, ndir;
+    unsigned expected;       // workgroups per direction
+    unsigned max_polls;
+    int hy_bytes;
+};
+
+__device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expected, unsigned max_polls,
+                                              unsigned* err) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned it = 0; it < max_polls; ++it) {
+        unsigned v = lane < 8 ? __hip_atomic_load(cnt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v = __shfl(v, 0, 64);
+        if (v >= expected) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <int JT, int NW, int CH>
+__global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {
+    constexpr int NC = 4 * JT;
+    constexpr int NT = NC / 16;
+    const int dir = blockIdx.y;
+    const int j0 = blockIdx.x * JT;
+    const int m0 = blockIdx.z * 32;
+    const int H = A.H, G = 4 * H;
+    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, r = lane & 15;
+    __shared__ float red[NW][32][NC + 1];
+
+    // resident slice of W_hh: CH 16-wide K blocks of NT x 16 gate columns per wavefront
+    const int nblk = A.KP >> 4;
+    const int per = (nblk + NW - 1) / NW;         // <= CH (host checked)
+    const int kb0 = wave * per;
+    const int kb1 = min(nblk, kb0 + per);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bq[CH][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cidx = nt * 16 + r;
+        const int gate = cidx / JT, uu = cidx - gate * JT;
+        const bool bv = j0 + uu < H;
+        const float* bp = A.w + ((long long)dir * G + gate * H + (bv ? j0 + uu : 0)) * A.KP + 4 * g4;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            bq[i][nt] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
+    }
+    const __amdgpu_buffer_rsrc_t hy_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.hy, 0, A.hy_bytes, 0x00020000);
+    unsigned* const myflags = A.flags + (size_t)dir * A.T * 8;
+    unsigned* const err = A.flags + (size_t)A.ndir * A.T * 8;
+    const int bl = tid / JT, u = tid - bl * JT;
+    const int b = m0 + bl;
+
+    for (int s = 0; s < A.T; ++s) {
+        const int t = dir == 0 ? s : A.T - 1 - s;
+        const int nb = A.bs[t];
+        const long long row0 = A.offs[t];
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        int nprev = 0;
+        long long prow0 = 0;
+        if (tp >= 0 && tp < A.T) {
+            nprev = min(A.bs[tp], nb);
+            prow0 = A.offs[tp];
+        }
+        const bool has_rec = nprev > m0;                 // workgroup-uniform
+        const bool act = tid < 32 * JT && b < nb && j0 + u < H;
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        float cprev = 0.f;
+        float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
+        if (act) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = gp[q * H];
+        }
+        if (has_rec) {
+            if (wave == 0) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
+            __syncthreads();
+            if (act && b < nprev)
+                cprev = __hip_atomic_load(A.c + (prow0 + b) * ld_h + dir * H + j0 + u, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+            const int mtiles = (min(nprev, m0 + 32) - m0 + 15) >> 4;
+            f32x4 a[CH][2];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int kb = kb0 + i;
+                const bool kin = kb < kb1 && (kb * 16 + 4 * g4 < H);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int irow = m0 + mt * 16 + r;
+                    const bool ok = kin && irow < nprev;
+                    const unsigned voff = ok ? (unsigned)(((prow0 + irow) * ld_h + dir * H + kb * 16 + 4 * g4) * 4) : 0u;
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hy_rsrc, voff, 0, 16 /* sc1 */);
+                    a[i][mt] = ok ? __builtin_bit_cast(f32x4, v) : zero;
+                }
+            }
+            f32x4 acc[2][NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (kb0 + i < kb1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0][q], bq[i][nt][q], acc[0][nt], 0, 0, 0);
+                            if (mtiles > 1)
+                                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1][q], bq[i][nt][q], acc[1][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            __syncthreads();
+            if (tid < 32 * JT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cidx = q * JT + u;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += red[w][bl][cidx];
+                    pre[q] += sum;
+                }
+            }
+        }
+        if (act) {
+            const float ig = sigmoidf_(pre[0]);
+            const float fg = sigmoidf_(pre[1]);
+            const float gg = tanhf(pre[2]);
+            const float og = sigmoidf_(pre[3]);
+            const float cn = fg * cprev + ig * gg;
+            const float h = og * tanhf(cn);
+            gp[0] = ig;
+            gp[H] = fg;
+            gp[2 * H] = gg;
+            gp[3 * H] = og;
+            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
+            __hip_atomic_store(A.c + o, cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+            __hip_atomic_store(A.hy + o, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // publish step s: every wavefront drains its stores, then one lane arrives
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Persistent backward-through-time: the mirror of lstm_fwd_persistent_kernel.  Workgroup tile =
+// 16 batch rows x 16 hidden units; its slice of W_hh^T (16 rows x 4H) stays in the registers of its
+// 16 wavefronts for all T steps; dgates rows are published write-through and chained by per-step
+// arrival counters per direction; the cell-state gradient of element (b, j) lives in a register of
+// the one thread that owns it for the whole sequence.
+struct LstmPersistBwdArgs {
+    const float* gates;
+    const float* c;
+    const float* dhy;
+    const float* wt;
+    float* dg;
+    const int32_t* bs;
+    const int64_t* offs;
+    unsigned* flags;
+    int T, H, ndir;
+    unsigned expected;
+    unsigned max_polls;
+    int dg_bytes;
+};
+
+template <int NW, int CH>
+__global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
+    const int dir = blockIdx.z;
+    const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * 16;
+    const int H = A.H, G = 4 * H;
+    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, r = lane & 15;
+    __shared__ float red[NW][16][17];
+
+    const int nblk = G >> 4;
+    const int per = (nblk + NW - 1) / NW;          // <= CH (host checked)
+    const int kb0 = wave * per;
+    const int kb1 = min(nblk, kb0 + per);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bq[CH];
+    {
+        const bool bv = n0 + r < H;
+        const float* bp = A.wt + ((long long)dir * H + (bv ? n0 + r : 0)) * G + 4 * g4;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            bq[i] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
+    }
+    const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.dg, 0, A.dg_bytes, 0x00020000);
+    unsigned* const myflags = A.flags + (size_t)dir * A.T * 8;
+    unsigned* const err = A.flags + (size_t)A.ndir * A.T * 8;
+    const int bl = (tid >> 4) & 15, jl = tid & 15;
+    const int b = m0 + bl, j = n0 + jl;
+    float dc_state = 0.f;      // d loss / d c of (b, j) flowing to the next (earlier) step
+
+    for (int s = 0; s < A.T; ++s) {
+        const int t = dir == 0 ? A.T - 1 - s : s;
+        const int nb = A.bs[t];
+        const long long row0 = A.offs[t];
+        const int tn = dir == 0 ? t + 1 : t - 1;     // processed in iteration s - 1
+        const int tp = dir == 0 ? t - 1 : t + 1;     // forward-sense predecessor (c_{t-1})
+        int nnext = 0, npv = 0;
+        long long nrow0 = 0, prow0 = 0;
+        if (tn >= 0 && tn < A.T) {
+            nnext = min(A.bs[tn], nb);
+            nrow0 = A.offs[tn];
+        }
+        if (tp >= 0 && tp < A.T) {
+            npv = min(A.bs[tp], nb);
+            prow0 = A.offs[tp];
+        }
+        const bool has_rec = nnext > m0;
+        const bool act = tid < 256 && b < nb && j < H;
+        float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cprev = 0.f;
+        const long long oh = (row0 + b) * ld_h + dir * H + j;
+        const long long og_ = (row0 + b) * ld_g + (long long)dir * G + j;
+        if (act) {
+            dh = A.dhy[oh];
+            ig = A.gates[og_];
+            fg = A.gates[og_ + H];
+            gg = A.gates[og_ + 2 * H];
+            og = A.gates[og_ + 3 * H];
+            cn = A.c[oh];
+            if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
+        }
+        if (has_rec) {
+            if (wave == 0) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
+            __syncthreads();
+            const bool av = m0 + r < nnext;
+            f32x4 a[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const bool ok = av && kb0 + i < kb1;
+                const unsigned voff =
+                    ok ? (unsigned)(((nrow0 + m0 + r) * ld_g + (long long)dir * G + (kb0 + i) * 16 + 4 * g4) * 4) : 0u;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, voff, 0, 16 /* sc1 */);
+                a[i] = ok ? __builtin_bit_cast(f32x4, v) : zero;
+            }
+            f32x4 acc = zero;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[wave][g4 * 4 + q][r] = acc[q];
+            __syncthreads();
+            if (tid < 256 && b < nnext) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += red[w][bl][jl];
+                dh += sum;
+            }
+        }
+        if (act) {
+            float dc = b < nnext ? dc_state : 0.f;     // rows without a successor step start from 0
+            const float tc = tanhf(cn);
+            const float d_o = dh * tc;
+            dc += dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg;
+            const float d_g = dc * ig;
+            const float d_f = dc * cprev;
+            dc_state = dc * fg;
+            float* dgp = A.dg + og_;
+            __hip_atomic_store(dgp, d_i * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgp + H, d_f * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgp + 2 * H, d_g * (1.f - gg * gg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dgp + 3 * H, d_o * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 static void neighbour(const int32_t* bs, const int64_t* offs, int T, int t, int tn, int* n, long long* row) {
     *n = 0;
     *row = 0;
@@ -400,6 +718,60 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, con
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
     return enqueue_backward(gates, c, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, max_batch, H, ndir,
                             static_cast<hipStream_t>(stream));
+}
+
+int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir) { return (int64_t)ndir * T * 8 + 8; }
+
+int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* w_hh_pad,
+                                 const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
+                                 int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,
+                                 ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!gates || !hy || !c || !w_hh_pad || !batch_sizes_dev || !offsets_dev || !flags, PTMI_E_INVALID);
+    PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
+    PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
+    constexpr int NW = 8, CH = 5;
+    // the resident W slice must fit CH K-blocks per wavefront; all workgroups must be co-resident
+    // (512-thread workgroups at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2)
+    PTMI_RETURN_IF((KP / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    const unsigned mz = (unsigned)((max_batch + 31) / 32);
+    const long long wgs = (long long)((H + 7) / 8) * ndir * mz;
+    PTMI_RETURN_IF(wgs > 448, PTMI_E_UNSUPPORTED);
+    const long long hy_bytes = rows * ndir * H * 4;
+    PTMI_RETURN_IF(hy_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir), st);
+    if (e != hipSuccess) return (int)e;
+    LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
+                      (unsigned)(((H + 7) / 8) * mz), 1u << 22, (int)hy_bytes};
+    hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH>), dim3((unsigned)((H + 7) / 8), (unsigned)ndir, mz),
+                       dim3(NW * 64), 0, st, A);
+    return launch_status();
+}
+
+int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* dhy, const float* w_hh_t,
+                                  float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
+                                  int32_t ndir, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || !dgates || !batch_sizes_dev || !offsets_dev || !flags,
+                   PTMI_E_INVALID);
+    PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
+    PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
+    constexpr int NW = 16, CH = 10;
+    PTMI_RETURN_IF((4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    // 1024-thread workgroups: one per CU must be resident
+    const long long wgs = (long long)((H + 15) / 16) * ((max_batch + 15) / 16) * ndir;
+    PTMI_RETURN_IF(wgs > 240, PTMI_E_UNSUPPORTED);
+    const long long dg_bytes = rows * ndir * 4 * H * 4;
+    PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir), st);
+    if (e != hipSuccess) return (int)e;
+    LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
+                         (unsigned)(((H + 15) / 16) * ((max_batch + 15) / 16)), 1u << 22, (int)dg_bytes};
+    hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>),
+                       dim3((unsigned)((H + 15) / 16), (unsigned)((max_batch + 15) / 16), (unsigned)ndir),
+                       dim3(NW * 64), 0, st, A);
+    return launch_status();
 }
 
 int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float* c, const float* w_hh_pad,

@@ -37,6 +37,9 @@ class _PackMeta:
         # host-side copies: the C ABI turns them into per-launch kernel arguments
         self.bs_host = np.ascontiguousarray(bs, dtype=np.int32)
         self.offs_host = np.ascontiguousarray(offs[:-1], dtype=np.int64)
+        # device copies for the persistent kernels (read in-kernel, step by step)
+        self.bs_dev = torch.from_numpy(self.bs_host).to(device)
+        self.offs_dev = torch.from_numpy(self.offs_host).to(device)
         # index of the predecessor row (forward sense) per direction; `rows` = "no predecessor"
         prev = np.full((2, self.rows), self.rows, dtype=np.int64)
         for t in range(self.T):
@@ -117,6 +120,33 @@ _MAX_KEYS = 16
 #: replay captured hipGraphs over pooled workspaces (saves host launches; the GPU time per step is
 #: the same as eager launches, so it only pays when the host is the bottleneck)
 USE_GRAPHS = False
+#: run the forward recurrence as ONE persistent launch per layer (W_hh resident in registers)
+PERSISTENT = True
+#: read back the error words of the persistent kernels after every call (host sync; tests only)
+CHECK_PERSISTENT_ERRORS = False
+#: per-device accumulator of the persistent kernels' error words; `check_errors()` reads it (the
+#: Trainer does so once per optimizer step, where it synchronises anyway)
+_ERR_ACC = {}
+
+
+def _note_errors(flags):
+    key = (flags.device.type, flags.device.index)
+    acc = _ERR_ACC.get(key)
+    if acc is None:
+        acc = _ERR_ACC[key] = torch.zeros((), dtype=torch.int32, device=flags.device)
+    acc += flags[-8:].abs().sum()
+
+
+def check_errors():
+    """Raise if a bounded spin of a persistent LSTM kernel ran out since the last check (the
+    recurrence results are then invalid).  One small device-to-host copy per device."""
+    for key, acc in _ERR_ACC.items():
+        if int(acc) != 0:
+            acc.zero_()
+            raise RuntimeError(
+                f'padertorch_amd: a persistent LSTM kernel on {key} timed out waiting for a step counter '
+                '(workgroups not co-resident, e.g. the GPU is shared with another long-running kernel). '
+                'Set padertorch_amd.ops.lstm.PERSISTENT = False.')
 
 
 def _acquire(meta, ndir, H, device):
@@ -168,10 +198,25 @@ class _LstmLayerFn(torch.autograd.Function):
             w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
             hy = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
             c = torch.empty_like(hy)
-            _lib.check(_lib.timed(
-                'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
-                w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T, meta.max_batch,
-                H, KP, ndir, st), 'ptmi_lstm_forward')
+            rc = -2
+            if PERSISTENT:
+                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir)), dtype=torch.int32,
+                                    device=x.device)
+                rc = _lib.timed(
+                    'lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(),
+                    c.data_ptr(), w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
+                    flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, KP, ndir, st)
+                if rc not in (0, -2):
+                    _lib.check(rc, 'ptmi_lstm_forward_persistent')
+                if rc == 0:
+                    _note_errors(flags)
+                    if CHECK_PERSISTENT_ERRORS:
+                        check_errors()
+            if rc == -2:        # configuration not resident-able: one launch per timestep
+                _lib.check(_lib.timed(
+                    'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
+                    w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T,
+                    meta.max_batch, H, KP, ndir, st), 'ptmi_lstm_forward')
             ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy)
             ctx.lease = None
         ctx.meta = meta
@@ -201,11 +246,26 @@ class _LstmLayerFn(torch.autograd.Function):
             dhy = dhy.contiguous()
             w_t = w_hh.transpose(1, 2).contiguous()                   # [ndir, H, 4H]
             dg = torch.empty_like(gates)
-            dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
-            _lib.check(_lib.timed(
-                'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
-                w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
-                meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
+            rc = -2
+            if PERSISTENT:
+                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir)), dtype=torch.int32,
+                                    device=x.device)
+                rc = _lib.timed(
+                    'lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(),
+                    dhy.data_ptr(), w_t.data_ptr(), dg.data_ptr(), meta.bs_dev.data_ptr(),
+                    meta.offs_dev.data_ptr(), flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, ndir, st)
+                if rc not in (0, -2):
+                    _lib.check(rc, 'ptmi_lstm_backward_persistent')
+                if rc == 0:
+                    _note_errors(flags)
+                    if CHECK_PERSISTENT_ERRORS:
+                        check_errors()
+            if rc == -2:
+                dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
+                _lib.check(_lib.timed(
+                    'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
+                    w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
+                    meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
         dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
         db = dg.sum(0)

@@ -275,7 +275,9 @@ class Trainer:
         """trainer.py:740-780 incl. the non-finite check (one host sync per optimizer step)."""
         summary.setdefault('scalars', {})
         summary.setdefault('histograms', {})
-        grad_norm = float(self.optimizer.clip_grad())
+        grad_norm = float(self.optimizer.clip_grad())      # host sync
+        from ..ops import lstm as _lstm
+        _lstm.check_errors()                               # persistent-kernel watchdog words
         if not np.isfinite(grad_norm):
             path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': summary})
             raise RuntimeError(f'The grad_norm ({grad_norm}) is not finite.\n'

@@ -15,8 +15,9 @@ DEV = 'cuda:0'
     (257, 600, 1, True, [40, 37, 37, 20, 9, 3]),          # model size, ragged, B < 16
     (1200, 600, 1, True, [23] * 40 + [11] * 5),           # B > 32: two M chunks
 ])
-def test_packed_lstm_vs_torch_cpu(I, H, layers, bidir, lens):
-    from padertorch_amd.ops import packed_lstm
+def test_packed_lstm_vs_torch_cpu(I, H, layers, bidir, lens, monkeypatch):
+    from padertorch_amd.ops import packed_lstm, lstm as L
+    monkeypatch.setattr(L, 'CHECK_PERSISTENT_ERRORS', True)
     torch.manual_seed(I + H)
     ref = torch.nn.LSTM(I, H, layers, bidirectional=bidir)
     dut = torch.nn.LSTM(I, H, layers, bidirectional=bidir)
