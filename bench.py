@@ -38,6 +38,7 @@ BATCH = 32
 K = 2
 SIZE, SHIFT = 512, 128
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak (MI355X_MICROARCH.md)
 FEATURE_BYTES_PER_FRAME = 3 * SHIFT * 4 + (1 + 2 * K) * (SIZE // 2 + 1) * 4   # 6676 B at K=2
 PIT_LOSS_BYTES_PER_FRAME = (1 + 3 * K) * (SIZE // 2 + 1) * 4                  # 7196 B at K=2
 LOSS_WEIGHTS = dict(pit_ips_loss=1., pit_mse_loss=0.)      # pit/train.py:68-71
@@ -177,6 +178,18 @@ def main():
                       achieved=pit_bytes[n] / (float(np.mean(v)) * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
                       unit='GB/s', frac=pit_bytes[n] / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS)
                  for n, v in by_name.items() if n in pit_bytes]
+        # the BLSTM recurrence launches dominate the step (one persistent launch per layer and pass):
+        # exact-fp32 matrix-core work 2*B*H*4H per step and direction against the 157.3 TFLOP/s fp32
+        # MFMA peak; they are bound by the per-step dependency chain, not by the matrix cores
+        Hh, T = model.blstm.hidden_size, frames_per_step // BATCH
+        rec_flop = 2.0 * 2 * BATCH * Hh * 4 * Hh * T
+        for n in ('lstm_forward', 'lstm_backward'):
+            if n in by_name:
+                ms = float(np.mean(by_name[n]))
+                other.append(dict(kernel=n + ' (persistent, per layer)', avg_launch_ms=ms, bound='mfma',
+                                  achieved=rec_flop / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
+                                  unit='TFLOP/s', frac=rec_flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                  us_per_timestep=ms * 1e3 / T))
         out = {
             'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)',
             'value': frames_per_step * world * args.steps / elapsed,

@@ -581,23 +581,30 @@ __global__ __launch_bounds__(256, 3) void istft_kernel(const InvArgs A) {
         tw1t[i] = tw_full<M>(A.twiddle, (2 * ll * k1) % PL::SIZE);
     }
 
-    // (a) raw one-sided spectra of this wavefront's frames -> LDS (coalesced row reads)
-    for (int idx = lane; idx < FPW * F; idx += 64) {
-        const int f = idx / F, k = idx - f * F;
-        const long long t = tstart + wave * FPW + f;
-        cpx X = cpx{0.f, 0.f};
-        if (t >= 0 && t < T_b) {
-            const long long r = (long long)b * A.num_frames + t;
+    // (a) raw one-sided spectra of this wavefront's frames -> LDS (coalesced row reads).  Loads are
+    // unconditional from clamped rows and zeroed by a select (a branch per load would serialise them).
+    {
+        const long long tmax = T_b > 0 ? T_b - 1 : 0;
+        const int nit = (FPW * F + 63) / 64;
+#pragma unroll 4
+        for (int it = 0; it < nit; ++it) {
+            const int idx = min(lane + 64 * it, FPW * F - 1);
+            const int f = idx / F, k = idx - f * F;
+            const long long t = tstart + wave * FPW + f;
+            const bool valid = t >= 0 && t < T_b;
+            const long long r = (long long)b * A.num_frames + min(max(t, 0LL), tmax);
+            cpx X;
             if (A.layout == PTMI_LAYOUT_INTERLEAVED) {
                 const float2 v = *reinterpret_cast<const float2*>(A.spec + (r * F + k) * 2);
                 X = cpx{v.x, v.y};
             } else {
                 X = cpx{A.spec[r * 2 * F + k], A.spec[r * 2 * F + F + k]};
             }
+            if (!valid) X = cpx{0.f, 0.f};
             // imaginary parts of DC / Nyquist never reach the output (_stft.py:37-40: sin(0)=sin(pi n)=0)
             if (k == 0 || k == M) X = cpx{X.x * A.edge_scale, 0.f};
+            if (lane + 64 * it < FPW * F) buf[(wave * FPW + f) * FS + k] = X;
         }
-        buf[(wave * FPW + f) * FS + k] = X;
     }
     __syncthreads();
 
