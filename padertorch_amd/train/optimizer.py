@@ -113,10 +113,10 @@ class Adam(Optimizer):
 
     def set_parameters(self, parameters):
         self.parameters = tuple(parameters)
-        kwargs = dict(self.optimizer_kwargs)
-        if self.parameters and self.parameters[0].is_cuda:
-            kwargs['fused'] = True      # one multi-tensor kernel instead of ~10 per parameter
-        self.optimizer = self.optimizer_cls(self.parameters, **kwargs)
+        try:        # one fused multi-tensor kernel per step (the model moves to the GPU later)
+            self.optimizer = self.optimizer_cls(self.parameters, fused=True, **self.optimizer_kwargs)
+        except (RuntimeError, TypeError, ValueError):
+            self.optimizer = self.optimizer_cls(self.parameters, **self.optimizer_kwargs)
 
 
 class SGD(Optimizer):
