@@ -136,3 +136,36 @@ def test_dc_loss_batched_full_size_vs_oracle():
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+def test_trainer_rccl_path_world_size_1(g6, tmp_path):
+    """The RCCL data-parallel code path (process group 'nccl', flat-bucket all_reduce, step-0
+    broadcast) with world_size 1 on the GPU: must reproduce the single-process result exactly."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
+    exs = [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+    kw = dict(loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), summary_trigger=(1000, 'iteration'),
+              checkpoint_trigger=(1000, 'iteration'), stop_trigger=(3, 'iteration'), virtual_minibatch_size=2)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+        t = pt.Trainer(model, tmp_path / 'dp', pt.optimizer.Adam(gradient_clipping=1.), **kw)
+        assert t.world_size == 1 and t.rank == 0
+        t.train(exs, device=DEV)
+        # force the collective path once (world_size 1: all_reduce(SUM) is the identity)
+        dist.all_reduce(t._flat.flat, op=dist.ReduceOp.SUM)
+        t._broadcast_parameters()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g6['pit_sd3_' + k], atol=2e-5, err_msg=k)
