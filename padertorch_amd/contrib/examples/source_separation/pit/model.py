@@ -116,6 +116,36 @@ class PermutationInvariantTrainingModel(base.Model):
         mask = PackedSequence(h_data.view(-1, self.K, self.F), h.batch_sizes)  # 'tb (k f) -> tb k f'
         return ops.unpack_sequence(mask)
 
+    @torch.no_grad()
+    def separate(self, y, num_samples=None, stft=None):
+        """Mixture waveforms -> separated waveforms, entirely on the device.
+
+        The evaluation path of ``pit/evaluate.py:149-163`` (``model(batch)``, ``Z = mask * Y[:, None, :]``,
+        ``paderbox.istft(Z, 512, 128)``, cut to the signal length) without leaving the GPU: HIP STFT,
+        mask estimator, complex masking, HIP iSTFT.
+
+        Args:
+            y: list of ``(N_b,)`` tensors (descending length) or a padded ``[B, N]`` tensor
+            num_samples: lengths when ``y`` is padded and ragged
+        Returns: list of ``(K, N_b)`` tensors.
+        """
+        from padertorch_amd.ops.features import _pad_rows
+        if stft is None:
+            stft = ops.STFT(512, 128)
+        if isinstance(y, (list, tuple)):
+            num_samples = [int(t.shape[-1]) for t in y]
+            y = _pad_rows(list(y), max(num_samples))
+        if num_samples is None:
+            num_samples = [y.shape[-1]] * y.shape[0]
+        feats = ops.pit_features(y, None, num_samples, stft=stft)
+        masks = self.forward(dict(Y_abs=feats['Y_abs']))                  # PaddedList, [T, B, K, F]
+        ns = torch.tensor(num_samples, dtype=torch.int32, device=y.device)
+        Y = stft(y, num_samples=ns)                                       # [B, T, F] complex
+        m = masks.padded if not masks.batch_first else masks.padded.transpose(0, 1)
+        Z = m.permute(1, 2, 0, 3) * Y[:, None, :, :]                      # 't b k f -> b k t f' times Y
+        z = stft.inverse(Z.contiguous())                                  # [B, K, samples]
+        return [z[b, :, :n] for b, n in enumerate(num_samples)]
+
     def review(self, batch, model_out):
         batch = self.prepare_batch(batch)
         if isinstance(model_out, PaddedList):

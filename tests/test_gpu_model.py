@@ -133,6 +133,31 @@ def test_dc_loss_batched_full_size_vs_oracle():
     np.testing.assert_allclose(x.grad.cpu().numpy(), xt.grad.numpy(), atol=1e-9, rtol=2e-4)
 
 
+def test_separate_vs_oracle():
+    """Evaluation path (pit/evaluate.py:149-163) on the device vs numpy stft -> torch-CPU masks ->
+    complex masking -> numpy istft."""
+    from oracle import features_np, stft_np, torch_ref
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    rng = np.random.RandomState(11)
+    lens = [5000, 4100, 2345]
+    ys = [features_np.synthetic_mixture(rng, n)[1] for n in lens]
+    torch.manual_seed(1)
+    kw = dict(F=257, recurrent_layers=2, units=16, K=2)
+    model = PermutationInvariantTrainingModel(**kw)
+    ref = torch_ref.PITModelRef(**kw)
+    ref.load_state_dict(model.state_dict())
+    model = model.to(DEV).eval()
+    out = model.separate([torch.from_numpy(y).to(DEV) for y in ys])
+    Ys = [stft_np.stft(y, 512, 128) for y in ys]
+    with torch.no_grad():
+        masks = ref(dict(Y_abs=[torch.from_numpy(np.abs(Y).astype(np.float32)) for Y in Ys]))
+    for b, (Y, m, n) in enumerate(zip(Ys, masks, lens)):
+        Z = m.numpy()[:, :, :] * Y[:, None, :]
+        z = stft_np.istft(np.transpose(Z, (1, 0, 2)), 512, 128)[:, :n]
+        assert out[b].shape == (2, n)
+        np.testing.assert_allclose(out[b].cpu().numpy(), z, atol=1e-4)
+
+
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
