@@ -1,23 +1,76 @@
 // In-register FFT codelets for gfx950 (wave64).  Everything is fully unrolled so that every
 // array index and every twiddle is a compile-time constant and the arrays live in VGPRs.
+//
+// The STFT kernels are VALU-bound (a wave64 VALU op takes 4 cycles on the 16-lane SIMD), so the
+// complex arithmetic is written for the PACKED fp32 pipe: a complex number is one even-aligned
+// VGPR pair and add / sub / multiply-by-(+-i) / complex multiply are one or two v_pk_*_f32 each,
+// with the (re, im) swizzles and sign flips carried by the op_sel / neg_lo / neg_hi modifiers
+// instead of extra moves.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace ptmi {
 
-struct cpx {
-    float x, y;
-};
+typedef float cpx __attribute__((ext_vector_type(2)));   // .x = re, .y = im
+
 __device__ __forceinline__ cpx mk(float a, float b) { return cpx{a, b}; }
-__device__ __forceinline__ cpx operator+(cpx a, cpx b) { return cpx{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cpx operator-(cpx a, cpx b) { return cpx{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ cpx cmul(cpx a, cpx b) {
-    return cpx{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-}
-__device__ __forceinline__ cpx cmulc(cpx a, cpx b) {  // a * conj(b)
-    return cpx{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
-}
 __device__ __forceinline__ cpx cconj(cpx a) { return cpx{a.x, -a.y}; }
+
+// a * w,  w in VGPRs
+__device__ __forceinline__ cpx cmul(cpx a, cpx w) {
+    cpx t, r;   // t = (-a.y w.y, a.y w.x);  r = (a.x w.x, a.x w.y) + t
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * conj(w),  w in VGPRs
+__device__ __forceinline__ cpx cmulc(cpx a, cpx w) {
+    cpx t, r;   // t = (a.y w.y, a.y w.x);  r = (a.x w.x, -a.x w.y) + t
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]"
+        : "=v"(r) : "v"(a), "v"(w), "v"(t));
+    return r;
+}
+// a * w with a compile-time constant w (lives in an SGPR pair)
+__device__ __forceinline__ cpx cmul_k(cpx a, cpx w) {
+    cpx t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "s"(w), "v"(t));
+    return r;
+}
+// (u - v) * (-i) = (u.y - v.y, v.x - u.x)
+__device__ __forceinline__ cpx sub_mul_mi(cpx u, cpx v) {
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(u), "v"(v));
+    return r;
+}
+// (u - v) * (+i) = (v.y - u.y, u.x - v.x)
+__device__ __forceinline__ cpx sub_mul_pi(cpx u, cpx v) {
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(u), "v"(v));
+    return r;
+}
+// a + conj(b),  a - conj(b),  a + i b,  a - i b
+__device__ __forceinline__ cpx add_conj(cpx a, cpx b) {
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cpx sub_conj(cpx a, cpx b) {
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cpx add_i(cpx a, cpx b) {   // (a.x - b.y, a.y + b.x)
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cpx sub_i(cpx a, cpx b) {   // (a.x + b.y, a.y - b.x)
+    cpx r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // cos/sin(2*pi*j/32), j = 0..15 (covers every radix <= 32: W_R^j = W_32^(j*32/R)).
 __device__ constexpr float kCos32[16] = {
@@ -41,15 +94,14 @@ __host__ __device__ constexpr int bitrev(int v) {
     return r;
 }
 
-// d * W_32^idx (forward, W = exp(-2*pi*i/32)) or d * conj(W_32^idx) (inverse); 0 <= idx < 16.
-// idx is a compile-time constant after unrolling, so the branches fold away.
+// (u - v) * W_32^idx (forward, W = exp(-2*pi*i/32)) or (u - v) * conj(W_32^idx) (inverse);
+// 0 <= idx < 16 is a compile-time constant after unrolling, so the branches fold away.
 template <bool INV>
-__device__ __forceinline__ cpx twiddle_mul32(cpx d, int idx) {
-    if (idx == 0) return d;
-    if (idx == 8) return INV ? cpx{-d.y, d.x} : cpx{d.y, -d.x};  // * (-i) fwd, * (+i) inv
-    const float c = kCos32[idx];
-    const float s = INV ? kSin32[idx] : -kSin32[idx];
-    return cpx{d.x * c - d.y * s, d.x * s + d.y * c};
+__device__ __forceinline__ cpx sub_twiddle32(cpx u, cpx v, int idx) {
+    if (idx == 0) return u - v;
+    if (idx == 8) return INV ? sub_mul_pi(u, v) : sub_mul_mi(u, v);
+    const cpx w = cpx{kCos32[idx], INV ? kSin32[idx] : -kSin32[idx]};
+    return cmul_k(u - v, w);
 }
 
 // Radix-2 decimation-in-frequency FFT of R points held in registers.
@@ -65,7 +117,7 @@ __device__ __forceinline__ void fft_dif(cpx (&a)[R]) {
                 const cpx u = a[g + j];
                 const cpx v = a[g + j + half];
                 a[g + j] = u + v;
-                a[g + j + half] = twiddle_mul32<INV>(u - v, j * (16 / half));  // W_{2*half}^j
+                a[g + j + half] = sub_twiddle32<INV>(u, v, j * (16 / half));  // W_{2*half}^j
             }
         }
     }

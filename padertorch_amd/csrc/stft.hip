@@ -40,6 +40,8 @@ struct Plan {
     static constexpr int FS0 = (R1 * P > F ? R1 * P : F);
     static constexpr int FS = (FS0 + 1) & ~1;      // per-frame LDS region (complex), even
     static constexpr int NIT = (FPW * F + 63) / 64;  // epilogue items per lane
+    // inverse kernel: waves per SIMD the register budget is sized for (its LDS footprint grows with M)
+    static constexpr int INV_WAVES = M <= 256 ? 3 : (M <= 512 ? 2 : 1);
 };
 
 struct FwdArgs {
@@ -341,11 +343,14 @@ __device__ __forceinline__ void split_pair(const cpx* zb, const cpx* tws, int k,
     const cpx z1 = zb[k & (M - 1)];
     const cpx z2 = zb[(M - k) & (M - 1)];
     const cpx w = tws[k];
-    const float ex = 0.5f * (z1.x + z2.x), ey = 0.5f * (z1.y - z2.y);
-    const float dx = 0.5f * (z1.x - z2.x), dy = 0.5f * (z1.y + z2.y);
-    const float qx = dy * w.x + dx * w.y, qy = dy * w.y - dx * w.x;   // (-i D) * w
-    Xk = cpx{ex + qx, ey + qy};
-    Xm = cpx{ex - qx, qy - ey};
+    const cpx e2 = add_conj(z1, z2);                    // 2 E
+    const cpx d = sub_conj(z1, z2) * cpx{0.5f, 0.5f};   // D
+    cpx t, q;                                           // Q = (-i D) * w
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[0,0] neg_hi:[0,1]" : "=v"(t) : "v"(d), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(q) : "v"(d), "v"(w), "v"(t));
+    const cpx h1 = cpx{0.5f, 0.5f}, h2 = cpx{0.5f, -0.5f};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(Xk) : "v"(e2), "s"(h1), "v"(q));                   // E + Q
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1]" : "=v"(Xm) : "v"(e2), "s"(h2), "v"(q));    // conj(E - Q)
 }
 
 template <class PL>
@@ -548,108 +553,216 @@ struct InvArgs {
     long long out_samples;
     long long out_row_stride;
     long long cut_left;
-    int nchunks;
+    long long batch;
+    int nchunks;    // runs per row
     int layout;
-    int halo;   // ceil(L / shift) - 1 frames recomputed per workgroup
+    int halo;       // ceil(L / shift) - 1 frames whose tails reach into a run
+    int run_hops;   // hops (= frames) whose output a run owns
+    int groups;     // groups of FPW frames a run walks (halo + run_hops + tail flush)
+    int dbg;        // PTMI_STFT_DBG ablation bits (1: no stores, 2: no FFT, 4: no loads, 8: no OLA terms)
     float edge_scale;
     Geo g;
 };
 
+// Inverse STFT as wave-private persistent pipelines.  Work item = a RUN of consecutive frames of one
+// row, owned by ONE wavefront from the spectrum loads to the sample stores: the frames are taken in
+// groups of FPW, each group is inverse-transformed in LDS (the synthesis window is applied by the
+// last FFT stage) and overlap-added into a small wave-private ring that carries the (L - shift)
+// samples still awaiting later frames; the first FPW*shift samples of every group are final and
+// stream out.  A run starts `halo` = ceil(L/shift) - 1 frames early (their tails reach into the
+// run's first hop), so every output sample is summed by exactly one wavefront in a fixed order
+// (deterministic, no atomics).  Spectra of interior groups are fetched one group AHEAD into
+// registers (FPW consecutive rows = one contiguous chunk), hiding HBM latency behind FFT + OLA.
 template <class PL>
-__global__ __launch_bounds__(256, 3) void istft_kernel(const InvArgs A) {
-    constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FPB = PL::FPB, FS = PL::FS, LPF = PL::LPF;
+__device__ __forceinline__ void ifft_windowed_to_lds_wave(cpx (&a)[PL::R1], cpx* fbuf, int l,
+                                                          const cpx* tw1t, const cpx* wsyn2) {
+    constexpr int R1 = PL::R1, R2 = PL::R2, P = PL::P;
+    if (l < R2) {
+        fft_dif<R1, true>(a);
+#pragma unroll
+        for (int k1 = 0; k1 < R1; ++k1) fbuf[k1 * P + l] = cmulc(a[bitrev<R1>(k1)], tw1t[k1 * PL::LPF + l]);
+    }
+    wave_sync();
+    cpx c[R2];
+    if (l < R1) {
+#pragma unroll
+        for (int n2 = 0; n2 < R2; ++n2) c[n2] = fbuf[l * P + n2];
+    }
+    wave_sync();
+    if (l < R1) {
+        fft_dif<R2, true>(c);
+#pragma unroll
+        for (int k2 = 0; k2 < R2; ++k2) {   // z[n] = x[2n] + i x[2n+1], times the window pair
+            fbuf[l + R1 * k2] = c[bitrev<R2>(k2)] * wsyn2[l + R1 * k2];
+        }
+    }
+    wave_sync();
+}
+
+template <class PL>
+__global__ __launch_bounds__(256, PL::INV_WAVES) void istft_kernel(const InvArgs A) {
+    constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cpx* buf = reinterpret_cast<cpx*>(smem);
-    cpx* tws = buf + FPB * FS;
+    cpx* tws = reinterpret_cast<cpx*>(smem);
     cpx* tw1t = tws + F + 1;
     float* wsyn = reinterpret_cast<float*>(tw1t + PL::R1 * LPF);
+    cpx* bufs = reinterpret_cast<cpx*>(wsyn + PL::SIZE);
+    const int shift = A.g.shift, L = A.g.L;
+    const int plen = max(L - shift, 0);                 // samples carried between groups
+    const int plen_pad = max((plen + 3) & ~3, 4);
+    float* rings = reinterpret_cast<float*>(bufs + 4 * FPW * FS);
 
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / A.nchunks;
-    const int c = blockIdx.x - b * A.nchunks;
-    const int nout = FPB - A.halo;                    // frames whose hop segment this block owns
-    const long long tstart = (long long)c * nout - A.halo;
-    const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.num_frames;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fl = lane / LPF, l = lane - fl * LPF;
-    const int fb = wave * FPW + fl;
+    cpx* wbuf = bufs + wave * FPW * FS;
+    float* ring0 = rings + wave * 2 * plen_pad;
 
     for (int i = tid; i <= M; i += 256) tws[i] = A.twiddle[i];
-    for (int i = tid; i < A.g.L; i += 256) wsyn[i] = A.syn_window[i];
+    for (int i = tid; i < PL::SIZE; i += 256) wsyn[i] = (i < L) ? A.syn_window[i] : 0.f;
     for (int i = tid; i < PL::R1 * LPF; i += 256) {
         const int k1 = i / LPF, ll = i - k1 * LPF;
         tw1t[i] = tw_full<M>(A.twiddle, (2 * ll * k1) % PL::SIZE);
     }
-
-    // (a) raw one-sided spectra of this wavefront's frames -> LDS (coalesced row reads).  Loads are
-    // unconditional from clamped rows and zeroed by a select (a branch per load would serialise them).
-    {
-        const long long tmax = T_b > 0 ? T_b - 1 : 0;
-        const int nit = (FPW * F + 63) / 64;
-#pragma unroll 4
-        for (int it = 0; it < nit; ++it) {
-            const int idx = min(lane + 64 * it, FPW * F - 1);
-            const int f = idx / F, k = idx - f * F;
-            const long long t = tstart + wave * FPW + f;
-            const bool valid = t >= 0 && t < T_b;
-            const long long r = (long long)b * A.num_frames + min(max(t, 0LL), tmax);
-            cpx X;
-            if (A.layout == PTMI_LAYOUT_INTERLEAVED) {
-                const float2 v = *reinterpret_cast<const float2*>(A.spec + (r * F + k) * 2);
-                X = cpx{v.x, v.y};
-            } else {
-                X = cpx{A.spec[r * 2 * F + k], A.spec[r * 2 * F + F + k]};
-            }
-            if (!valid) X = cpx{0.f, 0.f};
-            // imaginary parts of DC / Nyquist never reach the output (_stft.py:37-40: sin(0)=sin(pi n)=0)
-            if (k == 0 || k == M) X = cpx{X.x * A.edge_scale, 0.f};
-            if (lane + 64 * it < FPW * F) buf[(wave * FPW + f) * FS + k] = X;
-        }
-    }
     __syncthreads();
 
-    // (b) Z'[k] = (X[k] + conj X[M-k]) + i e^{+i pi k / M} (X[k] - conj X[M-k]),  k = R2*i1 + l
-    cpx a[PL::R1];
-    {
-        const cpx* raw = buf + fb * FS;
-#pragma unroll
-        for (int i1 = 0; i1 < PL::R1; ++i1) {
-            const int k = PL::R2 * i1 + l;
-            cpx v = cpx{0.f, 0.f};
-            if (l < PL::R2) {
-                const cpx x1 = raw[k], x2 = raw[M - k], w = tws[k];
-                const float sx = x1.x + x2.x, sy = x1.y - x2.y;   // X[k] + conj X[M-k]
-                const float dx = x1.x - x2.x, dy = x1.y + x2.y;   // X[k] - conj X[M-k]
-                // i * conj(w) * D, conj(w) = (w.x, -w.y):  conj(w) * D = (w.x dx + w.y dy, w.x dy - w.y dx)
-                const float px = w.x * dx + w.y * dy, py = w.x * dy - w.y * dx;
-                v = cpx{sx - py, sy + px};
-            }
-            a[i1] = v;
-        }
-    }
-    __syncthreads();  // every lane has consumed raw before the transposition overwrites it
-    fft_to_lds<PL, true>(a, buf + fb * FS, l, tw1t);
+    const int span = (FPW - 1) * shift + L;             // samples a group of FPW frames touches
+    const int adv = FPW * shift;                        // of which this many become final
+    const int pend = max(span, adv);                    // (shift > L leaves silent gaps to write)
+    constexpr int nit = (FPW * F + 63) / 64;
+    const bool interleaved = A.layout == PTMI_LAYOUT_INTERLEAVED;
+    const unsigned items = (unsigned)(A.batch * A.nchunks);
+    for (unsigned item = blockIdx.x * 4 + wave; item < items; item += gridDim.x * 4) {
+        const int b = (int)(item / (unsigned)A.nchunks);
+        const int run = (int)(item - (unsigned)b * (unsigned)A.nchunks);
+        const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.num_frames;
+        const long long own0 = (long long)run * A.run_hops * shift;      // owned OLA range starts here
+        const long long tfirst = (long long)run * A.run_hops - A.halo;   // first frame of the first group
+        // owned and wanted positions, relative to own0:  [rel_lo, rel_hi)
+        const long long lo64 = A.cut_left - own0, hi64 = A.cut_left + A.out_samples - own0;
+        const int own_len = A.run_hops * shift;
+        const int rel_lo = (int)min(max(lo64, 0LL), (long long)own_len);
+        const int rel_hi = (A.dbg & 1) ? 0 : (int)min(max(hi64, 0LL), (long long)own_len);
+        float* outb = A.out + (long long)b * A.out_row_stride + (own0 - A.cut_left);
+        const float* rowbase = A.spec + (long long)b * A.num_frames * 2 * F;
+        for (int i = lane; i < plen_pad; i += 64) ring0[i] = 0.f;        // the ring half group 0 reads
 
-    // (c) overlap-add from LDS: buf viewed as floats holds frame samples x[0..size)
-    const long long o0 = (long long)c * nout * A.g.shift;
-    const int seg = nout * A.g.shift;
-    const float* __restrict__ fr = reinterpret_cast<const float*>(buf);
-    for (int i = tid; i < seg; i += 256) {
-        const long long o = o0 + i;
-        const long long n = o - A.cut_left;
-        if (n < 0 || n >= A.out_samples) continue;
-        long long tlo = (o - A.g.L + A.g.shift) / A.g.shift;   // ceil((o - L + 1) / shift) for o-L+1 > 0
-        if (o - A.g.L + 1 <= 0) tlo = 0;
-        if (tlo < tstart) tlo = tstart;
-        long long thi = o / A.g.shift;
-        if (thi > tstart + FPB - 1) thi = tstart + FPB - 1;
-        if (thi > T_b - 1) thi = T_b - 1;
-        float acc = 0.f;
-        for (long long t = tlo; t <= thi; ++t) {
-            const int j = (int)(o - t * A.g.shift);
-            acc += fr[(int)(t - tstart) * (2 * FS) + j] * wsyn[j];
+        cpx pre[nit];
+        auto issue = [&](long long tg) {   // FPW consecutive interleaved rows = one contiguous chunk
+            const float2* base = reinterpret_cast<const float2*>(rowbase) + tg * F;
+#pragma unroll
+            for (int it = 0; it < nit; ++it) {
+                const float2 v = base[min(lane + 64 * it, FPW * F - 1)];
+                pre[it] = cpx{v.x, v.y};
+            }
+        };
+        // wave-uniform group classes: interior groups are prefetched, edge groups load in place
+        auto is_live = [&](long long tg) { return tg < T_b && tg + FPW > 0; };
+        auto is_interior = [&](long long tg) {
+            return interleaved && tg >= 0 && tg + FPW <= T_b && !(A.dbg & 4);
+        };
+        if (is_interior(tfirst)) issue(tfirst);
+
+        for (int g = 0; g < A.groups; ++g) {
+            const long long tg = tfirst + (long long)g * FPW;
+            float* rin = ring0 + (g & 1) * plen_pad;
+            float* rout = ring0 + ((g + 1) & 1) * plen_pad;
+            const bool live = is_live(tg);
+            // (a) raw one-sided spectra, frame f at wbuf[f * F ...] (dense: the FFT re-lays them out)
+            if (is_interior(tg)) {
+#pragma unroll
+                for (int it = 0; it < nit; ++it)
+                    if (it + 1 < nit || lane + 64 * it < FPW * F) wbuf[lane + 64 * it] = pre[it];
+            } else if (live && !(A.dbg & 4)) {
+                const long long tmax = T_b > 0 ? T_b - 1 : 0;
+#pragma unroll 4
+                for (int it = 0; it < nit; ++it) {
+                    const int idx = min(lane + 64 * it, FPW * F - 1);
+                    const int f = idx / F, k = idx - f * F;
+                    const long long t = tg + f;
+                    const long long r = min(max(t, 0LL), tmax);
+                    cpx X;
+                    if (interleaved) {
+                        const float2 v = *reinterpret_cast<const float2*>(rowbase + (r * F + k) * 2);
+                        X = cpx{v.x, v.y};
+                    } else {
+                        X = cpx{rowbase[r * 2 * F + k], rowbase[r * 2 * F + F + k]};
+                    }
+                    if (t < 0 || t >= T_b) X = cpx{0.f, 0.f};
+                    if (lane + 64 * it < FPW * F) wbuf[idx] = X;
+                }
+            }
+            if (g + 1 < A.groups && is_interior(tg + FPW)) issue(tg + FPW);
+            wave_sync();
+            // (b) Z'[k] = (X[k] + conj X[M-k]) + i e^{+i pi k / M} (X[k] - conj X[M-k]),  k = R2*i1 + l
+            if (live && !(A.dbg & 2)) {
+                cpx a[PL::R1];
+                const cpx* raw = wbuf + fl * F;
+#pragma unroll
+                for (int i1 = 0; i1 < PL::R1; ++i1) {
+                    const int k = PL::R2 * i1 + l;
+                    cpx v = cpx{0.f, 0.f};
+                    if (l < PL::R2) {
+                        cpx x1 = raw[k], x2 = raw[M - k];
+                        const cpx w = tws[k];
+                        if (i1 == 0 && l == 0) {
+                            // DC / Nyquist: imaginary parts never reach the output (_stft.py:37-40)
+                            x1 = cpx{x1.x * A.edge_scale, 0.f};
+                            x2 = cpx{x2.x * A.edge_scale, 0.f};
+                        }
+                        // S = X[k] + conj X[M-k],  D = X[k] - conj X[M-k],  Z' = S + i conj(w) D
+                        v = add_i(add_conj(x1, x2), cmulc(sub_conj(x1, x2), w));
+                    }
+                    a[i1] = v;
+                }
+                wave_sync();   // every lane has consumed raw before the transposition overwrites it
+                ifft_windowed_to_lds_wave<PL>(a, wbuf + fl * FS, l, tw1t, reinterpret_cast<const cpx*>(wsyn));
+            }
+            // (c) overlap-add: wbuf viewed as floats holds windowed frame f at [f * 2 FS, f * 2 FS + size).
+            // Frame f reaches group position p with its sample j = p - f * shift if 0 <= j < L.  Positions
+            // are taken in batches of U per lane: first ALL LDS reads of a batch (unconditional: clamped
+            // index + select, so they issue back to back), then its stores.
+            const float* fr = reinterpret_cast<const float*>(wbuf);
+            const int rel0 = (g * FPW - A.halo) * shift;     // group position 0 relative to own0
+            const bool terms = live && !(A.dbg & 8);
+            constexpr int U = 8;
+            for (int p0 = lane; p0 < pend; p0 += 64 * U) {
+                float v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + 64 * u;
+                    const float carried = rin[min(p, plen_pad - 1)];
+                    v[u] = (p < plen) ? carried : 0.f;
+                }
+                if (terms) {
+                    float x[U][FPW];
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int f = 0; f < FPW; ++f) {
+                            const int j = p0 + 64 * u - f * shift;
+                            x[u][f] = fr[f * 2 * FS + ((unsigned)j < (unsigned)L ? j : 0)];
+                        }
+#pragma unroll
+                    for (int u = 0; u < U; ++u)
+#pragma unroll
+                        for (int f = 0; f < FPW; ++f) {
+                            const int j = p0 + 64 * u - f * shift;
+                            v[u] += ((unsigned)j < (unsigned)L) ? x[u][f] : 0.f;
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int p = p0 + 64 * u;
+                    if (p < adv) {
+                        const int rel = rel0 + p;
+                        if (rel >= rel_lo && rel < rel_hi) outb[rel] = v[u];
+                    } else if (p - adv < plen) {
+                        rout[p - adv] = v[u];
+                    }
+                }
+            }
+            wave_sync();   // span - adv == plen: rout is completely rewritten; wbuf is free again
         }
-        A.out[(long long)b * A.out_row_stride + n] = acc;
     }
 }
 
@@ -740,11 +853,7 @@ __global__ __launch_bounds__(256) void istft_generic_kernel(const InvArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <class PL>
-static size_t inv_smem_bytes(const Geo& g) {
-    return sizeof(cpx) * ((size_t)PL::FPB * PL::FS + PL::F + 1 + PL::R1 * PL::LPF) +
-           sizeof(float) * (g.L + 4);
-}
+
 
 constexpr size_t kMaxSmem = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB LDS)
 
@@ -806,15 +915,51 @@ static int dispatch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t 
 
 template <class PL>
 static int launch_inv(InvArgs& A, long long batch, hipStream_t st) {
-    const size_t smem = inv_smem_bytes<PL>(A.g);
-    if (smem > kMaxSmem) return PTMI_E_UNSUPPORTED;
-    A.halo = (A.g.L + A.g.shift - 1) / A.g.shift - 1;
-    if (A.halo >= PL::FPB) return PTMI_E_UNSUPPORTED;
-    const long long seg = (long long)(PL::FPB - A.halo) * A.g.shift;
-    A.nchunks = (int)((A.cut_left + A.out_samples + seg - 1) / seg);
-    const long long blocks = batch * A.nchunks;
-    if (blocks <= 0) return PTMI_OK;
-    if (blocks > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
+    const int shift = A.g.shift, L = A.g.L;
+    A.halo = (L + shift - 1) / shift - 1;
+    const int plen_pad = std::max((std::max(L - shift, 0) + 3) & ~3, 4);
+    const size_t smem = sizeof(cpx) * (PL::F + 1 + PL::R1 * PL::LPF + (size_t)4 * PL::FPW * PL::FS) +
+                        sizeof(float) * (PL::SIZE + (size_t)4 * 2 * plen_pad);
+    if (smem > 160 * 1024) return PTMI_E_UNSUPPORTED;
+    if (smem > kMaxSmem &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel<PL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return PTMI_E_UNSUPPORTED;
+    thread_local size_t occ_smem = 0;
+    thread_local int occ_blocks = 0;
+    if (occ_blocks < 1 || occ_smem != smem) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, istft_kernel<PL>, 256, smem) != hipSuccess ||
+            occ_blocks < 1)
+            occ_blocks = 1;
+        occ_smem = smem;
+    }
+    const int per_cu = occ_blocks;
+    const long long resident_waves = 256LL * per_cu * 4;
+    // a run owns `run_hops` hops; it walks halo frames before them (their tails reach into the run)
+    // and is done when its last owned hop is final (frames past the row's end read as zeros, which
+    // flushes the tail).  Long runs amortise the halo; short ones are chosen when the whole call
+    // would otherwise not fill the chip.
+    const long long total = A.cut_left + A.out_samples;                 // OLA samples needed
+    const int min_hops = std::max(2 * PL::FPW, 2 * A.halo);
+    int run_hops = std::max(64, min_hops);
+    const char* rh_env = getenv("PTMI_ISTFT_RUN");
+    if (rh_env) {
+        run_hops = std::max(atoi(rh_env), 1);
+    } else {
+        while (run_hops / 2 >= min_hops &&
+               batch * ((total + (long long)run_hops * shift - 1) / ((long long)run_hops * shift)) < resident_waves)
+            run_hops /= 2;
+    }
+    A.run_hops = (run_hops + PL::FPW - 1) / PL::FPW * PL::FPW;
+    A.groups = (A.halo + A.run_hops + PL::FPW - 1) / PL::FPW;
+    const char* dbg_env = getenv("PTMI_STFT_DBG");
+    A.dbg = dbg_env ? atoi(dbg_env) : 0;
+    A.batch = batch;
+    A.nchunks = (int)((total + (long long)A.run_hops * shift - 1) / ((long long)A.run_hops * shift));
+    const long long items = batch * A.nchunks;
+    if (items <= 0) return PTMI_OK;
+    if (items > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
+    const long long blocks = std::min((items + 3) / 4, 256LL * per_cu);
     hipLaunchKernelGGL(istft_kernel<PL>, dim3((unsigned)blocks), dim3(256), smem, st, A);
     return launch_status();
 }

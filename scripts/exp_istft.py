@@ -1,0 +1,14 @@
+import os, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch
+import padertorch_amd as pt
+from bench_kernels import timeit
+dev = torch.device('cuda:0')
+B, N = 1536, 64000
+st = pt.ops.STFT(512, 128)
+x = (0.1 * torch.randn(B, N)).to(dev)
+X = st(x)
+t = timeit(lambda: st.inverse(X), iters=10)
+nbytes = X.numel() * 8 + B * N * 4
+print(f"DBG={os.environ.get('PTMI_STFT_DBG')} RUN={os.environ.get('PTMI_ISTFT_RUN')} istft {t:.1f} us {nbytes / t / 1e3:.0f} GB/s")
