@@ -60,7 +60,6 @@ struct FwdArgs {
     int nchunks;
     int layout;
     int K;
-    int ngroups;     // features: frame groups per workgroup
     int dbg;         // PTMI_STFT_DBG ablation bits (1: no stores, 2: no FFT, 4: no loads)
     bool aligned2;   // every frame start is 8-byte aligned -> float2 sample loads
     float edge_scale;
@@ -204,7 +203,7 @@ struct WaveLds {
     cpx* tw1t;   // [R1][LPF]  inter-stage twiddles
     float* win;  // [SIZE]     window, zero beyond window_length
     cpx* buf;    // [nwaves][FPW][FS]
-    cpx* yph;    // [ngroups][FPW][YS]  unit phasors of the mixture spectrum (features only)
+    cpx* yph;    // [nyph][FPW][YS]  unit phasors of the mixture spectrum (features: one per wavefront)
     static constexpr int YS = (PL::F + 1) & ~1;
     __device__ __forceinline__ WaveLds(char* smem, int nwaves) {
         tws = reinterpret_cast<cpx*>(smem);
@@ -213,9 +212,9 @@ struct WaveLds {
         buf = reinterpret_cast<cpx*>(win + PL::SIZE);
         yph = buf + nwaves * PL::FPW * PL::FS;
     }
-    static size_t bytes(int nwaves, int ngroups) {
+    static size_t bytes(int nwaves, int nyph) {
         return sizeof(cpx) * (PL::F + 1 + PL::R1 * PL::LPF + (size_t)nwaves * PL::FPW * PL::FS +
-                              (size_t)ngroups * PL::FPW * YS) + sizeof(float) * PL::SIZE;
+                              (size_t)nyph * PL::FPW * YS) + sizeof(float) * PL::SIZE;
     }
 };
 
@@ -337,12 +336,15 @@ __device__ __forceinline__ void fft_to_lds_wave(cpx (&a)[PL::R1], cpx* fbuf, int
 
 // Hermitian split of the bin pair (k, M-k) from Z[k], Z[M-k]:  with E = (Z[k] + conj Z[M-k])/2 and
 // Q = W^k (Z[k] - conj Z[M-k]) / (2i):  X[k] = E + Q,  X[M-k] = conj(E - Q).
+__device__ __forceinline__ void split_vals(cpx z1, cpx z2, cpx w, cpx& Xk, cpx& Xm);
+
 template <class PL>
 __device__ __forceinline__ void split_pair(const cpx* zb, const cpx* tws, int k, cpx& Xk, cpx& Xm) {
     constexpr int M = PL::M;
-    const cpx z1 = zb[k & (M - 1)];
-    const cpx z2 = zb[(M - k) & (M - 1)];
-    const cpx w = tws[k];
+    split_vals(zb[k & (M - 1)], zb[(M - k) & (M - 1)], tws[k], Xk, Xm);
+}
+
+__device__ __forceinline__ void split_vals(cpx z1, cpx z2, cpx w, cpx& Xk, cpx& Xm) {
     const cpx e2 = add_conj(z1, z2);                    // 2 E
     const cpx d = sub_conj(z1, z2) * cpx{0.5f, 0.5f};   // D
     cpx t, q;                                           // Q = (-i D) * w
@@ -354,7 +356,7 @@ __device__ __forceinline__ void split_pair(const cpx* zb, const cpx* tws, int k,
 }
 
 template <class PL>
-__global__ __launch_bounds__(256) void stft_fwd_kernel(const FwdArgs A) {
+__global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
     constexpr int NP = M / 2 + 1;   // bin pairs (k, M-k) per frame
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,19 +371,62 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(const FwdArgs A) {
     load_tables_w<PL>(S, A.window, A.twiddle, A.g.L, tid, 256);
     __syncthreads();
 
-    // persistent wavefronts: work item = FPW consecutive frames of one row; nchunks items per row
+    // persistent wavefronts: work item = FPW consecutive frames of one row; nchunks items per row.
+    // The samples of the NEXT item are fetched into registers before the current item's FFT and
+    // epilogue (interior items: one immediate-offset float2 load per FFT input), so that HBM
+    // latency hides behind compute instead of heading every item.
+    struct Item {
+        int b, tw0, n_b;
+        const float* xrow;
+        bool interior;
+    };
     const unsigned items = (unsigned)(A.batch * A.nchunks);
-    for (unsigned item = blockIdx.x * 4 + wave; item < items; item += gridDim.x * 4) {
-        const int b = (int)(item / (unsigned)A.nchunks);
-        const int tw0 = (int)(item - (unsigned)b * (unsigned)A.nchunks) * FPW;
-        const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
+    auto decode = [&](unsigned item) {
+        Item it;
+        it.b = (int)(item / (unsigned)A.nchunks);
+        it.tw0 = (int)(item - (unsigned)it.b * (unsigned)A.nchunks) * FPW;
+        it.n_b = A.row_samples ? A.row_samples[it.b] : (int)A.num_samples;
+        it.xrow = A.x + (long long)it.b * A.x_row_stride;
+        const int x_first = it.tw0 * A.g.shift - A.g.pad_left;
+        const int x_last = (it.tw0 + FPW - 1) * A.g.shift - A.g.pad_left + PL::SIZE;
+        it.interior = A.aligned2 && x_first >= 0 && x_last <= it.n_b && !(A.dbg & 4);   // wave-uniform
+        return it;
+    };
+    float2 pre[PL::R1];
+    auto issue = [&](const Item& it) {
+        const float2* __restrict__ px =
+            reinterpret_cast<const float2*>(it.xrow + it.tw0 * A.g.shift - A.g.pad_left + fl * A.g.shift) + l;
+        if (l < PL::R2) {
+#pragma unroll
+            for (int n1 = 0; n1 < PL::R1; ++n1) pre[n1] = px[PL::R2 * n1];
+        }
+    };
+    const unsigned stride = gridDim.x * 4;
+    unsigned item = blockIdx.x * 4 + wave;
+    Item cur = decode(item < items ? item : 0);
+    bool cur_pre = item < items && cur.interior;
+    if (cur_pre) issue(cur);
+    for (; item < items; item += stride) {
+        const int b = cur.b, tw0 = cur.tw0, n_b = cur.n_b;
         const int frames_b = (int)row_frames_of(A.g, n_b);
-        const float* xrow = A.x + (long long)b * A.x_row_stride;
         cpx a[PL::R1];
-        if (!(A.dbg & 4))
-            load_frames<PL>(a, xrow, n_b, tw0, fl, l, A.g, A.aligned2, S.win);
-        else
+        if (cur_pre) {
+            const cpx* pw = reinterpret_cast<const cpx*>(S.win) + l;
+            if (l < PL::R2) {
+#pragma unroll
+                for (int n1 = 0; n1 < PL::R1; ++n1) a[n1] = cpx{pre[n1].x, pre[n1].y} * pw[PL::R2 * n1];
+            }
+        } else if (!(A.dbg & 4)) {
+            load_frames<PL>(a, cur.xrow, n_b, tw0, fl, l, A.g, A.aligned2, S.win);
+        } else {
             for (int i = 0; i < PL::R1; ++i) a[i] = cpx{(float)(lane + i), 1.f};
+        }
+        {
+            const unsigned nxt = item + stride;
+            cur = decode(nxt < items ? nxt : 0);
+            cur_pre = nxt < items && cur.interior;
+            if (cur_pre) issue(cur);
+        }
         if (!(A.dbg & 2))
             fft_to_lds_wave<PL, false>(a, wbuf + fl * FS, l, S.tw1t);
         else
@@ -445,10 +490,9 @@ __global__ __launch_bounds__(256) void stft_fwd_kernel(const FwdArgs A) {
 
 // ------------------------------------------------------------------------------------------------
 // Fused PIT front-end: Y_abs [B,T,F], X_abs / cos_phase_difference [B,T,K,F].
-// Workgroup = NG frame groups x (K+1) wavefronts; wavefront (g, q) transforms signal q (0 = mixture,
-// q >= 1 = source q-1) of frame group g.  The mixture wavefront leaves the unit phasors of Y in LDS;
-// after ONE workgroup barrier the source wavefronts form cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)
-// (angle(0) := 0 like np.angle).
+// One wavefront owns FPW frames of one example for ALL K+1 signals: it transforms the mixture first
+// and keeps the unit phasors of Y in its private LDS slice, then each source, forming
+// cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)  (angle(0) := 0 like np.angle) on the way out.
 __device__ __forceinline__ void mag_phasor(cpx X, float& mag, cpx& ph) {
     const float p = X.x * X.x + X.y * X.y;
     const float r = __builtin_amdgcn_rsqf(p);            // 1/|X|; inf at 0, selected away below
@@ -457,88 +501,139 @@ __device__ __forceinline__ void mag_phasor(cpx X, float& mag, cpx& ph) {
 }
 
 template <class PL>
-__global__ __launch_bounds__(1024) void pit_features_kernel(const FwdArgs A) {
+__global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
     constexpr int NP = M / 2 + 1, YS = WaveLds<PL>::YS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const WaveLds<PL> S(smem, 4);
     const int nsig = A.s ? A.K + 1 : 1;
-    const int nwaves = blockDim.x >> 6;
-    const WaveLds<PL> S(smem, nwaves);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int grp = wave / nsig, q = wave - grp * nsig;
     const int fl = lane / LPF, l = lane - fl * LPF;
     cpx* wbuf = S.buf + wave * FPW * FS;
-    cpx* yph = S.yph + grp * FPW * YS;
+    cpx* yph = S.yph + wave * FPW * YS;
 
-    load_tables_w<PL>(S, A.window, A.twiddle, A.g.L, tid, blockDim.x);
+    load_tables_w<PL>(S, A.window, A.twiddle, A.g.L, tid, 256);
     __syncthreads();
 
-    // persistent workgroups: work item = FPW frames of one example, handled by the nsig wavefronts
-    // of one group (wavefront q transforms signal q); every wavefront runs the same number of
-    // iterations (two barriers each: phasors of Y ready / consumed).
+    // persistent wavefronts: work item = FPW frames of one example; the wavefront transforms the
+    // mixture first (magnitudes out, unit phasors kept in its private LDS slice), then every source
+    // (magnitudes and cos of the phase difference out).  No workgroup barrier on the way; the samples
+    // of the NEXT signal are fetched into registers before the current one is transformed.
+    struct Task {
+        int b, tw0, n_b;
+        const float* xrow;
+        bool interior;
+    };
     const unsigned items = (unsigned)(A.batch * A.nchunks);
-    const unsigned stride = gridDim.x * (unsigned)A.ngroups;
-    const unsigned iters = (items + stride - 1) / stride;
-    for (unsigned it = 0; it < iters; ++it) {
-        const unsigned item = it * stride + blockIdx.x * (unsigned)A.ngroups + grp;
-        const bool live = item < items;
-        const int b = live ? (int)(item / (unsigned)A.nchunks) : 0;
-        const int tw0 = live ? (int)(item - (unsigned)b * (unsigned)A.nchunks) * FPW : 0;
-        const int n_b = A.row_samples ? A.row_samples[b] : (int)A.num_samples;
-        const int frames_b = (int)row_frames_of(A.g, n_b);
-        const int nfr = live ? min(FPW, (int)A.out_frames - tw0) : 0;
-        if (live) {
-            const float* xrow = (q == 0) ? A.x + (long long)b * A.x_row_stride
-                                         : A.s + ((long long)b * A.K + (q - 1)) * A.x_row_stride;
-            cpx a[PL::R1];
-            load_frames<PL>(a, xrow, n_b, tw0, fl, l, A.g, A.aligned2, S.win);
-            fft_to_lds_wave<PL, false>(a, wbuf + fl * FS, l, S.tw1t);
-            if (q == 0) {
-                float* __restrict__ yo = A.out + ((long long)b * A.out_frames + tw0) * F;
-                for (int p = lane; p < nfr * NP; p += 64) {
-                    const int f = p / NP, k = p - f * NP, km = M - k;
+    const unsigned stride = gridDim.x * 4;
+    auto decode = [&](unsigned item, int q) {
+        Task I;
+        I.b = (int)(item / (unsigned)A.nchunks);
+        I.tw0 = (int)(item - (unsigned)I.b * (unsigned)A.nchunks) * FPW;
+        I.n_b = A.row_samples ? A.row_samples[I.b] : (int)A.num_samples;
+        I.xrow = (q == 0) ? A.x + (long long)I.b * A.x_row_stride
+                          : A.s + ((long long)I.b * A.K + (q - 1)) * A.x_row_stride;
+        const int x_first = I.tw0 * A.g.shift - A.g.pad_left;
+        const int x_last = (I.tw0 + FPW - 1) * A.g.shift - A.g.pad_left + PL::SIZE;
+        I.interior = A.aligned2 && x_first >= 0 && x_last <= I.n_b && !(A.dbg & 4);   // wave-uniform
+        return I;
+    };
+    float2 pre[PL::R1];
+    auto issue = [&](const Task& I) {
+        const float2* __restrict__ px =
+            reinterpret_cast<const float2*>(I.xrow + I.tw0 * A.g.shift - A.g.pad_left + fl * A.g.shift) + l;
+        if (l < PL::R2) {
+#pragma unroll
+            for (int n1 = 0; n1 < PL::R1; ++n1) pre[n1] = px[PL::R2 * n1];
+        }
+    };
+    unsigned item = blockIdx.x * 4 + wave;
+    Task cur = decode(item < items ? item : 0, 0);
+    bool cur_pre = item < items && cur.interior;
+    if (cur_pre) issue(cur);
+    for (; item < items; item += stride) {
+        for (int q = 0; q < nsig; ++q) {
+            const int b = cur.b, tw0 = cur.tw0;
+            const int frames_b = (int)row_frames_of(A.g, cur.n_b);
+            const int nfr = min(FPW, (int)A.out_frames - tw0);
+            {
+                cpx a[PL::R1];
+                if (cur_pre) {
+                    const cpx* pw = reinterpret_cast<const cpx*>(S.win) + l;
+                    if (l < PL::R2) {
+#pragma unroll
+                        for (int n1 = 0; n1 < PL::R1; ++n1) a[n1] = cpx{pre[n1].x, pre[n1].y} * pw[PL::R2 * n1];
+                    }
+                } else if (!(A.dbg & 4)) {
+                    load_frames<PL>(a, cur.xrow, cur.n_b, tw0, fl, l, A.g, A.aligned2, S.win);
+                } else {
+                    for (int i = 0; i < PL::R1; ++i) a[i] = cpx{(float)(lane + i), 1.f};
+                }
+                {   // next signal of this item, or the mixture of the wavefront's next item
+                    const bool last = q + 1 == nsig;
+                    const unsigned nitem = last ? item + stride : item;
+                    cur = decode(nitem < items ? nitem : 0, last ? 0 : q + 1);
+                    cur_pre = nitem < items && cur.interior;
+                    if (cur_pre) issue(cur);
+                }
+                if (!(A.dbg & 2)) fft_to_lds_wave<PL, false>(a, wbuf + fl * FS, l, S.tw1t);
+            }
+            // bin pairs (k, M-k) in batches of UA per lane: all LDS reads of a batch first, so that
+            // their latency is paid once per batch instead of once per pair
+            const int fstride = (q == 0) ? F : A.K * F;
+            const long long o0 = (q == 0) ? ((long long)b * A.out_frames + tw0) * F
+                                          : (((long long)b * A.out_frames + tw0) * A.K + (q - 1)) * F;
+            float* __restrict__ mag_out = (q == 0 ? A.out : A.X_abs) + o0;
+            float* __restrict__ cp = A.cos_pd + o0;      // q > 0 only
+            constexpr int UA = 3;
+            const int npairs = nfr * NP;
+            if (!(A.dbg & 8))
+            for (int p0 = lane; p0 < npairs; p0 += 64 * UA) {
+                cpx z1[UA], z2[UA], w[UA], yk[UA], ym[UA];
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    const int p = min(p0 + 64 * u, npairs - 1);
+                    const int f = p / NP, k = p - f * NP;
+                    z1[u] = wbuf[f * FS + (k & (M - 1))];
+                    z2[u] = wbuf[f * FS + ((M - k) & (M - 1))];
+                    w[u] = S.tws[k];
+                    if (q > 0) {
+                        yk[u] = yph[f * YS + k];
+                        ym[u] = yph[f * YS + M - k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UA; ++u) {
+                    const int p = p0 + 64 * u;
+                    const int pc = min(p, npairs - 1);
+                    const int f = pc / NP, k = pc - f * NP;
+                    const int km = (A.dbg & 32) ? M / 2 + k : M - k;   // (timing experiment: ascending stores)
+                    const bool valid = tw0 + f < frames_b;
                     cpx Xk, Xm, pk, pm;
                     float mk, mm;
-                    split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
-                    if (tw0 + f >= frames_b) Xk = Xm = cpx{0.f, 0.f};
+                    split_vals(z1[u], z2[u], w[u], Xk, Xm);
+                    if (!valid) Xk = Xm = cpx{0.f, 0.f};
                     mag_phasor(Xk, mk, pk);
                     mag_phasor(Xm, mm, pm);
-                    yo[f * F + k] = mk;
-                    yph[f * YS + k] = pk;
-                    if (km != k) {
-                        yo[f * F + km] = mm;
-                        yph[f * YS + km] = pm;
+                    if (p < npairs && (!(A.dbg & 1) || mk == 123456.f)) {
+                        mag_out[f * fstride + k] = mk;
+                        if (km != k) mag_out[f * fstride + km] = mm;
+                        if (q == 0) {
+                            yph[f * YS + k] = pk;
+                            if (km != k) yph[f * YS + km] = pm;
+                        } else {
+                            // cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)
+                            const cpx ck = yk[u] * pk, cm = ym[u] * pm;
+                            cp[f * fstride + k] = valid ? ck.x + ck.y : 0.f;
+                            if (km != k) cp[f * fstride + km] = valid ? cm.x + cm.y : 0.f;
+                        }
                     }
                 }
             }
+            wave_sync();   // the next transposition reuses wbuf; yph is read by the following signals
         }
-        __syncthreads();   // phasors of Y are in LDS
-        if (live && q > 0) {
-            const long long xo = (((long long)b * A.out_frames + tw0) * A.K + (q - 1)) * F;
-            float* __restrict__ xa = A.X_abs + xo;
-            float* __restrict__ cp = A.cos_pd + xo;
-            const int fstride = A.K * F;
-            for (int p = lane; p < nfr * NP; p += 64) {
-                const int f = p / NP, k = p - f * NP, km = M - k;
-                cpx Xk, Xm, pk, pm;
-                float mk, mm;
-                split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
-                const bool valid = tw0 + f < frames_b;
-                if (!valid) Xk = Xm = cpx{0.f, 0.f};
-                mag_phasor(Xk, mk, pk);
-                mag_phasor(Xm, mm, pm);
-                const cpx yk = yph[f * YS + k], ym = yph[f * YS + km];
-                xa[f * fstride + k] = mk;
-                cp[f * fstride + k] = valid ? yk.x * pk.x + yk.y * pk.y : 0.f;
-                if (km != k) {
-                    xa[f * fstride + km] = mm;
-                    cp[f * fstride + km] = valid ? ym.x * pm.x + ym.y * pm.y : 0.f;
-                }
-            }
-        }
-        __syncthreads();   // yph / wbuf are rewritten by the next iteration
     }
 }
 
@@ -857,6 +952,20 @@ __global__ __launch_bounds__(256) void istft_generic_kernel(const InvArgs A) {
 
 constexpr size_t kMaxSmem = 64 * 1024;  // keep >= 2 workgroups per CU (160 KiB LDS)
 
+// Workgroups of `Kernel` that stay resident per CU (registers AND LDS), cached per thread.
+template <auto Kernel>
+static int blocks_per_cu(int threads, size_t smem) {
+    thread_local size_t key_smem = ~(size_t)0;
+    thread_local int key_threads = 0, blocks = 0;
+    if (blocks < 1 || key_smem != smem || key_threads != threads) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, Kernel, threads, smem) != hipSuccess || blocks < 1)
+            blocks = 1;
+        key_smem = smem;
+        key_threads = threads;
+    }
+    return blocks;
+}
+
 template <class PL>
 static int launch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t st) {
     const char* dbg_env = getenv("PTMI_STFT_DBG");
@@ -873,30 +982,26 @@ static int launch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t st
         if (items <= 0) return PTMI_OK;
         if (items > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
         // persistent grid: as many workgroups as stay resident (LDS bound), never more than needed
-        const long long resident = 256LL * (long long)((160 * 1024) / smem);
+        const long long resident = 256LL * blocks_per_cu<stft_fwd_kernel<PL>>(256, smem);
         const long long blocks = std::min((items + 3) / 4, resident);
         hipLaunchKernelGGL(stft_fwd_kernel<PL>, dim3((unsigned)blocks), dim3(256), smem, st, A);
         return launch_status();
     }
-    const int nsig = A.s ? A.K + 1 : 1;
-    if (nsig > 16) return PTMI_E_UNSUPPORTED;
-    A.ngroups = nsig <= 4 ? 2 : 1;
-    const int nwaves = A.ngroups * nsig;
-    const size_t smem = WaveLds<PL>::bytes(nwaves, A.ngroups);
-    if (smem > 2 * kMaxSmem) return PTMI_E_UNSUPPORTED;
+    const size_t smem = WaveLds<PL>::bytes(4, 4);
     A.batch = batch;
     A.nchunks = (int)((A.out_frames + PL::FPW - 1) / PL::FPW);          // work items per example
     const long long items = batch * A.nchunks;
     if (items <= 0) return PTMI_OK;
     if (items > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
-    const long long resident = 256LL * (long long)((160 * 1024) / smem);
-    const long long blocks = std::min((items + A.ngroups - 1) / A.ngroups, resident);
+    if (smem > 160 * 1024) return PTMI_E_UNSUPPORTED;
     if (smem > kMaxSmem) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pit_features_kernel<PL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(pit_features_kernel<PL>, dim3((unsigned)blocks), dim3((unsigned)(64 * nwaves)), smem, st, A);
+    const long long resident = 256LL * blocks_per_cu<pit_features_kernel<PL>>(256, smem);
+    const long long blocks = std::min((items + 3) / 4, resident);
+    hipLaunchKernelGGL(pit_features_kernel<PL>, dim3((unsigned)blocks), dim3(256), smem, st, A);
     return launch_status();
 }
 
@@ -925,15 +1030,7 @@ static int launch_inv(InvArgs& A, long long batch, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(istft_kernel<PL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return PTMI_E_UNSUPPORTED;
-    thread_local size_t occ_smem = 0;
-    thread_local int occ_blocks = 0;
-    if (occ_blocks < 1 || occ_smem != smem) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_blocks, istft_kernel<PL>, 256, smem) != hipSuccess ||
-            occ_blocks < 1)
-            occ_blocks = 1;
-        occ_smem = smem;
-    }
-    const int per_cu = occ_blocks;
+    const int per_cu = blocks_per_cu<istft_kernel<PL>>(256, smem);
     const long long resident_waves = 256LL * per_cu * 4;
     // a run owns `run_hops` hops; it walks halo frames before them (their tails reach into the run)
     // and is done when its last owned hop is final (frames past the row's end read as zeros, which
