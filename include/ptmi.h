@@ -192,10 +192,10 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, con
 /* Persistent forward recurrence: ONE launch for all T steps; W_hh stays in registers and the steps
  * are chained by write-through stores + per-step arrival counters (see csrc/lstm.hip).  Same
  * results as ptmi_lstm_forward.  batch_sizes_dev / offsets_dev are DEVICE copies here; flags is a
- * device scratch of ptmi_lstm_flags_elems(T, ndir) uint32 (zeroed by the call; the last 8 words are
+ * device scratch of ptmi_lstm_flags_elems(T, ndir, max_batch) uint32 (zeroed by the call; the last 8 words are
  * error words: non-zero after the call = a bounded spin ran out).  Returns PTMI_E_UNSUPPORTED when
  * the configuration cannot be kept resident (caller falls back to ptmi_lstm_forward). */
-int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir);
+int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* w_hh_pad,
                                  const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
                                  int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,

@@ -46,7 +46,7 @@ SIGNATURES = {
     'ptmi_dc_loss_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P]),
     'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
-    'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32]),
+    'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                              c_int32, _P]),
     'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,

@@ -312,9 +312,11 @@ struct LstmPersistArgs {
     const int64_t* offs;     // device [T]
     unsigned* flags;         // device [ndir][T][8] arrival counters + 1 error word, zeroed per call
     int T, H, KP, ndir;
-    unsigned expected;       // workgroups per direction
+    unsigned expected;       // producer workgroups per chain (direction x row tile)
     unsigned max_polls;
     int hy_bytes;
+    unsigned err_off;        // index of the error words in flags
+    int dbg;                 // PTMI_LSTM_DBG timing ablations (16: no poll, 32: no drain, 64: no MFMA, 128: no operand loads)
 };
 
 __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expected, unsigned max_polls,
@@ -335,18 +337,22 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expe
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int JT, int NW, int CH>
+// MTL = 16-row M tiles per workgroup.  Row tiles are independent recurrences: each has its own
+// arrival counters, so with MTL = 1 a batch of 32 runs as TWO interleaved chains of 16 rows whose
+// workgroups share CUs, and one chain's hand-off latency hides behind the other chain's MFMAs.
+template <int JT, int NW, int CH, int MTL>
 __global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
+    constexpr int MR = 16 * MTL;                  // rows per workgroup
     const int dir = blockIdx.y;
     const int j0 = blockIdx.x * JT;
-    const int m0 = blockIdx.z * 32;
+    const int m0 = blockIdx.z * MR;
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[NW][32][NC + 1];
+    __shared__ float red[NW][MR][NC + 1];
 
     // resident slice of W_hh: CH 16-wide K blocks of NT x 16 gate columns per wavefront
     const int nblk = A.KP >> 4;
@@ -366,8 +372,8 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const L
             bq[i][nt] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
     const __amdgpu_buffer_rsrc_t hy_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.hy, 0, A.hy_bytes, 0x00020000);
-    unsigned* const myflags = A.flags + (size_t)dir * A.T * 8;
-    unsigned* const err = A.flags + (size_t)A.ndir * A.T * 8;
+    unsigned* const myflags = A.flags + ((size_t)dir * gridDim.z + blockIdx.z) * A.T * 8;   // this chain's
+    unsigned* const err = A.flags + A.err_off;
     const int bl = tid / JT, u = tid - bl * JT;
     const int b = m0 + bl;
 
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const L
             prow0 = A.offs[tp];
         }
         const bool has_rec = nprev > m0;                 // workgroup-uniform
-        const bool act = tid < 32 * JT && b < nb && j0 + u < H;
+        const bool act = tid < MR * JT && b < nb && j0 + u < H;
         float pre[4] = {0.f, 0.f, 0.f, 0.f};
         float cprev = 0.f;
         float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
@@ -392,53 +398,53 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const L
             for (int q = 0; q < 4; ++q) pre[q] = gp[q * H];
         }
         if (has_rec) {
-            if (wave == 0) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
             __syncthreads();
             if (act && b < nprev)
                 cprev = __hip_atomic_load(A.c + (prow0 + b) * ld_h + dir * H + j0 + u, __ATOMIC_RELAXED,
                                           __HIP_MEMORY_SCOPE_AGENT);
-            const int mtiles = (min(nprev, m0 + 32) - m0 + 15) >> 4;
-            f32x4 a[CH][2];
+            const int mtiles = (min(nprev, m0 + MR) - m0 + 15) >> 4;
+            f32x4 a[CH][MTL];
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int kb = kb0 + i;
                 const bool kin = kb < kb1 && (kb * 16 + 4 * g4 < H);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MTL; ++mt) {
                     const int irow = m0 + mt * 16 + r;
-                    const bool ok = kin && irow < nprev;
+                    const bool ok = kin && irow < nprev && !(A.dbg & 128);
                     const unsigned voff = ok ? (unsigned)(((prow0 + irow) * ld_h + dir * H + kb * 16 + 4 * g4) * 4) : 0u;
                     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hy_rsrc, voff, 0, 16 /* sc1 */);
                     a[i][mt] = ok ? __builtin_bit_cast(f32x4, v) : zero;
                 }
             }
-            f32x4 acc[2][NT];
+            f32x4 acc[MTL][NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                if (kb0 + i < kb1) {
+                if (kb0 + i < kb1 && !(A.dbg & 64)) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
                             acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0][q], bq[i][nt][q], acc[0][nt], 0, 0, 0);
-                            if (mtiles > 1)
-                                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][1][q], bq[i][nt][q], acc[1][nt], 0, 0, 0);
+                            if (MTL > 1 && mtiles > 1)
+                                acc[MTL - 1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][MTL - 1][q], bq[i][nt][q], acc[MTL - 1][nt], 0, 0, 0);
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
             __syncthreads();
-            if (tid < 32 * JT) {
+            if (tid < MR * JT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cidx = q * JT + u;
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const L
             __hip_atomic_store(A.hy + o, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // publish step s: every wavefront drains its stores, then one lane arrives
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
             __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
@@ -491,6 +497,7 @@ struct LstmPersistBwdArgs {
     unsigned expected;
     unsigned max_polls;
     int dg_bytes;
+    unsigned err_off;
 };
 
 template <int NW, int CH>
@@ -518,8 +525,8 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const L
             bq[i] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
     const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.dg, 0, A.dg_bytes, 0x00020000);
-    unsigned* const myflags = A.flags + (size_t)dir * A.T * 8;
-    unsigned* const err = A.flags + (size_t)A.ndir * A.T * 8;
+    unsigned* const myflags = A.flags + ((size_t)dir * gridDim.y + blockIdx.y) * A.T * 8;   // this row tile's chain
+    unsigned* const err = A.flags + A.err_off;
     const int bl = (tid >> 4) & 15, jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
     float dc_state = 0.f;      // d loss / d c of (b, j) flowing to the next (earlier) step
@@ -720,7 +727,9 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, con
                             static_cast<hipStream_t>(stream));
 }
 
-int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir) { return (int64_t)ndir * T * 8 + 8; }
+int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch) {
+    return (int64_t)ndir * ((max_batch + 15) / 16) * T * 8 + 8;   // one chain per 16-row tile + error words
+}
 
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* w_hh_pad,
                                  const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
@@ -733,18 +742,29 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     // the resident W slice must fit CH K-blocks per wavefront; all workgroups must be co-resident
     // (512-thread workgroups at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2)
     PTMI_RETURN_IF((KP / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
-    const unsigned mz = (unsigned)((max_batch + 31) / 32);
-    const long long wgs = (long long)((H + 7) / 8) * ndir * mz;
-    PTMI_RETURN_IF(wgs > 448, PTMI_E_UNSUPPORTED);
+    // 16-row workgroups (two interleaved chains per 32 rows) while all of them stay co-resident
+    // (512 threads at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2), else 32-row workgroups
+    const int jx = (H + 7) / 8;
     const long long hy_bytes = rows * ndir * H * 4;
     PTMI_RETURN_IF(hy_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    const unsigned mz16 = (unsigned)((max_batch + 15) / 16), mz32 = (unsigned)((max_batch + 31) / 32);
+    const char* mt_env = getenv("PTMI_LSTM_MTL");
+    const bool small = mt_env ? atoi(mt_env) == 1 : max_batch <= 16;   // measured: 8.3 (16-row) vs 6.9 us/step (32-row) at B = 32
+    const unsigned mz = small ? mz16 : mz32;
+    PTMI_RETURN_IF((long long)jx * ndir * mz > 448, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir), st);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
-                      (unsigned)(((H + 7) / 8) * mz), 1u << 22, (int)hy_bytes};
-    hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH>), dim3((unsigned)((H + 7) / 8), (unsigned)ndir, mz),
-                       dim3(NW * 64), 0, st, A);
+                      (unsigned)jx, 1u << 22, (int)hy_bytes,
+                      (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
+                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0};
+    if (small)
+        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1>), dim3((unsigned)jx, (unsigned)ndir, mz),
+                           dim3(NW * 64), 0, st, A);
+    else
+        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2>), dim3((unsigned)jx, (unsigned)ndir, mz),
+                           dim3(NW * 64), 0, st, A);
     return launch_status();
 }
 
@@ -764,10 +784,11 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     const long long dg_bytes = rows * ndir * 4 * H * 4;
     PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir), st);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
-                         (unsigned)(((H + 15) / 16) * ((max_batch + 15) / 16)), 1u << 22, (int)dg_bytes};
+                         (unsigned)((H + 15) / 16), 1u << 22, (int)dg_bytes,
+                         (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8)};
     hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>),
                        dim3((unsigned)((H + 15) / 16), (unsigned)((max_batch + 15) / 16), (unsigned)ndir),
                        dim3(NW * 64), 0, st, A);

@@ -200,7 +200,7 @@ class _LstmLayerFn(torch.autograd.Function):
             c = torch.empty_like(hy)
             rc = -2
             if PERSISTENT:
-                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir)), dtype=torch.int32,
+                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)), dtype=torch.int32,
                                     device=x.device)
                 rc = _lib.timed(
                     'lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(),
@@ -248,7 +248,7 @@ class _LstmLayerFn(torch.autograd.Function):
             dg = torch.empty_like(gates)
             rc = -2
             if PERSISTENT:
-                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir)), dtype=torch.int32,
+                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)), dtype=torch.int32,
                                     device=x.device)
                 rc = _lib.timed(
                     'lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(),
