@@ -11,9 +11,11 @@ Workload = BASELINE.json configs[1]: 2-speaker synthetic 8 kHz mixtures, batch 3
 23 480 914 parameters), STFT 512/128.  One micro-step per rank per optimizer step (weak scaling).
 
 The JSON line also carries
-  roofline     : the HBM-bound STFT feature kernel (pit_features_kernel), algorithmic bytes
-                 (6676 B per mixture frame at K=2) / HIP-event time of its
-                 launches inside the timed steps, against the 8 TB/s HBM3E peak;
+  roofline     : the kernel family with the most GPU time per step (the BLSTM recurrence), its
+                 algorithmic flops / HIP-event time of its launches inside the timed steps against the
+                 fp32 MFMA peak; other_kernels lists every other hand-written kernel of the step the
+                 same way (the STFT front-end: 6676 B per mixture frame at K=2, SURVEY.md section 8d,
+                 against the 8 TB/s HBM3E peak);
   cpu_baseline : the oracle's torch-CPU port of the reference step (oracle/torch_ref.py) timed on
                  this box's host cores on a bounded sample (rank 0, N=1 only).
 """
@@ -169,27 +171,48 @@ def main():
         by_name = {}
         for name, a, b in timers:
             by_name.setdefault(name, []).append(a.elapsed_time(b))
-        kern_ms = float(np.mean(by_name['pit_features']))
-        alg_bytes = FEATURE_BYTES_PER_FRAME * frames_per_step
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        pit_bytes = {'pit_pairwise_sse': PIT_LOSS_BYTES_PER_FRAME * frames_per_step,
-                     'pit_backward': (PIT_LOSS_BYTES_PER_FRAME + K * (SIZE // 2 + 1) * 4) * frames_per_step}
-        other = [dict(kernel=n, avg_launch_ms=float(np.mean(v)), bound='hbm',
-                      achieved=pit_bytes[n] / (float(np.mean(v)) * 1e-3) / 1e9, peak=HBM_PEAK_GBS,
-                      unit='GB/s', frac=pit_bytes[n] / (float(np.mean(v)) * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                 for n, v in by_name.items() if n in pit_bytes]
-        # the BLSTM recurrence launches dominate the step (one persistent launch per layer and pass):
-        # exact-fp32 matrix-core work 2*B*H*4H per step and direction against the 157.3 TFLOP/s fp32
-        # MFMA peak; they are bound by the per-step dependency chain, not by the matrix cores
+        # One entry per hand-written kernel family seen in the timed steps: HIP-event time of every
+        # launch (events recorded on the launch stream around the C-ABI call), algorithmic bytes or
+        # flops per launch (SURVEY.md section 8d figures x the frames one launch processes).
         Hh, T = model.blstm.hidden_size, frames_per_step // BATCH
-        rec_flop = 2.0 * 2 * BATCH * Hh * 4 * Hh * T
-        for n in ('lstm_forward', 'lstm_backward'):
-            if n in by_name:
-                ms = float(np.mean(by_name[n]))
-                other.append(dict(kernel=n + ' (persistent, per layer)', avg_launch_ms=ms, bound='mfma',
-                                  achieved=rec_flop / (ms * 1e-3) / 1e12, peak=FP32_MFMA_PEAK_TFLOPS,
-                                  unit='TFLOP/s', frac=rec_flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                                  us_per_timestep=ms * 1e3 / T))
+        rec_flop = 2.0 * 2 * BATCH * Hh * 4 * Hh * T          # both directions, one layer, one pass
+        F = SIZE // 2 + 1
+        spec = {
+            'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end)', 'hbm',
+                             FEATURE_BYTES_PER_FRAME * frames_per_step, 'pit_features'),
+            'pit_pairwise_sse': ('pit_pairwise_kernel<2> (PIT mse+ips pairwise SSE)', 'hbm',
+                                 PIT_LOSS_BYTES_PER_FRAME * frames_per_step, 'pit_pairwise_sse'),
+            'pit_backward': ('pit_backward_kernel (d loss / d mask)', 'hbm',
+                             (PIT_LOSS_BYTES_PER_FRAME + K * F * 4) * frames_per_step, 'pit_backward'),
+            'lstm_forward': ('lstm_fwd_persistent_kernel (BLSTM recurrence, one launch per layer)', 'mfma',
+                             rec_flop, 'lstm_fwd_persistent'),
+            'lstm_backward': ('lstm_bwd_persistent_kernel (BLSTM backward-through-time, one launch per layer)',
+                              'mfma', rec_flop, 'lstm_bwd_persistent'),
+        }
+        kernels = []
+        for n, v in by_name.items():
+            if n not in spec:
+                continue
+            label, bound, work, traffic_key = spec[n]
+            ms = float(np.mean(v))
+            if bound == 'hbm':
+                achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
+            else:
+                achieved, peak, unit = work / (ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s'
+            e = dict(kernel=label, bound=bound, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                     traffic=measured_traffic(traffic_key), avg_launch_ms=ms,
+                     launches_per_step=len(v) / args.steps, ms_per_step=float(np.sum(v)) / args.steps)
+            if bound == 'hbm':
+                e['algorithmic_bytes_per_launch'] = work
+            else:
+                e['algorithmic_flop_per_launch'] = work
+                e['us_per_timestep'] = ms * 1e3 / T
+            kernels.append(e)
+        # the dominant kernel = the family with the most GPU time per step.  At this workload that is
+        # the BLSTM recurrence: exact-fp32 matrix-core work against the 157.3 TFLOP/s fp32 MFMA peak,
+        # bound by the per-timestep dependency chain, not by the matrix cores.
+        kernels.sort(key=lambda e: -e['ms_per_step'])
+        dominant, other = kernels[0], kernels[1:]
         out = {
             'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)',
             'value': frames_per_step * world * args.steps / elapsed,
@@ -213,17 +236,7 @@ def main():
                 'parallelism': f'dp{world}',
                 'blstm': 'HIP recurrence (csrc/lstm.hip)' if model.hip_blstm else 'torch.nn.LSTM (MIOpen)',
             },
-            'roofline': {
-                'kernel': 'pit_features_kernel<Plan<16,16>> (fused STFT front-end)',
-                'bound': 'hbm',
-                'achieved': achieved,
-                'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK_GBS,
-                'traffic': measured_traffic('pit_features'),
-                'algorithmic_bytes_per_launch': alg_bytes,
-                'avg_launch_ms': kern_ms,
-            },
+            'roofline': dominant,
             'other_kernels': other,
         }
         if world == 1 and not args.no_cpu_baseline:

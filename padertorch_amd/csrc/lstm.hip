@@ -340,8 +340,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // MTL = 16-row M tiles per workgroup.  Row tiles are independent recurrences: each has its own
 // arrival counters, so with MTL = 1 a batch of 32 runs as TWO interleaved chains of 16 rows whose
 // workgroups share CUs, and one chain's hand-off latency hides behind the other chain's MFMAs.
-template <int JT, int NW, int CH, int MTL>
-__global__ __launch_bounds__(NW * 64, 4) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {
+// OCC = workgroups per CU the register budget allows (2: up to 448 co-resident workgroups; 1: up to
+// 256, twice the registers, no spills).
+template <int JT, int NW, int CH, int MTL, int OCC>
+__global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
     constexpr int MR = 16 * MTL;                  // rows per workgroup
@@ -759,12 +761,16 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                       (unsigned)jx, 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
                       getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0};
-    if (small)
-        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1>), dim3((unsigned)jx, (unsigned)ndir, mz),
-                           dim3(NW * 64), 0, st, A);
+    const dim3 grid((unsigned)jx, (unsigned)ndir, mz), block(NW * 64);
+    const bool one_per_cu = (long long)jx * ndir * mz <= 256;
+    if (small && one_per_cu)
+        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 1>), grid, block, 0, st, A);
+    else if (small)
+        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 2>), grid, block, 0, st, A);
+    else if (one_per_cu)
+        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 1>), grid, block, 0, st, A);
     else
-        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2>), dim3((unsigned)jx, (unsigned)ndir, mz),
-                           dim3(NW * 64), 0, st, A);
+        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 2>), grid, block, 0, st, A);
     return launch_status();
 }
 
