@@ -221,6 +221,29 @@ int ptmi_lstm_plan_forward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
 int ptmi_lstm_plan_backward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
 void ptmi_lstm_plan_destroy(ptmi_lstm_plan* plan);
 
+/* ---- Time-domain regression losses under PIT ------------------------------------------------------
+ * Replaces padertorch/ops/losses/regression.py:47-378 (mse_loss, log_mse_loss, sdr_loss, si_sdr_loss,
+ * log1p_mse_loss, source_aggregated_sdr_loss) evaluated per permutation by pit_loss
+ * (ops/losses/source_separation.py:110-119) and the TasNet loss loop
+ * (contrib/examples/source_separation/tasnet/model.py:154-176).
+ *
+ * ptmi_td_pair_stats: one streaming pass over est / tgt [batch, K, T] (time contiguous; strides[4] =
+ * {est_b, est_k, tgt_b, tgt_k} in elements, HOST array; lengths[b] <= T valid samples or NULL) ->
+ * stats [batch, K*K + 4K] float64 per example:  Set[i][j] = sum e_i t_j | See[i] | Stt[j] | Se[i] | St[j].
+ * workspace: ptmi_td_workspace_elems(batch, K, T) float64.  K <= 8, batch <= 65535.
+ *
+ * ptmi_td_lincomb: out[b,i,t] = a[b,i] x[b,i,t] + sum_j bmat[b,i,j] y[b,j,t] + c[b,i] for t < lengths[b],
+ * 0 beyond (the backward pass: d loss / d estimate with x = est, y = tgt; d / d target with the roles
+ * swapped).  strides[6] = {x_b, x_k, y_b, y_k, out_b, out_k}; coefficients are device float32. */
+int64_t ptmi_td_stats_elems(int32_t K);
+int64_t ptmi_td_workspace_elems(int64_t batch, int32_t K, int64_t T);
+int ptmi_td_pair_stats(const float* est, const float* tgt, const int32_t* lengths, int64_t batch, int32_t K,
+                       int64_t T, const int64_t* strides, double* workspace, double* stats,
+                       ptmi_stream_t stream);
+int ptmi_td_lincomb(const float* x, const float* y, const int32_t* lengths, const float* coef_a,
+                    const float* coef_b, const float* coef_c, int64_t batch, int32_t K, int64_t T,
+                    const int64_t* strides, float* out, ptmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -98,3 +98,96 @@ def pit_review_losses(masks, Y_abs, X_abs, cos_phase_difference):
         ips_l.append(l)
         pi.append(p)
     return float(np.mean(mse_l)), float(np.mean(ips_l)), pm, pi
+
+
+# ---- time-domain regression losses (padertorch/ops/losses/regression.py) ---------------------------
+def _reduce(array, reduction):
+    """regression.py:27-36."""
+    if reduction is None or reduction == 'none':
+        return array
+    if reduction == 'sum':
+        return np.sum(array)
+    if reduction == 'mean':
+        return np.mean(array)
+    raise ValueError(reduction)
+
+
+def _threshold(soft_sdr_max):
+    """regression.py:39-44."""
+    return None if soft_sdr_max is None else 10 ** (-soft_sdr_max / 10)
+
+
+def td_mse_loss(estimate, target, reduction='sum'):
+    """regression.py:47-68: mean over time, ``reduction`` over the rows."""
+    e, t = np.asarray(estimate, np.float64), np.asarray(target, np.float64)
+    return _reduce(np.mean((e - t) ** 2, axis=-1), reduction)
+
+
+def td_log_mse_loss(estimate, target, reduction='sum', soft_sdr_max=None):
+    """regression.py:71-128."""
+    e, t = np.asarray(estimate, np.float64), np.asarray(target, np.float64)
+    loss = np.mean((e - t) ** 2, axis=-1)
+    if soft_sdr_max:
+        loss = loss + _threshold(soft_sdr_max) * np.mean(t * t, axis=-1)
+    return _reduce(np.log10(loss), reduction)
+
+
+def td_log1p_mse_loss(estimate, target, reduction='sum'):
+    """regression.py:299-341."""
+    e, t = np.asarray(estimate, np.float64), np.asarray(target, np.float64)
+    return _reduce(np.log10(1 + np.mean((e - t) ** 2, axis=-1)), reduction)
+
+
+def td_sdr_loss(estimate, target, reduction='mean', soft_sdr_max=None):
+    """regression.py:131-175."""
+    e, t = np.asarray(estimate, np.float64), np.asarray(target, np.float64)
+    target_norm = np.sum(t * t, axis=-1)
+    den = np.sum((e - t) ** 2, axis=-1)
+    if soft_sdr_max is not None:
+        den = den + _threshold(soft_sdr_max) * target_norm
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return -_reduce(10 * np.log10(target_norm / den), reduction)
+
+
+def td_si_sdr_loss(estimate, target, reduction='mean', offset_invariant=False, grad_stop=False,
+                   soft_sdr_max=None):
+    """regression.py:178-296 (``grad_stop`` only changes gradients)."""
+    e, t = np.asarray(estimate, np.float64), np.asarray(target, np.float64)
+    if offset_invariant:
+        e = e - np.mean(e, axis=-1, keepdims=True)
+        t = t - np.mean(t, axis=-1, keepdims=True)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        alpha = np.sum(e * t, axis=-1, keepdims=True) / np.sum(t * t, axis=-1, keepdims=True)
+    return td_sdr_loss(e, alpha * t, reduction=reduction, soft_sdr_max=soft_sdr_max)
+
+
+def td_source_aggregated_sdr_loss(estimate, target, soft_sdr_max=None):
+    """regression.py:344-392."""
+    e, t = np.asarray(estimate, np.float64), np.asarray(target, np.float64)
+    target_norm = np.sum(t * t)
+    den = np.sum((e - t) ** 2)
+    if soft_sdr_max is not None:
+        den = den + _threshold(soft_sdr_max) * target_norm
+    return -10 * np.log10(target_norm / den)
+
+
+TD_LOSSES = {
+    'mse': td_mse_loss,
+    'log-mse': td_log_mse_loss,
+    'log1p-mse': td_log1p_mse_loss,
+    'sdr': td_sdr_loss,
+    'si-sdr': td_si_sdr_loss,
+    'sa-sdr': td_source_aggregated_sdr_loss,
+}
+
+
+def tasnet_losses(x, s, num_samples):
+    """TasNet.loss (contrib/examples/source_separation/tasnet/model.py:154-176): per example
+    ``pit_loss(estimated[..., :n], target[..., :n], axis=0, loss_fn)`` for si-sdr / log-mse /
+    log1p-mse, batch mean."""
+    out = {}
+    for name in ('si-sdr', 'log-mse', 'log1p-mse'):
+        vals = [pit_loss(e[..., :n], t[..., :n], axis=0, loss_fn=TD_LOSSES[name])
+                for n, e, t in zip(num_samples, x, s)]
+        out[name] = float(np.mean(vals))
+    return out

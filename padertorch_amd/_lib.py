@@ -44,6 +44,10 @@ SIGNATURES = {
     'ptmi_dc_workspace_elems': (c_int64, [c_int64, c_int64, c_int32]),
     'ptmi_dc_loss_forward': (c_int, [_P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     'ptmi_dc_loss_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    'ptmi_td_stats_elems': (c_int64, [c_int32]),
+    'ptmi_td_workspace_elems': (c_int64, [c_int64, c_int32, c_int64]),
+    'ptmi_td_pair_stats': (c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P, _P]),
+    'ptmi_td_lincomb': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P]),
     'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
@@ -118,6 +122,10 @@ def timed(name, fn, *args):
     e1.record()
     KERNEL_TIMERS.append((name, e0, e1))
     return rc
+
+
+def strides4(*vals):
+    return (c_int64 * 4)(*vals)
 
 
 def strides6(*vals):

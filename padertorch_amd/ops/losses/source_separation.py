@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional
 
 from ... import _lib
+from . import regression
 
 __all__ = [
     'deep_clustering_loss',
@@ -235,6 +236,17 @@ def pit_loss(
         min_loss = loss[0]
         if return_permutation:
             return min_loss, tuple(int(p) for p in perm[0, 0].tolist())
+        return min_loss
+
+    if estimate.ndim == 2 and axis % 2 == 0 and sources <= 8 and estimate.dtype == torch.float32 \
+            and target.dtype == torch.float32 and regression.resolve(loss_fn) is not None:
+        # time-domain losses of ops/losses/regression.py on (K, T) signals (TasNet loss,
+        # tasnet/model.py:164-174): all K! candidates from ONE pass over the signals
+        q = regression.pair_stats(estimate[None], target[None])
+        loss, perm = regression.pit_from_stats(q, loss_fn)
+        min_loss = loss[0].to(estimate.dtype)
+        if return_permutation:
+            return min_loss, tuple(int(p) for p in perm[0].tolist())
         return min_loss
 
     # generic loss_fn: the reference's brute-force algorithm, evaluated with torch ops on the device

@@ -67,6 +67,15 @@ def main():
         t = timeit(lambda: torch.autograd.grad(loss[1], mask, retain_graph=True))
         res.append(dict(kernel='pit_loss_bwd', B=B, frames=B * T, us=t,
                         GBs=B * T * (7196 + 2056) / t / 1e3))
+        # time-domain PIT losses (TasNet trio) from one statistics pass: 2*K*N*4 bytes read per example;
+        # backward: read 2*K*N*4, write K*N*4
+        from padertorch_amd.ops.losses import regression
+        x = (s.flip(1) + 0.01 * torch.randn_like(s)).requires_grad_(True)
+        t = timeit(lambda: regression.pair_stats(x.detach(), s))
+        res.append(dict(kernel='td_pair_stats', B=B, N=N, us=t, GBs=B * 2 * K * N * 4 / t / 1e3))
+        tot = sum(v[0].sum() for v in regression.pit_td_losses(x, s).values())
+        t = timeit(lambda: torch.autograd.grad(tot, x, retain_graph=True))
+        res.append(dict(kernel='td_lincomb (backward)', B=B, N=N, us=t, GBs=B * 3 * K * N * 4 / t / 1e3))
     for r in res:
         r['frac_of_8TBs'] = r['GBs'] / PEAK
         print(json.dumps(r))

@@ -70,3 +70,11 @@ def g6():
     d = _npz('g6_models.npz')
     d['train_example_indices'] = json.loads(str(d['train_example_indices']))
     return d
+
+
+@pytest.fixture(scope='session')
+def g7():
+    d = _npz('g7_td_losses.npz')
+    d['cases'] = json.loads(str(d['cases']))
+    d['names'] = json.loads(str(d['names']))
+    return d

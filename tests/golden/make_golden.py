@@ -17,6 +17,9 @@ Fixtures:
   g5_dc.npz               deep_clustering_loss
   g6_models.npz           tiny PIT + DC model: state_dict, inputs, outputs, losses, grads,
                           3 reference-Trainer optimizer steps (virtual_minibatch_size=2)
+  g7_td_losses.npz        ops/losses/regression.py: doctest answers, seeded (K, T) signals -> every loss
+                          (options grid), gradients w.r.t. the estimate, pit_loss over them, the
+                          TasNet loss of a ragged batch; StftEncoder / IstftDecoder outputs
 """
 import itertools
 import json
@@ -285,9 +288,102 @@ def g6():
     np.savez(HERE / 'g6_models.npz', **out)
 
 
+def g7():
+    """Time-domain regression losses + their PIT use + the TasNet coders."""
+    import functools
+    from padertorch.ops.losses import regression as R
+    from padertorch.contrib.examples.source_separation.tasnet.tas_coders import StftEncoder, IstftDecoder
+    rng = np.random.RandomState(7)
+    out = {}
+    fns = {
+        'mse': R.mse_loss, 'log-mse': R.log_mse_loss, 'log1p-mse': R.log1p_mse_loss, 'sdr': R.sdr_loss,
+        'si-sdr': R.si_sdr_loss, 'sa-sdr': R.source_aggregated_sdr_loss,
+        'log-mse@20': functools.partial(R.log_mse_loss, soft_sdr_max=20),
+        'sdr@20': functools.partial(R.sdr_loss, soft_sdr_max=20),
+        'si-sdr@30': functools.partial(R.si_sdr_loss, soft_sdr_max=30),
+        'si-sdr-oi': functools.partial(R.si_sdr_loss, offset_invariant=True),
+        'si-sdr-gs': functools.partial(R.si_sdr_loss, grad_stop=True),
+        'si-sdr-sum': functools.partial(R.si_sdr_loss, reduction='sum'),
+        'log-mse-mean': functools.partial(R.log_mse_loss, reduction='mean'),
+    }
+    # doctest pair (regression.py:60-67, 119-124, 148-153, 207-212, 333-338, 356-361)
+    de = torch.tensor([[1., 2, 3], [4, 5, 6]])
+    dt = torch.tensor([[2., 3, 4], [4, 0, 6]])
+    out['doc_estimate'], out['doc_target'] = de.numpy(), dt.numpy()
+    for n, f in fns.items():
+        out[f'doc/{n}'] = f(de, dt).numpy()
+    for n in ('mse', 'log-mse', 'log1p-mse', 'sdr', 'si-sdr'):
+        out[f'doc_none/{n}'] = fns[n](de, dt, reduction=None).numpy()
+    # seeded signals: K sources of T samples, estimate = mixture of the targets + noise
+    cases = []
+    for K, T in ((2, 777), (3, 400), (4, 257)):
+        tgt = (0.3 * rng.randn(K, T) + 0.05).astype(np.float32)
+        mix = np.eye(K)[::-1] * 0.8 + 0.15 * rng.rand(K, K)          # permuted, leaky
+        est = (mix @ tgt + 0.05 * rng.randn(K, T)).astype(np.float32)
+        key = f'K{K}_T{T}'
+        cases.append(key)
+        out[f'{key}/estimate'], out[f'{key}/target'] = est, tgt
+        for n, f in fns.items():
+            e = torch.tensor(est, requires_grad=True)
+            t = torch.tensor(tgt, requires_grad=True)
+            loss = f(e, t)
+            loss.backward()
+            out[f'{key}/{n}/loss'] = loss.detach().numpy()
+            out[f'{key}/{n}/grad_estimate'] = e.grad.numpy()
+            if n in ('si-sdr', 'mse'):
+                out[f'{key}/{n}/grad_target'] = t.grad.numpy()
+            e64 = torch.tensor(est, dtype=torch.float64)
+            out[f'{key}/{n}/loss64'] = f(e64, torch.tensor(tgt, dtype=torch.float64)).numpy()
+            if True:
+                e2 = torch.tensor(est, requires_grad=True)
+                pl, perm = pt.ops.losses.pit_loss(e2, torch.tensor(tgt), axis=0, loss_fn=f, return_permutation=True)
+                pl.backward()
+                out[f'{key}/{n}/pit_loss'] = pl.detach().numpy()
+                out[f'{key}/{n}/pit_perm'] = np.array(perm)
+                if n in ('si-sdr', 'log-mse', 'sa-sdr'):
+                    out[f'{key}/{n}/pit_grad_estimate'] = e2.grad.numpy()
+    out['cases'] = np.array(json.dumps(cases))
+    out['names'] = np.array(json.dumps(list(fns)))
+    # TasNet.loss on a ragged batch (tasnet/model.py:154-176), B=3, K=2, padded to 1200
+    B, K, T = 3, 2, 1200
+    num_samples = [1200, 1111, 640]
+    s = (0.3 * rng.randn(B, K, T)).astype(np.float32)
+    x = (s[:, ::-1] * 0.9 + 0.1 * s + 0.05 * rng.randn(B, K, T)).astype(np.float32)
+    x[1] = (s[1] * 0.9 + 0.05 * rng.randn(K, T)).astype(np.float32)       # identity permutation
+    xt = torch.tensor(x, requires_grad=True)
+    losses = {k: [] for k in ('si-sdr', 'log-mse', 'log1p-mse')}
+    tas = {'si-sdr': R.si_sdr_loss, 'log-mse': R.log_mse_loss, 'log1p-mse': R.log1p_mse_loss}
+    for n_, est_, tgt_ in zip(num_samples, xt, torch.tensor(s)):
+        for k, f in tas.items():
+            losses[k].append(pt.ops.losses.pit_loss(est_[..., :n_], tgt_[..., :n_], axis=0, loss_fn=f))
+    tl = {k: torch.mean(torch.stack(v)) for k, v in losses.items()}
+    (tl['si-sdr'] + 0.5 * tl['log-mse'] + 0.25 * tl['log1p-mse']).backward()
+    out['tas/x'], out['tas/s'], out['tas/num_samples'] = x, s, np.array(num_samples)
+    for k, v in tl.items():
+        out[f'tas/{k}'] = v.detach().numpy()
+    out['tas/grad_x'] = xt.grad.numpy()          # of si-sdr + 0.5 log-mse + 0.25 log1p-mse
+    # StftEncoder / IstftDecoder (tasnet/tas_coders.py:138-240)
+    mixture = torch.tensor(rng.rand(2, 3, 203).astype(np.float32))
+    enc = StftEncoder(feature_size=258)
+    encoded, num_frames = enc(mixture, [203, 150])
+    out['coder/mixture'] = mixture.numpy()
+    out['coder/encoded'] = encoded.numpy()
+    out['coder/num_frames'] = num_frames.numpy()
+    stft_signal = torch.tensor(rng.rand(2, 4, 258, 10).astype(np.float32))
+    out['coder/stft_signal'] = stft_signal.numpy()
+    out['coder/decoded'] = IstftDecoder(feature_size=258)(stft_signal).numpy()
+    enc2 = StftEncoder(window_length=16, feature_size=66, stride=4)
+    out['coder/encoded_16_66_4'] = enc2(mixture).numpy()
+    out['coder/roundtrip_16_66_4'] = IstftDecoder(window_length=16, feature_size=66, stride=4)(enc2(mixture)).numpy()
+    np.savez_compressed(HERE / 'g7_td_losses.npz', **out)
+
+
 if __name__ == '__main__':
     assert os.path.isdir('/root/reference'), 'run in the build container'
-    for fn in (g1, g2, g3, g4, g5, g6):
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g7):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print('wrote', fn.__name__)
     for p in sorted(HERE.glob('g*.*')):
