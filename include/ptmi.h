@@ -221,6 +221,23 @@ int ptmi_lstm_plan_forward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
 int ptmi_lstm_plan_backward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
 void ptmi_lstm_plan_destroy(ptmi_lstm_plan* plan);
 
+/* ---- (log-)mel features ----------------------------------------------------------------------------
+ * Replaces MelTransform.forward (padertorch/contrib/je/modules/features.py:297-330: spectrogram @
+ * fbanks, log(x + eps)) and, fused with the STFT, the extractor front-end features.py:171-176
+ * (power of the stacked STFT -> MelTransform) without materialising the spectrum.
+ * The [F, M] filterbank is passed band-compressed: filter m covers bins mel_lo[m] .. mel_lo[m] +
+ * mel_cnt[m] - 1 with weights mel_w[mel_off[m] ...] (device arrays; sum of mel_cnt = mel_nnz).
+ * ptmi_stft_logmel: x [batch, num_samples] -> out [batch, out_frames, mel_M] = f(|STFT|^power),
+ * power in {1, 2}; sizes 64..2048 (powers of two).  ptmi_mel_apply: spec [N, F] -> out [N, mel_M]. */
+int ptmi_stft_logmel(const float* x, int64_t batch, int64_t x_row_stride, int64_t num_samples,
+                     const int32_t* row_samples, const float* window, const float* twiddle,
+                     const ptmi_stft_geom* g, int64_t out_frames, const int32_t* mel_lo, const int32_t* mel_cnt,
+                     const int32_t* mel_off, const float* mel_w, int32_t mel_M, int32_t mel_nnz, int32_t power,
+                     int32_t log_, float eps, float* out, ptmi_stream_t stream);
+int ptmi_mel_apply(const float* spec, int64_t N, int32_t F, const int32_t* mel_lo, const int32_t* mel_cnt,
+                   const int32_t* mel_off, const float* mel_w, int32_t mel_M, int32_t mel_nnz, int32_t log_,
+                   float eps, float* out, ptmi_stream_t stream);
+
 /* ---- Time-domain regression losses under PIT ------------------------------------------------------
  * Replaces padertorch/ops/losses/regression.py:47-378 (mse_loss, log_mse_loss, sdr_loss, si_sdr_loss,
  * log1p_mse_loss, source_aggregated_sdr_loss) evaluated per permutation by pit_loss

@@ -44,6 +44,9 @@ SIGNATURES = {
     'ptmi_dc_workspace_elems': (c_int64, [c_int64, c_int64, c_int32]),
     'ptmi_dc_loss_forward': (c_int, [_P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P, _P, _P, _P]),
     'ptmi_dc_loss_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, c_int32, _P, _P, _P]),
+    'ptmi_stft_logmel': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _G, c_int64, _P, _P, _P, _P,
+                                 c_int32, c_int32, c_int32, c_int32, c_float, _P, _P]),
+    'ptmi_mel_apply': (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, _P, _P]),
     'ptmi_td_stats_elems': (c_int64, [c_int32]),
     'ptmi_td_workspace_elems': (c_int64, [c_int64, c_int32, c_int64]),
     'ptmi_td_pair_stats': (c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P, _P]),

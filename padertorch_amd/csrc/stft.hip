@@ -64,6 +64,13 @@ struct FwdArgs {
     bool aligned2;   // every frame start is 8-byte aligned -> float2 sample loads
     float edge_scale;
     Geo g;
+    // fused (log-)mel epilogue (stft_fwd_kernel<PL, true>): band-compressed filterbank
+    const int32_t* mel_lo;    // [M] first bin of filter m
+    const int32_t* mel_cnt;   // [M] number of bins
+    const int32_t* mel_off;   // [M] offset of its weights in mel_w
+    const float* mel_w;       // [nnz]
+    int mel_M, mel_nnz, mel_power, mel_log;
+    float mel_eps;
 };
 
 // W_size^j for 0 <= j < size from the half-circle table (j = 0..M): W^(j) = -W^(j-M) for j > M.
@@ -212,7 +219,7 @@ struct WaveLds {
         buf = reinterpret_cast<cpx*>(win + PL::SIZE);
         yph = buf + nwaves * PL::FPW * PL::FS;
     }
-    static size_t bytes(int nwaves, int nyph) {
+    __host__ __device__ static size_t bytes(int nwaves, int nyph) {
         return sizeof(cpx) * (PL::F + 1 + PL::R1 * PL::LPF + (size_t)nwaves * PL::FPW * PL::FS +
                               (size_t)nyph * PL::FPW * YS) + sizeof(float) * PL::SIZE;
     }
@@ -355,12 +362,28 @@ __device__ __forceinline__ void split_vals(cpx z1, cpx z2, cpx w, cpx& Xk, cpx& 
     asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[0,0,1]" : "=v"(Xm) : "v"(e2), "s"(h2), "v"(q));    // conj(E - Q)
 }
 
-template <class PL>
+// MEL = false: spectrum out.  MEL = true: |X|^power -> band-compressed mel filterbank -> log(. + eps)
+// out [rows, frames, mel_M] (contrib/je/modules/features.py:171-176, 297-330): the spectrum never
+// leaves LDS, HBM traffic per frame drops from 512 + 2056 B to 512 + 4 * mel_M B.
+template <class PL, bool MEL>
 __global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
     constexpr int NP = M / 2 + 1;   // bin pairs (k, M-k) per frame
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WaveLds<PL> S(smem, 4);
+    // mel tables behind the wave buffers: lo | cnt | off [mel_M] int32, weights [mel_nnz] float
+    int32_t* mlo = reinterpret_cast<int32_t*>(smem + WaveLds<PL>::bytes(4, 0));
+    int32_t* mcnt = mlo + A.mel_M;
+    int32_t* moff = mcnt + A.mel_M;
+    float* mw = reinterpret_cast<float*>(moff + A.mel_M);
+    if (MEL) {
+        for (int i = threadIdx.x; i < A.mel_M; i += 256) {
+            mlo[i] = A.mel_lo[i];
+            mcnt[i] = A.mel_cnt[i];
+            moff[i] = A.mel_off[i];
+        }
+        for (int i = threadIdx.x; i < A.mel_nnz; i += 256) mw[i] = A.mel_w[i];
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -432,8 +455,39 @@ __global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdA
         else
             for (int i = 0; i < PL::R1; ++i) wbuf[fl * FS + i * LPF + l] = a[i];
 
-        float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * (2 * F);
         const int nfr = min(FPW, (int)A.out_frames - tw0);
+        if (MEL) {
+            // |X[k]|^power IN PLACE over the spectrum (.x of slot k; k = 0 pairs with the spare slot M:
+            // both slots of a pair were read by this lane only), zero for frames past the row's end
+            for (int p = lane; p < FPW * NP; p += 64) {
+                const int f = p / NP, k = p - f * NP, km = M - k;
+                cpx Xk, Xm;
+                split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
+                float pk = Xk.x * Xk.x + Xk.y * Xk.y, pm = Xm.x * Xm.x + Xm.y * Xm.y;
+                if (A.mel_power == 1) {
+                    pk = sqrtf(pk);
+                    pm = sqrtf(pm);
+                }
+                if (tw0 + f >= frames_b) pk = pm = 0.f;
+                wbuf[f * FS + k].x = pk;
+                if (km != k) wbuf[f * FS + km].x = pm;
+            }
+            wave_sync();
+            float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * A.mel_M;
+            const int nout = nfr * A.mel_M;
+            for (int o = lane; o < nout; o += 64) {
+                const int f = o / A.mel_M, m = o - f * A.mel_M;
+                const cpx* pw = wbuf + f * FS + mlo[m];
+                const float* w = mw + moff[m];
+                const int cnt = mcnt[m];
+                float acc = 0.f;
+                for (int i = 0; i < cnt; ++i) acc = fmaf(pw[i].x, w[i], acc);
+                orow[o] = A.mel_log ? logf(acc + A.mel_eps) : acc;
+            }
+            wave_sync();   // the next item's transposition reuses wbuf
+            continue;
+        }
+        float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * (2 * F);
         const bool fast = nfr == FPW && tw0 + FPW <= frames_b && es == 1.f &&
                           A.layout == PTMI_LAYOUT_INTERLEAVED && !(A.dbg & 1);
         if (fast) {
@@ -974,7 +1028,8 @@ static int launch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t st
                  (reinterpret_cast<uintptr_t>(A.x) % 8 == 0) &&
                  (!A.s || reinterpret_cast<uintptr_t>(A.s) % 8 == 0);
     if (!features) {
-        const size_t smem = WaveLds<PL>::bytes(4, 0);
+        const bool mel = A.mel_w != nullptr;
+        const size_t smem = WaveLds<PL>::bytes(4, 0) + (mel ? sizeof(int32_t) * 3 * A.mel_M + sizeof(float) * A.mel_nnz : 0);
         if (smem > kMaxSmem) return PTMI_E_UNSUPPORTED;
         A.batch = batch;
         A.nchunks = (int)((A.out_frames + PL::FPW - 1) / PL::FPW);      // work items per row
@@ -982,9 +1037,15 @@ static int launch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t st
         if (items <= 0) return PTMI_OK;
         if (items > 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
         // persistent grid: as many workgroups as stay resident (LDS bound), never more than needed
-        const long long resident = 256LL * blocks_per_cu<stft_fwd_kernel<PL>>(256, smem);
-        const long long blocks = std::min((items + 3) / 4, resident);
-        hipLaunchKernelGGL(stft_fwd_kernel<PL>, dim3((unsigned)blocks), dim3(256), smem, st, A);
+        if (mel) {
+            const long long resident = 256LL * blocks_per_cu<stft_fwd_kernel<PL, true>>(256, smem);
+            hipLaunchKernelGGL((stft_fwd_kernel<PL, true>), dim3((unsigned)std::min((items + 3) / 4, resident)),
+                               dim3(256), smem, st, A);
+        } else {
+            const long long resident = 256LL * blocks_per_cu<stft_fwd_kernel<PL, false>>(256, smem);
+            hipLaunchKernelGGL((stft_fwd_kernel<PL, false>), dim3((unsigned)std::min((items + 3) / 4, resident)),
+                               dim3(256), smem, st, A);
+        }
         return launch_status();
     }
     const size_t smem = WaveLds<PL>::bytes(4, 4);
@@ -1074,6 +1135,50 @@ static int dispatch_inv(InvArgs& A, long long batch, hipStream_t st) {
     }
 }
 
+// Mel filterbank (+ log) of a given spectrogram [N, F] -> [N, M] (MelTransform.forward,
+// contrib/je/modules/features.py:297-330): 8 rows per workgroup staged in LDS, one thread per output.
+struct MelArgs {
+    const float* spec;
+    float* out;
+    const int32_t* lo;
+    const int32_t* cnt;
+    const int32_t* off;
+    const float* w;
+    long long N;
+    int F, M, nnz, log_;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void mel_apply_kernel(const MelArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R = 8;
+    float* rows = reinterpret_cast<float*>(smem);            // [R][F]
+    int32_t* mlo = reinterpret_cast<int32_t*>(rows + R * A.F);
+    int32_t* mcnt = mlo + A.M;
+    int32_t* moff = mcnt + A.M;
+    float* mw = reinterpret_cast<float*>(moff + A.M);
+    for (int i = threadIdx.x; i < A.M; i += 256) {
+        mlo[i] = A.lo[i];
+        mcnt[i] = A.cnt[i];
+        moff[i] = A.off[i];
+    }
+    for (int i = threadIdx.x; i < A.nnz; i += 256) mw[i] = A.w[i];
+    for (long long n0 = (long long)blockIdx.x * R; n0 < A.N; n0 += (long long)gridDim.x * R) {
+        const int nr = (int)min((long long)R, A.N - n0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * A.F; i += 256) rows[i] = A.spec[n0 * A.F + i];
+        __syncthreads();
+        for (int o = threadIdx.x; o < nr * A.M; o += 256) {
+            const int r = o / A.M, m = o - r * A.M;
+            const float* pw = rows + r * A.F + mlo[m];
+            const float* w = mw + moff[m];
+            float acc = 0.f;
+            for (int i = 0; i < mcnt[m]; ++i) acc = fmaf(pw[i], w[i], acc);
+            A.out[n0 * A.M + o] = A.log_ ? logf(acc + A.eps) : acc;
+        }
+    }
+}
+
 static bool geom_ok(const ptmi_stft_geom* g) {
     return g && g->size >= 2 && (g->size % 2 == 0) && g->shift >= 1 && g->window_length >= 1 &&
            g->pad_left >= 0 && g->pad_right >= 0;
@@ -1125,6 +1230,55 @@ int ptmi_stft_forward(const float* x, int64_t batch, int64_t x_row_stride, int64
     const size_t smem = sizeof(float) * (size_t)g->window_length;
     PTMI_RETURN_IF(smem > kMaxSmem, PTMI_E_UNSUPPORTED);
     hipLaunchKernelGGL(stft_generic_kernel, dim3((unsigned)blocks), dim3(256), smem, st, A);
+    return launch_status();
+}
+
+int ptmi_stft_logmel(const float* x, int64_t batch, int64_t x_row_stride, int64_t num_samples,
+                     const int32_t* row_samples, const float* window, const float* twiddle,
+                     const ptmi_stft_geom* g, int64_t out_frames, const int32_t* mel_lo, const int32_t* mel_cnt,
+                     const int32_t* mel_off, const float* mel_w, int32_t mel_M, int32_t mel_nnz, int32_t power,
+                     int32_t log_, float eps, float* out, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!geom_ok(g) || !x || !window || !twiddle || !out, PTMI_E_INVALID);
+    PTMI_RETURN_IF(!mel_lo || !mel_cnt || !mel_off || !mel_w || mel_M < 1 || mel_nnz < 1, PTMI_E_INVALID);
+    PTMI_RETURN_IF(batch < 0 || out_frames < 0 || (power != 1 && power != 2), PTMI_E_INVALID);
+    PTMI_RETURN_IF(g->window_length > g->size, PTMI_E_INVALID);
+    PTMI_RETURN_IF(num_samples > 0x7ff00000LL || out_frames > 0x7ff00000LL / (g->size + 2), PTMI_E_UNSUPPORTED);
+    if (batch == 0 || out_frames == 0) return PTMI_OK;
+    FwdArgs A{};
+    A.x = x;
+    A.row_samples = row_samples;
+    A.window = window;
+    A.twiddle = reinterpret_cast<const cpx*>(twiddle);
+    A.out = out;
+    A.x_row_stride = x_row_stride;
+    A.num_samples = num_samples;
+    A.out_frames = out_frames;
+    A.layout = PTMI_LAYOUT_INTERLEAVED;
+    A.edge_scale = 1.f;
+    A.g = to_geo(g);
+    A.mel_lo = mel_lo;
+    A.mel_cnt = mel_cnt;
+    A.mel_off = mel_off;
+    A.mel_w = mel_w;
+    A.mel_M = mel_M;
+    A.mel_nnz = mel_nnz;
+    A.mel_power = power;
+    A.mel_log = log_;
+    A.mel_eps = eps;
+    return dispatch_fwd(A, batch, false, static_cast<hipStream_t>(stream));   // power-of-two sizes 64..2048
+}
+
+int ptmi_mel_apply(const float* spec, int64_t N, int32_t F, const int32_t* mel_lo, const int32_t* mel_cnt,
+                   const int32_t* mel_off, const float* mel_w, int32_t mel_M, int32_t mel_nnz, int32_t log_,
+                   float eps, float* out, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!spec || !out || !mel_lo || !mel_cnt || !mel_off || !mel_w, PTMI_E_INVALID);
+    PTMI_RETURN_IF(N < 0 || F < 1 || mel_M < 1 || mel_nnz < 1, PTMI_E_INVALID);
+    if (N == 0) return PTMI_OK;
+    const size_t smem = sizeof(float) * (8 * (size_t)F + mel_nnz) + sizeof(int32_t) * 3 * (size_t)mel_M;
+    PTMI_RETURN_IF(smem > kMaxSmem, PTMI_E_UNSUPPORTED);
+    MelArgs A{spec, out, mel_lo, mel_cnt, mel_off, mel_w, N, F, mel_M, mel_nnz, log_, eps};
+    const long long blocks = std::min<long long>((N + 7) / 8, 256LL * 8);
+    hipLaunchKernelGGL(mel_apply_kernel, dim3((unsigned)blocks), dim3(256), smem, static_cast<hipStream_t>(stream), A);
     return launch_status();
 }
 

@@ -78,3 +78,10 @@ def g7():
     d['cases'] = json.loads(str(d['cases']))
     d['names'] = json.loads(str(d['names']))
     return d
+
+
+@pytest.fixture(scope='session')
+def g8():
+    d = _npz('g8_logmel.npz')
+    d['configs'] = json.loads(str(d['configs']))
+    return d

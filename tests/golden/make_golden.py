@@ -20,6 +20,10 @@ Fixtures:
   g7_td_losses.npz        ops/losses/regression.py: doctest answers, seeded (K, T) signals -> every loss
                           (options grid), gradients w.r.t. the estimate, pit_loss over them, the
                           TasNet loss of a ragged batch; StftEncoder / IstftDecoder outputs
+  g8_logmel.npz           contrib/je/modules/features.py MelTransform (forward / inverse / maxima) and
+                          the extractor front-end (stacked pt.ops.STFT -> power -> MelTransform); the
+                          filterbank comes from the shim's restatement of paderbox.get_fbanks (parity
+                          of that matrix to paderbox is UNPINNED; everything after it is reference code)
 """
 import itertools
 import json
@@ -378,10 +382,48 @@ def g7():
     np.savez_compressed(HERE / 'g7_td_losses.npz', **out)
 
 
+def g8():
+    from padertorch.contrib.je.modules.features import MelTransform
+    rng = np.random.RandomState(8)
+    out = {}
+    cfgs = []
+    for sr, size, nf, lo, hi, htk, log in ((16000, 512, 40, 50., None, True, True), (8000, 512, 80, 0., -200., True, True),
+                                           (16000, 1024, 64, 50., 7600., False, True), (16000, 256, 20, 50., None, True, False)):
+        key = f'sr{sr}_n{size}_m{nf}'
+        cfgs.append(dict(key=key, sample_rate=sr, stft_size=size, number_of_filters=nf, lowest_frequency=lo,
+                         highest_frequency=hi, htk_mel=htk, log=log))
+        mt = MelTransform(sr, size, nf, lowest_frequency=lo, highest_frequency=hi, htk_mel=htk, log=log)
+        mt.eval()
+        spec = torch.tensor((rng.rand(2, 3, 11, size // 2 + 1) ** 2).astype(np.float32))
+        y, maxima = mt(spec, return_maxima=True)
+        out[f'{key}/fbanks'] = mt.fbanks.detach().numpy()
+        out[f'{key}/spec'] = spec.numpy()
+        out[f'{key}/mel'] = y.numpy()
+        out[f'{key}/maxima'] = maxima.numpy()
+        out[f'{key}/inverse'] = mt.inverse(y).numpy()
+    out['configs'] = np.array(json.dumps(cfgs))
+    # extractor front-end (features.py:171-176) on waveforms: stacked STFT -> sum of squares -> mel -> log
+    x = (0.1 * rng.randn(3, 4000)).astype(np.float32)
+    stft = pt.ops.STFT(512, 128, window_length=512, complex_representation='stacked')
+    mt = MelTransform(16000, 512, 80)
+    mt.eval()
+    X = stft(torch.tensor(x))
+    out['front/x'] = x
+    out['front/logmel'] = mt(torch.sum(X ** 2, dim=(-1,))).numpy()
+    mt1 = MelTransform(16000, 512, 40, log=False)
+    mt1.eval()
+    out['front/mel_magnitude'] = mt1(torch.sum(X ** 2, dim=(-1,)).sqrt()).numpy()
+    stft2 = pt.ops.STFT(1024, 256, window_length=800, window='hann', fading='half', complex_representation='stacked')
+    mt2 = MelTransform(16000, 1024, 64)
+    mt2.eval()
+    out['front/logmel_1024_256_800'] = mt2(torch.sum(stft2(torch.tensor(x)) ** 2, dim=(-1,))).numpy()
+    np.savez_compressed(HERE / 'g8_logmel.npz', **out)
+
+
 if __name__ == '__main__':
     assert os.path.isdir('/root/reference'), 'run in the build container'
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
         if only and fn.__name__ not in only:
             continue
         fn()
