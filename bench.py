@@ -105,6 +105,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--default-gemms', action='store_true', help='library default GEMM kernel selection')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -123,6 +124,12 @@ def main():
         PermutationInvariantTrainingModel
 
     torch.manual_seed(0)
+    if not args.default_gemms:
+        # library GEMMs (input projections, linears, weight gradients): committed TunableOp selections
+        # for these shapes (padertorch_amd/tuned/, see padertorch_amd/tuning.py); same arithmetic,
+        # better hipBLASLt / rocBLAS kernels (fp32: 65-70 % -> 85-91 % of the MFMA peak)
+        from padertorch_amd import tuning
+        tuning.use_tuned_gemms()
     model = PermutationInvariantTrainingModel()          # defaults: F=257, 3 x BLSTM-600, K=2
     trainer = pt.Trainer(model, f'/tmp/ptmi_bench_{rank}', pt.optimizer.Adam(gradient_clipping=1.),
                          loss_weights=LOSS_WEIGHTS, virtual_minibatch_size=world)
@@ -235,6 +242,7 @@ def main():
                 'frames_per_step': frames_per_step * world,
                 'parallelism': f'dp{world}',
                 'blstm': 'HIP recurrence (csrc/lstm.hip)' if model.hip_blstm else 'torch.nn.LSTM (MIOpen)',
+                'gemms': 'library defaults' if args.default_gemms else 'hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)',
             },
             'roofline': dominant,
             'other_kernels': other,
