@@ -238,6 +238,37 @@ int ptmi_mel_apply(const float* spec, int64_t N, int32_t F, const int32_t* mel_l
                    const int32_t* mel_off, const float* mel_w, int32_t mel_M, int32_t mel_nnz, int32_t log_,
                    float eps, float* out, ptmi_stream_t stream);
 
+/* ---- Masked normalisation --------------------------------------------------------------------------
+ * Replaces padertorch/modules/normalization.py: normalize / _Normalize.forward (:345-372, statistics by
+ * mask_and_compute_stats :497-512), the hand-written backward (:374-411) and the running-statistics
+ * path Normalization._running_norm (:233-246).
+ * The tensor is contiguous, rank <= 5; per axis: its size, its stride in the statistics-group index
+ * (0 for an axis the statistics run over) and in the gamma / beta index (0 where those broadcast);
+ * batch_dim / seq_dim (or -1) locate the mask t < lengths[b].
+ *   ptmi_norm_reduce      mode 0: (sum m x, sum m x^2, sum m) per statistics group;
+ *                         mode 1: (sum ghat, sum ghat xc, sum xc), ghat = gy gamma, xc = x - mean (shift);
+ *                         mode 2: (sum gy xhat, sum gy, 0) per gamma / beta element (their gradients).
+ *                         out [groups, 3] float64; workspace: ptmi_norm_workspace_elems(geom, mode == 2).
+ *   ptmi_norm_elementwise backward = 0: y = m ((x - mean) rstd gamma + beta);
+ *                         backward = 1: dx = m (gy gamma rstd + c1[g] (x - mean) + c0[g]).
+ * mean / rstd / c0 / c1 are float32 per statistics group, gamma / beta float32 per independent index
+ * (NULL = absent). */
+typedef struct ptmi_norm_geom {
+    int32_t rank;
+    int64_t size[5];
+    int64_t stat_group_stride[5];
+    int64_t indep_stride[5];
+    int32_t batch_dim, seq_dim;
+} ptmi_norm_geom;
+int64_t ptmi_norm_workspace_elems(const ptmi_norm_geom* geom, int32_t which);
+int ptmi_norm_reduce(int32_t mode, const float* x, const float* gy, const int32_t* lengths, const float* mean,
+                     const float* rstd, const float* gamma, const ptmi_norm_geom* geom, int32_t shift,
+                     double* workspace, double* out, ptmi_stream_t stream);
+int ptmi_norm_elementwise(int32_t backward, const float* x, const float* gy, const int32_t* lengths,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* c0, const float* c1, const ptmi_norm_geom* geom, int32_t shift,
+                          int32_t scale, float* out, ptmi_stream_t stream);
+
 /* ---- Time-domain regression losses under PIT ------------------------------------------------------
  * Replaces padertorch/ops/losses/regression.py:47-378 (mse_loss, log_mse_loss, sdr_loss, si_sdr_loss,
  * log1p_mse_loss, source_aggregated_sdr_loss) evaluated per permutation by pit_loss

@@ -10,6 +10,8 @@ from . import data  # noqa: F401
 from . import ops  # noqa: F401
 from . import base  # noqa: F401
 from .base import Module, Model  # noqa: F401
+from . import modules  # noqa: F401
 from . import train  # noqa: F401
 from .train import optimizer  # noqa: F401
 from .train.trainer import Trainer  # noqa: F401
+from .ops import mappings  # noqa: F401

@@ -19,6 +19,12 @@ class StftGeom(ctypes.Structure):
                 ('pad_left', c_int32), ('pad_right', c_int32), ('pad', c_int32)]
 
 
+class NormGeom(ctypes.Structure):
+    """``ptmi_norm_geom`` (include/ptmi.h)."""
+    _fields_ = [('rank', c_int32), ('size', c_int64 * 5), ('stat_group_stride', c_int64 * 5),
+                ('indep_stride', c_int64 * 5), ('batch_dim', c_int32), ('seq_dim', c_int32)]
+
+
 _P = c_void_p   # device pointers travel as integers
 _G = POINTER(StftGeom)
 _I64P = POINTER(c_int64)
@@ -47,6 +53,10 @@ SIGNATURES = {
     'ptmi_stft_logmel': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P, _G, c_int64, _P, _P, _P, _P,
                                  c_int32, c_int32, c_int32, c_int32, c_float, _P, _P]),
     'ptmi_mel_apply': (c_int, [_P, c_int64, c_int32, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_float, _P, _P]),
+    'ptmi_norm_workspace_elems': (c_int64, [POINTER(NormGeom), c_int32]),
+    'ptmi_norm_reduce': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, POINTER(NormGeom), c_int32, _P, _P, _P]),
+    'ptmi_norm_elementwise': (c_int, [c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, POINTER(NormGeom), c_int32,
+                                      c_int32, _P, _P]),
     'ptmi_td_stats_elems': (c_int64, [c_int32]),
     'ptmi_td_workspace_elems': (c_int64, [c_int64, c_int32, c_int64]),
     'ptmi_td_pair_stats': (c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P, _P]),

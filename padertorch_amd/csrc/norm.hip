@@ -1,0 +1,340 @@
+// Masked normalisation (padertorch/modules/normalization.py:189-246 forward through
+// mask_and_compute_stats :497-512, hand-written backward :322-411; running-statistics path :218-246).
+//
+// x is a contiguous tensor of rank <= 5 described by its data_format; statistics are taken over a
+// subset of the axes ("stat groups" = one (mean, power, n) triple per index of the remaining axes),
+// gamma / beta live on the independent axes, and positions t >= sequence_lengths[b] are masked out.
+// Three kernels cover forward, backward and the running-statistics mode:
+//   norm_reduce_kernel  masked sums per group over the reduced axes (three integrand sets: statistics,
+//                       backward statistics, gamma/beta gradients), fp64 accumulation, deterministic
+//                       two-stage reduction.  Lanes run along the innermost axis: along the reduction
+//                       when that axis is reduced, along 64 neighbouring groups when it is kept, so
+//                       global reads are coalesced either way;
+//   norm_apply_kernel   y = mask * ((x - mean) * rstd * gamma + beta);
+//   norm_bwd_kernel     dx = mask * (ghat * rstd + c1[g] * xc + c0[g]).
+// All are one pass over the tensor: HBM bound.
+#include "common.h"
+
+namespace ptmi {
+
+constexpr int kNormRank = 5;
+
+struct NormGeo {
+    int rank;
+    int size[kNormRank];
+    long long stride[kNormRank];   // contiguous element strides
+    long long sgs[kNormRank];      // stride of the axis in the stat-group index (0: statistics axis)
+    long long igs[kNormRank];      // stride of the axis in the gamma / beta index (0: broadcast)
+    int bdim, tdim;                // batch / sequence axis or -1
+    // the reduction at hand: axes ordered outermost .. innermost
+    int nkept, nred;
+    int kept[kNormRank], red[kNormRank];
+    long long n_groups, n_red;
+    long long ogs[kNormRank];      // stride of the axis in the OUTPUT group index of this reduction
+};
+
+struct NormRedArgs {
+    const float* x;
+    const float* gy;
+    const int32_t* lengths;
+    const float* mean;    // [stat groups]
+    const float* rstd;    // [stat groups]
+    const float* gamma;   // [indep groups] or null
+    double* ws;           // [nchunks][n_groups][3]
+    NormGeo g;
+    int mode;             // 0 statistics, 1 backward statistics, 2 gamma / beta gradients
+    int shift;
+    int gt;               // groups per workgroup: 1 (innermost axis reduced) or 64 (innermost kept)
+    long long chunk;      // reduced elements per workgroup
+    int nchunks;
+};
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// IdxT = unsigned (tensors below 2^31 elements: 32-bit index decode) or long long
+template <typename IdxT>
+__global__ __launch_bounds__(256) void norm_reduce_kernel(const NormRedArgs A) {
+    const NormGeo& g = A.g;
+    const int gt = A.gt;
+    const int rows = 256 / gt;
+    const int col = threadIdx.x % gt, row = threadIdx.x / gt;
+    const long long grp = (long long)blockIdx.x * gt + col;
+    const bool gvalid = grp < g.n_groups;
+    // kept multi-index of this thread's group
+    int idx[kNormRank] = {0, 0, 0, 0, 0};
+    long long base = 0;
+    {
+        IdxT rem = (IdxT)(gvalid ? grp : 0);
+        for (int i = g.nkept - 1; i >= 0; --i) {
+            const int d = g.kept[i];
+            const IdxT q = rem / (IdxT)g.size[d];
+            idx[d] = (int)(rem - q * (IdxT)g.size[d]);
+            rem = q;
+            base += idx[d] * g.stride[d];
+        }
+    }
+    const long long r0 = (long long)blockIdx.y * A.chunk;
+    const long long r1 = min(r0 + A.chunk, g.n_red);
+    double s0 = 0., s1 = 0., s2 = 0.;
+    for (long long r = r0 + row; r < r1 && gvalid; r += rows) {
+        IdxT rem = (IdxT)r;
+        long long off = base;
+        for (int i = g.nred - 1; i >= 0; --i) {
+            const int d = g.red[i];
+            const IdxT q = rem / (IdxT)g.size[d];
+            idx[d] = (int)(rem - q * (IdxT)g.size[d]);
+            rem = q;
+            off += idx[d] * g.stride[d];
+        }
+        bool m = true;
+        if (A.lengths && g.bdim >= 0 && g.tdim >= 0) m = idx[g.tdim] < A.lengths[idx[g.bdim]];
+        if (!m) continue;
+        const float xv = A.x[off];
+        if (A.mode == 0) {
+            s0 += xv;
+            s1 += (double)xv * xv;
+            s2 += 1.;
+        } else {
+            long long sg = 0, ig = 0;
+            for (int d = 0; d < g.rank; ++d) {
+                sg += idx[d] * g.sgs[d];
+                ig += idx[d] * g.igs[d];
+            }
+            const float gyv = A.gy[off];
+            const float mu = A.shift ? A.mean[sg] : 0.f;
+            if (A.mode == 1) {
+                const float ghat = A.gamma ? gyv * A.gamma[ig] : gyv;
+                const float xc = xv - mu;
+                s0 += ghat;
+                s1 += (double)ghat * xc;
+                s2 += xc;
+            } else {
+                const float xhat = (xv - mu) * A.rstd[sg];
+                s0 += (double)gyv * xhat;
+                s1 += gyv;
+            }
+        }
+    }
+    __shared__ double red[3][256];
+    double* out = A.ws + ((long long)blockIdx.y * g.n_groups) * 3;
+    if (gt == 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        s0 = wsum(s0);
+        s1 = wsum(s1);
+        s2 = wsum(s2);
+        if (lane == 0) {
+            red[0][wave] = s0;
+            red[1][wave] = s1;
+            red[2][wave] = s2;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3 && gvalid)
+            out[grp * 3 + threadIdx.x] =
+                ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
+    } else {
+        red[0][threadIdx.x] = s0;
+        red[1][threadIdx.x] = s1;
+        red[2][threadIdx.x] = s2;
+        __syncthreads();
+        if (row == 0 && gvalid) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                double v = 0.;
+                for (int rr = 0; rr < rows; ++rr) v += red[k][rr * gt + col];
+                out[grp * 3 + k] = v;
+            }
+        }
+    }
+}
+
+// out[g][k] = sum_c ws[c][g][k] in chunk order (deterministic)
+__global__ void norm_reduce2_kernel(const double* __restrict__ ws, double* __restrict__ out, long long n, int nchunks) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = 0.;
+    for (int c = 0; c < nchunks; ++c) v += ws[(long long)c * n + i];
+    out[i] = v;
+}
+
+struct NormEwArgs {
+    const float* x;
+    const float* gy;
+    const int32_t* lengths;
+    const float* mean;
+    const float* rstd;
+    const float* gamma;
+    const float* beta;
+    const float* c0;   // backward: per stat group additive term
+    const float* c1;   // backward: per stat group factor of xc
+    float* out;
+    NormGeo g;
+    long long total;
+    int shift, scale, backward;
+};
+
+template <typename IdxT>
+__global__ __launch_bounds__(256) void norm_elementwise_kernel(const NormEwArgs A) {
+    const NormGeo& g = A.g;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < A.total; i += (long long)gridDim.x * 256) {
+        IdxT rem = (IdxT)i;
+        long long sg = 0, ig = 0;
+        int ib = 0, it = 0;
+        for (int d = g.rank - 1; d >= 0; --d) {
+            const IdxT q = rem / (IdxT)g.size[d];
+            const int id = (int)(rem - q * (IdxT)g.size[d]);
+            rem = q;
+            sg += id * g.sgs[d];
+            ig += id * g.igs[d];
+            if (d == g.bdim) ib = id;
+            if (d == g.tdim) it = id;
+        }
+        bool m = true;
+        if (A.lengths && g.bdim >= 0 && g.tdim >= 0) m = it < A.lengths[ib];
+        float r = 0.f;
+        if (m) {
+            const float xv = A.x[i];
+            const float mu = A.shift ? A.mean[sg] : 0.f;
+            const float rs = A.scale ? A.rstd[sg] : 1.f;
+            if (!A.backward) {
+                r = (xv - mu) * rs;
+                if (A.gamma) r *= A.gamma[ig];
+                if (A.beta) r += A.beta[ig];
+            } else {
+                const float ghat = A.gamma ? A.gy[i] * A.gamma[ig] : A.gy[i];
+                r = ghat * rs + A.c1[sg] * (xv - mu) + A.c0[sg];
+            }
+        }
+        A.out[i] = r;
+    }
+}
+
+static bool geo_from(const ptmi_norm_geom* in, int which, NormGeo* g) {
+    if (!in || in->rank < 1 || in->rank > kNormRank) return false;
+    g->rank = in->rank;
+    long long stride = 1;
+    for (int d = in->rank - 1; d >= 0; --d) {
+        if (in->size[d] < 1 || in->size[d] > 0x7fffffff) return false;
+        g->size[d] = (int)in->size[d];
+        g->stride[d] = stride;
+        stride *= in->size[d];
+    }
+    for (int d = 0; d < kNormRank; ++d) {
+        g->sgs[d] = d < in->rank ? in->stat_group_stride[d] : 0;
+        g->igs[d] = d < in->rank ? in->indep_stride[d] : 0;
+        g->ogs[d] = 0;
+    }
+    g->bdim = in->batch_dim;
+    g->tdim = in->seq_dim;
+    // which: 0 = reduce over the statistics axes (groups = stat groups), 1 = reduce over the axes
+    // gamma / beta are broadcast along (groups = independent groups)
+    g->nkept = g->nred = 0;
+    g->n_groups = g->n_red = 1;
+    for (int d = 0; d < in->rank; ++d) {
+        const long long gs = which == 0 ? in->stat_group_stride[d] : in->indep_stride[d];
+        const bool kept = gs != 0 || (in->size[d] == 1);
+        if (kept) {
+            g->kept[g->nkept++] = d;
+            g->n_groups *= g->size[d];
+        } else {
+            g->red[g->nred++] = d;
+            g->n_red *= g->size[d];
+        }
+    }
+    return true;
+}
+
+}  // namespace ptmi
+
+using namespace ptmi;
+
+extern "C" {
+
+int64_t ptmi_norm_workspace_elems(const ptmi_norm_geom* geom, int32_t which) {
+    NormGeo g;
+    if (!geo_from(geom, which, &g)) return PTMI_E_INVALID;
+    return 3 * g.n_groups * 64;   // up to 64 chunks of the reduced range
+}
+
+int ptmi_norm_reduce(int32_t mode, const float* x, const float* gy, const int32_t* lengths, const float* mean,
+                     const float* rstd, const float* gamma, const ptmi_norm_geom* geom, int32_t shift,
+                     double* workspace, double* out, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!x || !geom || !workspace || !out || mode < 0 || mode > 2, PTMI_E_INVALID);
+    PTMI_RETURN_IF(mode > 0 && !gy, PTMI_E_INVALID);
+    PTMI_RETURN_IF(mode == 2 && !rstd, PTMI_E_INVALID);
+    PTMI_RETURN_IF(mode > 0 && shift && !mean, PTMI_E_INVALID);
+    NormRedArgs A{};
+    PTMI_RETURN_IF(!geo_from(geom, mode == 2 ? 1 : 0, &A.g), PTMI_E_INVALID);
+    A.x = x;
+    A.gy = gy;
+    A.lengths = lengths;
+    A.mean = mean;
+    A.rstd = rstd;
+    A.gamma = gamma;
+    A.ws = workspace;
+    A.mode = mode;
+    A.shift = shift;
+    const NormGeo& g = A.g;
+    // lanes along the innermost axis: reduced -> one group per workgroup; kept -> 64 groups per workgroup
+    const bool inner_reduced = g.nred > 0 && g.red[g.nred - 1] == g.rank - 1 && g.size[g.rank - 1] > 1;
+    A.gt = (inner_reduced || g.n_groups == 1) ? 1 : 64;
+    const long long tiles = (g.n_groups + A.gt - 1) / A.gt;
+    // split the reduced range while the grid is small (<= 64 chunks, >= 256 rows of work each)
+    long long want = (2048 + tiles - 1) / tiles;
+    const long long rows = 256 / A.gt;
+    long long max_chunks = (g.n_red + rows * 4 - 1) / (rows * 4);
+    if (want > max_chunks) want = max_chunks;
+    if (want > 64) want = 64;
+    if (want < 1) want = 1;
+    A.chunk = (g.n_red + want - 1) / want;
+    A.nchunks = (int)((g.n_red + A.chunk - 1) / A.chunk);
+    PTMI_RETURN_IF(tiles > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (g.n_groups * g.n_red < 0x7fffffffLL)
+        hipLaunchKernelGGL(norm_reduce_kernel<unsigned>, dim3((unsigned)tiles, (unsigned)A.nchunks), dim3(256), 0, st, A);
+    else
+        hipLaunchKernelGGL(norm_reduce_kernel<long long>, dim3((unsigned)tiles, (unsigned)A.nchunks), dim3(256), 0, st, A);
+    int rc = launch_status();
+    if (rc) return rc;
+    const long long n = 3 * g.n_groups;
+    hipLaunchKernelGGL(norm_reduce2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, out, n,
+                       A.nchunks);
+    return launch_status();
+}
+
+int ptmi_norm_elementwise(int32_t backward, const float* x, const float* gy, const int32_t* lengths,
+                          const float* mean, const float* rstd, const float* gamma, const float* beta,
+                          const float* c0, const float* c1, const ptmi_norm_geom* geom, int32_t shift,
+                          int32_t scale, float* out, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!x || !geom || !out, PTMI_E_INVALID);
+    PTMI_RETURN_IF(backward && (!gy || !c0 || !c1), PTMI_E_INVALID);
+    PTMI_RETURN_IF((shift && !mean) || (scale && !rstd), PTMI_E_INVALID);
+    NormEwArgs A{};
+    PTMI_RETURN_IF(!geo_from(geom, 0, &A.g), PTMI_E_INVALID);
+    A.x = x;
+    A.gy = gy;
+    A.lengths = lengths;
+    A.mean = mean;
+    A.rstd = rstd;
+    A.gamma = gamma;
+    A.beta = beta;
+    A.c0 = c0;
+    A.c1 = c1;
+    A.out = out;
+    A.total = A.g.n_groups * A.g.n_red;
+    A.shift = shift;
+    A.scale = scale;
+    A.backward = backward;
+    const long long blocks = std::min<long long>((A.total + 255) / 256, 256LL * 16);
+    if (blocks <= 0) return PTMI_OK;
+    if (A.total < 0x7fffffffLL)
+        hipLaunchKernelGGL(norm_elementwise_kernel<unsigned>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    else
+        hipLaunchKernelGGL(norm_elementwise_kernel<long long>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), A);
+    return launch_status();
+}
+
+}  // extern "C"

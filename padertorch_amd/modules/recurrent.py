@@ -1,0 +1,50 @@
+"""``StatefulLSTM`` (reference: ``padertorch/modules/recurrent.py:5-47``) on the HIP BLSTM recurrence.
+
+Same constructor; the parameters live in a ``torch.nn.LSTM`` (same ``state_dict`` keys:
+``lstm.weight_ih_l0`` ...).  The time loop runs in ``csrc/lstm.hip`` (``ops.lstm.packed_lstm``).
+Gap: the HIP recurrence starts from the zero state, so carrying ``(h_n, c_n)`` over to the next call
+(``save_states=True`` with a second call) is not implemented yet and raises.
+"""
+import torch
+from torch.nn.utils.rnn import PackedSequence
+
+from ..ops.lstm import packed_lstm
+
+
+class StatefulLSTM(torch.nn.Module):
+    _states = None
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int = 1, bidirectional: bool = False,
+                 dropout: float = 0., batch_first: bool = True, save_states: bool = True):
+        super().__init__()
+        self.lstm = torch.nn.LSTM(input_size=input_size, hidden_size=hidden_size, num_layers=num_layers,
+                                  bidirectional=bidirectional, dropout=dropout, batch_first=batch_first)
+        self.hidden_size = hidden_size
+        self.bidirectional = bidirectional
+        self.num_layers = num_layers
+        self.batch_first = batch_first
+        self.save_states = save_states
+
+    @property
+    def states(self):
+        return self._states
+
+    @states.deleter
+    def states(self):
+        self._states = None
+
+    @states.setter
+    def states(self, states):
+        self._states = states
+
+    def forward(self, x):
+        if self.save_states or self.states is not None:
+            raise NotImplementedError(
+                'StatefulLSTM on the HIP recurrence starts from the zero state: use save_states=False '
+                '(carrying (h_n, c_n) across calls is not implemented yet)')
+        assert x.dim() == 3, x.shape
+        xt = x.transpose(0, 1) if self.batch_first else x            # [T, B, F]
+        T, B = xt.shape[:2]
+        packed = PackedSequence(xt.reshape(T * B, -1), torch.full((T,), B, dtype=torch.int64))
+        h = packed_lstm(self.lstm, packed).data.reshape(T, B, -1)
+        return h.transpose(0, 1) if self.batch_first else h

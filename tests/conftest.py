@@ -85,3 +85,11 @@ def g8():
     d = _npz('g8_logmel.npz')
     d['configs'] = json.loads(str(d['configs']))
     return d
+
+
+@pytest.fixture(scope='session')
+def g9():
+    d = _npz('g9_norm.npz')
+    d['cases'] = json.loads(str(d['cases']))
+    d['modules'] = json.loads(str(d['modules']))
+    return d

@@ -20,6 +20,9 @@ Fixtures:
   g7_td_losses.npz        ops/losses/regression.py: doctest answers, seeded (K, T) signals -> every loss
                           (options grid), gradients w.r.t. the estimate, pit_loss over them, the
                           TasNet loss of a ragged batch; StftEncoder / IstftDecoder outputs
+  g9_norm.npz             modules/normalization.py: normalize() outputs + reference-autograd gradients over
+                          a grid of formats / axes / shift / scale / lengths; Normalization and
+                          InputNormalization training steps + eval; SimpleMaskEstimator forward / loss / grads
   g8_logmel.npz           contrib/je/modules/features.py MelTransform (forward / inverse / maxima) and
                           the extractor front-end (stacked pt.ops.STFT -> power -> MelTransform); the
                           filterbank comes from the shim's restatement of paderbox.get_fbanks (parity
@@ -420,10 +423,100 @@ def g8():
     np.savez_compressed(HERE / 'g8_logmel.npz', **out)
 
 
+def g9():
+    from padertorch.modules.normalization import normalize, Normalization, InputNormalization
+    from padertorch.contrib.examples.speech_enhancement.mask_estimator.model import SimpleMaskEstimator
+    rng = np.random.RandomState(9)
+    out, cases = {}, []
+    grid = [
+        # data_format, shape, statistics axes, independent axes, lengths
+        ('bct', (2, 3, 5), 'bt', 'c', [5, 3]),              # the reference's own test (test_norm.py:38-71)
+        ('btf', (3, 7, 6), 't', 'f', [7, 4, 2]),            # SimpleMaskEstimator's normalisation
+        ('bcft', (2, 3, 4, 9), 'bft', 'c', [9, 6]),
+        ('bcft', (2, 3, 4, 9), 'bt', 'cf', [9, 5]),
+        ('bft', (4, 5, 8), 'f', None, None),
+        ('tbf', (6, 3, 5), 'tb', 'f', [6, 2, 1]),
+        ('bcft', (2, 2, 3, 70), 'bf', 'c', [70, 33]),       # alternating kept / reduced axes
+    ]
+    for fmt, shape, stat, indep, lens in grid:
+        for shift, scale in ((True, True), (True, False), (False, True), (False, False)):
+            key = f'{fmt}_{stat}_{indep}_{int(shift)}{int(scale)}'
+            x = torch.tensor(rng.randn(*shape).astype(np.float32) * 1.5 + 0.7, requires_grad=True)
+            gshape = [shape[i] if (indep and fmt[i] in indep) else 1 for i in range(len(shape))]
+            gamma = torch.tensor((1 + 0.3 * rng.randn(*gshape)).astype(np.float32), requires_grad=True) if indep and scale else None
+            beta = torch.tensor((0.3 * rng.randn(*gshape)).astype(np.float32), requires_grad=True) if indep and shift else None
+            axes = [fmt.index(a) for a in stat]
+            b_ax = fmt.index('b')
+            t_ax = fmt.index('t')
+            y, mean, power, n = normalize(x, gamma, beta, axes, b_ax, t_ax, lens, shift, scale, 1e-3)
+            w = torch.tensor(rng.randn(*shape).astype(np.float32))
+            (y * w).sum().backward()
+            cases.append(dict(key=key, fmt=fmt, shape=list(shape), stat=stat, indep=indep, lens=lens, shift=shift,
+                              scale=scale, axes=axes, b_ax=b_ax, t_ax=t_ax))
+            out[f'{key}/x'], out[f'{key}/w'] = x.detach().numpy(), w.numpy()
+            out[f'{key}/y'], out[f'{key}/mean'] = y.detach().numpy(), mean.detach().numpy()
+            out[f'{key}/power'], out[f'{key}/n'] = power.detach().numpy(), n.detach().numpy()
+            out[f'{key}/grad_x'] = x.grad.numpy()
+            if gamma is not None:
+                out[f'{key}/gamma'], out[f'{key}/grad_gamma'] = gamma.detach().numpy(), gamma.grad.numpy()
+            if beta is not None:
+                out[f'{key}/beta'], out[f'{key}/grad_beta'] = beta.detach().numpy(), beta.grad.numpy()
+    out['cases'] = np.array(json.dumps(cases))
+    # module behaviour: three training steps (running statistics), then eval, for both classes and momenta
+    mods = []
+    for cls, name in ((Normalization, 'norm'), (InputNormalization, 'inorm')):
+        for momentum in (0.5, None):
+            key = f'{name}_m{momentum}'
+            mods.append(dict(key=key, cls=name, momentum=momentum))
+            m = cls(data_format='bct', shape=(None, 4, None), statistics_axis='bt', momentum=momentum)
+            m.train()
+            with torch.no_grad():
+                m.gamma.copy_(torch.tensor((1 + 0.2 * rng.randn(1, 4, 1)).astype(np.float32)))
+                m.beta.copy_(torch.tensor((0.2 * rng.randn(1, 4, 1)).astype(np.float32)))
+            out[f'{key}/gamma'], out[f'{key}/beta'] = m.gamma.detach().numpy(), m.beta.detach().numpy()
+            for step, lens in enumerate(([6, 4, 1], [6, 6, 6], [3, 2, 2])):
+                x = torch.tensor((rng.randn(3, 4, 6) * (1 + step) + step).astype(np.float32), requires_grad=True)
+                y = m(x, lens)
+                y.sum().backward()
+                out[f'{key}/s{step}/x'], out[f'{key}/s{step}/lens'] = x.detach().numpy(), np.array(lens)
+                out[f'{key}/s{step}/y'], out[f'{key}/s{step}/grad_x'] = y.detach().numpy(), x.grad.numpy()
+                for b in ('num_tracked_values', 'running_mean', 'running_power'):
+                    out[f'{key}/s{step}/{b}'] = getattr(m, b).detach().numpy().copy()
+            m.eval()
+            x = torch.tensor(rng.randn(2, 4, 5).astype(np.float32), requires_grad=True)
+            y = m(x, [5, 2])
+            (y ** 2).sum().backward()
+            out[f'{key}/eval/x'], out[f'{key}/eval/y'] = x.detach().numpy(), y.detach().numpy()
+            out[f'{key}/eval/grad_x'] = x.grad.numpy()
+            out[f'{key}/eval/grad_gamma'] = m.gamma.grad.numpy()
+            out[f'{key}/eval/inverse'] = m.inverse(y.detach(), [5, 2]).detach().numpy()
+    out['modules'] = np.array(json.dumps(mods))
+    # SimpleMaskEstimator (speech_enhancement/mask_estimator/model.py): eval-mode forward + loss + grads
+    torch.manual_seed(9)
+    me = SimpleMaskEstimator(17, num_units=32, dropout=0.)
+    me.eval()
+    for k, v in me.state_dict().items():
+        out[f'me/sd/{k}'] = v.numpy()
+    obs = torch.tensor(np.abs(rng.randn(3, 11, 17)).astype(np.float32))
+    batch = dict(observation_abs=obs, speech_mask_target=torch.tensor(rng.rand(3, 11, 17).astype(np.float32)),
+                 noise_mask_target=torch.tensor(rng.rand(3, 11, 17).astype(np.float32)))
+    o = me(batch)
+    loss = me.review(batch, o)['loss']
+    loss.backward()
+    out['me/observation_abs'] = obs.numpy()
+    out['me/speech_mask_target'], out['me/noise_mask_target'] = batch['speech_mask_target'].numpy(), batch['noise_mask_target'].numpy()
+    out['me/speech_mask_prediction'] = o['speech_mask_prediction'].detach().numpy()
+    out['me/noise_mask_prediction'] = o['noise_mask_prediction'].detach().numpy()
+    out['me/loss'] = loss.detach().numpy()
+    for k, p_ in me.named_parameters():
+        out[f'me/grad/{k}'] = p_.grad.numpy()
+    np.savez_compressed(HERE / 'g9_norm.npz', **out)
+
+
 if __name__ == '__main__':
     assert os.path.isdir('/root/reference'), 'run in the build container'
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
         if only and fn.__name__ not in only:
             continue
         fn()

@@ -1,0 +1,107 @@
+"""HIP masked normalisation / StatefulLSTM / SimpleMaskEstimator vs the reference goldens g9 and the
+oracle (GPU, through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import norm_np as N
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(a, grad=False):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(DEV).requires_grad_(grad)
+
+
+def test_normalize_outputs_and_grads(g9):
+    """The reference's own test (tests/test_modules/test_norm.py:38-71: outputs to 6 decimals, gradients
+    to 4) over a grid of formats / axes / shift / scale."""
+    from padertorch_amd.modules import normalize
+    for c in g9['cases']:
+        k = c['key']
+        x = dev(g9[f'{k}/x'], True)
+        gamma, beta = dev(g9.get(f'{k}/gamma'), True), dev(g9.get(f'{k}/beta'), True)
+        y, mean, power, n = normalize(x, gamma, beta, c['axes'], c['b_ax'], c['t_ax'], c['lens'], c['shift'],
+                                      c['scale'], 1e-3)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g9[f'{k}/y'], rtol=1e-5, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(mean.detach().cpu().numpy(), g9[f'{k}/mean'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(power.detach().cpu().numpy(), g9[f'{k}/power'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(n.detach().cpu().numpy(), g9[f'{k}/n'])
+        assert mean.shape == g9[f'{k}/mean'].shape
+        (y * dev(g9[f'{k}/w'])).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g9[f'{k}/grad_x'], rtol=2e-4, atol=2e-5, err_msg=k)
+        if gamma is not None:
+            np.testing.assert_allclose(gamma.grad.cpu().numpy(), g9[f'{k}/grad_gamma'], rtol=2e-4, atol=2e-5, err_msg=k)
+        if beta is not None:
+            np.testing.assert_allclose(beta.grad.cpu().numpy(), g9[f'{k}/grad_beta'], rtol=2e-4, atol=2e-5, err_msg=k)
+    with pytest.raises(RuntimeError):          # no CPU fallback
+        normalize(torch.ones(2, 3, 4), None, None, [0, 2], 0, 2, None, True, True, 1e-3)
+
+
+def test_modules_running_statistics_and_eval(g9):
+    from padertorch_amd.modules import Normalization, InputNormalization
+    for mod in g9['modules']:
+        k = mod['key']
+        cls = Normalization if mod['cls'] == 'norm' else InputNormalization
+        m = cls(data_format='bct', shape=(None, 4, None), statistics_axis='bt', momentum=mod['momentum']).to(DEV)
+        with torch.no_grad():
+            m.gamma.copy_(dev(g9[f'{k}/gamma']))
+            m.beta.copy_(dev(g9[f'{k}/beta']))
+        m.train()
+        for step in range(3):
+            x = dev(g9[f'{k}/s{step}/x'], True)
+            y = m(x, g9[f'{k}/s{step}/lens'].tolist())
+            np.testing.assert_allclose(y.detach().cpu().numpy(), g9[f'{k}/s{step}/y'], rtol=1e-4, atol=1e-4)
+            y.sum().backward()
+            np.testing.assert_allclose(x.grad.cpu().numpy(), g9[f'{k}/s{step}/grad_x'], rtol=2e-4, atol=2e-5)
+            for b in ('num_tracked_values', 'running_mean', 'running_power'):
+                np.testing.assert_allclose(getattr(m, b).cpu().numpy(), g9[f'{k}/s{step}/{b}'], rtol=1e-5, atol=1e-6)
+        m.eval()        # (gamma.grad keeps accumulating over the training steps, as in the golden script)
+        x = dev(g9[f'{k}/eval/x'], True)
+        y = m(x, [5, 2])
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g9[f'{k}/eval/y'], rtol=1e-4, atol=1e-4)
+        (y ** 2).sum().backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g9[f'{k}/eval/grad_x'], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(m.gamma.grad.cpu().numpy(), g9[f'{k}/eval/grad_gamma'], rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(m.inverse(y.detach(), [5, 2]).detach().cpu().numpy(), g9[f'{k}/eval/inverse'], rtol=1e-4, atol=1e-4)
+    # state_dict layout equals the reference's (buffers + parameters)
+    assert set(m.state_dict()) == {'num_tracked_values', 'running_mean', 'running_power', 'gamma', 'beta'}
+
+
+def test_simple_mask_estimator(g9):
+    from padertorch_amd.contrib.examples.speech_enhancement.mask_estimator.model import SimpleMaskEstimator
+    me = SimpleMaskEstimator(17, num_units=32, dropout=0.)
+    sd = {k[len('me/sd/'):]: torch.from_numpy(v) for k, v in g9.items() if k.startswith('me/sd/')}
+    me.load_state_dict(sd, strict=True)          # the reference's checkpoint loads as is
+    me.to(DEV).eval()
+    batch = {k: dev(g9[f'me/{k}']) for k in ('observation_abs', 'speech_mask_target', 'noise_mask_target')}
+    out = me(batch)
+    for k in ('speech_mask_prediction', 'noise_mask_prediction'):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g9[f'me/{k}'], atol=1e-5)
+    review = me.review(batch, out)
+    np.testing.assert_allclose(review['loss'].item(), g9['me/loss'], rtol=1e-5)
+    review['loss'].backward()
+    for k, p in me.named_parameters():
+        want = g9[f'me/grad/{k}']
+        assert np.abs(p.grad.cpu().numpy() - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-3), k
+    assert set(review['images']) >= {'speech_mask', 'observed_stft', 'noise_mask'}
+
+
+def test_full_size_properties():
+    """B x T x F = 64 x 503 x 257 (BASELINE config 3 shape), ragged: masked positions are exactly
+    zero, every (b, f) row of valid frames has mean 0 / power 1, the op is idempotent."""
+    from padertorch_amd.modules import normalize
+    g = torch.Generator().manual_seed(0)
+    x = (3 * torch.randn(64, 503, 257, generator=g) + 1.5).to(DEV)
+    lens = [503 - 7 * b for b in range(64)]
+    y, mean, power, n = normalize(x, None, None, [1], 0, 1, lens, True, True, 1e-8)
+    assert n.shape == (64, 1, 257) and n[:, 0, 0].detach().cpu().tolist() == [float(v) for v in lens]
+    for b in (5, 17, 63):
+        assert float(y[b, lens[b]:].detach().abs().max()) == 0.
+        v = y[b, :lens[b]].detach()
+        assert float(v.mean(0).abs().max()) < 1e-5 and float(((v ** 2).mean(0) - 1).abs().max()) < 1e-4
+    y2 = normalize(y, None, None, [1], 0, 1, lens, True, True, 1e-8)[0]
+    np.testing.assert_allclose(y2.detach().cpu().numpy()[::9, ::50], y.detach().cpu().numpy()[::9, ::50], atol=1e-5)
+    want = N.normalize(x[5].cpu().numpy()[None], None, None, [1], 0, 1, [lens[5]], True, True, 1e-8)[0]
+    np.testing.assert_allclose(y[5].detach().cpu().numpy(), want[0], rtol=1e-4, atol=1e-4)
