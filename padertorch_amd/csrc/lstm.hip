@@ -317,6 +317,7 @@ struct LstmPersistArgs {
     int hy_bytes;
     unsigned err_off;        // index of the error words in flags
     int dbg;                 // PTMI_LSTM_DBG timing ablations (16: no poll, 32: no drain, 64: no MFMA, 128: no operand loads)
+    int tile0, ntiles;       // first row tile of this launch / row tiles of the whole batch
 };
 
 __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expected, unsigned max_polls,
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
     constexpr int MR = 16 * MTL;                  // rows per workgroup
     const int dir = blockIdx.y;
     const int j0 = blockIdx.x * JT;
-    const int m0 = blockIdx.z * MR;
+    const int m0 = (A.tile0 + blockIdx.z) * MR;
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             bq[i][nt] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
     const __amdgpu_buffer_rsrc_t hy_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.hy, 0, A.hy_bytes, 0x00020000);
-    unsigned* const myflags = A.flags + ((size_t)dir * gridDim.z + blockIdx.z) * A.T * 8;   // this chain's
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * A.T * 8;   // this chain's
     unsigned* const err = A.flags + A.err_off;
     const int bl = tid / JT, u = tid - bl * JT;
     const int b = m0 + bl;
@@ -500,13 +501,15 @@ struct LstmPersistBwdArgs {
     unsigned max_polls;
     int dg_bytes;
     unsigned err_off;
+    int tile0, ntiles;   // first 16-row tile of this launch / tiles of the whole batch
+    int dbg;             // PTMI_LSTM_DBG timing ablations (as in the forward kernel)
 };
 
 template <int NW, int CH>
 __global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
     const int dir = blockIdx.z;
     const int n0 = blockIdx.x * 16;
-    const int m0 = blockIdx.y * 16;
+    const int m0 = (A.tile0 + blockIdx.y) * 16;
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const L
             bq[i] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
     const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.dg, 0, A.dg_bytes, 0x00020000);
-    unsigned* const myflags = A.flags + ((size_t)dir * gridDim.y + blockIdx.y) * A.T * 8;   // this row tile's chain
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.y) * A.T * 8;   // this row tile's chain
     unsigned* const err = A.flags + A.err_off;
     const int bl = (tid >> 4) & 15, jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
@@ -564,23 +567,25 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const L
             if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
         }
         if (has_rec) {
-            if (wave == 0) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
             __syncthreads();
             const bool av = m0 + r < nnext;
             f32x4 a[CH];
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const bool ok = av && kb0 + i < kb1;
+                const bool ok = av && kb0 + i < kb1 && !(A.dbg & 128);
                 const unsigned voff =
                     ok ? (unsigned)(((nrow0 + m0 + r) * ld_g + (long long)dir * G + (kb0 + i) * 16 + 4 * g4) * 4) : 0u;
                 const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, voff, 0, 16 /* sc1 */);
                 a[i] = ok ? __builtin_bit_cast(f32x4, v) : zero;
             }
             f32x4 acc = zero;
+            if (!(A.dbg & 64)) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
+                for (int i = 0; i < CH; ++i) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc, 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) red[wave][g4 * 4 + q][r] = acc[q];
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const L
             __hip_atomic_store(dgp + 2 * H, d_g * (1.f - gg * gg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(dgp + 3 * H, d_o * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
             __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
@@ -746,32 +751,50 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     PTMI_RETURN_IF((KP / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
     // 16-row workgroups (two interleaved chains per 32 rows) while all of them stay co-resident
     // (512 threads at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2), else 32-row workgroups
-    const int jx = (H + 7) / 8;
+    const int jx8 = (H + 7) / 8;
     const long long hy_bytes = rows * ndir * H * 4;
     PTMI_RETURN_IF(hy_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
-    const unsigned mz16 = (unsigned)((max_batch + 15) / 16), mz32 = (unsigned)((max_batch + 31) / 32);
-    const char* mt_env = getenv("PTMI_LSTM_MTL");
-    const bool small = mt_env ? atoi(mt_env) == 1 : max_batch <= 16;   // measured: 8.3 (16-row) vs 6.9 us/step (32-row) at B = 32
-    const unsigned mz = small ? mz16 : mz32;
-    PTMI_RETURN_IF((long long)jx * ndir * mz > 448, PTMI_E_UNSUPPORTED);
+    // Workgroup tile (rows x hidden units), measured forward us per step at H = 600, T = 253:
+    //   B <= 16: 16 x 8 (4.9);  B <= 32: two independent chains of 16 x 16 on separate CUs (5.8; 32 x 8:
+    //   6.6, 16 x 8 with 300 workgroups sharing CUs: 8.3);  B > 32: 32 x 16 (B = 64: 8.8; 32 x 8: 11.6).
+    int jt = max_batch <= 16 ? 8 : 16, mtl = max_batch <= 32 ? 1 : 2;
+    if (const char* v = getenv("PTMI_LSTM_JT")) jt = atoi(v) == 16 ? 16 : 8;
+    if (const char* v = getenv("PTMI_LSTM_MTL")) mtl = atoi(v) == 1 ? 1 : 2;
+    const bool small = mtl == 1, wide = jt == 16;
+    const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
+    const int jx = wide ? (H + 15) / 16 : jx8;
+    const int cap = wide ? 256 : 448;     // 16-unit tiles need the whole register file: one workgroup per CU
+    PTMI_RETURN_IF((long long)jx * ndir > cap, PTMI_E_UNSUPPORTED);
+    // row tiles are independent recurrences: a batch whose tiles do not all fit runs as several launches
+    const int per_launch = std::min(ntiles, cap / (jx * ndir));
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
                       (unsigned)jx, 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
-                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0};
-    const dim3 grid((unsigned)jx, (unsigned)ndir, mz), block(NW * 64);
-    const bool one_per_cu = (long long)jx * ndir * mz <= 256;
-    if (small && one_per_cu)
-        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 1>), grid, block, 0, st, A);
-    else if (small)
-        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 2>), grid, block, 0, st, A);
-    else if (one_per_cu)
-        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 1>), grid, block, 0, st, A);
-    else
-        hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 2>), grid, block, 0, st, A);
-    return launch_status();
+                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles};
+    for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
+        A.tile0 = t0;
+        const int nt = std::min(per_launch, ntiles - t0);
+        const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt), block(NW * 64);
+        const bool one_per_cu = (long long)jx * ndir * nt <= 256;
+        if (wide && small)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 1, 1>), grid, block, 0, st, A);
+        else if (wide)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 2, 1>), grid, block, 0, st, A);
+        else if (small && one_per_cu)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 1>), grid, block, 0, st, A);
+        else if (small)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 2>), grid, block, 0, st, A);
+        else if (one_per_cu)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 1>), grid, block, 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 2>), grid, block, 0, st, A);
+        int rc = launch_status();
+        if (rc) return rc;
+    }
+    return PTMI_OK;
 }
 
 int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* dhy, const float* w_hh_t,
@@ -784,21 +807,29 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
     constexpr int NW = 16, CH = 10;
     PTMI_RETURN_IF((4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
-    // 1024-thread workgroups: one per CU must be resident
-    const long long wgs = (long long)((H + 15) / 16) * ((max_batch + 15) / 16) * ndir;
-    PTMI_RETURN_IF(wgs > 240, PTMI_E_UNSUPPORTED);
+    // 1024-thread workgroups: one per CU must be resident.  Row tiles are independent recurrences, so a
+    // batch whose tiles do not fit at once runs as several launches over groups of tiles.
+    const int nx = (H + 15) / 16, ntiles = (max_batch + 15) / 16;
+    PTMI_RETURN_IF((long long)nx * ndir > 240, PTMI_E_UNSUPPORTED);
+    const int per_launch = std::min(ntiles, 240 / (nx * ndir));
     const long long dg_bytes = rows * ndir * 4 * H * 4;
     PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
-                         (unsigned)((H + 15) / 16), 1u << 22, (int)dg_bytes,
-                         (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8)};
-    hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>),
-                       dim3((unsigned)((H + 15) / 16), (unsigned)((max_batch + 15) / 16), (unsigned)ndir),
-                       dim3(NW * 64), 0, st, A);
-    return launch_status();
+                         (unsigned)nx, 1u << 22, (int)dg_bytes,
+                         (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
+                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0};
+    for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
+        A.tile0 = t0;
+        const int nt = std::min(per_launch, ntiles - t0);
+        hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3((unsigned)nx, (unsigned)nt, (unsigned)ndir),
+                           dim3(NW * 64), 0, st, A);
+        int rc = launch_status();
+        if (rc) return rc;
+    }
+    return PTMI_OK;
 }
 
 int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float* c, const float* w_hh_pad,

@@ -14,6 +14,7 @@ DEV = 'cuda:0'
     (33, 40, 3, True, [17] * 5),
     (257, 600, 1, True, [40, 37, 37, 20, 9, 3]),          # model size, ragged, B < 16
     (1200, 600, 1, True, [23] * 40 + [11] * 5),           # B > 32: two M chunks
+    (64, 600, 1, True, [9] * 60 + [7] * 6 + [2] * 4),     # B = 70: row tiles run as several persistent launches
 ])
 def test_packed_lstm_vs_torch_cpu(I, H, layers, bidir, lens, monkeypatch):
     from padertorch_amd.ops import packed_lstm, lstm as L
