@@ -19,7 +19,7 @@ from pathlib import Path
 import torch
 
 TUNED_DIR = Path(__file__).resolve().parent / 'tuned'
-DEFAULT_FILE = TUNED_DIR / 'gfx950_pit_blstm600_frames8096.csv'
+DEFAULT_FILE = TUNED_DIR / 'gfx950_pit_dc.csv'   # PIT (B = 4 / 32 / 64) and DC (B = 32 / 64) shapes, scripts/tune_gemms.py
 
 
 def use_tuned_gemms(results_file=None, search=False, device=None):

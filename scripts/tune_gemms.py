@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""One-off TunableOp search over the GEMM shapes of the BASELINE configurations (run on the GPU box):
+
+    python scripts/tune_gemms.py gpurun_out/tune/gfx950.csv
+
+Starts from the committed selections, runs a few optimizer steps of every configuration with the
+search enabled and writes the merged result file (commit it as padertorch_amd/tuned/<name>.csv).
+"""
+import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch.cuda.tunable as tunable  # noqa: E402
+
+import bench_configs as bc  # noqa: E402
+
+out = Path(sys.argv[1])
+out.parent.mkdir(parents=True, exist_ok=True)
+bc.tuning.use_tuned_gemms(search=True)
+for fn, args in ((bc.pit, (4, 8000, 4, 'C1')), (bc.pit, (32, 8000, 4, 'C2')), (bc.pit, (64, 16000, 4, 'C3')),
+                 (bc.dc, (64, 16000, 4, 'C5')), (bc.dc, (32, 8000, 4, 'DC-B32')))[int(sys.argv[2]) if len(sys.argv) > 2 else 0:]:
+    print(fn(*args), flush=True)
+with open(out, 'w') as f:          # same layout TunableOp writes on exit
+    for k, v in tunable.get_validators():
+        f.write(f'Validator,{k},{v}\n')
+    for op, params, solution, t in tunable.get_results():
+        f.write(f'{op},{params},{solution},{t}\n')
+print('wrote', out, len(tunable.get_results()), 'entries')
