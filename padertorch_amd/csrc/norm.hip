@@ -31,7 +31,24 @@ struct NormGeo {
     int kept[kNormRank], red[kNormRank];
     long long n_groups, n_red;
     long long ogs[kNormRank];      // stride of the axis in the OUTPUT group index of this reduction
+    unsigned fdm[kNormRank], fds1[kNormRank], fds2[kNormRank];   // division by size[d] as multiply + shifts
 };
+
+// n / size[d] and n % size[d] for 32-bit n without a hardware divide (Granlund-Montgomery round-up
+// method: q = (t + ((n - t) >> s1)) >> s2 with t = mulhi(m, n); exact for every n < 2^32).
+template <typename IdxT>
+__device__ __forceinline__ void divmod(const NormGeo& g, int d, IdxT n, IdxT& q, int& r);
+template <>
+__device__ __forceinline__ void divmod<unsigned>(const NormGeo& g, int d, unsigned n, unsigned& q, int& r) {
+    const unsigned t = __umulhi(g.fdm[d], n);
+    q = (t + ((n - t) >> g.fds1[d])) >> g.fds2[d];
+    r = (int)(n - q * (unsigned)g.size[d]);
+}
+template <>
+__device__ __forceinline__ void divmod<long long>(const NormGeo& g, int d, long long n, long long& q, int& r) {
+    q = n / g.size[d];
+    r = (int)(n - q * g.size[d]);
+}
 
 struct NormRedArgs {
     const float* x;
@@ -71,8 +88,8 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormRedArgs A) {
         IdxT rem = (IdxT)(gvalid ? grp : 0);
         for (int i = g.nkept - 1; i >= 0; --i) {
             const int d = g.kept[i];
-            const IdxT q = rem / (IdxT)g.size[d];
-            idx[d] = (int)(rem - q * (IdxT)g.size[d]);
+            IdxT q;
+            divmod<IdxT>(g, d, rem, q, idx[d]);
             rem = q;
             base += idx[d] * g.stride[d];
         }
@@ -85,8 +102,8 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormRedArgs A) {
         long long off = base;
         for (int i = g.nred - 1; i >= 0; --i) {
             const int d = g.red[i];
-            const IdxT q = rem / (IdxT)g.size[d];
-            idx[d] = (int)(rem - q * (IdxT)g.size[d]);
+            IdxT q;
+            divmod<IdxT>(g, d, rem, q, idx[d]);
             rem = q;
             off += idx[d] * g.stride[d];
         }
@@ -151,13 +168,25 @@ __global__ __launch_bounds__(256) void norm_reduce_kernel(const NormRedArgs A) {
     }
 }
 
-// out[g][k] = sum_c ws[c][g][k] in chunk order (deterministic)
+// out[i] = sum_c ws[c][i], always in the same order (deterministic).  Few chunks: one thread per output
+// (coalesced across outputs); many chunks: one wavefront per output, lanes over chunks + shuffle tree
+// (a serial walk over hundreds of chunks would be one dependent load latency per chunk).
 __global__ void norm_reduce2_kernel(const double* __restrict__ ws, double* __restrict__ out, long long n, int nchunks) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double v = 0.;
-    for (int c = 0; c < nchunks; ++c) v += ws[(long long)c * n + i];
-    out[i] = v;
+    if (nchunks <= 8) {
+        const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i >= n) return;
+        double v = 0.;
+        for (int c = 0; c < nchunks; ++c) v += ws[(long long)c * n + i];
+        out[i] = v;
+    } else {
+        const int lane = threadIdx.x & 63;
+        const long long i = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (i >= n) return;
+        double v = 0.;
+        for (int c = lane; c < nchunks; c += 64) v += ws[(long long)c * n + i];
+        v = wsum(v);
+        if (lane == 0) out[i] = v;
+    }
 }
 
 struct NormEwArgs {
@@ -184,8 +213,9 @@ __global__ __launch_bounds__(256) void norm_elementwise_kernel(const NormEwArgs 
         long long sg = 0, ig = 0;
         int ib = 0, it = 0;
         for (int d = g.rank - 1; d >= 0; --d) {
-            const IdxT q = rem / (IdxT)g.size[d];
-            const int id = (int)(rem - q * (IdxT)g.size[d]);
+            IdxT q;
+            int id;
+            divmod<IdxT>(g, d, rem, q, id);
             rem = q;
             sg += id * g.sgs[d];
             ig += id * g.igs[d];
@@ -221,6 +251,11 @@ static bool geo_from(const ptmi_norm_geom* in, int which, NormGeo* g) {
         g->size[d] = (int)in->size[d];
         g->stride[d] = stride;
         stride *= in->size[d];
+        int l = 0;
+        while ((1ull << l) < (unsigned long long)in->size[d]) ++l;
+        g->fdm[d] = (unsigned)((((1ull << 32) * ((1ull << l) - (unsigned long long)in->size[d])) / (unsigned long long)in->size[d]) + 1);
+        g->fds1[d] = l < 1 ? l : 1;
+        g->fds2[d] = l < 1 ? 0 : l - 1;
     }
     for (int d = 0; d < kNormRank; ++d) {
         g->sgs[d] = d < in->rank ? in->stat_group_stride[d] : 0;
@@ -253,10 +288,31 @@ using namespace ptmi;
 
 extern "C" {
 
+// Chunks of the reduced range: enough workgroups to fill the chip (the loops are latency bound: one
+// load per thread and iteration), bounded by the traffic of the fp64 partials.
+static int group_tile(const NormGeo& g) {
+    const bool inner_reduced = g.nred > 0 && g.red[g.nred - 1] == g.rank - 1 && g.size[g.rank - 1] > 1;
+    return (inner_reduced || g.n_groups == 1) ? 1 : 64;
+}
+
+static int plan_chunks(const NormGeo& g, int gt, long long* chunk) {
+    const long long tiles = (g.n_groups + gt - 1) / gt;
+    const long long rows = 256 / gt;
+    long long want = (4096 + tiles - 1) / tiles;
+    const long long max_chunks = (g.n_red + rows * 2 - 1) / (rows * 2);     // >= 2 iterations per thread
+    // the fp64 partials (24 B per group and chunk) stay below ~1/4 of the bytes the pass reads
+    const long long ws_cap = std::max<long long>(1, g.n_red / 24);
+    want = std::min(std::min(want, max_chunks), std::min<long long>(ws_cap, 1024));
+    if (want < 1) want = 1;
+    *chunk = (g.n_red + want - 1) / want;
+    return (int)((g.n_red + *chunk - 1) / *chunk);
+}
+
 int64_t ptmi_norm_workspace_elems(const ptmi_norm_geom* geom, int32_t which) {
     NormGeo g;
     if (!geo_from(geom, which, &g)) return PTMI_E_INVALID;
-    return 3 * g.n_groups * 64;   // up to 64 chunks of the reduced range
+    long long chunk;
+    return 3 * g.n_groups * plan_chunks(g, group_tile(g), &chunk);
 }
 
 int ptmi_norm_reduce(int32_t mode, const float* x, const float* gy, const int32_t* lengths, const float* mean,
@@ -279,18 +335,9 @@ int ptmi_norm_reduce(int32_t mode, const float* x, const float* gy, const int32_
     A.shift = shift;
     const NormGeo& g = A.g;
     // lanes along the innermost axis: reduced -> one group per workgroup; kept -> 64 groups per workgroup
-    const bool inner_reduced = g.nred > 0 && g.red[g.nred - 1] == g.rank - 1 && g.size[g.rank - 1] > 1;
-    A.gt = (inner_reduced || g.n_groups == 1) ? 1 : 64;
+    A.gt = group_tile(g);
     const long long tiles = (g.n_groups + A.gt - 1) / A.gt;
-    // split the reduced range while the grid is small (<= 64 chunks, >= 256 rows of work each)
-    long long want = (2048 + tiles - 1) / tiles;
-    const long long rows = 256 / A.gt;
-    long long max_chunks = (g.n_red + rows * 4 - 1) / (rows * 4);
-    if (want > max_chunks) want = max_chunks;
-    if (want > 64) want = 64;
-    if (want < 1) want = 1;
-    A.chunk = (g.n_red + want - 1) / want;
-    A.nchunks = (int)((g.n_red + A.chunk - 1) / A.chunk);
+    A.nchunks = plan_chunks(g, A.gt, &A.chunk);
     PTMI_RETURN_IF(tiles > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (g.n_groups * g.n_red < 0x7fffffffLL)
@@ -300,8 +347,8 @@ int ptmi_norm_reduce(int32_t mode, const float* x, const float* gy, const int32_
     int rc = launch_status();
     if (rc) return rc;
     const long long n = 3 * g.n_groups;
-    hipLaunchKernelGGL(norm_reduce2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, out, n,
-                       A.nchunks);
+    const long long blocks2 = A.nchunks <= 8 ? (n + 255) / 256 : (n + 3) / 4;
+    hipLaunchKernelGGL(norm_reduce2_kernel, dim3((unsigned)blocks2), dim3(256), 0, st, workspace, out, n, A.nchunks);
     return launch_status();
 }
 
