@@ -169,12 +169,15 @@ int ptmi_dc_loss_backward(const float* x, const float* t, const double* gram, co
 /* Forward through time.
  *   gates      device [rows, ndir, 4, H]  in: x W_ih^T + b_ih + b_hh; out: activated i,f,g,o (in place)
  *   hy, c      device [rows, ndir, H]     out: hidden / cell state of every step
+ *   c0         device [ndir, max_batch, H] initial cell state of every sequence, or NULL (zero).  The
+ *              initial HIDDEN state enters through `gates`: the caller adds h0 W_hh^T to the rows of
+ *              each sequence's first processed step (torch.nn.LSTM(x, (h0, c0)) semantics).
  *   w_hh_pad   device [ndir, 4H, KP]      recurrent weights, K zero-padded to KP = roundup(H, 16)
  *   batch_sizes HOST int32 [T], offsets HOST int64 [T] (PackedSequence bookkeeping; per-step row
  *              ranges travel as kernel arguments)
  *   H % 4 == 0 is required (16-byte aligned operand rows), else PTMI_E_UNSUPPORTED.
  */
-int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, const int32_t* batch_sizes,
+int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad, const int32_t* batch_sizes,
                       const int64_t* offsets, int32_t T, int32_t max_batch, int32_t H, int32_t KP,
                       int32_t ndir, ptmi_stream_t stream);
 
@@ -185,7 +188,7 @@ int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, 
  *   dc_state   device [max_batch, ndir, H] scratch (need not be initialised)
  * dW_ih, dW_hh, db and dx follow from dgates by dense GEMMs on the caller's side.
  */
-int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
+int ptmi_lstm_backward(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t, float* dgates,
                        float* dc_state, const int32_t* batch_sizes, const int64_t* offsets, int32_t T,
                        int32_t max_batch, int32_t H, int32_t ndir, ptmi_stream_t stream);
 
@@ -196,14 +199,14 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, con
  * error words: non-zero after the call = a bounded spin ran out).  Returns PTMI_E_UNSUPPORTED when
  * the configuration cannot be kept resident (caller falls back to ptmi_lstm_forward). */
 int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch);
-int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* w_hh_pad,
+int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
                                  int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,
                                  ptmi_stream_t stream);
 
 /* Persistent backward-through-time (mirror of ptmi_lstm_forward_persistent; same results as
  * ptmi_lstm_backward; no dc_state scratch: the cell-state gradient stays in registers). */
-int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* dhy, const float* w_hh_t,
+int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t,
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                   uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
                                   int32_t ndir, ptmi_stream_t stream);

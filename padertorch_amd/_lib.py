@@ -61,12 +61,12 @@ SIGNATURES = {
     'ptmi_td_workspace_elems': (c_int64, [c_int64, c_int32, c_int64]),
     'ptmi_td_pair_stats': (c_int, [_P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P, _P]),
     'ptmi_td_lincomb': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P]),
-    'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
-    'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
+    'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
-    'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
+    'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                              c_int32, _P]),
-    'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
+    'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
                                               c_int32, _P]),
     'ptmi_lstm_plan_create': (c_int, [POINTER(c_void_p), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
                                       c_int32, c_int32, c_int32]),

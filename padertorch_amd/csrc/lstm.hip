@@ -48,6 +48,8 @@ struct LstmArgs {
     const float* w;
     int H, KP, ndir, dbg;
     StepMeta m;
+    const float* c0;   // [ndir, max_batch, H] initial cell state of every sequence, or null (= 0)
+    int max_batch;
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -89,6 +91,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(const LstmArgs A
 #pragma unroll
         for (int q = 0; q < 4; ++q) pre[q] = gp[q * H];
         if (b < nprev) cprev = A.c[(prow0 + b) * ld_h + dir * H + j0 + u];
+        else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];   // first step of sequence b
     }
 
     if (has_rec) {
@@ -193,6 +196,8 @@ struct LstmBwdArgs {
     float* dcs;
     int H, ndir;
     StepMeta m;
+    const float* c0;
+    int max_batch;
 };
 
 // One backward timestep.  grid = (ceil(H / 16), ceil(maxB / 16), ndir), NW * 64 threads.
@@ -235,6 +240,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(const LstmBwdArg
         og = A.gates[og_ + 3 * H];
         cn = A.c[oh];
         if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
+        else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
     }
 
     if (has_rec) {
@@ -318,6 +324,8 @@ struct LstmPersistArgs {
     unsigned err_off;        // index of the error words in flags
     int dbg;                 // PTMI_LSTM_DBG timing ablations (16: no poll, 32: no drain, 64: no MFMA, 128: no operand loads)
     int tile0, ntiles;       // first row tile of this launch / row tiles of the whole batch
+    const float* c0;         // [ndir, max_batch, H] initial cell state or null
+    int max_batch;
 };
 
 __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expected, unsigned max_polls,
@@ -399,6 +407,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         if (act) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) pre[q] = gp[q * H];
+            if (b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];   // first step of sequence b
         }
         if (has_rec) {
             if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
@@ -503,6 +512,8 @@ struct LstmPersistBwdArgs {
     unsigned err_off;
     int tile0, ntiles;   // first 16-row tile of this launch / tiles of the whole batch
     int dbg;             // PTMI_LSTM_DBG timing ablations (as in the forward kernel)
+    const float* c0;
+    int max_batch;
 };
 
 template <int NW, int CH>
@@ -565,6 +576,7 @@ __global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const L
             og = A.gates[og_ + 3 * H];
             cn = A.c[oh];
             if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
+            else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
         }
         if (has_rec) {
             if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
@@ -630,11 +642,11 @@ static void neighbour(const int32_t* bs, const int64_t* offs, int T, int t, int 
 }
 
 // Enqueue the T forward step kernels on `st` (eagerly, or into a stream capture).
-static int enqueue_forward(float* gates, float* hy, float* c, const float* w_hh_pad, const int32_t* batch_sizes,
+static int enqueue_forward(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad, const int32_t* batch_sizes,
                            const int64_t* offsets, int T, int max_batch, int H, int KP, int ndir, hipStream_t st) {
     const char* dbg_env = getenv("PTMI_LSTM_DBG");
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
-    LstmArgs A{gates, hy, c, w_hh_pad, H, KP, ndir, dbg, {}};
+    LstmArgs A{gates, hy, c, w_hh_pad, H, KP, ndir, dbg, {}, c0, max_batch};
     // JT = 8 (32 gate columns per workgroup) reads h_{t-1} from half as many workgroups as JT = 4;
     // measured faster at H = 600 (9.4 vs 10.3 us per step, B = 32) because the step is bound by
     // operand traffic, not by the matrix cores.  JT = 4 only when H is too small to fill the chip.
@@ -658,10 +670,10 @@ static int enqueue_forward(float* gates, float* hy, float* c, const float* w_hh_
     return launch_status();
 }
 
-static int enqueue_backward(const float* gates, const float* c, const float* dhy, const float* w_hh_t,
+static int enqueue_backward(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t,
                             float* dgates, float* dc_state, const int32_t* batch_sizes, const int64_t* offsets,
                             int T, int max_batch, int H, int ndir, hipStream_t st) {
-    LstmBwdArgs A{gates, c, dhy, w_hh_t, dgates, dc_state, H, ndir, {}};
+    LstmBwdArgs A{gates, c, dhy, w_hh_t, dgates, dc_state, H, ndir, {}, c0, max_batch};
     const dim3 grid((unsigned)((H + 15) / 16), (unsigned)((max_batch + 15) / 16), (unsigned)ndir);
     for (int s = 0; s < T; ++s) {
         for (int d = 0; d < ndir; ++d) {
@@ -713,24 +725,24 @@ static int capture_graph(hipGraphExec_t* exec, F&& enqueue) {
 
 extern "C" {
 
-int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* w_hh_pad, const int32_t* batch_sizes,
+int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad, const int32_t* batch_sizes,
                       const int64_t* offsets, int32_t T, int32_t max_batch, int32_t H, int32_t KP,
                       int32_t ndir, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !hy || !c || !w_hh_pad || !batch_sizes || !offsets, PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 0 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2), PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
-    return enqueue_forward(gates, hy, c, w_hh_pad, batch_sizes, offsets, T, max_batch, H, KP, ndir,
+    return enqueue_forward(gates, hy, c, c0, w_hh_pad, batch_sizes, offsets, T, max_batch, H, KP, ndir,
                            static_cast<hipStream_t>(stream));
 }
 
-int ptmi_lstm_backward(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
+int ptmi_lstm_backward(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t, float* dgates,
                        float* dc_state, const int32_t* batch_sizes, const int64_t* offsets, int32_t T,
                        int32_t max_batch, int32_t H, int32_t ndir, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || !dgates || !dc_state || !batch_sizes || !offsets,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 0 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2), PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
-    return enqueue_backward(gates, c, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, max_batch, H, ndir,
+    return enqueue_backward(gates, c, c0, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, max_batch, H, ndir,
                             static_cast<hipStream_t>(stream));
 }
 
@@ -738,7 +750,7 @@ int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch) {
     return (int64_t)ndir * ((max_batch + 15) / 16) * T * 8 + 8;   // one chain per 16-row tile + error words
 }
 
-int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* w_hh_pad,
+int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
                                  int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,
                                  ptmi_stream_t stream) {
@@ -773,7 +785,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
                       (unsigned)jx, 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
-                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles};
+                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
@@ -797,7 +809,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     return PTMI_OK;
 }
 
-int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* dhy, const float* w_hh_t,
+int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t,
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                   uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
                                   int32_t ndir, ptmi_stream_t stream) {
@@ -820,7 +832,7 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
                          (unsigned)nx, 1u << 22, (int)dg_bytes,
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
-                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0};
+                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
@@ -841,11 +853,11 @@ int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float*
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
     ptmi_lstm_plan* p = new ptmi_lstm_plan();
     int rc = capture_graph(&p->fwd, [&](hipStream_t cs) {
-        return enqueue_forward(gates, hy, c, w_hh_pad, batch_sizes, offsets, T, max_batch, H, KP, ndir, cs);
+        return enqueue_forward(gates, hy, c, nullptr, w_hh_pad, batch_sizes, offsets, T, max_batch, H, KP, ndir, cs);
     });
     if (rc == PTMI_OK && dhy && w_hh_t && dgates && dc_state) {
         rc = capture_graph(&p->bwd, [&](hipStream_t cs) {
-            return enqueue_backward(gates, c, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, max_batch,
+            return enqueue_backward(gates, c, nullptr, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, max_batch,
                                     H, ndir, cs);
         });
     }

@@ -1,9 +1,10 @@
 """``StatefulLSTM`` (reference: ``padertorch/modules/recurrent.py:5-47``) on the HIP BLSTM recurrence.
 
 Same constructor; the parameters live in a ``torch.nn.LSTM`` (same ``state_dict`` keys:
-``lstm.weight_ih_l0`` ...).  The time loop runs in ``csrc/lstm.hip`` (``ops.lstm.packed_lstm``).
-Gap: the HIP recurrence starts from the zero state, so carrying ``(h_n, c_n)`` over to the next call
-(``save_states=True`` with a second call) is not implemented yet and raises.
+``lstm.weight_ih_l0`` ...).  The time loop runs in ``csrc/lstm.hip`` (``ops.lstm.packed_lstm``); ``(h_n, c_n)`` of a call is
+carried into the next one like the reference does.  Documented difference: the carried states are
+constants of the next call (detached) - backpropagation does not reach across calls (the reference
+would need ``retain_graph`` for that; streaming use detaches anyway).
 """
 import torch
 from torch.nn.utils.rnn import PackedSequence
@@ -38,13 +39,16 @@ class StatefulLSTM(torch.nn.Module):
         self._states = states
 
     def forward(self, x):
-        if self.save_states or self.states is not None:
-            raise NotImplementedError(
-                'StatefulLSTM on the HIP recurrence starts from the zero state: use save_states=False '
-                '(carrying (h_n, c_n) across calls is not implemented yet)')
         assert x.dim() == 3, x.shape
         xt = x.transpose(0, 1) if self.batch_first else x            # [T, B, F]
         T, B = xt.shape[:2]
         packed = PackedSequence(xt.reshape(T * B, -1), torch.full((T,), B, dtype=torch.int64))
-        h = packed_lstm(self.lstm, packed).data.reshape(T, B, -1)
+        if self.save_states or self.states is not None:
+            out, states = packed_lstm(self.lstm, packed, hx=self.states, return_state=True)
+            self.states = tuple(s.detach() for s in states)
+            if not self.save_states:
+                del self.states
+        else:
+            out = packed_lstm(self.lstm, packed)
+        h = out.data.reshape(T, B, -1)
         return h.transpose(0, 1) if self.batch_first else h

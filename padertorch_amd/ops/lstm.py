@@ -48,6 +48,19 @@ class _PackMeta:
             if t + 1 < self.T:
                 prev[1, offs[t]:offs[t] + bs[t + 1]] = offs[t + 1] + np.arange(bs[t + 1])
         self.prev_dev = torch.tensor(prev, device=device)
+        # per sequence b: rows of its first / last processed step per direction (initial / final states),
+        # and the predecessor table with "no predecessor" pointing at row rows + 1 + b (= h0[b])
+        lens = (bs[None, :] > np.arange(self.max_batch)[:, None]).sum(1) if self.T else np.zeros(0, np.int64)
+        b_idx = np.arange(self.max_batch)
+        end_rows = offs[np.maximum(lens - 1, 0)] + b_idx
+        self.first_rows = torch.tensor(np.stack([b_idx, end_rows]), device=device)
+        self.last_rows = torch.tensor(np.stack([end_rows, b_idx]), device=device)
+        prev_h0 = prev.copy()
+        row_b = np.concatenate([np.arange(n) for n in bs]) if self.T else np.zeros(0, np.int64)
+        for d in range(2):
+            fresh = prev[d] == self.rows
+            prev_h0[d, fresh] = self.rows + 1 + row_b[fresh]
+        self.prev_h0_dev = torch.tensor(prev_h0, device=device)
 
 
 @functools.lru_cache(maxsize=64)
@@ -175,12 +188,17 @@ class _LstmLayerFn(torch.autograd.Function):
     """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, bias, w_hh, meta):
+    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None):
         lib = _lib.load()
         ndir, G, H = w_hh.shape
         assert G == 4 * H
         KP = (H + 15) // 16 * 16
-        lease = _acquire(meta, ndir, H, x.device)
+        stateful = h0 is not None or c0 is not None
+        if stateful:            # [ndir, B, H] constants (no gradient flows into the initial state)
+            h0 = torch.zeros_like(c0) if h0 is None else h0.detach().to(torch.float32).contiguous()
+            c0 = torch.zeros_like(h0) if c0 is None else c0.detach().to(torch.float32).contiguous()
+            assert h0.shape == c0.shape == (ndir, meta.max_batch, H), (h0.shape, c0.shape, meta.max_batch)
+        lease = None if stateful else _acquire(meta, ndir, H, x.device)
         st = _lib.stream(x.device)
         if lease is not None:
             ws = lease.ws
@@ -195,6 +213,10 @@ class _LstmLayerFn(torch.autograd.Function):
                 lease.release()
         else:
             gates = torch.addmm(bias, x, w_ih.t())
+            if stateful:        # h0 W_hh^T enters the pre-activations of each sequence's first processed step
+                gv = gates.view(meta.rows, ndir, G)
+                for d in range(ndir):
+                    gv[:, d].index_add_(0, meta.first_rows[d], h0[d] @ w_hh[d].t())
             w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
             hy = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
             c = torch.empty_like(hy)
@@ -204,7 +226,7 @@ class _LstmLayerFn(torch.autograd.Function):
                                     device=x.device)
                 rc = _lib.timed(
                     'lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(),
-                    c.data_ptr(), w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
+                    c.data_ptr(), _lib.ptr(c0), w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
                     flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, KP, ndir, st)
                 if rc not in (0, -2):
                     _lib.check(rc, 'ptmi_lstm_forward_persistent')
@@ -215,16 +237,20 @@ class _LstmLayerFn(torch.autograd.Function):
             if rc == -2:        # configuration not resident-able: one launch per timestep
                 _lib.check(_lib.timed(
                     'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
-                    w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T,
+                    _lib.ptr(c0), w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T,
                     meta.max_batch, H, KP, ndir, st), 'ptmi_lstm_forward')
-            ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy)
+            ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
             ctx.lease = None
         ctx.meta = meta
+        if stateful:
+            ctx.mark_non_differentiable(c)
+            return hy, c
         return hy
 
     @staticmethod
-    def backward(ctx, dhy):
+    def backward(ctx, dhy, _dc=None):
         meta, lease = ctx.meta, ctx.lease
+        h0 = c0 = None
         lib = _lib.load()
         st = _lib.stream(dhy.device)
         if lease is not None:
@@ -241,7 +267,7 @@ class _LstmLayerFn(torch.autograd.Function):
                        'ptmi_lstm_plan_backward')
             dg, hy = ws.dg, ws.hy
         else:
-            x, w_ih, w_hh, gates, c, hy = ctx.saved_tensors
+            x, w_ih, w_hh, gates, c, hy, h0, c0 = ctx.saved_tensors
             ndir, G, H = w_hh.shape
             dhy = dhy.contiguous()
             w_t = w_hh.transpose(1, 2).contiguous()                   # [ndir, H, 4H]
@@ -251,7 +277,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)), dtype=torch.int32,
                                     device=x.device)
                 rc = _lib.timed(
-                    'lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(),
+                    'lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                     dhy.data_ptr(), w_t.data_ptr(), dg.data_ptr(), meta.bs_dev.data_ptr(),
                     meta.offs_dev.data_ptr(), flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, ndir, st)
                 if rc not in (0, -2):
@@ -263,20 +289,24 @@ class _LstmLayerFn(torch.autograd.Function):
             if rc == -2:
                 dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
                 _lib.check(_lib.timed(
-                    'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
+                    'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0), dhy.data_ptr(),
                     w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
                     meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
         dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
         db = dg.sum(0)
-        hy_pad = torch.cat([hy.view(meta.rows, ndir, H),
-                            hy.new_zeros(1, ndir, H)], 0)             # row `rows` = zero state
+        parts = [hy.view(meta.rows, ndir, H), hy.new_zeros(1, ndir, H)]   # row `rows` = zero state
+        prev = meta.prev_dev
+        if h0 is not None:                                                # rows rows+1+b = h0[:, b]
+            parts.append(h0.transpose(0, 1))
+            prev = meta.prev_h0_dev
+        hy_pad = torch.cat(parts, 0)
         dgv = dg.view(meta.rows, ndir, G)
-        dw_hh = torch.stack([dgv[:, d].t() @ hy_pad[:, d].index_select(0, meta.prev_dev[d])
+        dw_hh = torch.stack([dgv[:, d].t() @ hy_pad[:, d].index_select(0, prev[d])
                              for d in range(ndir)])
         if lease is not None:
             lease.release()
-        return dx, dw_ih, db, dw_hh, None
+        return dx, dw_ih, db, dw_hh, None, None, None
 
 
 def supported(lstm, data):
@@ -284,8 +314,13 @@ def supported(lstm, data):
             and lstm.bias and data.is_cuda and data.dtype == torch.float32)
 
 
-def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None):
-    """``lstm(packed)[0]`` through the HIP recurrence (zero initial state)."""
+def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False):
+    """``lstm(packed, hx)`` through the HIP recurrence.
+
+    ``hx = (h_0, c_0)``, each ``[num_layers * num_directions, B, H]`` like ``torch.nn.LSTM``, are taken
+    as constants (no gradient flows into the initial state).  Returns the output PackedSequence, or
+    ``(output, (h_n, c_n))`` when ``hx`` is given or ``return_state`` is set.
+    """
     data = packed.data
     _lib.require_gpu(data)
     if not supported(lstm, data):
@@ -295,13 +330,33 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None):
     training = lstm.training if training is None else training
     meta = pack_meta(packed.batch_sizes, data.device)
     sfx = ['', '_reverse'] if lstm.bidirectional else ['']
+    ndir, H = len(sfx), lstm.hidden_size
+    want_state = return_state or hx is not None
+    if hx is not None:
+        h_all, c_all = hx
+        if h_all.requires_grad or c_all.requires_grad:
+            raise NotImplementedError('gradients w.r.t. the initial LSTM state are not implemented: detach it')
+        assert h_all.shape == c_all.shape == (lstm.num_layers * ndir, meta.max_batch, H), (h_all.shape, meta.max_batch)
+    h_n, c_n = [], []
     h = data.contiguous()
     for layer in range(lstm.num_layers):
         w_ih = torch.cat([getattr(lstm, f'weight_ih_l{layer}{s}') for s in sfx], 0)
         bias = torch.cat([getattr(lstm, f'bias_ih_l{layer}{s}') + getattr(lstm, f'bias_hh_l{layer}{s}')
                           for s in sfx], 0)
         w_hh = torch.stack([getattr(lstm, f'weight_hh_l{layer}{s}') for s in sfx], 0)
-        h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta)
+        if want_state:
+            sl = slice(layer * ndir, (layer + 1) * ndir)
+            h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
+            c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
+            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0)
+            hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
+            h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
+            c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
+        else:
+            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta)
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
-    return PackedSequence(h, packed.batch_sizes)
+    out = PackedSequence(h, packed.batch_sizes)
+    if want_state:
+        return out, (torch.stack(h_n), torch.stack(c_n))
+    return out

@@ -95,3 +95,61 @@ def test_model_uses_hip_lstm_and_matches_library_lstm():
     b = model(batch)
     for x, y in zip(a, b):
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize('persistent', [True, False])
+def test_initial_and_final_states_vs_torch_cpu(persistent, monkeypatch):
+    """``lstm(packed, (h0, c0))`` semantics of torch.nn.LSTM: the initial state applies to every
+    sequence's first processed step (per direction, also for ragged batches), (h_n, c_n) are the states
+    after each sequence's last step; gradients w.r.t. inputs and weights include the state terms."""
+    from padertorch_amd.ops import packed_lstm, lstm as L
+    monkeypatch.setattr(L, 'CHECK_PERSISTENT_ERRORS', True)
+    monkeypatch.setattr(L, 'PERSISTENT', persistent)
+    torch.manual_seed(11)
+    I, H, layers, lens = 13, 24, 2, [9, 9, 7, 4, 4, 1]
+    ref = torch.nn.LSTM(I, H, layers, bidirectional=True)
+    dut = torch.nn.LSTM(I, H, layers, bidirectional=True)
+    dut.load_state_dict(ref.state_dict())
+    dut = dut.to(DEV)
+    h0, c0 = torch.randn(layers * 2, len(lens), H), torch.randn(layers * 2, len(lens), H)
+    xs = [torch.randn(l, I) for l in lens]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    xd = [x.clone().to(DEV).requires_grad_(True) for x in xs]
+    yr, (hr, cr) = ref(pack_sequence(xr), (h0, c0))
+    yd, (hd, cd) = packed_lstm(dut, pack_sequence(xd), hx=(h0.to(DEV), c0.to(DEV)))
+    np.testing.assert_allclose(yd.data.detach().cpu().numpy(), yr.data.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(hd.cpu().numpy(), hr.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(cd.cpu().numpy(), cr.detach().numpy(), atol=3e-6)
+    g = torch.randn(yr.data.shape)
+    (yr.data * g).sum().backward()
+    (yd.data * g.to(DEV)).sum().backward()
+    for a, b in zip(xd, xr):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), atol=2e-5, rtol=1e-4)
+    for (n, pd), pr in zip(dut.named_parameters(), ref.parameters()):
+        np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.numpy(),
+                                   atol=3e-5 * max(1., pr.grad.abs().max().item()), err_msg=n)
+    # zero-state call with return_state == plain call + states
+    y0, (hn0, cn0) = packed_lstm(dut, pack_sequence([x.detach() for x in xd]), return_state=True)
+    yr0, (hr0, cr0) = ref(pack_sequence(xs))
+    np.testing.assert_allclose(hn0.cpu().numpy(), hr0.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(cn0.cpu().numpy(), cr0.detach().numpy(), atol=3e-6)
+    with pytest.raises(NotImplementedError):
+        packed_lstm(dut, pack_sequence(xd), hx=(h0.to(DEV).requires_grad_(True), c0.to(DEV)))
+
+
+def test_stateful_lstm_streams_like_the_reference_module():
+    """StatefulLSTM (modules/recurrent.py:5-47): chunked calls with carried states == one long call."""
+    from padertorch_amd.modules import StatefulLSTM
+    torch.manual_seed(5)
+    m = StatefulLSTM(17, 20, num_layers=2, bidirectional=False, batch_first=True, save_states=True).to(DEV)
+    ref = torch.nn.LSTM(17, 20, 2, batch_first=True)
+    ref.load_state_dict({k[len('lstm.'):]: v.cpu() for k, v in m.state_dict().items()})
+    x = torch.randn(3, 30, 17)
+    want, _ = ref(x)
+    got = torch.cat([m(x[:, :12].to(DEV)), m(x[:, 12:19].to(DEV)), m(x[:, 19:].to(DEV))], 1)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), atol=5e-6)
+    assert m.states is not None and m.states[0].shape == (2, 3, 20)
+    del m.states
+    np.testing.assert_allclose(m(x.to(DEV)).detach().cpu().numpy(), want.detach().numpy(), atol=5e-6)
+    m2 = StatefulLSTM(17, 20, bidirectional=True, save_states=False).to(DEV)
+    assert m2(x.to(DEV)).shape == (3, 30, 40) and m2.states is None
