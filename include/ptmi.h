@@ -228,8 +228,9 @@ void ptmi_lstm_plan_destroy(ptmi_lstm_plan* plan);
  * Replaces MelTransform.forward (padertorch/contrib/je/modules/features.py:297-330: spectrogram @
  * fbanks, log(x + eps)) and, fused with the STFT, the extractor front-end features.py:171-176
  * (power of the stacked STFT -> MelTransform) without materialising the spectrum.
- * The [F, M] filterbank is passed band-compressed: filter m covers bins mel_lo[m] .. mel_lo[m] +
- * mel_cnt[m] - 1 with weights mel_w[mel_off[m] ...] (device arrays; sum of mel_cnt = mel_nnz).
+ * The [F, M] filterbank is passed band-compressed in 16-byte aligned groups of 8 bins: filter m covers
+ * bins 4 mel_lo[m] .. 4 mel_lo[m] + 8 mel_cnt[m] - 1 with the (zero-padded) weights
+ * mel_w[4 mel_off[m] ...] (device arrays; mel_nnz = number of floats in mel_w, a multiple of 8).
  * ptmi_stft_logmel: x [batch, num_samples] -> out [batch, out_frames, mel_M] = f(|STFT|^power),
  * power in {1, 2}; sizes 64..2048 (powers of two).  ptmi_mel_apply: spec [N, F] -> out [N, mel_M]. */
 int ptmi_stft_logmel(const float* x, int64_t batch, int64_t x_row_stride, int64_t num_samples,

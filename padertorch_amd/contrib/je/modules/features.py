@@ -59,18 +59,24 @@ def get_fbanks(sample_rate: int, stft_size: int, number_of_filters: int, lowest_
 
 
 class _Bands:
-    """Band-compressed copy of an ``[F, M]`` filterbank, cached per device."""
+    """Band-compressed copy of an ``[F, M]`` filterbank, cached per device: filter m covers the
+    16-byte aligned bin groups ``4 lo[m] .. 4 lo[m] + 8 cnt[m]`` with zero-padded weights at
+    ``w[4 off[m]:]`` (the layout ``ptmi_mel_apply`` / ``ptmi_stft_logmel`` read with b128 loads)."""
 
     def __init__(self, fbanks: np.ndarray):
         F, M = fbanks.shape
         lo, cnt, off, w = [], [], [], []
         for m in range(M):
             nz = np.flatnonzero(fbanks[:, m])
-            a, b = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 1)     # an empty filter keeps one zero weight
-            lo.append(a)
-            cnt.append(b - a)
-            off.append(len(w))
-            w.extend(fbanks[a:b, m].tolist())
+            a, b = (int(nz[0]), int(nz[-1]) + 1) if len(nz) else (0, 1)     # an empty filter keeps one zero group
+            a4 = a // 4 * 4
+            groups = (b - a4 + 7) // 8
+            seg = np.zeros(groups * 8, np.float32)
+            seg[a - a4:b - a4] = fbanks[a:b, m]
+            lo.append(a4 // 4)
+            cnt.append(groups)
+            off.append(len(w) // 4)
+            w.extend(seg.tolist())
         self.F, self.M, self.nnz = F, M, len(w)
         self.host = dict(lo=np.array(lo, np.int32), cnt=np.array(cnt, np.int32), off=np.array(off, np.int32),
                          w=np.array(w, np.float32))

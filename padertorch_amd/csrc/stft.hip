@@ -64,11 +64,12 @@ struct FwdArgs {
     bool aligned2;   // every frame start is 8-byte aligned -> float2 sample loads
     float edge_scale;
     Geo g;
-    // fused (log-)mel epilogue (stft_fwd_kernel<PL, true>): band-compressed filterbank
-    const int32_t* mel_lo;    // [M] first bin of filter m
-    const int32_t* mel_cnt;   // [M] number of bins
-    const int32_t* mel_off;   // [M] offset of its weights in mel_w
-    const float* mel_w;       // [nnz]
+    // fused (log-)mel epilogue (stft_fwd_kernel<PL, true>): band-compressed filterbank in 16-byte
+    // aligned groups of 8 bins
+    const int32_t* mel_lo;    // [M] first bin of filter m's first group / 4
+    const int32_t* mel_cnt;   // [M] number of 8-bin groups
+    const int32_t* mel_off;   // [M] offset of its weights in mel_w / 4
+    const float* mel_w;       // [nnz] weights, zero-padded to whole groups
     int mel_M, mel_nnz, mel_power, mel_log;
     float mel_eps;
 };
@@ -372,10 +373,10 @@ __global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdA
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WaveLds<PL> S(smem, 4);
     // mel tables behind the wave buffers: lo | cnt | off [mel_M] int32, weights [mel_nnz] float
-    int32_t* mlo = reinterpret_cast<int32_t*>(smem + WaveLds<PL>::bytes(4, 0));
+    float* mw = reinterpret_cast<float*>(smem + ((WaveLds<PL>::bytes(4, 0) + 15) & ~(size_t)15));   // 16-byte aligned
+    int32_t* mlo = reinterpret_cast<int32_t*>(mw + A.mel_nnz);
     int32_t* mcnt = mlo + A.mel_M;
     int32_t* moff = mcnt + A.mel_M;
-    float* mw = reinterpret_cast<float*>(moff + A.mel_M);
     if (MEL) {
         for (int i = threadIdx.x; i < A.mel_M; i += 256) {
             mlo[i] = A.mel_lo[i];
@@ -457,31 +458,61 @@ __global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdA
 
         const int nfr = min(FPW, (int)A.out_frames - tw0);
         if (MEL) {
-            // |X[k]|^power IN PLACE over the spectrum (.x of slot k; k = 0 pairs with the spare slot M:
-            // both slots of a pair were read by this lane only), zero for frames past the row's end
-            for (int p = lane; p < FPW * NP; p += 64) {
-                const int f = p / NP, k = p - f * NP, km = M - k;
+            // |X[k]|^power of all pairs into registers, then written DENSELY (frame f at float offset
+            // f * 2 FS, 16-byte aligned rows) over the spectrum; zero for frames past the row's end
+            constexpr int NITP = (FPW * NP + 63) / 64;
+            float pk[NITP], pm[NITP];
+#pragma unroll
+            for (int it = 0; it < NITP; ++it) {
+                const int p = min(lane + 64 * it, FPW * NP - 1);
+                const int f = p / NP, k = p - f * NP;
                 cpx Xk, Xm;
                 split_pair<PL>(wbuf + f * FS, S.tws, k, Xk, Xm);
-                float pk = Xk.x * Xk.x + Xk.y * Xk.y, pm = Xm.x * Xm.x + Xm.y * Xm.y;
+                pk[it] = Xk.x * Xk.x + Xk.y * Xk.y;
+                pm[it] = Xm.x * Xm.x + Xm.y * Xm.y;
                 if (A.mel_power == 1) {
-                    pk = sqrtf(pk);
-                    pm = sqrtf(pm);
+                    pk[it] = sqrtf(pk[it]);
+                    pm[it] = sqrtf(pm[it]);
                 }
-                if (tw0 + f >= frames_b) pk = pm = 0.f;
-                wbuf[f * FS + k].x = pk;
-                if (km != k) wbuf[f * FS + km].x = pm;
+                if (tw0 + f >= frames_b) pk[it] = pm[it] = 0.f;
             }
             wave_sync();
+            float* P = reinterpret_cast<float*>(wbuf);
+#pragma unroll
+            for (int it = 0; it < NITP; ++it) {
+                const int p = lane + 64 * it;
+                if (p < FPW * NP) {
+                    const int f = p / NP, k = p - f * NP, km = M - k;
+                    P[f * 2 * FS + k] = pk[it];
+                    if (km != k) P[f * 2 * FS + km] = pm[it];
+                }
+            }
+            constexpr int PADN = ((F + 3) & ~3) + 8 - F;      // the 8-bin groups may reach past bin M: zeros
+            for (int i = lane; i < FPW * PADN; i += 64) P[(i / PADN) * 2 * FS + F + i % PADN] = 0.f;
+            wave_sync();
+            // one lane per (frame, filter): the filter's band in 16-byte aligned groups of 8 bins
+            // (weights zero-padded), two b128 reads of the spectrum and two of the weights per group
             float* __restrict__ orow = A.out + ((long long)b * A.out_frames + tw0) * A.mel_M;
             const int nout = nfr * A.mel_M;
+            const float4* P4 = reinterpret_cast<const float4*>(P);
+            const float4* W4 = reinterpret_cast<const float4*>(mw);
             for (int o = lane; o < nout; o += 64) {
                 const int f = o / A.mel_M, m = o - f * A.mel_M;
-                const cpx* pw = wbuf + f * FS + mlo[m];
-                const float* w = mw + moff[m];
+                const float4* pw = P4 + f * (FS / 2) + mlo[m];
+                const float4* w = W4 + moff[m];
                 const int cnt = mcnt[m];
                 float acc = 0.f;
-                for (int i = 0; i < cnt; ++i) acc = fmaf(pw[i].x, w[i], acc);
+                for (int i = 0; i < cnt; ++i) {
+                    const float4 p0 = pw[2 * i], p1 = pw[2 * i + 1], w0 = w[2 * i], w1 = w[2 * i + 1];
+                    acc = fmaf(p0.x, w0.x, acc);
+                    acc = fmaf(p0.y, w0.y, acc);
+                    acc = fmaf(p0.z, w0.z, acc);
+                    acc = fmaf(p0.w, w0.w, acc);
+                    acc = fmaf(p1.x, w1.x, acc);
+                    acc = fmaf(p1.y, w1.y, acc);
+                    acc = fmaf(p1.z, w1.z, acc);
+                    acc = fmaf(p1.w, w1.w, acc);
+                }
                 orow[o] = A.mel_log ? logf(acc + A.mel_eps) : acc;
             }
             wave_sync();   // the next item's transposition reuses wbuf
@@ -1029,7 +1060,7 @@ static int launch_fwd(FwdArgs& A, long long batch, bool features, hipStream_t st
                  (!A.s || reinterpret_cast<uintptr_t>(A.s) % 8 == 0);
     if (!features) {
         const bool mel = A.mel_w != nullptr;
-        const size_t smem = WaveLds<PL>::bytes(4, 0) + (mel ? sizeof(int32_t) * 3 * A.mel_M + sizeof(float) * A.mel_nnz : 0);
+        const size_t smem = WaveLds<PL>::bytes(4, 0) + (mel ? 16 + sizeof(int32_t) * 3 * A.mel_M + sizeof(float) * A.mel_nnz : 0);
         if (smem > kMaxSmem) return PTMI_E_UNSUPPORTED;
         A.batch = batch;
         A.nchunks = (int)((A.out_frames + PL::FPW - 1) / PL::FPW);      // work items per row
@@ -1152,28 +1183,41 @@ struct MelArgs {
 __global__ __launch_bounds__(256) void mel_apply_kernel(const MelArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = 8;
-    float* rows = reinterpret_cast<float*>(smem);            // [R][F]
-    int32_t* mlo = reinterpret_cast<int32_t*>(rows + R * A.F);
+    const int PS = ((A.F + 3) & ~3) + 8;                     // padded row: the 8-bin groups may reach past F
+    float* rows = reinterpret_cast<float*>(smem);            // [R][PS]
+    float* mw = rows + R * PS;
+    int32_t* mlo = reinterpret_cast<int32_t*>(mw + A.nnz);
     int32_t* mcnt = mlo + A.M;
     int32_t* moff = mcnt + A.M;
-    float* mw = reinterpret_cast<float*>(moff + A.M);
     for (int i = threadIdx.x; i < A.M; i += 256) {
         mlo[i] = A.lo[i];
         mcnt[i] = A.cnt[i];
         moff[i] = A.off[i];
     }
     for (int i = threadIdx.x; i < A.nnz; i += 256) mw[i] = A.w[i];
+    for (int i = threadIdx.x; i < R * (PS - A.F); i += 256) rows[(i / (PS - A.F)) * PS + A.F + i % (PS - A.F)] = 0.f;
+    const float4* W4 = reinterpret_cast<const float4*>(mw);
     for (long long n0 = (long long)blockIdx.x * R; n0 < A.N; n0 += (long long)gridDim.x * R) {
         const int nr = (int)min((long long)R, A.N - n0);
         __syncthreads();
-        for (int i = threadIdx.x; i < nr * A.F; i += 256) rows[i] = A.spec[n0 * A.F + i];
+        for (int i = threadIdx.x; i < nr * A.F; i += 256) rows[(i / A.F) * PS + i % A.F] = A.spec[n0 * A.F + i];
         __syncthreads();
         for (int o = threadIdx.x; o < nr * A.M; o += 256) {
             const int r = o / A.M, m = o - r * A.M;
-            const float* pw = rows + r * A.F + mlo[m];
-            const float* w = mw + moff[m];
+            const float4* pw = reinterpret_cast<const float4*>(rows + r * PS) + mlo[m];
+            const float4* w = W4 + moff[m];
             float acc = 0.f;
-            for (int i = 0; i < mcnt[m]; ++i) acc = fmaf(pw[i], w[i], acc);
+            for (int i = 0; i < mcnt[m]; ++i) {
+                const float4 p0 = pw[2 * i], p1 = pw[2 * i + 1], w0 = w[2 * i], w1 = w[2 * i + 1];
+                acc = fmaf(p0.x, w0.x, acc);
+                acc = fmaf(p0.y, w0.y, acc);
+                acc = fmaf(p0.z, w0.z, acc);
+                acc = fmaf(p0.w, w0.w, acc);
+                acc = fmaf(p1.x, w1.x, acc);
+                acc = fmaf(p1.y, w1.y, acc);
+                acc = fmaf(p1.z, w1.z, acc);
+                acc = fmaf(p1.w, w1.w, acc);
+            }
             A.out[n0 * A.M + o] = A.log_ ? logf(acc + A.eps) : acc;
         }
     }
@@ -1274,7 +1318,7 @@ int ptmi_mel_apply(const float* spec, int64_t N, int32_t F, const int32_t* mel_l
     PTMI_RETURN_IF(!spec || !out || !mel_lo || !mel_cnt || !mel_off || !mel_w, PTMI_E_INVALID);
     PTMI_RETURN_IF(N < 0 || F < 1 || mel_M < 1 || mel_nnz < 1, PTMI_E_INVALID);
     if (N == 0) return PTMI_OK;
-    const size_t smem = sizeof(float) * (8 * (size_t)F + mel_nnz) + sizeof(int32_t) * 3 * (size_t)mel_M;
+    const size_t smem = sizeof(float) * (8 * ((((size_t)F + 3) & ~(size_t)3) + 8) + mel_nnz) + sizeof(int32_t) * 3 * (size_t)mel_M;
     PTMI_RETURN_IF(smem > kMaxSmem, PTMI_E_UNSUPPORTED);
     MelArgs A{spec, out, mel_lo, mel_cnt, mel_off, mel_w, N, F, mel_M, mel_nnz, log_, eps};
     const long long blocks = std::min<long long>((N + 7) / 8, 256LL * 8);
