@@ -9,6 +9,8 @@
 // tile of rows in LDS and accumulates V'V with v_mfma_f32_32x32x2_f32 (exact fp32; both operands of
 // the symmetric product are the SAME register).  Per-workgroup partial Grams are reduced in fp64 in a
 // fixed order (bitwise reproducible).  Backward: dX = 4/N^2 (X (X'X) - T (T'X)) as a streaming kernel.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace ptmi {
@@ -29,6 +31,7 @@ struct DcArgs {
     long long ts[4];             // t element (b, t, k, f) likewise
     int E, K, F;                 // F = inner extent per time step (rows n = t*F + f)
     int nchunks;                 // workgroups per example
+    int dbg;                     // PTMI_DC_DBG timing ablations (1: no MFMA, 2: no loads, 4: no LDS staging)
 };
 
 // Stage rows [n0, n0 + kDcTile) of example b (row n = (t, f) = (n / F, n % F)) of V^T into LDS:
@@ -64,6 +67,40 @@ __device__ __forceinline__ void dc_stage(float* lds, const DcArgs& A, int b, lon
     }
 }
 
+// Inner-contiguous layouts (xs[3] == 1: the model's (t, e, f) embedding): thread i owns row n0 + i of a
+// tile for ALL columns, so (t, f) = divmod(n, F) is computed once per row and the D loads of a row are
+// issued back to back; consecutive threads read consecutive f (coalesced per column).
+struct DcRow {
+    long long ox, ot;
+    bool valid, in_range;     // row of the example / row of the padded [T, F] extent
+};
+
+__device__ __forceinline__ DcRow dc_row(const DcArgs& A, long long n, long long N_b) {
+    DcRow r;
+    r.valid = n < N_b;
+    r.in_range = n < A.T * A.F;
+    const unsigned nn = (unsigned)(r.in_range ? n : 0);   // T * F < 2^31 (host checked)
+    const unsigned tt = nn / (unsigned)A.F;
+    const unsigned f = nn - tt * (unsigned)A.F;
+    r.ox = (long long)tt * A.xs[1] + (long long)f * A.xs[3];
+    r.ot = (long long)tt * A.ts[1] + (long long)f * A.ts[3];
+    return r;
+}
+
+__device__ __forceinline__ void dc_load_row(float (&v)[kDcMaxD], const DcArgs& A, const float* xb, const float* tb,
+                                            const DcRow& r) {
+#pragma unroll
+    for (int c = 0; c < kDcMaxD; ++c) {
+        float val = 0.f;
+        if (c < A.E) {
+            if (r.valid) val = xb[r.ox + c * A.xs[2]];
+        } else if (c < A.E + A.K) {
+            if (r.valid) val = tb[r.ot + (c - A.E) * A.ts[2]];
+        }
+        v[c] = val;
+    }
+}
+
 // partial[b, chunk, 32, 32] (fp32) = V'V over the chunk's tiles
 __global__ __launch_bounds__(256) void dc_gram_kernel(const DcArgs A, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[kDcMaxD * kDcPitch];
@@ -79,19 +116,39 @@ __global__ __launch_bounds__(256) void dc_gram_kernel(const DcArgs A, float* __r
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const bool along_rows = A.xs[3] == 1 && A.ts[3] == 1;
+    const float* xb = A.x + b * A.xs[0];
+    const float* tb = A.t + b * A.ts[0];
+    float v[kDcMaxD];
+    const long long tile0 = (long long)chunk * kDcTilesPerWg;
+    if (A.dbg & 2)
+        for (int c2 = 0; c2 < kDcMaxD; ++c2) v[c2] = (float)(tid + c2);
+    if (along_rows && tile0 < ntiles && !(A.dbg & 2)) dc_load_row(v, A, xb, tb, dc_row(A, tile0 * kDcTile + tid, N_b));
     for (int it = 0; it < kDcTilesPerWg; ++it) {
-        const long long tile = (long long)chunk * kDcTilesPerWg + it;
+        const long long tile = tile0 + it;
         if (tile >= ntiles) break;                      // uniform
         __syncthreads();                                // previous tile consumed
-        dc_stage(lds, A, b, tile * kDcTile, N_b, tid);
+        if (along_rows) {
+            if (!(A.dbg & 4)) {
+#pragma unroll
+                for (int c = 0; c < kDcMaxD; ++c) lds[c * kDcPitch + tid] = v[c];
+            }
+        } else {
+            dc_stage(lds, A, b, tile * kDcTile, N_b, tid);
+        }
         __syncthreads();
+        // the next tile's rows travel from HBM while this tile runs through the matrix cores
+        if (along_rows && it + 1 < kDcTilesPerWg && tile + 1 < ntiles && !(A.dbg & 2))
+            dc_load_row(v, A, xb, tb, dc_row(A, (tile + 1) * kDcTile + tid, N_b));
         // wave w takes rows [64 w, 64 w + 64) of the tile; lane (c, h) rows 64 w + 32 h + 2 j + {0, 1}
         const float* col = lds + c * kDcPitch + 64 * wave + 32 * h;
+        if (!(A.dbg & 1)) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float2 v = *reinterpret_cast<const float2*>(col + 2 * j);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, v.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, v.y, acc, 0, 0, 0);
+            for (int j = 0; j < 16; ++j) {
+                const float2 v2 = *reinterpret_cast<const float2*>(col + 2 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v2.x, v2.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v2.y, v2.y, acc, 0, 0, 0);
+            }
         }
     }
     // C layout of mfma_f32_32x32x2: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -164,10 +221,46 @@ __global__ __launch_bounds__(256) void dc_backward_kernel(const DcBwdArgs B) {
     const int D = A.E + A.K;
     const double N = (double)T_b * A.F;
     const float coef = T_b > 0 ? B.gscale[0] * (float)(4.0 / (N * N * (double)B.batch)) : 0.f;
+    for (int idx = tid; idx < kDcMaxD * (kDcMaxD + 1); idx += 256) (&Cm[0][0])[idx] = 0.f;
+    __syncthreads();
     for (int idx = tid; idx < D * A.E; idx += 256) {
         const int i = idx / A.E, e = idx - i * A.E;
         const double g = B.gram[((long long)b << 10) + i * 32 + e];
         Cm[i][e] = (float)(i < A.E ? g : -g) * coef;
+    }
+    __syncthreads();                                    // Cm is complete
+    if (A.xs[3] == 1 && A.ts[3] == 1) {
+        // register path: thread i owns row n0 + i: D loads, E dot products against C (LDS broadcast
+        // reads), E stores; consecutive threads touch consecutive f (coalesced per column)
+        const float* xb = A.x + b * A.xs[0];
+        const float* tb = A.t + b * A.ts[0];
+        float* dxb = B.dx + b * A.xs[0];
+        const long long tile0 = (long long)chunk * kDcTilesPerWg;
+        const long long ntiles_all = (A.T * A.F + kDcTile - 1) / kDcTile;   // incl. the padded frames: zeros
+        float v[kDcMaxD];
+        DcRow r = dc_row(A, tile0 * kDcTile + tid, N_b);
+        if (tile0 < ntiles_all) dc_load_row(v, A, xb, tb, r);
+        for (int it = 0; it < kDcTilesPerWg; ++it) {
+            const long long tile = tile0 + it;
+            if (tile >= ntiles_all) break;
+            float cur[kDcMaxD];
+#pragma unroll
+            for (int q = 0; q < kDcMaxD; ++q) cur[q] = v[q];
+            const DcRow rc = r;
+            if (it + 1 < kDcTilesPerWg && tile + 1 < ntiles_all) {
+                r = dc_row(A, (tile + 1) * kDcTile + tid, N_b);
+                dc_load_row(v, A, xb, tb, r);
+            }
+            if (rc.in_range) {                  // rows past the example's length get zeros (v = 0 there)
+                for (int e = 0; e < A.E; ++e) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < kDcMaxD; ++q) sum = fmaf(cur[q], Cm[q][e], sum);   // rows q >= D of Cm are zero
+                    dxb[rc.ox + e * A.xs[2]] = sum;
+                }
+            }
+        }
+        return;
     }
     for (int it = 0; it < kDcTilesPerWg; ++it) {
         const long long tile = (long long)chunk * kDcTilesPerWg + it;
@@ -201,7 +294,7 @@ __global__ __launch_bounds__(256) void dc_backward_kernel(const DcBwdArgs B) {
 static int dc_fill(DcArgs& A, const float* x, const float* t, int64_t T, const int64_t* strides, int32_t E,
                    int32_t K, int32_t F, const int32_t* row_frames) {
     if (!x || !t || !strides || E < 1 || K < 1 || F < 1 || T < 0) return PTMI_E_INVALID;
-    if (E + K > kDcMaxD) return PTMI_E_UNSUPPORTED;
+    if (E + K > kDcMaxD || T * F >= 0x7fffffffLL) return PTMI_E_UNSUPPORTED;
     A.x = x;
     A.t = t;
     A.row_frames = row_frames;
@@ -215,6 +308,7 @@ static int dc_fill(DcArgs& A, const float* x, const float* t, int64_t T, const i
     A.F = F;
     A.nchunks = (int)(((T * F + kDcTile - 1) / kDcTile + kDcTilesPerWg - 1) / kDcTilesPerWg);
     if (A.nchunks < 1) A.nchunks = 1;
+    A.dbg = getenv("PTMI_DC_DBG") ? atoi(getenv("PTMI_DC_DBG")) : 0;
     return PTMI_OK;
 }
 

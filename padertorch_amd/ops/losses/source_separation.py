@@ -53,8 +53,10 @@ class _DcFn(torch.autograd.Function):
         x, t, row_frames, gram = ctx.saved_tensors
         B, T, E, K, F, xs, ts = ctx.geom
         lib = _lib.load()
-        # rows past an example's length are never touched by the kernel -> zeros
-        dx = torch.zeros_like(x, memory_format=torch.preserve_format) if row_frames is not None \
+        # inner-contiguous layouts: the kernel writes every (t < T, f) row, zeros past an example's
+        # length; the generic layout path touches valid rows only
+        inner = xs[3] == 1 and ts[3] == 1
+        dx = torch.zeros_like(x, memory_format=torch.preserve_format) if (row_frames is not None and not inner) \
             else torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
         gs = g_loss.to(torch.float32).reshape(1).contiguous()
         _lib.check(_lib.timed(
