@@ -767,15 +767,18 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     const long long hy_bytes = rows * ndir * H * 4;
     PTMI_RETURN_IF(hy_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     // Workgroup tile (rows x hidden units), measured forward us per step at H = 600, T = 253:
-    //   B <= 16: 16 x 8 (4.9);  B <= 32: two independent chains of 16 x 16 on separate CUs (5.8; 32 x 8:
-    //   6.6, 16 x 8 with 300 workgroups sharing CUs: 8.3);  B > 32: 32 x 16 (B = 64: 8.8; 32 x 8: 11.6).
-    int jt = max_batch <= 16 ? 8 : 16, mtl = max_batch <= 32 ? 1 : 2;
-    if (const char* v = getenv("PTMI_LSTM_JT")) jt = atoi(v) == 16 ? 16 : 8;
+    //   B <= 16: 16 x 8 (4.9);  B <= 32: two independent chains of 16 x 12 on separate CUs (200 workgroups:
+    //   5.4; 16 x 16 on 152: 5.8; 32 x 8: 6.6; 16 x 8 with 300 workgroups sharing CUs: 8.3);
+    //   B > 32: 32 x 12 (B = 64: 32 x 16 8.8, 32 x 8 11.6).
+    int jt = max_batch <= 16 ? 8 : 12, mtl = max_batch <= 32 ? 1 : 2;
+    if (jt == 12 && (long long)((H + 11) / 12) * ndir > 256) jt = 16;      // wide tiles: one workgroup per CU
+    if (jt == 16 && (long long)((H + 15) / 16) * ndir > 256) jt = 8;
+    if (const char* v = getenv("PTMI_LSTM_JT")) jt = atoi(v) == 16 ? 16 : (atoi(v) == 12 ? 12 : 8);
     if (const char* v = getenv("PTMI_LSTM_MTL")) mtl = atoi(v) == 1 ? 1 : 2;
-    const bool small = mtl == 1, wide = jt == 16;
+    const bool small = mtl == 1, wide = jt >= 12;
     const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
-    const int jx = wide ? (H + 15) / 16 : jx8;
-    const int cap = wide ? 256 : 448;     // 16-unit tiles need the whole register file: one workgroup per CU
+    const int jx = wide ? (H + jt - 1) / jt : jx8;
+    const int cap = wide ? 256 : 448;     // 12/16-unit tiles need the whole register file: one workgroup per CU
     PTMI_RETURN_IF((long long)jx * ndir > cap, PTMI_E_UNSUPPORTED);
     // row tiles are independent recurrences: a batch whose tiles do not all fit runs as several launches
     const int per_launch = std::min(ntiles, cap / (jx * ndir));
@@ -791,8 +794,12 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
         const int nt = std::min(per_launch, ntiles - t0);
         const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt), block(NW * 64);
         const bool one_per_cu = (long long)jx * ndir * nt <= 256;
-        if (wide && small)
+        if (jt == 12 && small)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1>), grid, block, 0, st, A);
+        else if (wide && small)
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 1, 1>), grid, block, 0, st, A);
+        else if (jt == 12)
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 2, 1>), grid, block, 0, st, A);
         else if (wide)
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 2, 1>), grid, block, 0, st, A);
         else if (small && one_per_cu)
