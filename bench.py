@@ -106,6 +106,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--default-gemms', action='store_true', help='library default GEMM kernel selection')
+    ap.add_argument('--overlap', action='store_true',
+                    help='EXPERIMENTAL: LSTM weight gradients on a side stream (ops.lstm.DEFER_WGRAD)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -138,6 +140,10 @@ def main():
     if world > 1:
         trainer._broadcast_parameters()
     model.train()
+    from padertorch_amd.ops import lstm as _lstm
+    _lstm.DEFER_WGRAD = args.overlap             # off by default (see the hazard note in ops/lstm.py)
+    if _lstm.DEFER_WGRAD:
+        _lstm.warm_side_stream(device)
 
     n = FS * SECONDS
     data = synthetic_batch(1000 + rank, BATCH, n, device)

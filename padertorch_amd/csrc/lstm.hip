@@ -786,7 +786,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
-                      (unsigned)jx, 1u << 22, (int)hy_bytes,
+                      (unsigned)jx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
                       getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
@@ -837,7 +837,7 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
-                         (unsigned)nx, 1u << 22, (int)dg_bytes,
+                         (unsigned)nx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)dg_bytes,
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
                          getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {

@@ -137,6 +137,58 @@ USE_GRAPHS = False
 PERSISTENT = True
 #: read back the error words of the persistent kernels after every call (host sync; tests only)
 CHECK_PERSISTENT_ERRORS = False
+#: EXPERIMENTAL (off by default).  Accumulate the weight gradients of the LSTM layers straight into the
+#: parameters' ``.grad`` buffers on a SIDE stream: the backward recurrence of the next (lower) layer
+#: occupies ~150-200 of the 256 CUs exclusively - its workgroups hold a CU's whole register file - so
+#: the dW GEMMs of the layer above can run on the idle CUs meanwhile (bench config: 18.2 -> 17.2 ms per
+#: step).  HAZARD: the persistent recurrence kernels need all their workgroups co-resident, and the
+#: library GEMMs that now run next to them are Stream-K kernels (``SK3`` in their names) that also spin
+#: on sibling workgroups; with B >= 48 at T = 503 the first unsynchronised training step was observed
+#: to hang the GPU (not bounded by the recurrence kernels' own spin limits).  Until the side-stream
+#: GEMMs are replaced by kernels without inter-workgroup waits this stays opt-in
+#: (``Trainer(overlap_wgrad=True)``, ``bench.py --overlap``).  ``sync_deferred()`` must run before
+#: anything reads the gradients.
+DEFER_WGRAD = False
+#: False: the deferred accumulation runs on the current stream (same GEMM shapes, no overlap; used by the
+#: one-off GEMM tuning, which must not time kernels next to a running recurrence)
+WGRAD_SIDE_STREAM = True
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream(device):
+    key = (device.type, device.index)
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[key]
+
+
+def warm_side_stream(device, nbytes=1 << 30):
+    """Create the weight-gradient side stream of ``device`` and exercise everything it will need (its
+    hardware queue, the allocator pool of that stream, the BLAS handle, the kernels) while the GPU is
+    otherwise IDLE.  First use of a stream next to a running persistent recurrence kernel has been
+    observed to stall the GPU (queue creation / first large allocations while a kernel that needs all of
+    its workgroups co-resident is only partly dispatched); after this warm-up it does not."""
+    device = torch.device(device)
+    torch.cuda.synchronize(device)
+    side = _wgrad_stream(device)
+    with torch.cuda.stream(side):
+        big = torch.empty(nbytes // 4, dtype=torch.float32, device=device)      # grows the side pool once
+        a = torch.randn(512, 256, device=device)
+        idx = torch.arange(512, device=device)
+        acc = torch.zeros(256, 256, device=device)
+        acc.addmm_(a.t(), torch.cat([a, a[:1]], 0).index_select(0, idx))
+        acc.add_(a.sum(0))
+        del big, a, idx, acc
+    torch.cuda.synchronize(device)
+
+
+def sync_deferred(device=None):
+    """Make the current stream wait for every deferred weight-gradient accumulation."""
+    for (typ, idx), side in _WGRAD_STREAMS.items():
+        if device is None or (torch.device(device).type, torch.device(device).index) == (typ, idx):
+            torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(side)
+
+
 #: per-device accumulator of the persistent kernels' error words; `check_errors()` reads it (the
 #: Trainer does so once per optimizer step, where it synchronises anyway)
 _ERR_ACC = {}
@@ -188,7 +240,7 @@ class _LstmLayerFn(torch.autograd.Function):
     """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None):
+    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None):
         lib = _lib.load()
         ndir, G, H = w_hh.shape
         assert G == 4 * H
@@ -242,6 +294,7 @@ class _LstmLayerFn(torch.autograd.Function):
             ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
             ctx.lease = None
         ctx.meta = meta
+        ctx.params = params
         if stateful:
             ctx.mark_non_differentiable(c)
             return hy, c
@@ -293,6 +346,30 @@ class _LstmLayerFn(torch.autograd.Function):
                     w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
                     meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
         dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
+        params = ctx.params
+        if DEFER_WGRAD and lease is None and params is not None and all(p.grad is not None for ps in params for p in ps):
+            # weight gradients on the side stream, accumulated in place (see DEFER_WGRAD)
+            main = torch.cuda.current_stream(x.device)
+            side = _wgrad_stream(x.device) if WGRAD_SIDE_STREAM else main
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                parts = [hy.view(meta.rows, ndir, H), hy.new_zeros(1, ndir, H)]
+                prev = meta.prev_dev
+                if h0 is not None:
+                    parts.append(h0.transpose(0, 1))
+                    prev = meta.prev_h0_dev
+                hy_pad = torch.cat(parts, 0)
+                dgv = dg.view(meta.rows, ndir, G)
+                for d, (p_wih, p_whh, p_bih, p_bhh) in enumerate(params):
+                    dgd = dgv[:, d]
+                    p_wih.grad.addmm_(dgd.t(), x)
+                    p_whh.grad.addmm_(dgd.t(), hy_pad[:, d].index_select(0, prev[d]))
+                    db_d = dgd.sum(0)
+                    p_bih.grad.add_(db_d)
+                    p_bhh.grad.add_(db_d)
+            for t in (dg, x, hy) + (() if h0 is None else (h0,)):
+                t.record_stream(side)           # keep the operands alive until the side stream is done
+            return dx, None, None, None, None, None, None, None
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
         db = dg.sum(0)
         parts = [hy.view(meta.rows, ndir, H), hy.new_zeros(1, ndir, H)]   # row `rows` = zero state
@@ -306,7 +383,7 @@ class _LstmLayerFn(torch.autograd.Function):
                              for d in range(ndir)])
         if lease is not None:
             lease.release()
-        return dx, dw_ih, db, dw_hh, None, None, None
+        return dx, dw_ih, db, dw_hh, None, None, None, None
 
 
 def supported(lstm, data):
@@ -344,16 +421,18 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         bias = torch.cat([getattr(lstm, f'bias_ih_l{layer}{s}') + getattr(lstm, f'bias_hh_l{layer}{s}')
                           for s in sfx], 0)
         w_hh = torch.stack([getattr(lstm, f'weight_hh_l{layer}{s}') for s in sfx], 0)
+        params = tuple((getattr(lstm, f'weight_ih_l{layer}{s}'), getattr(lstm, f'weight_hh_l{layer}{s}'),
+                        getattr(lstm, f'bias_ih_l{layer}{s}'), getattr(lstm, f'bias_hh_l{layer}{s}')) for s in sfx)
         if want_state:
             sl = slice(layer * ndir, (layer + 1) * ndir)
             h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
-            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0)
+            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params)
             hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
             h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:
-            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta)
+            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params)
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
     out = PackedSequence(h, packed.batch_sizes)

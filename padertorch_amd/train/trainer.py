@@ -73,6 +73,7 @@ class Trainer:
             checkpoint_trigger=(1, 'epoch'),
             stop_trigger=(1, 'epoch'),
             virtual_minibatch_size=1,
+            overlap_wgrad=False,
     ):
         if not isinstance(model, torch.nn.Module):
             raise TypeError('Expect that the model is a subclass from padertorch.Module.\n'
@@ -87,6 +88,9 @@ class Trainer:
         self.epoch = -1
         self.loss_weights = loss_weights
         self.virtual_minibatch_size = virtual_minibatch_size
+        #: EXPERIMENTAL, off by default: LSTM weight gradients on a side stream while the next layer's
+        #: recurrence runs (ops.lstm.DEFER_WGRAD; +5 % at the bench config, but see the hazard noted there)
+        self.overlap_wgrad = overlap_wgrad
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
         self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)
         self.stop_trigger = EndTrigger.new(stop_trigger)
@@ -148,6 +152,11 @@ class Trainer:
         if W > 1:
             self._broadcast_parameters()
         self.optimizer.zero_grad()
+        from ..ops import lstm as _lstm
+        defer_before = _lstm.DEFER_WGRAD
+        _lstm.DEFER_WGRAD = bool(self.overlap_wgrad) and self._flat.flat.is_cuda
+        if _lstm.DEFER_WGRAD:
+            _lstm.warm_side_stream(self._flat.flat.device)
 
         try:
             train_iterable = None
@@ -191,6 +200,8 @@ class Trainer:
         except StopTraining:
             pass
         finally:
+            _lstm.sync_deferred()
+            _lstm.DEFER_WGRAD = defer_before
             self._close()
 
     # ------------------------------------------------------------------ hooks (fixed set)
@@ -260,6 +271,8 @@ class Trainer:
     def optimizer_step(self):
         """clip (global norm) -> lr summary -> optimizer.step -> zero_grad (trainer.py:512-532).
         With W > 1 the flat gradient bucket is summed over all ranks first (one collective)."""
+        from ..ops import lstm as _lstm
+        _lstm.sync_deferred()          # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
         if self.world_size > 1:
             t0 = time.perf_counter()
             dist.all_reduce(self._flat.flat, op=dist.ReduceOp.SUM)

@@ -87,6 +87,10 @@ def dc(batch, fs, seconds, name, K=3):
 
 
 if __name__ == '__main__':
+    from padertorch_amd.ops import lstm as _lstm
+    _lstm.DEFER_WGRAD = '--overlap' in sys.argv
+    if _lstm.DEFER_WGRAD:
+        _lstm.warm_side_stream(dev)
     if '--default-gemms' not in sys.argv:
         tuning.use_tuned_gemms(search='--search' in sys.argv)
     for res in (pit(4, 8000, 4, 'C1 (B=4, 8 kHz)'), pit(64, 16000, 4, 'C3 (B=64, 16 kHz)'),

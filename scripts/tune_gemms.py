@@ -17,6 +17,9 @@ import bench_configs as bc  # noqa: E402
 
 out = Path(sys.argv[1])
 out.parent.mkdir(parents=True, exist_ok=True)
+from padertorch_amd.ops import lstm as _lstm  # noqa: E402
+_lstm.DEFER_WGRAD = '--overlap' in sys.argv     # also tune the per-direction shapes of the experimental side-stream path
+_lstm.WGRAD_SIDE_STREAM = False                 # ... timed on the main stream, nothing else running
 bc.tuning.use_tuned_gemms(search=True)
 for fn, args in ((bc.pit, (4, 8000, 4, 'C1')), (bc.pit, (32, 8000, 4, 'C2')), (bc.pit, (64, 16000, 4, 'C3')),
                  (bc.dc, (64, 16000, 4, 'C5')), (bc.dc, (32, 8000, 4, 'DC-B32')))[int(sys.argv[2]) if len(sys.argv) > 2 else 0:]:
