@@ -162,6 +162,30 @@ def _wgrad_stream(device):
     return _WGRAD_STREAMS[key]
 
 
+_SIDE_SAFE = {}
+
+
+def _side_stream_safe(rows, I, H, ndir):
+    """True when every GEMM of the deferred path has a pinned rocBLAS solution in the loaded TunableOp
+    results: rocBLAS kernels are plain tiled GEMMs (split-K through a second kernel), hipBLASLt's carry a
+    Stream-K mode that spins on sibling workgroups - the latter must not run next to a persistent
+    recurrence kernel (see DEFER_WGRAD).  Unknown shapes run on the main stream."""
+    key = (rows, I, H, ndir)
+    if key not in _SIDE_SAFE:
+        ok = False
+        try:
+            import torch.cuda.tunable as tunable
+            if tunable.is_enabled():
+                res = {params: sol for _op, params, sol, _t in tunable.get_results()}
+                G = 4 * H
+                need = (f'nt_{I}_{G}_{rows}_ld_{I}_{ndir * G}_{I}', f'nt_{H}_{G}_{rows}_ld_{H}_{ndir * G}_{H}')
+                ok = all('Rocblas' in res.get(k, '') for k in need)
+        except Exception:
+            ok = False
+        _SIDE_SAFE[key] = ok
+    return _SIDE_SAFE[key]
+
+
 def warm_side_stream(device, nbytes=1 << 30):
     """Create the weight-gradient side stream of ``device`` and exercise everything it will need (its
     hardware queue, the allocator pool of that stream, the BLAS handle, the kernels) while the GPU is
@@ -350,7 +374,8 @@ class _LstmLayerFn(torch.autograd.Function):
         if DEFER_WGRAD and lease is None and params is not None and all(p.grad is not None for ps in params for p in ps):
             # weight gradients on the side stream, accumulated in place (see DEFER_WGRAD)
             main = torch.cuda.current_stream(x.device)
-            side = _wgrad_stream(x.device) if WGRAD_SIDE_STREAM else main
+            use_side = WGRAD_SIDE_STREAM and _side_stream_safe(meta.rows, x.shape[1], H, ndir)
+            side = _wgrad_stream(x.device) if use_side else main
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 parts = [hy.view(meta.rows, ndir, H), hy.new_zeros(1, ndir, H)]

@@ -6,8 +6,14 @@
 Starts from the committed selections, runs a few optimizer steps of every configuration with the
 search enabled and writes the merged result file (commit it as padertorch_amd/tuned/<name>.csv).
 """
+import os
 import sys
 from pathlib import Path
+
+if '--overlap' in sys.argv:
+    # shapes of the side-stream weight-gradient path: rocBLAS candidates only (no Stream-K kernels: they
+    # must not spin on sibling workgroups next to a persistent recurrence kernel)
+    os.environ['PYTORCH_TUNABLEOP_HIPBLASLT_ENABLED'] = '0'
 
 sys.path.insert(0, str(Path(__file__).resolve().parent))
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -22,7 +28,7 @@ _lstm.DEFER_WGRAD = '--overlap' in sys.argv     # also tune the per-direction sh
 _lstm.WGRAD_SIDE_STREAM = False                 # ... timed on the main stream, nothing else running
 bc.tuning.use_tuned_gemms(search=True)
 for fn, args in ((bc.pit, (4, 8000, 4, 'C1')), (bc.pit, (32, 8000, 4, 'C2')), (bc.pit, (64, 16000, 4, 'C3')),
-                 (bc.dc, (64, 16000, 4, 'C5')), (bc.dc, (32, 8000, 4, 'DC-B32')))[int(sys.argv[2]) if len(sys.argv) > 2 else 0:]:
+                 (bc.dc, (64, 16000, 4, 'C5')), (bc.dc, (32, 8000, 4, 'DC-B32')))[int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0:]:
     print(fn(*args), flush=True)
 with open(out, 'w') as f:          # same layout TunableOp writes on exit
     for k, v in tunable.get_validators():
