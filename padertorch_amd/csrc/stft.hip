@@ -693,8 +693,7 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
                 for (int u = 0; u < UA; ++u) {
                     const int p = p0 + 64 * u;
                     const int pc = min(p, npairs - 1);
-                    const int f = pc / NP, k = pc - f * NP;
-                    const int km = (A.dbg & 32) ? M / 2 + k : M - k;   // (timing experiment: ascending stores)
+                    const int f = pc / NP, k = pc - f * NP, km = M - k;
                     const bool valid = tw0 + f < frames_b;
                     cpx Xk, Xm, pk, pm;
                     float mk, mm;
