@@ -143,10 +143,11 @@ class MelTransform(nn.Module):
         spec = x.to(torch.float32).reshape(-1, F).contiguous()
         out = torch.empty((spec.shape[0], self._bands.M), dtype=torch.float32, device=x.device)
         tb = self._bands.get(x.device)
-        _lib.check(_lib.timed(
-            'mel_apply', lib.ptmi_mel_apply, spec.data_ptr(), spec.shape[0], F, tb['lo'].data_ptr(),
-            tb['cnt'].data_ptr(), tb['off'].data_ptr(), tb['w'].data_ptr(), self._bands.M, self._bands.nnz,
-            int(bool(self.log)), float(self.eps), out.data_ptr(), _lib.stream(x.device)), 'ptmi_mel_apply')
+        if spec.shape[0] > 0:           # (an empty tensor has no device pointer)
+            _lib.check(_lib.timed(
+                'mel_apply', lib.ptmi_mel_apply, spec.data_ptr(), spec.shape[0], F, tb['lo'].data_ptr(),
+                tb['cnt'].data_ptr(), tb['off'].data_ptr(), tb['w'].data_ptr(), self._bands.M, self._bands.nnz,
+                int(bool(self.log)), float(self.eps), out.data_ptr(), _lib.stream(x.device)), 'ptmi_mel_apply')
         out = out.reshape(*lead, self._bands.M)
         if return_maxima:
             fb = self.fbanks
