@@ -106,8 +106,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--default-gemms', action='store_true', help='library default GEMM kernel selection')
-    ap.add_argument('--overlap', action='store_true',
-                    help='EXPERIMENTAL: LSTM weight gradients on a side stream (ops.lstm.DEFER_WGRAD)')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='LSTM weight gradients through autograd on the main stream (ops.lstm.DEFER_WGRAD off)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -141,7 +141,7 @@ def main():
         trainer._broadcast_parameters()
     model.train()
     from padertorch_amd.ops import lstm as _lstm
-    _lstm.DEFER_WGRAD = args.overlap             # off by default (see the hazard note in ops/lstm.py)
+    _lstm.DEFER_WGRAD = not args.no_overlap      # what Trainer.train() sets (side stream only for rocBLAS-pinned shapes)
     if _lstm.DEFER_WGRAD:
         _lstm.warm_side_stream(device)
 
@@ -249,6 +249,7 @@ def main():
                 'parallelism': f'dp{world}',
                 'blstm': 'HIP recurrence (csrc/lstm.hip)' if model.hip_blstm else 'torch.nn.LSTM (MIOpen)',
                 'gemms': 'library defaults' if args.default_gemms else 'hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)',
+                'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence (rocBLAS-pinned shapes)',
             },
             'roofline': dominant,
             'other_kernels': other,

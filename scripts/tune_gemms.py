@@ -26,7 +26,11 @@ out.parent.mkdir(parents=True, exist_ok=True)
 from padertorch_amd.ops import lstm as _lstm  # noqa: E402
 _lstm.DEFER_WGRAD = '--overlap' in sys.argv     # also tune the per-direction shapes of the experimental side-stream path
 _lstm.WGRAD_SIDE_STREAM = False                 # ... timed on the main stream, nothing else running
-bc.tuning.use_tuned_gemms(search=True)
+start = bc.tuning.DEFAULT_FILE
+if '--overlap' in sys.argv:     # rocBLAS-only search from scratch (hipBLASLt solution ids cannot be loaded with
+    import tempfile             # that backend switched off); merge its n = 4H "nt" entries into the committed file
+    start = Path(tempfile.mkdtemp()) / 'empty.csv'
+bc.tuning.use_tuned_gemms(results_file=start, search=True)
 for fn, args in ((bc.pit, (4, 8000, 4, 'C1')), (bc.pit, (32, 8000, 4, 'C2')), (bc.pit, (64, 16000, 4, 'C3')),
                  (bc.dc, (64, 16000, 4, 'C5')), (bc.dc, (32, 8000, 4, 'DC-B32')))[int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0:]:
     print(fn(*args), flush=True)
