@@ -108,9 +108,9 @@ class PermutationInvariantTrainingModel(base.Model):
             h, _ = self.blstm(h)                      # library LSTM (MIOpen)
 
         h_data = self.dropout_linear(h.data)
-        h_data = self.linear1(h_data)
+        h_data = ops.linear.linear(self.linear1, h_data)      # (weight gradients may join ops.lstm.DEFER_WGRAD)
         h_data = self.relu(h_data)
-        h_data = self.linear2(h_data)
+        h_data = ops.linear.linear(self.linear2, h_data)
         h_data = self.output_activation(h_data)
 
         mask = PackedSequence(h_data.view(-1, self.K, self.F), h.batch_sizes)  # 'tb (k f) -> tb k f'

@@ -55,7 +55,7 @@ class DeepClusteringModel(base.Model):
             h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
         else:
             h, _ = self.blstm(h)
-        h_data = self.linear(h.data).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
+        h_data = ops.linear.linear(self.linear, h.data).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
         # Hershey 2016 page 2 top right paragraph: Unit norm
         h_data = torch.nn.functional.normalize(h_data, dim=-2)
         return ops.unpack_sequence(PackedSequence(h_data, h.batch_sizes))

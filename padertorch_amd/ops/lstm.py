@@ -167,25 +167,34 @@ def _wgrad_stream(device):
 _SIDE_SAFE = {}
 
 
-def _side_stream_safe(rows, I, H, ndir):
-    """True when every GEMM of the deferred path has a pinned rocBLAS solution in the loaded TunableOp
-    results: rocBLAS kernels are plain tiled GEMMs (split-K through a second kernel), hipBLASLt's carry a
-    Stream-K mode that spins on sibling workgroups - the latter must not run next to a persistent
-    recurrence kernel (see DEFER_WGRAD).  Unknown shapes run on the main stream."""
-    key = (rows, I, H, ndir)
-    if key not in _SIDE_SAFE:
+def gemm_keys_safe(keys):
+    """True when every TunableOp GEMM key has a pinned rocBLAS solution in the loaded results: rocBLAS
+    kernels are plain tiled GEMMs (split-K through a second kernel), hipBLASLt's carry a Stream-K mode
+    that spins on sibling workgroups - the latter must not run next to a persistent recurrence kernel
+    (see DEFER_WGRAD).  Unknown shapes run on the main stream."""
+    keys = tuple(keys)
+    if keys not in _SIDE_SAFE:
         ok = False
         try:
             import torch.cuda.tunable as tunable
             if tunable.is_enabled():
                 res = {params: sol for _op, params, sol, _t in tunable.get_results()}
-                G = 4 * H
-                need = (f'nt_{I}_{G}_{rows}_ld_{I}_{ndir * G}_{I}', f'nt_{H}_{G}_{rows}_ld_{H}_{ndir * G}_{H}')
-                ok = all('Rocblas' in res.get(k, '') for k in need)
+                ok = all('Rocblas' in res.get(k, '') for k in keys)
         except Exception:
             ok = False
-        _SIDE_SAFE[key] = ok
-    return _SIDE_SAFE[key]
+        _SIDE_SAFE[keys] = ok
+    return _SIDE_SAFE[keys]
+
+
+def wgrad_key(n_in, n_out, rows, ld_g=None):
+    """TunableOp key of ``W.grad[n_out, n_in].addmm_(g[rows, n_out].t(), x[rows, n_in])`` (``ld_g``: row
+    stride of ``g`` when it is a column block of a wider matrix)."""
+    return f'nt_{n_in}_{n_out}_{rows}_ld_{n_in}_{ld_g or n_out}_{n_in}'
+
+
+def _side_stream_safe(rows, I, H, ndir):
+    G = 4 * H
+    return gemm_keys_safe((wgrad_key(I, G, rows, ndir * G), wgrad_key(H, G, rows, ndir * G)))
 
 
 def warm_side_stream(device, nbytes=1 << 30):
