@@ -517,7 +517,7 @@ struct LstmPersistBwdArgs {
 };
 
 template <int NW, int CH>
-__global__ __launch_bounds__(NW * 64, 4) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
     const int dir = blockIdx.z;
     const int n0 = blockIdx.x * 16;
     const int m0 = (A.tile0 + blockIdx.y) * 16;
@@ -843,8 +843,15 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
-        hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3((unsigned)nx, (unsigned)nt, (unsigned)ndir),
-                           dim3(NW * 64), 0, st, A);
+        // opt-in variant: 8 wavefronts x 19 K blocks.  6.9 vs 7.3 us per step in isolation at H = 600, but
+        // the training step as a whole is not faster with it (the half-empty CUs then also host the
+        // side-stream GEMMs), so 16 x 10 stays the default
+        if (getenv("PTMI_LSTM_BWD8") && (4 * H / 16 + 7) / 8 <= 19)
+            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3((unsigned)nx, (unsigned)nt, (unsigned)ndir),
+                               dim3(512), 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3((unsigned)nx, (unsigned)nt, (unsigned)ndir),
+                               dim3(NW * 64), 0, st, A);
         int rc = launch_status();
         if (rc) return rc;
     }
