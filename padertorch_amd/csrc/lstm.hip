@@ -387,6 +387,16 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
     unsigned* const err = A.flags + A.err_off;
     const int bl = tid / JT, u = tid - bl * JT;
     const int b = m0 + bl;
+    float pre_n[4] = {0.f, 0.f, 0.f, 0.f};       // input pre-activations of the step about to run
+    float c_reg = 0.f;                           // cell state of (b, u) after the previous step
+    {
+        const int t0 = dir == 0 ? 0 : A.T - 1;
+        if (tid < MR * JT && b < A.bs[t0] && j0 + u < H) {
+            const float* np = A.gx + (A.offs[t0] + b) * ld_g + (long long)dir * G + j0 + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
+        }
+    }
 
     for (int s = 0; s < A.T; ++s) {
         const int t = dir == 0 ? s : A.T - 1 - s;
@@ -401,20 +411,28 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         }
         const bool has_rec = nprev > m0;                 // workgroup-uniform
         const bool act = tid < MR * JT && b < nb && j0 + u < H;
-        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
         float cprev = 0.f;
         float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
-        if (act) {
+        if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];   // first step of sequence b
+        // next step's input pre-activations come from HBM; they are requested AFTER this step's operand
+        // loads (loads retire in order) so that their latency sits under the MFMAs, not in the chain
+        const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
+        const bool more = s + 1 < A.T;
+        const int nb1 = more ? A.bs[t1] : 0;
+        const long long row1 = more ? A.offs[t1] : 0;
+        auto prefetch = [&]() {
+            if (tid < MR * JT && b < nb1 && j0 + u < H && !(A.dbg & 256)) {
+                const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pre[q] = gp[q * H];
-            if (b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];   // first step of sequence b
-        }
+                for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
+            }
+        };
+        if (!has_rec) prefetch();
         if (has_rec) {
             if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
             __syncthreads();
-            if (act && b < nprev)
-                cprev = __hip_atomic_load(A.c + (prow0 + b) * ld_h + dir * H + j0 + u, __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
+            if (act && b < nprev) cprev = c_reg;          // this thread wrote c_{t-1}(b, u) itself
             const int mtiles = (min(nprev, m0 + MR) - m0 + 15) >> 4;
             f32x4 a[CH][MTL];
 #pragma unroll
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
                     a[i][mt] = ok ? __builtin_bit_cast(f32x4, v) : zero;
                 }
             }
+            prefetch();
             f32x4 acc[MTL][NT];
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
@@ -474,12 +493,13 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             const float og = sigmoidf_(pre[3]);
             const float cn = fg * cprev + ig * gg;
             const float h = og * tanhf(cn);
+            c_reg = cn;
             gp[0] = ig;
             gp[H] = fg;
             gp[2 * H] = gg;
             gp[3 * H] = og;
             const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
-            __hip_atomic_store(A.c + o, cn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through
+            A.c[o] = cn;                                  // saved for the backward pass only
             __hip_atomic_store(A.hy + o, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // publish step s: every wavefront drains its stores, then one lane arrives
