@@ -106,6 +106,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--default-gemms', action='store_true', help='library default GEMM kernel selection')
+    ap.add_argument('--sync-checks', action='store_true',
+                    help='loss / grad-norm finiteness checks in the step they belong to (two host syncs per step, '
+                         'the reference behaviour) instead of Trainer(deferred_checks=True)')
     ap.add_argument('--no-overlap', action='store_true',
                     help='LSTM weight gradients through autograd on the main stream (ops.lstm.DEFER_WGRAD off)')
     args = ap.parse_args()
@@ -134,7 +137,8 @@ def main():
         tuning.use_tuned_gemms()
     model = PermutationInvariantTrainingModel()          # defaults: F=257, 3 x BLSTM-600, K=2
     trainer = pt.Trainer(model, f'/tmp/ptmi_bench_{rank}', pt.optimizer.Adam(gradient_clipping=1.),
-                         loss_weights=LOSS_WEIGHTS, virtual_minibatch_size=world)
+                         loss_weights=LOSS_WEIGHTS, virtual_minibatch_size=world,
+                         deferred_checks=not args.sync_checks)
     trainer.to(device)
     trainer._flat = trainer.optimizer.use_flat_grads()
     if world > 1:
@@ -170,6 +174,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    trainer._check_pending(flush=True)       # the last step's staged loss / grad-norm checks (deferred_checks)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -249,6 +254,7 @@ def main():
                 'parallelism': f'dp{world}',
                 'blstm': 'HIP recurrence (csrc/lstm.hip)' if model.hip_blstm else 'torch.nn.LSTM (MIOpen)',
                 'gemms': 'library defaults' if args.default_gemms else 'hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)',
+                'host_checks': 'same step (2 syncs)' if args.sync_checks else 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence (rocBLAS-pinned shapes)',
             },
             'roofline': dominant,

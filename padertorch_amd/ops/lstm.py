@@ -224,29 +224,43 @@ def sync_deferred(device=None):
             torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(side)
 
 
-#: per-device accumulator of the persistent kernels' error words; `check_errors()` reads it (the
-#: Trainer does so once per optimizer step, where it synchronises anyway)
-_ERR_ACC = {}
+#: error words of the persistent kernels launched since the last check, per device: views of their
+#: flag buffers, folded into ONE small reduction when somebody asks (`error_word` / `check_errors`; the
+#: Trainer does so once per optimizer step)
+_ERR_FLAGS = {}
 
 
 def _note_errors(flags):
-    key = (flags.device.type, flags.device.index)
-    acc = _ERR_ACC.get(key)
-    if acc is None:
-        acc = _ERR_ACC[key] = torch.zeros((), dtype=torch.int32, device=flags.device)
-    acc += flags[-8:].abs().sum()
+    views = _ERR_FLAGS.setdefault((flags.device.type, flags.device.index), [])
+    views.append(flags[-8:])
+    if len(views) >= 64:            # nobody is checking: fold, so the flag buffers can be recycled
+        views[:] = [torch.stack(views).ne(0).any().to(torch.int32).expand(8)]
+
+
+def error_word(device):
+    """0-dim int32 DEVICE tensor, non-zero iff a bounded spin of a persistent LSTM kernel on `device` ran
+    out since the previous call (no host sync: the caller decides when the value crosses over)."""
+    device = torch.device(device)
+    views = _ERR_FLAGS.pop((device.type, device.index if device.index is not None else torch.cuda.current_device()), [])
+    if not views:
+        return torch.zeros((), dtype=torch.int32, device=device)
+    return torch.stack(views).ne(0).any().to(torch.int32)
+
+
+def raise_timeout(device):
+    raise RuntimeError(
+        f'padertorch_amd: a persistent LSTM kernel on {device} timed out waiting for a step counter '
+        '(workgroups not co-resident, e.g. the GPU is shared with another long-running kernel). '
+        'Set padertorch_amd.ops.lstm.PERSISTENT = False.')
 
 
 def check_errors():
     """Raise if a bounded spin of a persistent LSTM kernel ran out since the last check (the
     recurrence results are then invalid).  One small device-to-host copy per device."""
-    for key, acc in _ERR_ACC.items():
-        if int(acc) != 0:
-            acc.zero_()
-            raise RuntimeError(
-                f'padertorch_amd: a persistent LSTM kernel on {key} timed out waiting for a step counter '
-                '(workgroups not co-resident, e.g. the GPU is shared with another long-running kernel). '
-                'Set padertorch_amd.ops.lstm.PERSISTENT = False.')
+    for key in list(_ERR_FLAGS):
+        device = torch.device(key[0], key[1])
+        if int(error_word(device)) != 0:
+            raise_timeout(device)
 
 
 def _acquire(meta, ndir, H, device):

@@ -55,9 +55,8 @@ class _Summary:
                          buffers={}, snapshots={})
 
     def update(self, review):
-        for key, value in review.get('scalars', {}).items():
-            self.data['scalars'].setdefault(key, []).append(
-                float(value.item() if torch.is_tensor(value) else value))
+        for key, value in review.get('scalars', {}).items():      # floats, or staged 0-dim host tensors
+            self.data['scalars'].setdefault(key, []).append(value)
         for kind in ('images', 'audios', 'texts', 'figures', 'histograms'):
             self.data[kind].update(review.get(kind, {}))
 
@@ -74,6 +73,7 @@ class Trainer:
             stop_trigger=(1, 'epoch'),
             virtual_minibatch_size=1,
             overlap_wgrad=True,
+            deferred_checks=False,
     ):
         if not isinstance(model, torch.nn.Module):
             raise TypeError('Expect that the model is a subclass from padertorch.Module.\n'
@@ -91,6 +91,15 @@ class Trainer:
         #: LSTM weight gradients accumulate in place; on a side stream, next to the next layer's recurrence,
         #: for the shapes whose GEMMs are pinned to kernels without inter-workgroup waits (ops.lstm.DEFER_WGRAD)
         self.overlap_wgrad = overlap_wgrad
+        #: False: the loss and the gradient norm cross to the host in the step they belong to (two device
+        #: syncs per step, as in the reference).  True: they are staged into pinned memory and inspected one
+        #: optimizer step later; the optimizer update itself is gated ON THE DEVICE by their finiteness
+        #: (fused optimizers' ``found_inf``), so a non-finite step still leaves the parameters untouched and
+        #: raises the reference's RuntimeError -- one iteration late.  The host then runs ahead of the GPU.
+        self.deferred_checks = deferred_checks
+        self._pending = []           # [(what, event, host tensor, context, optimizer step)]
+        self._opt_step = 0
+        self._bad = None             # device flag: a loss of the current optimizer step is not finite
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
         self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)
         self.stop_trigger = EndTrigger.new(stop_trigger)
@@ -202,7 +211,13 @@ class Trainer:
         finally:
             _lstm.sync_deferred()
             _lstm.DEFER_WGRAD = defer_before
-            self._close()
+            opt = self.optimizer.optimizer
+            if getattr(opt, 'found_inf', None) is not None:
+                opt.found_inf = None
+            try:
+                self._check_pending(flush=True)
+            finally:
+                self._close()
 
     # ------------------------------------------------------------------ hooks (fixed set)
     def _pre_step(self):
@@ -232,6 +247,9 @@ class Trainer:
         if not data['scalars']:
             summary.reset()
             return None
+        self._check_pending(flush=True)        # staged scalars (deferred_checks) are final after this
+        data['scalars'] = {k: [float(x.item() if torch.is_tensor(x) else x) for x in v]
+                           for k, v in data['scalars'].items()}
         data = self.model.modify_summary(data) if hasattr(self.model, 'modify_summary') else data
         scalars = {k: float(np.mean(v)) for k, v in data['scalars'].items()}
         self.summaries.append((self.iteration, prefix, scalars))
@@ -282,14 +300,31 @@ class Trainer:
             summary['scalars'][f'lr/param_group_{i}'] = param_group['lr']
         self.optimizer.step()
         self.optimizer.zero_grad()
+        self._opt_step += 1
         return summary
 
     def clip_grad(self, summary: dict):
         """trainer.py:740-780 incl. the non-finite check (one host sync per optimizer step)."""
         summary.setdefault('scalars', {})
         summary.setdefault('histograms', {})
-        grad_norm = float(self.optimizer.clip_grad())      # host sync
         from ..ops import lstm as _lstm
+        grad_norm = self.optimizer.clip_grad()
+        if self._deferred(grad_norm):
+            self._check_pending()                          # the PREVIOUS optimizer step's loss / norm / watchdog
+            bad = ~torch.isfinite(grad_norm)
+            if self._bad is not None:
+                bad, self._bad = bad | self._bad, None
+            opt = self.optimizer.optimizer
+            found = bad.to(torch.float32)
+            if self.world_size > 1:                        # a rank-local non-finite loss skips the update everywhere
+                dist.all_reduce(found, op=dist.ReduceOp.MAX)
+            opt.found_inf, opt.grad_scale = found, None    # gates optimizer.step on the device
+            host = self._stage('grad_norm', torch.stack(
+                [grad_norm.detach().float(), _lstm.error_word(grad_norm.device).float()]), summary)
+            summary['scalars']['grad_norm'] = host[0]
+            summary['histograms']['grad_norm_'] = host[:1]
+            return summary
+        grad_norm = float(grad_norm)                       # host sync
         _lstm.check_errors()                               # persistent-kernel watchdog words
         if not np.isfinite(grad_norm):
             path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': summary})
@@ -356,8 +391,16 @@ class Trainer:
                     loss = loss + (weight * value)
                 review['scalars'][f'{key}_loss_weight'] = weight
             keys = list(losses)
-            host = torch.stack([losses[k].detach().reshape(()) for k in keys]
-                               + [loss.detach().reshape(())]).tolist()
+            vals = torch.stack([losses[k].detach().reshape(()) for k in keys] + [loss.detach().reshape(())])
+            if self._deferred(loss):
+                host = self._stage('loss', vals, review)
+                for i, k in enumerate(keys):
+                    review['scalars'][k] = host[i]
+                review['scalars']['loss'] = host[-1]
+                del review['losses']
+                assert loss.dim() == 0, loss
+                return loss, review
+            host = vals.tolist()
             for k, v in zip(keys, host[:-1]):
                 review['scalars'][k] = v
             loss_value = host[-1]
@@ -365,6 +408,10 @@ class Trainer:
         else:
             assert 'loss' in review, review
             loss = review.pop('loss')
+            if self._deferred(loss):
+                review['scalars']['loss'] = self._stage('loss', loss.detach().reshape(1), review)[0]
+                assert loss.dim() == 0, loss
+                return loss, review
             loss_value = loss.item()
         review['scalars']['loss'] = loss_value
         assert loss.dim() == 0, loss
@@ -373,6 +420,45 @@ class Trainer:
             raise RuntimeError(f'The loss ({loss_value}) is not finite.\n'
                                f'See error states (model, example, model_out and review) in {path}.')
         return loss, review
+
+    # ------------------------------------------------------------------ deferred host checks
+    def _deferred(self, t):
+        """deferred_checks needs a CUDA step and an optimizer whose update can be gated on the device."""
+        opt = getattr(self.optimizer, 'optimizer', None)
+        return bool(self.deferred_checks and torch.is_tensor(t) and t.is_cuda and self.model.training
+                    and opt is not None and opt.defaults.get('fused'))
+
+    def _stage(self, what, vals, context):
+        """Asynchronous device -> pinned host copy of a few scalars; ``_check_pending`` inspects them later."""
+        vals = vals.detach().to(torch.float32)
+        if what == 'loss':
+            bad = ~torch.isfinite(vals[-1])
+            self._bad = bad if self._bad is None else self._bad | bad
+        host = torch.empty(vals.shape, dtype=torch.float32, pin_memory=True)
+        host.copy_(vals, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._pending.append((what, event, host, context, self._opt_step))
+        return host
+
+    def _check_pending(self, flush=False):
+        """Raise the reference's errors for the staged values of EARLIER optimizer steps (all with flush)."""
+        todo = [p for p in self._pending if flush or p[4] < self._opt_step]
+        self._pending = [p for p in self._pending if not (flush or p[4] < self._opt_step)]
+        for what, event, host, context, _ in todo:
+            event.synchronize()
+            if what == 'loss' and not np.isfinite(float(host[-1])):
+                path = self.log_error_state({'state_dict': self.state_dict(), 'review': context})
+                raise RuntimeError(f'The loss ({float(host[-1])}) is not finite.\n'
+                                   f'See error states (model, example, model_out and review) in {path}.')
+            if what == 'grad_norm':
+                if host[1] != 0:
+                    from ..ops import lstm as _lstm
+                    _lstm.raise_timeout(self._flat.flat.device)
+                if not np.isfinite(float(host[0])):
+                    path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': context})
+                    raise RuntimeError(f'The grad_norm ({float(host[0])}) is not finite.\n'
+                                       f'See error states (model, example, model_out and review) in {path}.')
 
     def log_error_state(self, data_dict, folder='log'):
         """trainer.py:640-690: one file per object so a non-picklable one does not lose the rest."""
@@ -414,6 +500,7 @@ class Trainer:
 
     def save_checkpoint(self, checkpoint_path=None):
         """``ckpt_{iteration}.pth`` + relative symlink ``ckpt_latest.pth`` (trainer.py:812-828)."""
+        self._check_pending(flush=True)
         path = Path(checkpoint_path or self.default_checkpoint_path())
         path.parent.mkdir(parents=True, exist_ok=True)
         torch.save(self.state_dict(), str(path))

@@ -14,5 +14,5 @@ _lstm.warm_side_stream(bc.dev)
 bc.tuning.use_tuned_gemms()
 B, fs, kind = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 r = (bc.pit if kind == 'pit' else bc.dc)(B, fs, 4, f'{kind}-B{B}-{fs}')
-err = int(sum(v.item() for v in _lstm._ERR_ACC.values())) if _lstm._ERR_ACC else 0
+err = int(_lstm.error_word(torch.device('cuda:0')))
 print(r['config'], round(r['ms_per_step'], 2), 'ms/step, spin errors', err, flush=True)

@@ -65,6 +65,53 @@ def test_trainer_three_steps_vs_reference(g6, tmp_path):
         np.testing.assert_allclose(v.cpu().numpy(), g6['pit_sd3_' + k], atol=2e-5, err_msg=k)
 
 
+def test_trainer_deferred_checks_match_golden(g6, tmp_path):
+    """deferred_checks=True (loss / grad norm inspected one step late, update gated on the device) trains
+    to the same parameters as the reference's three optimizer steps."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+    batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
+    exs = [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+    t = pt.Trainer(model, tmp_path, pt.optimizer.Adam(gradient_clipping=1.),
+                   loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), summary_trigger=(1000, 'iteration'),
+                   checkpoint_trigger=(1000, 'iteration'), stop_trigger=(3, 'iteration'), virtual_minibatch_size=2,
+                   deferred_checks=True)
+    t.train(exs, device=DEV)
+    assert not t._pending
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g6['pit_sd3_' + k], atol=2e-5, err_msg=k)
+    scalars = t.summaries[-1][2]
+    assert np.isfinite(scalars['loss']) and np.isfinite(scalars['grad_norm']), scalars
+
+
+@pytest.mark.parametrize('deferred', [False, True])
+def test_trainer_non_finite_loss_raises_and_keeps_parameters(g6, tmp_path, deferred):
+    """A NaN in the third optimizer step's input: RuntimeError('The loss (nan) is not finite...') as in
+    trainer.py:620-638, the parameters are those after step two (the deferred mode skips the update on
+    the device and raises one iteration late)."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
+    exs = [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+    exs = (exs + exs)[:8]
+    kw = dict(loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), summary_trigger=(1000, 'iteration'),
+              checkpoint_trigger=(1000, 'iteration'), virtual_minibatch_size=2)
+    ref = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+    pt.Trainer(ref, tmp_path / 'a', pt.optimizer.Adam(gradient_clipping=1.), stop_trigger=(2, 'iteration'),
+               **kw).train(exs, device=DEV)
+    bad = [dict(e) for e in exs]
+    bad[4] = dict(bad[4], X_abs=[x * float('nan') for x in bad[4]['X_abs']])
+    model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+    t = pt.Trainer(model, tmp_path / 'b', pt.optimizer.Adam(gradient_clipping=1.), stop_trigger=(4, 'iteration'),
+                   deferred_checks=deferred, **kw)
+    with pytest.raises(RuntimeError, match='is not finite'):
+        t.train(bad, device=DEV)
+    assert t.iteration == (3 if deferred else 2), t.iteration        # optimizer steps gone through (the third one skipped on the device)
+    for (k, v), (_, r) in zip(model.state_dict().items(), ref.state_dict().items()):
+        np.testing.assert_array_equal(v.cpu().numpy(), r.cpu().numpy(), err_msg=k)
+
+
 def test_trainer_test_run_on_gpu(g6, tmp_path):
     import padertorch_amd as pt
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
