@@ -48,6 +48,10 @@ class _PackMeta:
             if t + 1 < self.T:
                 prev[1, offs[t]:offs[t] + bs[t + 1]] = offs[t + 1] + np.arange(bs[t + 1])
         self.prev_dev = torch.tensor(prev, device=device)
+        # equal-length batch: the predecessor of packed row r is row r - bs[0] (forward direction) or
+        # r + bs[0] (reverse direction), which `_LstmLayerFn` turns into shifted views of a padded buffer
+        self.bs0 = int(bs[0]) if self.T else 0
+        self.equal_lengths = bool(self.T and (bs == bs[0]).all())
         # per sequence b: rows of its first / last processed step per direction (initial / final states),
         # and the predecessor table with "no predecessor" pointing at row rows + 1 + b (= h0[b])
         lens = (bs[None, :] > np.arange(self.max_batch)[:, None]).sum(1) if self.T else np.zeros(0, np.int64)
@@ -310,6 +314,7 @@ class _LstmLayerFn(torch.autograd.Function):
             hy = ws.hy.clone()                                        # outputs never alias the workspace
             ctx.save_for_backward(x, w_ih, w_hh)
             ctx.lease = lease
+            ctx.ext = None
             if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
                 lease.release()
         else:
@@ -319,8 +324,20 @@ class _LstmLayerFn(torch.autograd.Function):
                 for d in range(ndir):
                     gv[:, d].index_add_(0, meta.first_rows[d], h0[d] @ w_hh[d].t())
             w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
-            hy = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
-            c = torch.empty_like(hy)
+            # equal-length batch: bs[0] rows of "state before the first step" (zero or h0) in front of and
+            # behind the output rows, so that the backward pass reads h_{t-1} as a shifted view (no gather)
+            pad = meta.bs0 if meta.equal_lengths else 0
+            ext = torch.empty((meta.rows + 2 * pad, ndir * H), dtype=torch.float32, device=x.device)
+            hy = ext[pad:pad + meta.rows]
+            if pad:
+                ext[:pad].zero_()
+                ext[pad + meta.rows:].zero_()
+                if stateful:
+                    ext[:pad].view(pad, ndir, H)[:, 0] = h0[0]
+                    if ndir > 1:
+                        ext[pad + meta.rows:].view(pad, ndir, H)[:, 1] = h0[1]
+            ctx.ext = ext if pad else None
+            c = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
             rc = -2
             if PERSISTENT:
                 flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)), dtype=torch.int32,
@@ -403,37 +420,40 @@ class _LstmLayerFn(torch.autograd.Function):
             side = _wgrad_stream(x.device) if use_side else main
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                parts = [hy.view(meta.rows, ndir, H), hy.new_zeros(1, ndir, H)]
-                prev = meta.prev_dev
-                if h0 is not None:
-                    parts.append(h0.transpose(0, 1))
-                    prev = meta.prev_h0_dev
-                hy_pad = torch.cat(parts, 0)
-                dgv = dg.view(meta.rows, ndir, G)
-                for d, (p_wih, p_whh, p_bih, p_bhh) in enumerate(params):
-                    dgd = dgv[:, d]
+                for (p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev) in zip(
+                        params, _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)):
                     p_wih.grad.addmm_(dgd.t(), x)
-                    p_whh.grad.addmm_(dgd.t(), hy_pad[:, d].index_select(0, prev[d]))
+                    p_whh.grad.addmm_(dgd.t(), h_prev)
                     db_d = dgd.sum(0)
                     p_bih.grad.add_(db_d)
                     p_bhh.grad.add_(db_d)
-            for t in (dg, x, hy) + (() if h0 is None else (h0,)):
+            for t in (dg, x, hy) + (() if h0 is None else (h0,)) + (() if ctx.ext is None else (ctx.ext,)):
                 t.record_stream(side)           # keep the operands alive until the side stream is done
             return dx, None, None, None, None, None, None, None
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
         db = dg.sum(0)
-        parts = [hy.view(meta.rows, ndir, H), hy.new_zeros(1, ndir, H)]   # row `rows` = zero state
-        prev = meta.prev_dev
-        if h0 is not None:                                                # rows rows+1+b = h0[:, b]
-            parts.append(h0.transpose(0, 1))
-            prev = meta.prev_h0_dev
-        hy_pad = torch.cat(parts, 0)
-        dgv = dg.view(meta.rows, ndir, G)
-        dw_hh = torch.stack([dgv[:, d].t() @ hy_pad[:, d].index_select(0, prev[d])
-                             for d in range(ndir)])
+        dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
         if lease is not None:
             lease.release()
         return dx, dw_ih, db, dw_hh, None, None, None, None
+
+
+def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
+    """Per direction d the operands (a, b) of dW_hh[d] = a^T @ b: the gate gradients of every row and the
+    hidden state that row's step consumed (zero / h0 for a sequence's first processed step)."""
+    rows, G = meta.rows, 4 * H
+    dgv = dg.view(rows, ndir, G)
+    if ext is not None:             # equal lengths: the padded buffer of the forward pass, shifted by one step
+        n0 = meta.bs0
+        extv = ext.view(rows + 2 * n0, ndir, H)
+        return [(dgv[:, d], extv[:rows, 0] if d == 0 else extv[2 * n0:, 1]) for d in range(ndir)]
+    parts = [hy.view(rows, ndir, H), hy.new_zeros(1, ndir, H)]      # row `rows` = zero state
+    prev = meta.prev_dev
+    if h0 is not None:                                              # rows rows+1+b = h0[:, b]
+        parts.append(h0.transpose(0, 1))
+        prev = meta.prev_h0_dev
+    hy_pad = torch.cat(parts, 0)
+    return [(dgv[:, d], hy_pad[:, d].index_select(0, prev[d])) for d in range(ndir)]
 
 
 def supported(lstm, data):

@@ -1,6 +1,7 @@
 """Repeated cold starts of several configurations with the side-stream weight gradients enabled (each
 process includes an unsynchronised first step, the situation that hung with Stream-K side GEMMs)."""
 import faulthandler
+import torch
 import sys
 from pathlib import Path
 

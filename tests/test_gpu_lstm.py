@@ -97,8 +97,9 @@ def test_model_uses_hip_lstm_and_matches_library_lstm():
         np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), atol=1e-5)
 
 
+@pytest.mark.parametrize('lens', [[9, 9, 7, 4, 4, 1], [6] * 5])     # ragged / equal lengths (shifted-view weight gradients)
 @pytest.mark.parametrize('persistent', [True, False])
-def test_initial_and_final_states_vs_torch_cpu(persistent, monkeypatch):
+def test_initial_and_final_states_vs_torch_cpu(persistent, lens, monkeypatch):
     """``lstm(packed, (h0, c0))`` semantics of torch.nn.LSTM: the initial state applies to every
     sequence's first processed step (per direction, also for ragged batches), (h_n, c_n) are the states
     after each sequence's last step; gradients w.r.t. inputs and weights include the state terms."""
@@ -106,7 +107,7 @@ def test_initial_and_final_states_vs_torch_cpu(persistent, monkeypatch):
     monkeypatch.setattr(L, 'CHECK_PERSISTENT_ERRORS', True)
     monkeypatch.setattr(L, 'PERSISTENT', persistent)
     torch.manual_seed(11)
-    I, H, layers, lens = 13, 24, 2, [9, 9, 7, 4, 4, 1]
+    I, H, layers = 13, 24, 2
     ref = torch.nn.LSTM(I, H, layers, bidirectional=True)
     dut = torch.nn.LSTM(I, H, layers, bidirectional=True)
     dut.load_state_dict(ref.state_dict())
