@@ -64,6 +64,7 @@ SIGNATURES = {
     'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
+    'ptmi_lstm_scratch_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                              c_int32, _P]),
     'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,

@@ -534,13 +534,38 @@ struct LstmPersistBwdArgs {
     int dbg;             // PTMI_LSTM_DBG timing ablations (as in the forward kernel)
     const float* c0;
     int max_batch;
+    int nx, nt, span;    // 1-D grid: unit tiles, row tiles of this launch, XCDs per chain (0: plain order)
+    float* dgt;          // tile-major copy of dgates for the hand-off: [T][row tile][dir][4H / 16][16 rows][16]
 };
+
+// Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)
+// exchanges its operand rows among its own workgroups every step; they are written through one XCD's L2
+// and read over the fabric by the others, which is what bounds the hand-off at batch >= 16.  With
+// `span` = 8 / chains XCDs per chain, a chain's workgroups sit on `span` neighbouring XCDs instead of all
+// eight, so 1/span of what a workgroup reads is local.  Returns false for the padding workgroups.
+__device__ __forceinline__ bool chain_tile(int nx, int nt, int span, int* x, int* y, int* dir) {
+    const int L = blockIdx.x;
+    int chain;
+    if (span > 0) {
+        const int xcd = L & 7;
+        chain = xcd / span;
+        *x = (L >> 3) * span + (xcd - chain * span);
+        if (*x >= nx) return false;
+    } else {
+        *x = L % nx;
+        chain = L / nx;
+    }
+    *y = chain % nt;
+    *dir = chain / nt;
+    return true;
+}
 
 template <int NW, int CH>
 __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
-    const int dir = blockIdx.z;
-    const int n0 = blockIdx.x * 16;
-    const int m0 = (A.tile0 + blockIdx.y) * 16;
+    int bx, by, dir;
+    if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
+    const int n0 = bx * 16;
+    const int m0 = (A.tile0 + by) * 16;
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -551,6 +576,8 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
     const int per = (nblk + NW - 1) / NW;          // <= CH (host checked)
     const int kb0 = wave * per;
     const int kb1 = min(nblk, kb0 + per);
+    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));          // wavefront-uniform
+    const int ilast = __builtin_amdgcn_readfirstlane(max(kb1 - kb0 - 1, 0));
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bq[CH];
     {
@@ -560,8 +587,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         for (int i = 0; i < CH; ++i)
             bq[i] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
-    const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.dg, 0, A.dg_bytes, 0x00020000);
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.y) * A.T * 8;   // this row tile's chain
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * A.T * 8;   // this row tile's chain
     unsigned* const err = A.flags + A.err_off;
     const int bl = (tid >> 4) & 15, jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
@@ -601,16 +627,21 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         if (has_rec) {
             if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
             __syncthreads();
-            const bool av = m0 + r < nnext;
+            // The operand comes from the TILE-MAJOR copy: one load instruction of a wavefront = one 16 x 16
+            // tile = 1 KB of consecutive bytes (8 full cache lines; from the row-major dgates it would be
+            // 16 half lines, measured 1.9 us per step slower at batch 32).  All CH loads go out back to
+            // back and are consumed in order; rows past the batch get an out-of-range offset (the buffer
+            // returns 0), K blocks past the end of this wavefront's slice re-read its last valid tile
+            // (finite data x zero weights).
+            const bool av = m0 + r < nnext && !(A.dbg & 128);
+            const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                A.dgt + (((size_t)tn * A.ntiles + A.tile0 + by) * A.ndir + dir) * (size_t)G * 16, 0, G * 64, 0x00020000);
+            const unsigned vbase = av ? (unsigned)(kfirst * 1024 + r * 64 + g4 * 16) : 0x80000000u;
             f32x4 a[CH];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const bool ok = av && kb0 + i < kb1 && !(A.dbg & 128);
-                const unsigned voff =
-                    ok ? (unsigned)(((nrow0 + m0 + r) * ld_g + (long long)dir * G + (kb0 + i) * 16 + 4 * g4) * 4) : 0u;
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, voff, 0, 16 /* sc1 */);
-                a[i] = ok ? __builtin_bit_cast(f32x4, v) : zero;
-            }
+            for (int i = 0; i < CH; ++i)
+                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(i, ilast) * 1024, 16 /* sc1 */));
+            __builtin_amdgcn_sched_barrier(0);      // or the scheduler re-serialises load / wait / 4 MFMAs to save registers
             f32x4 acc = zero;
             if (!(A.dbg & 64)) {
 #pragma unroll
@@ -638,16 +669,25 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             const float d_g = dc * ig;
             const float d_f = dc * cprev;
             dc_state = dc * fg;
-            float* dgp = A.dg + og_;
-            __hip_atomic_store(dgp, d_i * ig * (1.f - ig), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dgp + H, d_f * fg * (1.f - fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dgp + 2 * H, d_g * (1.f - gg * gg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dgp + 3 * H, d_o * og * (1.f - og), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float gi = d_i * ig * (1.f - ig), gf = d_f * fg * (1.f - fg), gc = d_g * (1.f - gg * gg),
+                        go = d_o * og * (1.f - og);
+            float* dgp = A.dg + og_;                  // row-major: what the weight / input gradient GEMMs read
+            dgp[0] = gi;
+            dgp[H] = gf;
+            dgp[2 * H] = gc;
+            dgp[3 * H] = go;
+            // tile-major, written through: what the other workgroups of this chain read in the next step
+            float* tp = A.dgt + (((size_t)t * A.ntiles + A.tile0 + by) * A.ndir + dir) * (size_t)G * 16 + bl * 16;
+            const int c0_ = j, c1_ = H + j, c2_ = 2 * H + j, c3_ = 3 * H + j;
+            __hip_atomic_store(tp + (c0_ >> 4) * 256 + (c0_ & 15), gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tp + (c1_ >> 4) * 256 + (c1_ & 15), gf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tp + (c2_ >> 4) * 256 + (c2_ & 15), gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tp + (c3_ >> 4) * 256 + (c3_ & 15), go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
-            __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
+            __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (bx & 7), 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -770,6 +810,15 @@ int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch) {
     return (int64_t)ndir * ((max_batch + 15) / 16) * T * 8 + 8;   // one chain per 16-row tile + error words
 }
 
+// tile-major hand-off copy: [T][16-row tiles][ndir][cols / 16] tiles of 16 x 16 floats
+static int64_t lstm_tile_elems(int32_t T, int32_t ndir, int32_t max_batch, int32_t cols) {
+    return (int64_t)T * ((max_batch + 15) / 16) * ndir * cols * 16;
+}
+
+int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward) {
+    return (backward ? lstm_tile_elems(T, ndir, max_batch, 4 * H) : 0) + ptmi_lstm_flags_elems(T, ndir, max_batch);
+}
+
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
                                  int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,
@@ -854,24 +903,30 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     const long long dg_bytes = rows * ndir * 4 * H * 4;
     PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // scratch = [tile-major dgates | arrival counters | 8 error words]; only the counters need zeroing
+    float* const dgt = reinterpret_cast<float*>(flags);
+    flags += lstm_tile_elems(T, ndir, max_batch, 4 * H);
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
                          (unsigned)nx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)dg_bytes,
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
-                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch};
+                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
         // opt-in variant: 8 wavefronts x 19 K blocks.  6.9 vs 7.3 us per step in isolation at H = 600, but
         // the training step as a whole is not faster with it (the half-empty CUs then also host the
         // side-stream GEMMs), so 16 x 10 stays the default
+        const int chains = nt * ndir;
+        A.nx = nx;
+        A.nt = nt;
+        A.span = (chains <= 8 && 8 % chains == 0 && !getenv("PTMI_LSTM_NO_XCD")) ? 8 / chains : 0;
+        const unsigned nwg = A.span ? (unsigned)((nx + A.span - 1) / A.span * 8) : (unsigned)(nx * chains);
         if (getenv("PTMI_LSTM_BWD8") && (4 * H / 16 + 7) / 8 <= 19)
-            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3((unsigned)nx, (unsigned)nt, (unsigned)ndir),
-                               dim3(512), 0, st, A);
+            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3(nwg), dim3(512), 0, st, A);
         else
-            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3((unsigned)nx, (unsigned)nt, (unsigned)ndir),
-                               dim3(NW * 64), 0, st, A);
+            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3(nwg), dim3(NW * 64), 0, st, A);
         int rc = launch_status();
         if (rc) return rc;
     }

@@ -393,8 +393,8 @@ class _LstmLayerFn(torch.autograd.Function):
             dg = torch.empty_like(gates)
             rc = -2
             if PERSISTENT:
-                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)), dtype=torch.int32,
-                                    device=x.device)
+                flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)),
+                                    dtype=torch.int32, device=x.device)
                 rc = _lib.timed(
                     'lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                     dhy.data_ptr(), w_t.data_ptr(), dg.data_ptr(), meta.bs_dev.data_ptr(),
