@@ -326,6 +326,8 @@ struct LstmPersistArgs {
     int tile0, ntiles;       // first row tile of this launch / row tiles of the whole batch
     const float* c0;         // [ndir, max_batch, H] initial cell state or null
     int max_batch;
+    float* hyt;              // tile-major copy of hy for the hand-off: [T][16-row tile][dir][KP / 16][16 rows][16]
+    int nt16;                // 16-row tiles of the whole batch
 };
 
 __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expected, unsigned max_polls,
@@ -370,6 +372,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
     const int per = (nblk + NW - 1) / NW;         // <= CH (host checked)
     const int kb0 = wave * per;
     const int kb1 = min(nblk, kb0 + per);
+    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));          // wavefront-uniform
+    const int ilast = __builtin_amdgcn_readfirstlane(max(kb1 - kb0 - 1, 0));
     const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 bq[CH][NT];
 #pragma unroll
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         for (int i = 0; i < CH; ++i)
             bq[i][nt] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
-    const __amdgpu_buffer_rsrc_t hy_rsrc = __builtin_amdgcn_make_buffer_rsrc(A.hy, 0, A.hy_bytes, 0x00020000);
+    const size_t tile_elems = (size_t)A.KP * 16;         // one 16-row tile of the tile-major h copy
+    const int tile16 = (A.tile0 + blockIdx.z) * MTL;     // first 16-row tile of this workgroup
     unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * A.T * 8;   // this chain's
     unsigned* const err = A.flags + A.err_off;
     const int bl = tid / JT, u = tid - bl * JT;
@@ -434,19 +439,20 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             __syncthreads();
             if (act && b < nprev) cprev = c_reg;          // this thread wrote c_{t-1}(b, u) itself
             const int mtiles = (min(nprev, m0 + MR) - m0 + 15) >> 4;
+            // h_{t-1} comes from the TILE-MAJOR copy (see the backward kernel): one load = one 16 x 16 tile =
+            // 1 KB of consecutive bytes.  Rows past the batch: out-of-range offset (the buffer returns 0);
+            // K blocks past this wavefront's slice re-read its last valid tile (x zero weights); the
+            // padding columns H..KP-1 of the last tile are written as zeros by the producer.
             f32x4 a[CH][MTL];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const int kb = kb0 + i;
-                const bool kin = kb < kb1 && (kb * 16 + 4 * g4 < H);
+            for (int mt = 0; mt < MTL; ++mt) {
+                const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    A.hyt + (((size_t)tp * A.nt16 + tile16 + mt) * A.ndir + dir) * tile_elems, 0, A.KP * 64, 0x00020000);
+                const bool ok = m0 + mt * 16 + r < nprev && !(A.dbg & 128);
+                const unsigned vbase = ok ? (unsigned)(kfirst * 1024 + r * 64 + g4 * 16) : 0x80000000u;
 #pragma unroll
-                for (int mt = 0; mt < MTL; ++mt) {
-                    const int irow = m0 + mt * 16 + r;
-                    const bool ok = kin && irow < nprev && !(A.dbg & 128);
-                    const unsigned voff = ok ? (unsigned)(((prow0 + irow) * ld_h + dir * H + kb * 16 + 4 * g4) * 4) : 0u;
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(hy_rsrc, voff, 0, 16 /* sc1 */);
-                    a[i][mt] = ok ? __builtin_bit_cast(f32x4, v) : zero;
-                }
+                for (int i = 0; i < CH; ++i)
+                    a[i][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, vbase, min(i, ilast) * 1024, 16 /* sc1 */));
             }
             prefetch();
             f32x4 acc[MTL][NT];
@@ -500,7 +506,19 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             gp[3 * H] = og;
             const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
             A.c[o] = cn;                                  // saved for the backward pass only
-            __hip_atomic_store(A.hy + o, h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            A.hy[o] = h;                                  // row-major: the layer output
+            // tile-major, written through: what this chain's workgroups read in the next step
+            float* tq = A.hyt + (((size_t)t * A.nt16 + tile16 + (bl >> 4)) * A.ndir + dir) * tile_elems;
+            __hip_atomic_store(tq + ((j0 + u) >> 4) * 256 + (bl & 15) * 16 + ((j0 + u) & 15), h, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (j0 < H && j0 + JT >= H && tid < MR * (A.KP - H)) {      // owner of the last unit: zero padding columns
+            const int pw = A.KP - H, rl = tid / pw, col = H + tid - rl * pw;
+            if (m0 + rl < nb) {
+                float* tq = A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems;
+                __hip_atomic_store(tq + (col >> 4) * 256 + (rl & 15) * 16 + (col & 15), 0.f, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // publish step s: every wavefront drains its stores, then one lane arrives
         if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -816,7 +834,7 @@ static int64_t lstm_tile_elems(int32_t T, int32_t ndir, int32_t max_batch, int32
 }
 
 int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward) {
-    return (backward ? lstm_tile_elems(T, ndir, max_batch, 4 * H) : 0) + ptmi_lstm_flags_elems(T, ndir, max_batch);
+    return lstm_tile_elems(T, ndir, max_batch, backward ? 4 * H : (H + 15) / 16 * 16) + ptmi_lstm_flags_elems(T, ndir, max_batch);
 }
 
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
@@ -852,12 +870,16 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     // row tiles are independent recurrences: a batch whose tiles do not all fit runs as several launches
     const int per_launch = std::min(ntiles, cap / (jx * ndir));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // scratch = [tile-major hy | arrival counters | 8 error words]; only the counters need zeroing
+    PTMI_RETURN_IF(KP != (H + 15) / 16 * 16, PTMI_E_UNSUPPORTED);
+    float* const hyt = reinterpret_cast<float*>(flags);
+    flags += lstm_tile_elems(T, ndir, max_batch, KP);
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
                       (unsigned)jx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
-                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch};
+                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch, hyt, (max_batch + 15) / 16};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);

@@ -340,8 +340,8 @@ class _LstmLayerFn(torch.autograd.Function):
             c = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
             rc = -2
             if PERSISTENT:
-                flags = torch.empty(int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)), dtype=torch.int32,
-                                    device=x.device)
+                flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 0)),
+                                    dtype=torch.int32, device=x.device)
                 rc = _lib.timed(
                     'lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(),
                     c.data_ptr(), _lib.ptr(c0), w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
