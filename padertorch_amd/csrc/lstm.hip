@@ -52,7 +52,16 @@ struct LstmArgs {
     int max_batch;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, about 1 ulp each): they
+// sit on the serial chain of every time step, where the library expf / tanhf / IEEE division cost about
+// 0.4 us per step.  Absolute error < 2e-7 (checked against torch's CPU LSTM in tests/test_gpu_lstm.py).
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+    const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));       // exp(-2|x|)
+    return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
+}
 
 // One forward timestep.  grid = (ceil(H / JT), ndir, ceil(maxB / 32)), NW * 64 threads.
 // Workgroup tile: 32 batch rows x (4 gates x JT hidden units) = 32 x NC outputs, NC = 4 JT (16 or 32).
@@ -173,10 +182,10 @@ __global__ __launch_bounds__(NW * 64) void lstm_fwd_step_kernel(const LstmArgs A
     if (act) {
         const float ig = sigmoidf_(pre[0]);
         const float fg = sigmoidf_(pre[1]);
-        const float gg = tanhf(pre[2]);
+        const float gg = tanhf_(pre[2]);
         const float og = sigmoidf_(pre[3]);
         const float cn = fg * cprev + ig * gg;
-        const float h = og * tanhf(cn);
+        const float h = og * tanhf_(cn);
         gp[0] = ig;
         gp[H] = fg;
         gp[2 * H] = gg;
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(const LstmBwdArg
         }
     }
     if (act) {
-        const float tc = tanhf(cn);
+        const float tc = tanhf_(cn);
         const float d_o = dh * tc;
         dc += dh * og * (1.f - tc * tc);
         const float d_i = dc * gg;
@@ -495,10 +504,10 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         if (act) {
             const float ig = sigmoidf_(pre[0]);
             const float fg = sigmoidf_(pre[1]);
-            const float gg = tanhf(pre[2]);
+            const float gg = tanhf_(pre[2]);
             const float og = sigmoidf_(pre[3]);
             const float cn = fg * cprev + ig * gg;
-            const float h = og * tanhf(cn);
+            const float h = og * tanhf_(cn);
             c_reg = cn;
             gp[0] = ig;
             gp[H] = fg;
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         }
         if (act) {
             float dc = b < nnext ? dc_state : 0.f;     // rows without a successor step start from 0
-            const float tc = tanhf(cn);
+            const float tc = tanhf_(cn);
             const float d_o = dh * tc;
             dc += dh * og * (1.f - tc * tc);
             const float d_i = dc * gg;
