@@ -190,15 +190,18 @@ def gemm_keys_safe(keys):
     return _SIDE_SAFE[keys]
 
 
-def wgrad_key(n_in, n_out, rows, ld_g=None):
-    """TunableOp key of ``W.grad[n_out, n_in].addmm_(g[rows, n_out].t(), x[rows, n_in])`` (``ld_g``: row
-    stride of ``g`` when it is a column block of a wider matrix)."""
-    return f'nt_{n_in}_{n_out}_{rows}_ld_{n_in}_{ld_g or n_out}_{n_in}'
+def wgrad_key(n_in, n_out, rows, ld_g=None, ld_x=None):
+    """TunableOp key of ``W.grad[n_out, n_in].addmm_(g[rows, n_out].t(), x[rows, n_in])`` (``ld_g`` / ``ld_x``:
+    row strides of ``g`` / ``x`` when they are column blocks of wider matrices)."""
+    return f'nt_{n_in}_{n_out}_{rows}_ld_{ld_x or n_in}_{ld_g or n_out}_{n_in}'
 
 
-def _side_stream_safe(rows, I, H, ndir):
+def _side_stream_safe(rows, I, H, ndir, shifted_views):
+    """`shifted_views`: h_{t-1} is a column block of the padded output buffer (row stride ndir * H), not a
+    gathered copy."""
     G = 4 * H
-    return gemm_keys_safe((wgrad_key(I, G, rows, ndir * G), wgrad_key(H, G, rows, ndir * G)))
+    return gemm_keys_safe((wgrad_key(I, G, rows, ndir * G),
+                           wgrad_key(H, G, rows, ndir * G, ndir * H if shifted_views else None)))
 
 
 def warm_side_stream(device, nbytes=1 << 30):
@@ -416,7 +419,7 @@ class _LstmLayerFn(torch.autograd.Function):
         if DEFER_WGRAD and lease is None and params is not None and all(p.grad is not None for ps in params for p in ps):
             # weight gradients on the side stream, accumulated in place (see DEFER_WGRAD)
             main = torch.cuda.current_stream(x.device)
-            use_side = WGRAD_SIDE_STREAM and _side_stream_safe(meta.rows, x.shape[1], H, ndir)
+            use_side = WGRAD_SIDE_STREAM and _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None)
             side = _wgrad_stream(x.device) if use_side else main
             side.wait_stream(main)
             with torch.cuda.stream(side):
