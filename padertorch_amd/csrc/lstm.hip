@@ -501,22 +501,16 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
                 }
             }
         }
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
         if (act) {
-            const float ig = sigmoidf_(pre[0]);
-            const float fg = sigmoidf_(pre[1]);
-            const float gg = tanhf_(pre[2]);
-            const float og = sigmoidf_(pre[3]);
-            const float cn = fg * cprev + ig * gg;
-            const float h = og * tanhf_(cn);
-            c_reg = cn;
-            gp[0] = ig;
-            gp[H] = fg;
-            gp[2 * H] = gg;
-            gp[3 * H] = og;
-            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
-            A.c[o] = cn;                                  // saved for the backward pass only
-            A.hy[o] = h;                                  // row-major: the layer output
-            // tile-major, written through: what this chain's workgroups read in the next step
+            ig = sigmoidf_(pre[0]);
+            fg = sigmoidf_(pre[1]);
+            gg = tanhf_(pre[2]);
+            og = sigmoidf_(pre[3]);
+            c_reg = fg * cprev + ig * gg;
+            h = og * tanhf_(c_reg);
+            // tile-major, written through: what this chain's workgroups read in the next step.  It is the
+            // only store the arrival below has to wait for; the row-major results follow after it.
             float* tq = A.hyt + (((size_t)t * A.nt16 + tile16 + (bl >> 4)) * A.ndir + dir) * tile_elems;
             __hip_atomic_store(tq + ((j0 + u) >> 4) * 256 + (bl & 15) * 16 + ((j0 + u) & 15), h, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -535,6 +529,15 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         if (tid == 0)
             __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+        if (act) {                                        // nobody in this launch reads these
+            gp[0] = ig;
+            gp[H] = fg;
+            gp[2 * H] = gg;
+            gp[3 * H] = og;
+            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
+            A.c[o] = c_reg;                               // saved for the backward pass only
+            A.hy[o] = h;                                  // row-major: the layer output
+        }
     }
 }
 
