@@ -565,7 +565,8 @@ struct LstmPersistBwdArgs {
     const float* c0;
     int max_batch;
     int nx, nt, span;    // 1-D grid: unit tiles, row tiles of this launch, XCDs per chain (0: plain order)
-    float* dgt;          // tile-major copy of dgates for the hand-off: [T][row tile][dir][4H / 16][16 rows][16]
+    float* dgt;          // tile-major copy of dgates for the hand-off: [T][16-row tile][dir][4H / 16][16 rows][16]
+    int nt16;            // 16-row tiles of the whole batch
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)
@@ -590,17 +591,21 @@ __device__ __forceinline__ bool chain_tile(int nx, int nt, int span, int* x, int
     return true;
 }
 
-template <int NW, int CH>
+// MTL = 16-row tiles per workgroup (2: a batch of 64 stays ONE launch of 32-row chains; the weights in
+// registers serve both tiles, the second tile's operands are requested while the first one multiplies).
+template <int NW, int CH, int MTL = 1>
 __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
     const int n0 = bx * 16;
-    const int m0 = (A.tile0 + by) * 16;
+    constexpr int MR = 16 * MTL;                   // rows per workgroup
+    const int m0 = (A.tile0 + by) * MR;
+    const int tile16 = (A.tile0 + by) * MTL;       // first 16-row tile (index into the tile-major copy)
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[NW][16][17];
+    __shared__ float red[NW][MR][17];
 
     const int nblk = G >> 4;
     const int per = (nblk + NW - 1) / NW;          // <= CH (host checked)
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
     }
     unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * A.T * 8;   // this row tile's chain
     unsigned* const err = A.flags + A.err_off;
-    const int bl = (tid >> 4) & 15, jl = tid & 15;
+    const int bl = (tid >> 4) & (MR - 1), jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
     float dc_state = 0.f;      // d loss / d c of (b, j) flowing to the next (earlier) step
 
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             prow0 = A.offs[tp];
         }
         const bool has_rec = nnext > m0;
-        const bool act = tid < 256 && b < nb && j < H;
+        const bool act = tid < 16 * MR && b < nb && j < H;
         float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cprev = 0.f;
         const long long oh = (row0 + b) * ld_h + dir * H + j;
         const long long og_ = (row0 + b) * ld_g + (long long)dir * G + j;
@@ -663,27 +668,56 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             // back and are consumed in order; rows past the batch get an out-of-range offset (the buffer
             // returns 0), K blocks past the end of this wavefront's slice re-read its last valid tile
             // (finite data x zero weights).
+            const size_t tile_stride = (size_t)A.ndir * G * 16;     // to the workgroup's second 16-row tile (MTL = 2)
+            const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * (size_t)G * 16;
+            const unsigned vin = (unsigned)(kfirst * 1024 + r * 64 + g4 * 16);
             const bool av = m0 + r < nnext && !(A.dbg & 128);
-            const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                A.dgt + (((size_t)tn * A.ntiles + A.tile0 + by) * A.ndir + dir) * (size_t)G * 16, 0, G * 64, 0x00020000);
-            const unsigned vbase = av ? (unsigned)(kfirst * 1024 + r * 64 + g4 * 16) : 0x80000000u;
+            const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, G * 64, 0x00020000);
+            const unsigned vbase = av ? vin : 0x80000000u;
             f32x4 a[CH];
 #pragma unroll
             for (int i = 0; i < CH; ++i)
                 a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(i, ilast) * 1024, 16 /* sc1 */));
             __builtin_amdgcn_sched_barrier(0);      // or the scheduler re-serialises load / wait / 4 MFMAs to save registers
-            f32x4 acc = zero;
-            if (!(A.dbg & 64)) {
+            f32x4 acc[MTL];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt) acc[mt] = zero;
+            if (MTL == 1) {
+                if (!(A.dbg & 64)) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[0], 0, 0, 0);
+                    }
+                }
+            } else {
+                const bool second = m0 + 16 < nnext;        // workgroup-uniform
+                const __amdgpu_buffer_rsrc_t dg_rsrc1 =
+                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase + tile_stride), 0, G * 64, 0x00020000);
+                const unsigned vbase1 = (m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
 #pragma unroll
                 for (int i = 0; i < CH; ++i) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc, 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[0], 0, 0, 0);
+                    if (second)                     // the fragment just consumed makes room for the second tile's
+                        a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc1, vbase1, min(i, ilast) * 1024, 16));
+                }
+                if (second) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            acc[MTL - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[MTL - 1], 0, 0, 0);
+                    }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) red[wave][g4 * 4 + q][r] = acc[q];
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][r] = acc[mt][q];
             __syncthreads();
-            if (tid < 256 && b < nnext) {
+            if (tid < 16 * MR && b < nnext) {
                 float sum = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) sum += red[w][bl][jl];
@@ -707,7 +741,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             dgp[2 * H] = gc;
             dgp[3 * H] = go;
             // tile-major, written through: what the other workgroups of this chain read in the next step
-            float* tp = A.dgt + (((size_t)t * A.ntiles + A.tile0 + by) * A.ndir + dir) * (size_t)G * 16 + bl * 16;
+            float* tp = A.dgt + (((size_t)t * A.nt16 + tile16 + (bl >> 4)) * A.ndir + dir) * (size_t)G * 16 + (bl & 15) * 16;
             const int c0_ = j, c1_ = H + j, c2_ = 2 * H + j, c3_ = 3 * H + j;
             __hip_atomic_store(tp + (c0_ >> 4) * 256 + (c0_ & 15), gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(tp + (c1_ >> 4) * 256 + (c1_ & 15), gf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -931,8 +965,14 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     PTMI_RETURN_IF((4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
     // 1024-thread workgroups: one per CU must be resident.  Row tiles are independent recurrences, so a
     // batch whose tiles do not fit at once runs as several launches over groups of tiles.
-    const int nx = (H + 15) / 16, ntiles = (max_batch + 15) / 16;
+    // A batch that needs more than one launch of 16-row chains runs as 32-row chains instead (8-wavefront
+    // workgroups, MTL = 2: one launch up to batch 64 at H = 600; per step ~7.5 us instead of 2 x 5.6).
+    const int nx = (H + 15) / 16, nt16 = (max_batch + 15) / 16;
     PTMI_RETURN_IF((long long)nx * ndir > 240, PTMI_E_UNSUPPORTED);
+    const bool fits8 = (4 * H / 16 + 7) / 8 <= 19;
+    int mtl = (nt16 > 240 / (nx * ndir) && fits8) ? 2 : 1;
+    if (const char* v = getenv("PTMI_LSTM_BWD_MTL")) mtl = (atoi(v) == 2 && fits8) ? 2 : 1;
+    const int ntiles = (nt16 + mtl - 1) / mtl;
     const int per_launch = std::min(ntiles, 240 / (nx * ndir));
     const long long dg_bytes = rows * ndir * 4 * H * 4;
     PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
@@ -945,19 +985,18 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
                          (unsigned)nx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)dg_bytes,
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
-                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt};
+                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
-        // opt-in variant: 8 wavefronts x 19 K blocks.  6.9 vs 7.3 us per step in isolation at H = 600, but
-        // the training step as a whole is not faster with it (the half-empty CUs then also host the
-        // side-stream GEMMs), so 16 x 10 stays the default
         const int chains = nt * ndir;
         A.nx = nx;
         A.nt = nt;
         A.span = (chains <= 8 && 8 % chains == 0 && !getenv("PTMI_LSTM_NO_XCD")) ? 8 / chains : 0;
         const unsigned nwg = A.span ? (unsigned)((nx + A.span - 1) / A.span * 8) : (unsigned)(nx * chains);
-        if (getenv("PTMI_LSTM_BWD8") && (4 * H / 16 + 7) / 8 <= 19)
+        if (mtl == 2)
+            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19, 2>), dim3(nwg), dim3(512), 0, st, A);
+        else if (getenv("PTMI_LSTM_BWD8") && fits8)      // 8 wavefronts x 19 K blocks: same speed as 16 x 10 (5.5 vs 5.6 us)
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3(nwg), dim3(512), 0, st, A);
         else
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3(nwg), dim3(NW * 64), 0, st, A);
