@@ -195,9 +195,11 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* c0, cons
 /* Persistent forward recurrence: ONE launch for all T steps; W_hh stays in registers and the steps
  * are chained by write-through stores + per-step arrival counters (see csrc/lstm.hip).  Same
  * results as ptmi_lstm_forward.  batch_sizes_dev / offsets_dev are DEVICE copies here; flags is a
- * device scratch of ptmi_lstm_flags_elems(T, ndir, max_batch) uint32 (zeroed by the call; the last 8 words are
- * error words: non-zero after the call = a bounded spin ran out).  Returns PTMI_E_UNSUPPORTED when
- * the configuration cannot be kept resident (caller falls back to ptmi_lstm_forward). */
+ * device scratch of ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 0) uint32: the tile-major copy of hy the
+ * workgroups hand to each other, ptmi_lstm_flags_elems(T, ndir, max_batch) arrival counters (zeroed by
+ * the call) and, as the LAST 8 words, the error words (non-zero after the call = a bounded spin ran
+ * out).  KP must be H rounded up to 16.  Returns PTMI_E_UNSUPPORTED when the configuration cannot be
+ * kept resident (caller falls back to ptmi_lstm_forward). */
 int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
