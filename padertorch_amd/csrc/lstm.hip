@@ -6,15 +6,21 @@
 //
 // The input projections X W_ih^T + b (60 % of the LSTM FLOPs) are ONE dense GEMM per layer for
 // both directions and stay on the BLAS library.  What is hand-written here is the part that is
-// sequential in time: per timestep ONE launch that covers both directions
+// sequential in time:
 //     gates = gx[t] + h_{t-1} W_hh^T   (exact fp32 on the matrix cores: v_mfma_f32_16x16x4_f32,
-//                                        operands streamed L2 -> VGPR as K-contiguous float4,
-//                                        K split over the 4 wavefronts of a workgroup, LDS reduce)
+//                                        K split over the wavefronts of a workgroup, LDS reduce)
 //     i,f,o = sigmoid, g = tanh, c_t = f c_{t-1} + i g, h_t = o tanh(c_t)      (fused epilogue)
 // and the mirrored step of the backward pass (dh_rec = dgates_{t+1} W_hh, then the gate
-// derivatives).  A per-timestep all-gather of h is an all-to-all seam, so the time loop is cut at
-// kernel boundaries (MI355X guide: megakernel verdict) instead of a persistent kernel with grid
-// barriers; MIOpen spends 4 launches (2 GEMMs + 2 pointwise) per step and direction here.
+// derivatives), both directions in one launch.  Two execution forms with the same results:
+//   * lstm_{fwd,bwd}_step_kernel: one launch per timestep (MIOpen spends 4 launches, 2 GEMMs + 2
+//     pointwise, per step and direction here); no residency requirement, also captured as hipGraphs;
+//   * lstm_{fwd,bwd}_persistent_kernel (default): ONE launch per layer and pass.  The workgroup's slice
+//     of W_hh lives in registers for all T steps; steps are chained by write-through stores into a
+//     tile-major hand-off copy (one contiguous KB per operand load), a drain, and per-chain arrival
+//     counters.  All workgroups must be co-resident (host-checked); every spin is bounded.
+// Environment knobs (experiments / ablations): PTMI_LSTM_DBG (16 no poll, 32 no drain,
+// 64 no MFMA, 128 no operand loads, 256 no look-ahead loads: results void), PTMI_LSTM_JT, PTMI_LSTM_MTL,
+// PTMI_LSTM_BWD8, PTMI_LSTM_BWD_MTL, PTMI_LSTM_NO_XCD, PTMI_LSTM_MAX_POLLS.
 //
 // Layouts (rows = packed time-major rows of the PackedSequence, row(t, b) = offs[t] + b):
 //   gx / gates / dgates  [rows][ndir][4][H]   (pre-activations in, activations out: in place)
