@@ -209,8 +209,9 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
 /* Persistent backward-through-time (mirror of ptmi_lstm_forward_persistent; same results as
  * ptmi_lstm_backward; no dc_state scratch: the cell-state gradient stays in registers).  `flags` is a device
  * scratch of ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 1) uint32: a tile-major copy of dgates that the
- * workgroups hand to each other (16 x 16 tiles, one contiguous KB per load), then the arrival counters
- * (zeroed by the call), then the 8 error words (still the LAST 8 words). */
+ * workgroups hand to each other (16 x 16 tiles, one contiguous KB per load), then [ndir][4H] floats that
+ * receive the BIAS GRADIENT (sum of dgates over all rows, out), then the ptmi_lstm_flags_elems arrival
+ * counters (both zeroed by the call), then the 8 error words (still the LAST 8 words). */
 int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward);
 int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t,
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,

@@ -20,7 +20,7 @@
 //     counters.  All workgroups must be co-resident (host-checked); every spin is bounded.
 // Environment knobs (experiments / ablations): PTMI_LSTM_DBG (16 no poll, 32 no drain,
 // 64 no MFMA, 128 no operand loads, 256 no look-ahead loads: results void), PTMI_LSTM_JT, PTMI_LSTM_MTL,
-// PTMI_LSTM_BWD8, PTMI_LSTM_BWD_MTL, PTMI_LSTM_NO_XCD, PTMI_LSTM_MAX_POLLS.
+// PTMI_LSTM_BWD16, PTMI_LSTM_BWD_MTL, PTMI_LSTM_NO_XCD, PTMI_LSTM_MAX_POLLS.
 //
 // Layouts (rows = packed time-major rows of the PackedSequence, row(t, b) = offs[t] + b):
 //   gx / gates / dgates  [rows][ndir][4][H]   (pre-activations in, activations out: in place)
@@ -573,6 +573,7 @@ struct LstmPersistBwdArgs {
     int nx, nt, span;    // 1-D grid: unit tiles, row tiles of this launch, XCDs per chain (0: plain order)
     float* dgt;          // tile-major copy of dgates for the hand-off: [T][16-row tile][dir][4H / 16][16 rows][16]
     int nt16;            // 16-row tiles of the whole batch
+    float* dbias;        // [ndir][4H] sum of dgates over all rows (zeroed by the host call, accumulated atomically)
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)
@@ -633,6 +634,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
     const int bl = (tid >> 4) & (MR - 1), jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
     float dc_state = 0.f;      // d loss / d c of (b, j) flowing to the next (earlier) step
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;      // bias gradient: this thread's dgates summed over time
 
     for (int s = 0; s < A.T; ++s) {
         const int t = dir == 0 ? A.T - 1 - s : s;
@@ -741,6 +743,10 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             dc_state = dc * fg;
             const float gi = d_i * ig * (1.f - ig), gf = d_f * fg * (1.f - fg), gc = d_g * (1.f - gg * gg),
                         go = d_o * og * (1.f - og);
+            sb0 += gi;
+            sb1 += gf;
+            sb2 += gc;
+            sb3 += go;
             float* dgp = A.dg + og_;                  // row-major: what the weight / input gradient GEMMs read
             dgp[0] = gi;
             dgp[H] = gf;
@@ -759,6 +765,23 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         if (tid == 0)
             __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (bx & 7), 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // bias gradient = sum of dgates over all rows: fold this workgroup's rows, one atomic per (gate, unit)
+    float* const fold = &red[0][0][0];              // >= 4 * MR * 16 floats (NW >= 4)
+    __syncthreads();
+    if (tid < 16 * MR) {
+        fold[(0 * MR + bl) * 16 + jl] = sb0;
+        fold[(1 * MR + bl) * 16 + jl] = sb1;
+        fold[(2 * MR + bl) * 16 + jl] = sb2;
+        fold[(3 * MR + bl) * 16 + jl] = sb3;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + jl < H) {
+        const int g = tid >> 4;
+        float sum = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < MR; ++rr) sum += fold[(g * MR + rr) * 16 + jl];
+        atomicAdd(A.dbias + (size_t)dir * G + g * H + n0 + jl, sum);
     }
 }
 
@@ -886,7 +909,8 @@ static int64_t lstm_tile_elems(int32_t T, int32_t ndir, int32_t max_batch, int32
 }
 
 int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward) {
-    return lstm_tile_elems(T, ndir, max_batch, backward ? 4 * H : (H + 15) / 16 * 16) + ptmi_lstm_flags_elems(T, ndir, max_batch);
+    return lstm_tile_elems(T, ndir, max_batch, backward ? 4 * H : (H + 15) / 16 * 16) + (backward ? (int64_t)ndir * 4 * H : 0) +
+           ptmi_lstm_flags_elems(T, ndir, max_batch);
 }
 
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
@@ -983,15 +1007,18 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     const long long dg_bytes = rows * ndir * 4 * H * 4;
     PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // scratch = [tile-major dgates | arrival counters | 8 error words]; only the counters need zeroing
+    // scratch = [tile-major dgates | bias gradient [ndir][4H] | arrival counters | 8 error words];
+    // the bias gradient and the counters are zeroed here (one memset)
     float* const dgt = reinterpret_cast<float*>(flags);
     flags += lstm_tile_elems(T, ndir, max_batch, 4 * H);
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
+    float* const dbias = reinterpret_cast<float*>(flags);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(ndir * 4 * H + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
     if (e != hipSuccess) return (int)e;
+    flags += ndir * 4 * H;
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
                          (unsigned)nx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)dg_bytes,
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
-                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16};
+                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16, dbias};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
@@ -1002,7 +1029,7 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
         const unsigned nwg = A.span ? (unsigned)((nx + A.span - 1) / A.span * 8) : (unsigned)(nx * chains);
         if (mtl == 2)
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19, 2>), dim3(nwg), dim3(512), 0, st, A);
-        else if (getenv("PTMI_LSTM_BWD8") && fits8)      // 8 wavefronts x 19 K blocks: same speed as 16 x 10 (5.5 vs 5.6 us)
+        else if (!getenv("PTMI_LSTM_BWD16") && fits8)    // 8 wavefronts x 19 K blocks; 16 x 10 (128 VGPRs per lane, spills) only for wider layers
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3(nwg), dim3(512), 0, st, A);
         else
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3(nwg), dim3(NW * 64), 0, st, A);

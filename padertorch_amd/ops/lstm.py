@@ -372,7 +372,7 @@ class _LstmLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dhy, _dc=None):
         meta, lease = ctx.meta, ctx.lease
-        h0 = c0 = None
+        h0 = c0 = db_kernel = None
         lib = _lib.load()
         st = _lib.stream(dhy.device)
         if lease is not None:
@@ -408,6 +408,9 @@ class _LstmLayerFn(torch.autograd.Function):
                     _note_errors(flags)
                     if CHECK_PERSISTENT_ERRORS:
                         check_errors()
+                    # the kernel also summed dgates over the rows: [ndir * 4H] floats in front of the counters
+                    nflags = int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch))
+                    db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
             if rc == -2:
                 dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
                 _lib.check(_lib.timed(
@@ -423,18 +426,18 @@ class _LstmLayerFn(torch.autograd.Function):
             side = _wgrad_stream(x.device) if use_side else main
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for (p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev) in zip(
-                        params, _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)):
+                for d, ((p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev)) in enumerate(zip(
+                        params, _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H))):
                     p_wih.grad.addmm_(dgd.t(), x)
                     p_whh.grad.addmm_(dgd.t(), h_prev)
-                    db_d = dgd.sum(0)
+                    db_d = dgd.sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
                     p_bih.grad.add_(db_d)
                     p_bhh.grad.add_(db_d)
-            for t in (dg, x, hy) + (() if h0 is None else (h0,)) + (() if ctx.ext is None else (ctx.ext,)):
+            for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel) if v is not None):
                 t.record_stream(side)           # keep the operands alive until the side stream is done
             return dx, None, None, None, None, None, None, None
         dw_ih = dg.t() @ x                                            # [ndir*4H, I]
-        db = dg.sum(0)
+        db = dg.sum(0) if db_kernel is None else db_kernel
         dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
         if lease is not None:
             lease.release()
