@@ -355,7 +355,7 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expe
         v += __shfl_xor(v, 4, 64);
         v = __shfl(v, 0, 64);
         if (v >= expected) return true;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(4);
     }
     if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return false;
