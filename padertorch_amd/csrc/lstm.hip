@@ -331,7 +331,7 @@ struct LstmPersistArgs {
     const float* w;
     const int32_t* bs;       // device [T]
     const int64_t* offs;     // device [T]
-    unsigned* flags;         // device [ndir][T][8] arrival counters + 1 error word, zeroed per call
+    unsigned* flags;         // device [ndir][row tiles][kSlots] hand-off slots + 8 error words, zeroed per call
     int T, H, KP, ndir;
     unsigned expected;       // producer workgroups per chain (direction x row tile)
     unsigned max_polls;
@@ -345,17 +345,25 @@ struct LstmPersistArgs {
     int nt16;                // 16-row tiles of the whole batch
 };
 
-__device__ __forceinline__ bool wait_arrivals(const unsigned* cnt, unsigned expected, unsigned max_polls,
-                                              unsigned* err) {
-    const int lane = threadIdx.x & 63;
+// Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has
+// finished (a plain write-through store: no read-modify-write, no two producers on one address); a
+// consumer reads all slots of its chain with one or two loads per lane and goes on when every one of them
+// has reached the step it needs.  (First form: 8 sharded arrival counters per step; the ~6 atomic adds
+// queueing on each shard were part of every step's chain.)
+constexpr int kSlots = 128;          // slots per chain = most producer workgroups a chain may have
+
+__device__ __forceinline__ bool wait_arrivals(const unsigned* slots, unsigned producers, unsigned step,
+                                              unsigned max_polls, unsigned* err) {
+    const unsigned lane = threadIdx.x & 63;
     for (unsigned it = 0; it < max_polls; ++it) {
-        unsigned v = lane < 8 ? __hip_atomic_load(cnt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v = __shfl(v, 0, 64);
-        if (v >= expected) return true;
-        __builtin_amdgcn_s_sleep(4);
+        unsigned v = lane < producers ? __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+        if (producers > 64) {
+            const unsigned w = lane + 64 < producers
+                                   ? __hip_atomic_load(slots + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
+            v = min(v, w);
+        }
+        if (__all(v >= step)) return true;
+        __builtin_amdgcn_s_sleep(2);
     }
     if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return false;
@@ -368,7 +376,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // workgroups share CUs, and one chain's hand-off latency hides behind the other chain's MFMAs.
 // OCC = workgroups per CU the register budget allows (2: up to 448 co-resident workgroups; 1: up to
 // 256, twice the registers, no spills).
-template <int JT, int NW, int CH, int MTL, int OCC>
+// PHASES: instrumented variant (PTMI_LSTM_PHASES): lane 0 of workgroup 0 sums the 100 MHz clock over the
+// phases of a step and leaves the sums in the first words of the scratch.
+template <int JT, int NW, int CH, int MTL, int OCC, bool PHASES = false>
 __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
@@ -403,12 +413,21 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
     }
     const size_t tile_elems = (size_t)A.KP * 16;         // one 16-row tile of the tile-major h copy
     const int tile16 = (A.tile0 + blockIdx.z) * MTL;     // first 16-row tile of this workgroup
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * A.T * 8;   // this chain's
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * kSlots;   // this chain's slots
     unsigned* const err = A.flags + A.err_off;
     const int bl = tid / JT, u = tid - bl * JT;
     const int b = m0 + bl;
     float pre_n[4] = {0.f, 0.f, 0.f, 0.f};       // input pre-activations of the step about to run
     float c_reg = 0.f;                           // cell state of (b, u) after the previous step
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
+    auto mark = [&](int kk) {
+        if (PHASES && tid == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            ph[kk] += now - ph_last;
+            ph_last = now;
+        }
+    };
+    if (PHASES && tid == 0) ph_last = __builtin_amdgcn_s_memrealtime();
     {
         const int t0 = dir == 0 ? 0 : A.T - 1;
         if (tid < MR * JT && b < A.bs[t0] && j0 + u < H) {
@@ -450,8 +469,11 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         };
         if (!has_rec) prefetch();
         if (has_rec) {
-            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
+            mark(0);
+            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            mark(1);
             __syncthreads();
+            mark(2);
             if (act && b < nprev) cprev = c_reg;          // this thread wrote c_{t-1}(b, u) itself
             const int mtiles = (min(nprev, m0 + MR) - m0 + 15) >> 4;
             // h_{t-1} comes from the TILE-MAJOR copy (see the backward kernel): one load = one 16 x 16 tile =
@@ -470,6 +492,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
                     a[i][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, vbase, min(i, ilast) * 1024, 16 /* sc1 */));
             }
             prefetch();
+            mark(3);
             f32x4 acc[MTL][NT];
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
@@ -495,7 +518,9 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            mark(4);
             __syncthreads();
+            mark(5);
             if (tid < MR * JT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -530,11 +555,13 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             }
         }
         // publish step s: every wavefront drains its stores, then one lane arrives
+        mark(6);
         if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mark(7);
         __syncthreads();
+        mark(8);
         if (tid == 0)
-            __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (blockIdx.x & 7), 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(myflags + blockIdx.x, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (act) {                                        // nobody in this launch reads these
             gp[0] = ig;
             gp[H] = fg;
@@ -544,6 +571,11 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             A.c[o] = c_reg;                               // saved for the backward pass only
             A.hy[o] = h;                                  // row-major: the layer output
         }
+        mark(9);
+    }
+    if (PHASES && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(A.hyt);
+        for (int kk = 0; kk < 10; ++kk) out[kk] = ph[kk];
     }
 }
 
@@ -629,7 +661,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         for (int i = 0; i < CH; ++i)
             bq[i] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
     }
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * A.T * 8;   // this row tile's chain
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * kSlots;   // this row tile's chain
     unsigned* const err = A.flags + A.err_off;
     const int bl = (tid >> 4) & (MR - 1), jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
@@ -668,7 +700,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
         }
         if (has_rec) {
-            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags + (size_t)(s - 1) * 8, A.expected, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
             __syncthreads();
             // The operand comes from the TILE-MAJOR copy: one load instruction of a wavefront = one 16 x 16
             // tile = 1 KB of consecutive bytes (8 full cache lines; from the row-major dgates it would be
@@ -763,8 +795,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0)
-            __hip_atomic_fetch_add(myflags + (size_t)s * 8 + (bx & 7), 1u, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // bias gradient = sum of dgates over all rows: fold this workgroup's rows, one atomic per (gate, unit)
     float* const fold = &red[0][0][0];              // >= 4 * MR * 16 floats (NW >= 4)
@@ -900,7 +931,8 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* c0, cons
 }
 
 int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch) {
-    return (int64_t)ndir * ((max_batch + 15) / 16) * T * 8 + 8;   // one chain per 16-row tile + error words
+    (void)T;
+    return (int64_t)ndir * ((max_batch + 15) / 16) * kSlots + 8;   // one chain per 16-row tile + error words
 }
 
 // tile-major hand-off copy: [T][16-row tiles][ndir][cols / 16] tiles of 16 x 16 floats
@@ -942,7 +974,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
     const int jx = wide ? (H + jt - 1) / jt : jx8;
     const int cap = wide ? 256 : 448;     // 12/16-unit tiles need the whole register file: one workgroup per CU
-    PTMI_RETURN_IF((long long)jx * ndir > cap, PTMI_E_UNSUPPORTED);
+    PTMI_RETURN_IF((long long)jx * ndir > cap || jx > kSlots, PTMI_E_UNSUPPORTED);
     // row tiles are independent recurrences: a batch whose tiles do not all fit runs as several launches
     const int per_launch = std::min(ntiles, cap / (jx * ndir));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -961,7 +993,9 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
         const int nt = std::min(per_launch, ntiles - t0);
         const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt), block(NW * 64);
         const bool one_per_cu = (long long)jx * ndir * nt <= 256;
-        if (jt == 12 && small)
+        if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
+            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1, true>), grid, block, 0, st, A);
+        else if (jt == 12 && small)
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1>), grid, block, 0, st, A);
         else if (wide && small)
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 1, 1>), grid, block, 0, st, A);
@@ -998,7 +1032,7 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     // A batch that needs more than one launch of 16-row chains runs as 32-row chains instead (8-wavefront
     // workgroups, MTL = 2: one launch up to batch 64 at H = 600; per step ~7.5 us instead of 2 x 5.6).
     const int nx = (H + 15) / 16, nt16 = (max_batch + 15) / 16;
-    PTMI_RETURN_IF((long long)nx * ndir > 240, PTMI_E_UNSUPPORTED);
+    PTMI_RETURN_IF((long long)nx * ndir > 240 || nx > kSlots, PTMI_E_UNSUPPORTED);
     const bool fits8 = (4 * H / 16 + 7) / 8 <= 19;
     int mtl = (nt16 > 240 / (nx * ndir) && fits8) ? 2 : 1;
     if (const char* v = getenv("PTMI_LSTM_BWD_MTL")) mtl = (atoi(v) == 2 && fits8) ? 2 : 1;
