@@ -280,6 +280,17 @@ int ptmi_norm_elementwise(int32_t backward, const float* x, const float* gy, con
                           const float* c0, const float* c1, const ptmi_norm_geom* geom, int32_t shift,
                           int32_t scale, float* out, ptmi_stream_t stream);
 
+/* ---- Unit-norm embeddings ------------------------------------------------------------------------
+ * Replaces torch.nn.functional.normalize(h, dim=-2) of padertorch/contrib/tcl/dc.py:70 (and its autograd
+ * backward) on the [N, E, F] embedding (F contiguous, E <= 32):
+ *   forward : y = x / max(||x[n, :, f]||_2, eps);  inv_norm [N, F] = 1 / max(norm, eps) is kept for
+ *   backward: dx = inv_norm (gy - y <gy, y>_E)   (inv_norm gy where the norm was clamped to eps).
+ * One HBM pass each. */
+int ptmi_unit_norm_forward(const float* x, float* y, float* inv_norm, int64_t N, int32_t E, int32_t F, float eps,
+                           ptmi_stream_t stream);
+int ptmi_unit_norm_backward(const float* gy, const float* y, const float* inv_norm, float* dx, int64_t N, int32_t E,
+                            int32_t F, float eps, ptmi_stream_t stream);
+
 /* ---- Time-domain regression losses under PIT ------------------------------------------------------
  * Replaces padertorch/ops/losses/regression.py:47-378 (mse_loss, log_mse_loss, sdr_loss, si_sdr_loss,
  * log1p_mse_loss, source_aggregated_sdr_loss) evaluated per permutation by pit_loss

@@ -80,3 +80,21 @@ def running_norm(x, state, gamma, beta, batch_axis, sequence_axis, sequence_leng
     if beta is not None:
         x = x + beta
     return x * compute_mask(x.shape, sequence_lengths, batch_axis, sequence_axis)
+
+
+def unit_norm(x, eps=1e-12):
+    """``torch.nn.functional.normalize(x, p=2, dim=-2, eps)`` as used on the deep-clustering embedding
+    (padertorch/contrib/tcl/dc.py:70): x / max(||x||_2 over axis -2, eps)."""
+    x = np.asarray(x)
+    n = np.sqrt((x.astype(np.float64) ** 2).sum(-2, keepdims=True))
+    return (x / np.maximum(n, eps)).astype(x.dtype)
+
+
+def unit_norm_backward(gy, x, eps=1e-12):
+    """d/dx of ``sum(gy * unit_norm(x))`` (autograd of normalize: the clamp passes no gradient)."""
+    x64, g64 = np.asarray(x, np.float64), np.asarray(gy, np.float64)
+    n = np.sqrt((x64 ** 2).sum(-2, keepdims=True))
+    d = np.maximum(n, eps)
+    y = x64 / d
+    proj = (g64 * y).sum(-2, keepdims=True) * np.where(n > eps, 1.0, 0.0)
+    return ((g64 - y * proj) / d).astype(np.asarray(x).dtype)

@@ -63,6 +63,8 @@ SIGNATURES = {
     'ptmi_td_lincomb': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, _I64P, _P, _P]),
     'ptmi_lstm_forward': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
+    'ptmi_unit_norm_forward': (c_int, [_P, _P, _P, c_int64, c_int32, c_int32, c_float, c_void_p]),
+    'ptmi_unit_norm_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_void_p]),
     'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
     'ptmi_lstm_scratch_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,

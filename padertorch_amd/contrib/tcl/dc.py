@@ -57,7 +57,10 @@ class DeepClusteringModel(base.Model):
             h, _ = self.blstm(h)
         h_data = ops.linear.linear(self.linear, h.data).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
         # Hershey 2016 page 2 top right paragraph: Unit norm
-        h_data = torch.nn.functional.normalize(h_data, dim=-2)
+        if h_data.is_cuda and h_data.dtype == torch.float32 and self.E <= 32:
+            h_data = ops.unit_norm(h_data)            # one HIP pass forward, one backward (csrc/norm.hip)
+        else:
+            h_data = torch.nn.functional.normalize(h_data, dim=-2)
         return ops.unpack_sequence(PackedSequence(h_data, h.batch_sizes))
 
     def review(self, batch, model_out):

@@ -385,3 +385,161 @@ int ptmi_norm_elementwise(int32_t backward, const float* x, const float* gy, con
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Unit-norm embeddings: y[n, e, f] = x[n, e, f] / max(||x[n, :, f]||_2, eps), the
+// torch.nn.functional.normalize(h, dim=-2) of padertorch/contrib/tcl/dc.py:70 (Hershey 2016), forward
+// and backward as ONE pass each over the [N, E, F] tensor (F contiguous).  torch runs it as a norm
+// reduction, a clamp and a broadcast division (and five element-wise kernels backward), each a full
+// HBM round trip over the 660 MB embedding of the BASELINE deep-clustering batch.
+// One thread owns one column f (four when F % 4 == 0) of one n: E strided loads into registers, the sum of
+// squares, the scaled stores - HBM traffic = one read + one write (backward: two reads + one write).
+namespace ptmi {
+
+// W = columns per thread: 4 (b128 accesses) when F % 4 == 0, else 1 (rows of odd length are not 16-byte
+// aligned; one column per lane keeps every wavefront access one contiguous 256 B segment).
+template <int EMAX, int W>
+__global__ __launch_bounds__(256) void unit_norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            float* __restrict__ inv, long long N, int E, int F, float eps) {
+    const int fq = F / W;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * fq) return;
+    const long long n = gid / fq;
+    const int f0 = (int)(gid - n * fq) * W;
+    const float* xp = x + n * (long long)E * F + f0;
+    float* yp = y + n * (long long)E * F + f0;
+    float v[EMAX][W];
+    float ss[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) ss[q] = 0.f;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e < E) {
+            if (W == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(xp + (long long)e * F);
+                v[e][0] = t.x; v[e][W > 1 ? 1 : 0] = t.y; v[e][W > 2 ? 2 : 0] = t.z; v[e][W > 3 ? 3 : 0] = t.w;
+            } else {
+                v[e][0] = xp[(long long)e * F];
+            }
+#pragma unroll
+            for (int q = 0; q < W; ++q) ss[q] += v[e][q] * v[e][q];
+        }
+    }
+    float r[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        r[q] = 1.f / fmaxf(sqrtf(ss[q]), eps);
+        inv[n * F + f0 + q] = r[q];
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e < E) {
+            if (W == 4)
+                *reinterpret_cast<float4*>(yp + (long long)e * F) =
+                    make_float4(v[e][0] * r[0], v[e][W > 1 ? 1 : 0] * r[W > 1 ? 1 : 0], v[e][W > 2 ? 2 : 0] * r[W > 2 ? 2 : 0],
+                                v[e][W > 3 ? 3 : 0] * r[W > 3 ? 3 : 0]);
+            else
+                yp[(long long)e * F] = v[e][0] * r[0];
+        }
+    }
+}
+
+// dx = inv (g - y <g, y>) where the norm was not clamped, inv g where it was (the clamp has no gradient)
+template <int EMAX, int W>
+__global__ __launch_bounds__(256) void unit_norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            const float* __restrict__ inv, float* __restrict__ dx,
+                                                            long long N, int E, int F, float eps) {
+    const int fq = F / W;
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * fq) return;
+    const long long n = gid / fq;
+    const int f0 = (int)(gid - n * fq) * W;
+    const long long base = n * (long long)E * F + f0;
+    float gv[EMAX][W], yv[EMAX][W];
+    float dot[W], r[W];
+#pragma unroll
+    for (int q = 0; q < W; ++q) {
+        dot[q] = 0.f;
+        r[q] = inv[n * F + f0 + q];
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e < E) {
+            if (W == 4) {
+                const float4 a = *reinterpret_cast<const float4*>(g + base + (long long)e * F);
+                const float4 c = *reinterpret_cast<const float4*>(y + base + (long long)e * F);
+                gv[e][0] = a.x; gv[e][W > 1 ? 1 : 0] = a.y; gv[e][W > 2 ? 2 : 0] = a.z; gv[e][W > 3 ? 3 : 0] = a.w;
+                yv[e][0] = c.x; yv[e][W > 1 ? 1 : 0] = c.y; yv[e][W > 2 ? 2 : 0] = c.z; yv[e][W > 3 ? 3 : 0] = c.w;
+            } else {
+                gv[e][0] = g[base + (long long)e * F];
+                yv[e][0] = y[base + (long long)e * F];
+            }
+#pragma unroll
+            for (int q = 0; q < W; ++q) dot[q] += gv[e][q] * yv[e][q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < W; ++q)
+        if (r[q] * eps >= 1.f) dot[q] = 0.f;            // norm <= eps: y = x / eps, no d norm term
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+        if (e < E) {
+            float o[W];
+#pragma unroll
+            for (int q = 0; q < W; ++q) o[q] = r[q] * (gv[e][q] - yv[e][q] * dot[q]);
+            if (W == 4)
+                *reinterpret_cast<float4*>(dx + base + (long long)e * F) =
+                    make_float4(o[0], o[W > 1 ? 1 : 0], o[W > 2 ? 2 : 0], o[W > 3 ? 3 : 0]);
+            else
+                dx[base + (long long)e * F] = o[0];
+        }
+    }
+}
+
+}  // namespace ptmi
+
+extern "C" {
+
+int ptmi_unit_norm_forward(const float* x, float* y, float* inv_norm, int64_t N, int32_t E, int32_t F, float eps,
+                           ptmi_stream_t stream) {
+    PTMI_RETURN_IF(N < 0 || E < 1 || F < 1 || !(eps > 0.f), PTMI_E_INVALID);
+    if (N == 0) return PTMI_OK;
+    PTMI_RETURN_IF(!x || !y || !inv_norm, PTMI_E_INVALID);
+    PTMI_RETURN_IF(E > 32, PTMI_E_UNSUPPORTED);
+    const int W = (F & 3) == 0 ? 4 : 1;
+    const long long blocks = (N * (F / W) + 255) / 256;
+    PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PTMI_UN_FWD(EM, WW) hipLaunchKernelGGL((ptmi::unit_norm_fwd_kernel<EM, WW>), grid, block, 0, st, x, y, inv_norm, (long long)N, E, F, eps)
+    if (W == 4) {
+        if (E <= 8) PTMI_UN_FWD(8, 4); else if (E <= 20) PTMI_UN_FWD(20, 4); else PTMI_UN_FWD(32, 4);
+    } else {
+        if (E <= 8) PTMI_UN_FWD(8, 1); else if (E <= 20) PTMI_UN_FWD(20, 1); else PTMI_UN_FWD(32, 1);
+    }
+#undef PTMI_UN_FWD
+    return ptmi::launch_status();
+}
+
+int ptmi_unit_norm_backward(const float* gy, const float* y, const float* inv_norm, float* dx, int64_t N, int32_t E,
+                            int32_t F, float eps, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(N < 0 || E < 1 || F < 1 || !(eps > 0.f), PTMI_E_INVALID);
+    if (N == 0) return PTMI_OK;
+    PTMI_RETURN_IF(!gy || !y || !inv_norm || !dx, PTMI_E_INVALID);
+    PTMI_RETURN_IF(E > 32, PTMI_E_UNSUPPORTED);
+    const int W = (F & 3) == 0 ? 4 : 1;
+    const long long blocks = (N * (F / W) + 255) / 256;
+    PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define PTMI_UN_BWD(EM, WW) hipLaunchKernelGGL((ptmi::unit_norm_bwd_kernel<EM, WW>), grid, block, 0, st, gy, y, inv_norm, dx, (long long)N, E, F, eps)
+    if (W == 4) {
+        if (E <= 8) PTMI_UN_BWD(8, 4); else if (E <= 20) PTMI_UN_BWD(20, 4); else PTMI_UN_BWD(32, 4);
+    } else {
+        if (E <= 8) PTMI_UN_BWD(8, 1); else if (E <= 20) PTMI_UN_BWD(20, 1); else PTMI_UN_BWD(32, 1);
+    }
+#undef PTMI_UN_BWD
+    return ptmi::launch_status();
+}
+
+}  // extern "C"

@@ -10,3 +10,4 @@ from .features import pit_features  # noqa: F401
 from . import lstm  # noqa: F401
 from . import linear  # noqa: F401
 from .lstm import packed_lstm  # noqa: F401
+from .unit_norm import unit_norm  # noqa: F401

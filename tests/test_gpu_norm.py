@@ -105,3 +105,29 @@ def test_full_size_properties():
     np.testing.assert_allclose(y2.detach().cpu().numpy()[::9, ::50], y.detach().cpu().numpy()[::9, ::50], atol=1e-5)
     want = N.normalize(x[5].cpu().numpy()[None], None, None, [1], 0, 1, [lens[5]], True, True, 1e-8)[0]
     np.testing.assert_allclose(y[5].detach().cpu().numpy(), want[0], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(37, 20, 257), (5, 4, 9), (3, 8, 64), (2, 32, 12), (1, 1, 1), (0, 20, 257)])
+def test_unit_norm_vs_oracle_and_torch(shape):
+    """ops.unit_norm (ptmi_unit_norm_forward / _backward) == F.normalize(dim=-2) of dc.py:70: forward and
+    input gradient against the numpy oracle and torch on the CPU, incl. zero vectors (eps clamp), F not a
+    multiple of 4, empty input."""
+    import torch
+    from oracle import norm_np
+    from padertorch_amd import ops
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(shape).astype(np.float32)
+    if x.size:
+        x[0, :, 0] = 0.0
+    g = rng.standard_normal(shape).astype(np.float32)
+    xd = torch.tensor(x, device='cuda:0', requires_grad=True)
+    yd = ops.unit_norm(xd)
+    (yd * torch.tensor(g, device='cuda:0')).sum().backward()
+    xt = torch.tensor(x, requires_grad=True)
+    yt = torch.nn.functional.normalize(xt, dim=-2)
+    (yt * torch.tensor(g)).sum().backward()
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), norm_np.unit_norm(x), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), yt.detach().numpy(), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), norm_np.unit_norm_backward(g, x), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), rtol=2e-5, atol=2e-6)

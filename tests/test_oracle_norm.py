@@ -39,3 +39,20 @@ def test_running_statistics_and_eval(g9):
                 np.testing.assert_allclose(state[b], g9[f'{k}/s{step}/{b}'], rtol=1e-5, atol=1e-6)
         y = N.running_norm(g9[f'{k}/eval/x'], state, gamma, beta, 0, 2, [5, 2], True, True, 1e-5)
         np.testing.assert_allclose(y, g9[f'{k}/eval/y'], rtol=1e-4, atol=1e-4)
+
+
+def test_unit_norm_oracle_matches_torch_normalize():
+    """oracle.norm_np.unit_norm / unit_norm_backward == torch.nn.functional.normalize(dim=-2) and its
+    autograd (the op of padertorch/contrib/tcl/dc.py:70), incl. all-zero vectors (eps clamp)."""
+    import torch
+    from oracle import norm_np
+    rng = np.random.default_rng(5)
+    for shape in [(7, 20, 257), (3, 4, 9), (1, 1, 1), (5, 32, 12)]:
+        x = rng.standard_normal(shape).astype(np.float32)
+        x[0, :, 0] = 0.0                                   # clamped norm
+        g = rng.standard_normal(shape).astype(np.float32)
+        xt = torch.tensor(x, requires_grad=True)
+        yt = torch.nn.functional.normalize(xt, dim=-2)
+        (yt * torch.tensor(g)).sum().backward()
+        np.testing.assert_allclose(norm_np.unit_norm(x), yt.detach().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(norm_np.unit_norm_backward(g, x), xt.grad.numpy(), rtol=2e-5, atol=1e-6)
