@@ -69,6 +69,11 @@ def as_padded(seq, batch_first=True):
 
 def pack_sequence(sequences, enforce_sorted=True):
     """``torch.nn.utils.rnn.pack_sequence`` (``pack_module.py:14``); PaddedList skips the re-pad."""
+    if isinstance(sequences, PaddedList) and not sequences.ragged and not sequences.batch_first \
+            and sequences.padded.is_contiguous():
+        padded = sequences.padded                      # time-major, equal lengths: a view
+        T, B = padded.shape[:2]
+        return PackedSequence(padded.view(T * B, *padded.shape[2:]), torch.full((T,), B, dtype=torch.int64))
     if isinstance(sequences, PaddedList):
         return pack_padded_sequence(sequences.padded, torch.tensor(sequences.lengths),
                                     batch_first=sequences.batch_first, enforce_sorted=enforce_sorted)
@@ -77,6 +82,13 @@ def pack_sequence(sequences, enforce_sorted=True):
 
 def unpack_sequence(packed_sequence: PackedSequence) -> list:
     """``pack_module.py:29-30``; returns a :class:`PaddedList` (time-major storage)."""
+    bs = packed_sequence.batch_sizes
+    if packed_sequence.sorted_indices is None and len(bs) and int(bs[0]) == int(bs[-1]):
+        # equal lengths: the packed rows ARE the time-major padded tensor (no fill, no copy, and none in
+        # the backward pass either)
+        T, B = len(bs), int(bs[0])
+        data = packed_sequence.data
+        return PaddedList(data.view(T, B, *data.shape[1:]), [T] * B, batch_first=False)
     padded, lengths = pad_packed_sequence(packed_sequence)
     return PaddedList(padded, lengths.tolist(), batch_first=False)
 

@@ -1,0 +1,38 @@
+"""ops.sequence.pack_module: same results as the torch rnn utilities the reference wraps
+(padertorch/ops/sequence/pack_module.py:14-34), incl. the copy-free paths for equal lengths."""
+import numpy as np
+import torch
+from torch.nn.utils.rnn import pack_sequence as torch_pack, pad_packed_sequence
+
+
+def test_unpack_equal_lengths_is_a_view_and_matches_torch():
+    from padertorch_amd.ops.sequence import pack_module as pm
+    xs = [torch.randn(7, 3, 5, requires_grad=True) for _ in range(4)]
+    packed = torch_pack(xs)
+    out = pm.unpack_sequence(packed)
+    ref, lengths = pad_packed_sequence(packed)
+    assert out.lengths == lengths.tolist() and not out.ragged and not out.batch_first
+    assert out.padded.data_ptr() == packed.data.data_ptr()          # no copy
+    np.testing.assert_array_equal(out.padded.detach().numpy(), ref.detach().numpy())
+    for a, b in zip(out, xs):
+        np.testing.assert_array_equal(a.detach().numpy(), b.detach().numpy())
+    out.padded.square().sum().backward()                            # gradients flow through the view
+    np.testing.assert_allclose(xs[1].grad.numpy(), 2 * xs[1].detach().numpy(), rtol=1e-6)
+    # and back: packing the time-major PaddedList again is a view too
+    again = pm.pack_sequence(out)
+    assert again.data.data_ptr() == packed.data.data_ptr()
+    np.testing.assert_array_equal(again.batch_sizes.numpy(), packed.batch_sizes.numpy())
+
+
+def test_unpack_ragged_matches_torch():
+    from padertorch_amd.ops.sequence import pack_module as pm
+    xs = [torch.randn(l, 6) for l in (9, 7, 7, 2)]
+    packed = torch_pack(xs)
+    out = pm.unpack_sequence(packed)
+    ref, lengths = pad_packed_sequence(packed)
+    assert out.lengths == lengths.tolist() and out.ragged
+    np.testing.assert_array_equal(out.padded.numpy(), ref.numpy())
+    for a, b in zip(out, xs):
+        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    again = pm.pack_sequence(out)
+    np.testing.assert_array_equal(again.data.numpy(), packed.data.numpy())
