@@ -76,6 +76,16 @@ def main():
         tot = sum(v[0].sum() for v in regression.pit_td_losses(x, s).values())
         t = timeit(lambda: torch.autograd.grad(tot, x, retain_graph=True))
         res.append(dict(kernel='td_lincomb (backward)', B=B, N=N, us=t, GBs=B * 3 * K * N * 4 / t / 1e3))
+    # unit-norm embeddings (dc.py:70) at the C5 batch: 8 E F bytes per row forward, 12 E F backward
+    for rows in ((8096, 32192) if args.big else (8096,)):
+        E, F = 20, 257
+        x = torch.randn(rows, E, F, device=dev, requires_grad=True)
+        gy = torch.randn(rows, E, F, device=dev)
+        t = timeit(lambda: pt.ops.unit_norm(x.detach()))
+        res.append(dict(kernel='unit_norm_fwd', rows=rows, us=t, GBs=rows * E * F * 8 / t / 1e3))
+        yy = pt.ops.unit_norm(x)
+        t = timeit(lambda: torch.autograd.grad(yy, x, gy, retain_graph=True))
+        res.append(dict(kernel='unit_norm_bwd', rows=rows, us=t, GBs=rows * E * F * 12 / t / 1e3))
     for r in res:
         r['frac_of_8TBs'] = r['GBs'] / PEAK
         print(json.dumps(r))
