@@ -32,6 +32,7 @@ struct DcArgs {
     int E, K, F;                 // F = inner extent per time step (rows n = t*F + f)
     int nchunks;                 // workgroups per example
     int dbg;                     // PTMI_DC_DBG timing ablations (1: no MFMA, 2: no loads, 4: no LDS staging)
+    unsigned x_span, t_span;     // bytes one example of x / t spans (0: not known to fit the fast kernels)
 };
 
 // Stage rows [n0, n0 + kDcTile) of example b (row n = (t, f) = (n / F, n % F)) of V^T into LDS:
@@ -291,6 +292,142 @@ __global__ __launch_bounds__(256) void dc_backward_kernel(const DcBwdArgs B) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast forms for the model's layout (inner index contiguous, E <= 24, K <= 8, an example within 1 GiB).
+// Same arithmetic as dc_gram_kernel / dc_backward_kernel; what differs is how a row gets into registers:
+// BUFFER loads without a single branch.  Rows past the example get an out-of-range voffset, columns past
+// E (K) an out-of-range soffset, and the hardware returns 0 for both.  With an `if` per column (the
+// generic kernels) the compiler's merged wait counts put an s_waitcnt vmcnt(0) behind every load: 32
+// serial HBM round trips per tile, 1.0-1.5 TB/s.
+constexpr int kDcKX = 8;
+constexpr unsigned kDcOobRow = 0x80000000u, kDcOobCol = 0x40000000u;
+
+template <int EX>
+struct DcFastRow {
+    float x[EX];
+    float t[kDcKX];
+};
+
+template <int EX>
+__device__ __forceinline__ void dc_fast_load(DcFastRow<EX>& v, const DcArgs& A, __amdgpu_buffer_rsrc_t rx,
+                                             __amdgpu_buffer_rsrc_t rt, const DcRow& r) {
+    const unsigned vx = r.valid ? (unsigned)(r.ox * 4) : kDcOobRow;
+    const unsigned vt = r.valid ? (unsigned)(r.ot * 4) : kDcOobRow;
+#pragma unroll
+    for (int c = 0; c < EX; ++c)
+        v.x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               rx, vx, c < A.E ? (unsigned)(c * A.xs[2] * 4) : kDcOobCol, 0));
+#pragma unroll
+    for (int k = 0; k < kDcKX; ++k)
+        v.t[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                               rt, vt, k < A.K ? (unsigned)(k * A.ts[2] * 4) : kDcOobCol, 0));
+}
+
+template <int EX>
+__global__ __launch_bounds__(256) void dc_gram_fast_kernel(const DcArgs A, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float lds[kDcMaxD * kDcPitch];
+    __shared__ float red[4][32][33];
+    const int b = blockIdx.x / A.nchunks;
+    const int chunk = blockIdx.x - b * A.nchunks;
+    const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.T;
+    const long long N_b = T_b * A.F;
+    const long long ntiles = (N_b + kDcTile - 1) / kDcTile;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x + b * A.xs[0]), 0, A.x_span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.t + b * A.ts[0]), 0, A.t_span, 0x00020000);
+    for (int idx = tid; idx < kDcMaxD * kDcPitch; idx += 256) lds[idx] = 0.f;      // rows nobody stages stay 0
+    DcFastRow<EX> v;
+    const long long tile0 = (long long)chunk * kDcTilesPerWg;
+    if (tile0 < ntiles) dc_fast_load<EX>(v, A, rx, rt, dc_row(A, tile0 * kDcTile + tid, N_b));
+    for (int it = 0; it < kDcTilesPerWg; ++it) {
+        const long long tile = tile0 + it;
+        if (tile >= ntiles) break;                      // uniform
+        __syncthreads();                                // previous tile consumed
+#pragma unroll
+        for (int q = 0; q < EX; ++q) lds[q * kDcPitch + tid] = v.x[q];              // columns E..EX-1 are zeros
+#pragma unroll
+        for (int k = 0; k < kDcKX; ++k)
+            if (A.E + k < kDcMaxD) lds[(A.E + k) * kDcPitch + tid] = v.t[k];        // after x: row E + k belongs to t
+        __syncthreads();
+        if (it + 1 < kDcTilesPerWg && tile + 1 < ntiles)
+            dc_fast_load<EX>(v, A, rx, rt, dc_row(A, (tile + 1) * kDcTile + tid, N_b));
+        const float* col = lds + c * kDcPitch + 64 * wave + 32 * h;
+        if (!(A.dbg & 1)) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float2 v2 = *reinterpret_cast<const float2*>(col + 2 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v2.x, v2.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(v2.y, v2.y, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int i = idx >> 5, j = idx & 31;
+        partial[((long long)blockIdx.x << 10) + idx] = (red[0][i][j] + red[1][i][j]) + (red[2][i][j] + red[3][i][j]);
+    }
+}
+
+template <int EX>
+__global__ __launch_bounds__(256) void dc_backward_fast_kernel(const DcBwdArgs B) {
+    const DcArgs& A = B.a;
+    __shared__ float Cm[kDcMaxD + kDcKX][kDcMaxD + 1];
+    const int b = blockIdx.x / A.nchunks;
+    const int chunk = blockIdx.x - b * A.nchunks;
+    const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.T;
+    const long long N_b = T_b * A.F;
+    const int tid = threadIdx.x;
+    const int D = A.E + A.K;
+    const double N = (double)T_b * A.F;
+    const float coef = T_b > 0 ? B.gscale[0] * (float)(4.0 / (N * N * (double)B.batch)) : 0.f;
+    for (int idx = tid; idx < (kDcMaxD + kDcKX) * (kDcMaxD + 1); idx += 256) (&Cm[0][0])[idx] = 0.f;
+    __syncthreads();
+    for (int idx = tid; idx < D * A.E; idx += 256) {
+        const int i = idx / A.E, e = idx - i * A.E;
+        const double g = B.gram[((long long)b << 10) + i * 32 + e];
+        Cm[i][e] = (float)(i < A.E ? g : -g) * coef;
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.x + b * A.xs[0]), 0, A.x_span, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rt =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.t + b * A.ts[0]), 0, A.t_span, 0x00020000);
+    float* dxb = B.dx + b * A.xs[0];
+    const long long tile0 = (long long)chunk * kDcTilesPerWg;
+    const long long ntiles_all = (A.T * A.F + kDcTile - 1) / kDcTile;   // incl. the padded frames: zeros
+    DcFastRow<EX> v;
+    DcRow r = dc_row(A, tile0 * kDcTile + tid, N_b);
+    if (tile0 < ntiles_all) dc_fast_load<EX>(v, A, rx, rt, r);
+    for (int it = 0; it < kDcTilesPerWg; ++it) {
+        const long long tile = tile0 + it;
+        if (tile >= ntiles_all) break;
+        const DcFastRow<EX> cur = v;
+        const DcRow rc = r;
+        if (it + 1 < kDcTilesPerWg && tile + 1 < ntiles_all) {
+            r = dc_row(A, (tile + 1) * kDcTile + tid, N_b);
+            dc_fast_load<EX>(v, A, rx, rt, r);
+        }
+        if (rc.in_range) {                  // rows past the example's length get zeros (v = 0 there)
+            for (int e = 0; e < A.E; ++e) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < EX; ++q) sum = fmaf(cur.x[q], Cm[q][e], sum);          // x[q] = 0 for q >= E
+#pragma unroll
+                for (int k = 0; k < kDcKX; ++k) sum = fmaf(cur.t[k], Cm[A.E + k][e], sum);  // t[k] = 0, Cm row 0 for k >= K
+                dxb[rc.ox + e * A.xs[2]] = sum;
+            }
+        }
+    }
+}
+
 static int dc_fill(DcArgs& A, const float* x, const float* t, int64_t T, const int64_t* strides, int32_t E,
                    int32_t K, int32_t F, const int32_t* row_frames) {
     if (!x || !t || !strides || E < 1 || K < 1 || F < 1 || T < 0) return PTMI_E_INVALID;
@@ -309,6 +446,18 @@ static int dc_fill(DcArgs& A, const float* x, const float* t, int64_t T, const i
     A.nchunks = (int)(((T * F + kDcTile - 1) / kDcTile + kDcTilesPerWg - 1) / kDcTilesPerWg);
     if (A.nchunks < 1) A.nchunks = 1;
     A.dbg = getenv("PTMI_DC_DBG") ? atoi(getenv("PTMI_DC_DBG")) : 0;
+    // fast kernels: inner-contiguous, non-negative strides, one example within 1 GiB, E <= 24, K <= 8
+    A.x_span = A.t_span = 0;
+    bool fast = T > 0 && A.xs[3] == 1 && A.ts[3] == 1 && E <= 24 && K <= kDcKX && !(A.dbg & 8);
+    for (int i = 1; i < 3; ++i) fast = fast && A.xs[i] >= 0 && A.ts[i] >= 0;
+    if (fast) {
+        const long long xsp = ((T - 1) * A.xs[1] + (E - 1) * A.xs[2] + F) * 4;
+        const long long tsp = ((T - 1) * A.ts[1] + (K - 1) * A.ts[2] + F) * 4;
+        if (xsp <= 0x40000000LL && tsp <= 0x40000000LL) {
+            A.x_span = (unsigned)xsp;
+            A.t_span = (unsigned)tsp;
+        }
+    }
     return PTMI_OK;
 }
 
@@ -334,7 +483,10 @@ int ptmi_dc_loss_forward(const float* x, const float* t, int64_t batch, int64_t 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long blocks = (long long)batch * A.nchunks;
     PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
-    hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, workspace);
+    if (A.x_span && E <= 8) hipLaunchKernelGGL(dc_gram_fast_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, A, workspace);
+    else if (A.x_span && E <= 16) hipLaunchKernelGGL(dc_gram_fast_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, A, workspace);
+    else if (A.x_span) hipLaunchKernelGGL(dc_gram_fast_kernel<24>, dim3((unsigned)blocks), dim3(256), 0, st, A, workspace);
+    else hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)blocks), dim3(256), 0, st, A, workspace);
     rc = launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(dc_reduce_kernel, dim3((unsigned)batch), dim3(256), 0, st, workspace, gram, ex_loss,
@@ -356,7 +508,11 @@ int ptmi_dc_loss_backward(const float* x, const float* t, const double* gram, co
     B.batch = batch;
     const long long blocks = (long long)batch * B.a.nchunks;
     PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
-    hipLaunchKernelGGL(dc_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), B);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (B.a.x_span && E <= 8) hipLaunchKernelGGL(dc_backward_fast_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, B);
+    else if (B.a.x_span && E <= 16) hipLaunchKernelGGL(dc_backward_fast_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, B);
+    else if (B.a.x_span) hipLaunchKernelGGL(dc_backward_fast_kernel<24>, dim3((unsigned)blocks), dim3(256), 0, st, B);
+    else hipLaunchKernelGGL(dc_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, B);
     return launch_status();
 }
 
