@@ -414,16 +414,20 @@ __global__ __launch_bounds__(256) void unit_norm_fwd_kernel(const float* __restr
     for (int q = 0; q < W; ++q) ss[q] = 0.f;
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-        if (e < E) {
-            if (W == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(xp + (long long)e * F);
-                v[e][0] = t.x; v[e][W > 1 ? 1 : 0] = t.y; v[e][W > 2 ? 2 : 0] = t.z; v[e][W > 3 ? 3 : 0] = t.w;
-            } else {
-                v[e][0] = xp[(long long)e * F];
-            }
-#pragma unroll
-            for (int q = 0; q < W; ++q) ss[q] += v[e][q] * v[e][q];
+        // no branch around a load (rows past E re-read row E - 1 and count as 0): with one, the compiler
+        // waits for every load before it issues the next
+        const long long eo = (long long)(e < E ? e : E - 1) * F;
+        if (W == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xp + eo);
+            v[e][0] = t.x; v[e][W > 1 ? 1 : 0] = t.y; v[e][W > 2 ? 2 : 0] = t.z; v[e][W > 3 ? 3 : 0] = t.w;
+        } else {
+            v[e][0] = xp[eo];
         }
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) ss[q] += e < E ? v[e][q] * v[e][q] : 0.f;
     }
     float r[W];
 #pragma unroll
@@ -464,19 +468,21 @@ __global__ __launch_bounds__(256) void unit_norm_bwd_kernel(const float* __restr
     }
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) {
-        if (e < E) {
-            if (W == 4) {
-                const float4 a = *reinterpret_cast<const float4*>(g + base + (long long)e * F);
-                const float4 c = *reinterpret_cast<const float4*>(y + base + (long long)e * F);
-                gv[e][0] = a.x; gv[e][W > 1 ? 1 : 0] = a.y; gv[e][W > 2 ? 2 : 0] = a.z; gv[e][W > 3 ? 3 : 0] = a.w;
-                yv[e][0] = c.x; yv[e][W > 1 ? 1 : 0] = c.y; yv[e][W > 2 ? 2 : 0] = c.z; yv[e][W > 3 ? 3 : 0] = c.w;
-            } else {
-                gv[e][0] = g[base + (long long)e * F];
-                yv[e][0] = y[base + (long long)e * F];
-            }
-#pragma unroll
-            for (int q = 0; q < W; ++q) dot[q] += gv[e][q] * yv[e][q];
+        const long long eo = base + (long long)(e < E ? e : E - 1) * F;       // branch-free, see the forward kernel
+        if (W == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(g + eo);
+            const float4 c = *reinterpret_cast<const float4*>(y + eo);
+            gv[e][0] = a.x; gv[e][W > 1 ? 1 : 0] = a.y; gv[e][W > 2 ? 2 : 0] = a.z; gv[e][W > 3 ? 3 : 0] = a.w;
+            yv[e][0] = c.x; yv[e][W > 1 ? 1 : 0] = c.y; yv[e][W > 2 ? 2 : 0] = c.z; yv[e][W > 3 ? 3 : 0] = c.w;
+        } else {
+            gv[e][0] = g[eo];
+            yv[e][0] = y[eo];
         }
+    }
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+#pragma unroll
+        for (int q = 0; q < W; ++q) dot[q] += e < E ? gv[e][q] * yv[e][q] : 0.f;
     }
 #pragma unroll
     for (int q = 0; q < W; ++q)

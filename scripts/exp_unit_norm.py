@@ -4,7 +4,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 from padertorch_amd import ops
 dev = 'cuda:0'
-N, E, F = 32192, 20, 257
+N, E, F = 32192, 20, int(sys.argv[1]) if len(sys.argv) > 1 else 257
 x = torch.randn(N, E, F, device=dev, requires_grad=True)
 g = torch.randn(N, E, F, device=dev)
 def run(fn, n=10):
