@@ -32,6 +32,11 @@
 
 #include "common.h"
 
+// fragments of the backward K slice in flight per wavefront (8-wavefront kernel, see HALF there)
+#ifndef PTMI_BWD_CA
+#define PTMI_BWD_CA 5
+#endif
+
 namespace ptmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -714,12 +719,13 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             const bool av = m0 + r < nnext && !(A.dbg & 128);
             const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, G * 64, 0x00020000);
             const unsigned vbase = av ? vin : 0x80000000u;
-            // HALF (8-wavefront, one row tile): the K slice goes through the registers in two halves, the second
-            // half requested into the fragments the first half's MFMAs have just consumed: 10 instead of 19
-            // loads in front of the first MFMA and ~40 VGPRs less per lane (5.37 -> 5.15 us per step at B = 32;
-            // a rolling window of 6-13 fragments instead of two passes: 5.4-6.7)
+            // HALF (8-wavefront, one row tile): the K slice goes through the registers in passes of PTMI_BWD_CA
+            // fragments, each re-requested as soon as its MFMAs have consumed it (a scheduler barrier per pass
+            // keeps the order): 5 instead of 19 loads in front of the first MFMA, 50 VGPRs less per lane.
+            // us per step at B = 32 / 16 / 1: all 19 up front 5.37 / 5.15 / 4.69, passes of 10: 5.10 / 4.84 / 4.45,
+            // 7: 5.06 / 4.76 / 4.66, 5: 4.93 / 4.62 / 4.62, 4: 4.91 / 4.68 / 4.80, 3: 4.92 / 4.70 / 5.31.
             constexpr bool HALF = NW == 8 && MTL == 1 && CH > 10;
-            constexpr int CA = HALF ? (CH + 1) / 2 : CH;
+            constexpr int CA = HALF ? PTMI_BWD_CA : CH;
             f32x4 a[CA];
 #pragma unroll
             for (int i = 0; i < CA; ++i)
@@ -730,17 +736,17 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             for (int mt = 0; mt < MTL; ++mt) acc[mt] = zero;
             if (HALF) {
 #pragma unroll
-                for (int i = 0; i < CA; ++i) {
+                for (int p0 = 0; p0 < CH; p0 += CA) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[0], 0, 0, 0);
-                    if (i + CA < CH)
-                        a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(i + CA, ilast) * 1024, 16));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int i = 0; i < CA; ++i) {
+                        if (p0 + i < CH) {
 #pragma unroll
-                for (int i = 0; i + CA < CH; ++i) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i + CA][q], acc[0], 0, 0, 0);
+                            for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[p0 + i][q], acc[0], 0, 0, 0);
+                            if (p0 + i + CA < CH)
+                                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(p0 + i + CA, ilast) * 1024, 16));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else if (MTL == 1) {
                 if (!(A.dbg & 64)) {
