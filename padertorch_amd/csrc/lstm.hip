@@ -724,57 +724,45 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             // keeps the order): 5 instead of 19 loads in front of the first MFMA, 50 VGPRs less per lane.
             // us per step at B = 32 / 16 / 1: all 19 up front 5.37 / 5.15 / 4.69, passes of 10: 5.10 / 4.84 / 4.45,
             // 7: 5.06 / 4.76 / 4.66, 5: 4.93 / 4.62 / 4.62, 4: 4.91 / 4.68 / 4.80, 3: 4.92 / 4.70 / 5.31.
-            constexpr bool HALF = NW == 8 && MTL == 1 && CH > 10;
+            constexpr bool HALF = NW == 8 && CH > 10;
+            constexpr int NF = MTL * CH;                   // fragments: K blocks of the first row tile, then of the second
             constexpr int CA = HALF ? PTMI_BWD_CA : CH;
+            // second row tile (MTL = 2): its own 16 x 16 tiles; rows past the batch are out of range (zeros)
+            const __amdgpu_buffer_rsrc_t dg_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(tbase + (MTL > 1 ? tile_stride : 0)), 0, G * 64, 0x00020000);
+            const unsigned vbase1 = (MTL > 1 && m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
+            auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
+                return __builtin_bit_cast(f32x4, f < CH ? __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(f, ilast) * 1024, 16 /* sc1 */)
+                                                        : __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc1, vbase1, min(f - CH, ilast) * 1024, 16));
+            };
             f32x4 a[CA];
 #pragma unroll
-            for (int i = 0; i < CA; ++i)
-                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(i, ilast) * 1024, 16 /* sc1 */));
+            for (int i = 0; i < CA; ++i) a[i] = fragment(i);
             __builtin_amdgcn_sched_barrier(0);      // or the scheduler re-serialises load / wait / 4 MFMAs to save registers
             f32x4 acc[MTL];
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt) acc[mt] = zero;
             if (HALF) {
 #pragma unroll
-                for (int p0 = 0; p0 < CH; p0 += CA) {
+                for (int p0 = 0; p0 < NF; p0 += CA) {
 #pragma unroll
                     for (int i = 0; i < CA; ++i) {
-                        if (p0 + i < CH) {
+                        if (p0 + i < NF) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[p0 + i][q], acc[0], 0, 0, 0);
-                            if (p0 + i + CA < CH)
-                                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(p0 + i + CA, ilast) * 1024, 16));
+                            for (int q = 0; q < 4; ++q)
+                                acc[(p0 + i) / CH] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[(p0 + i) % CH][q], acc[(p0 + i) / CH], 0, 0, 0);
+                            if (p0 + i + CA < NF) a[i] = fragment(p0 + i + CA);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            } else if (MTL == 1) {
+            } else {
+                static_assert(MTL == 1 || HALF, "two row tiles only in the 8-wavefront kernel");
                 if (!(A.dbg & 64)) {
 #pragma unroll
                     for (int i = 0; i < CH; ++i) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[0], 0, 0, 0);
-                    }
-                }
-            } else {
-                const bool second = m0 + 16 < nnext;        // workgroup-uniform
-                const __amdgpu_buffer_rsrc_t dg_rsrc1 =
-                    __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase + tile_stride), 0, G * 64, 0x00020000);
-                const unsigned vbase1 = (m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
-#pragma unroll
-                for (int i = 0; i < CH; ++i) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[0], 0, 0, 0);
-                    if (second)                     // the fragment just consumed makes room for the second tile's
-                        a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc1, vbase1, min(i, ilast) * 1024, 16));
-                }
-                if (second) {
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            acc[MTL - 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[MTL - 1], 0, 0, 0);
                     }
                 }
             }
