@@ -447,12 +447,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         const int nb = A.bs[t];
         const long long row0 = A.offs[t];
         const int tp = dir == 0 ? t - 1 : t + 1;
-        int nprev = 0;
-        long long prow0 = 0;
-        if (tp >= 0 && tp < A.T) {
-            nprev = min(A.bs[tp], nb);
-            prow0 = A.offs[tp];
-        }
+        const int nprev = (tp >= 0 && tp < A.T) ? min(A.bs[tp], nb) : 0;      // rows that have a previous step
         const bool has_rec = nprev > m0;                 // workgroup-uniform
         const bool act = tid < MR * JT && b < nb && j0 + u < H;
         float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
@@ -480,41 +475,49 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
             __syncthreads();
             mark(2);
             if (act && b < nprev) cprev = c_reg;          // this thread wrote c_{t-1}(b, u) itself
-            const int mtiles = (min(nprev, m0 + MR) - m0 + 15) >> 4;
             // h_{t-1} comes from the TILE-MAJOR copy (see the backward kernel): one load = one 16 x 16 tile =
             // 1 KB of consecutive bytes.  Rows past the batch: out-of-range offset (the buffer returns 0);
             // K blocks past this wavefront's slice re-read its last valid tile (x zero weights); the
             // padding columns H..KP-1 of the last tile are written as zeros by the producer.
-            f32x4 a[CH][MTL];
+            // fragments = K blocks of the first row tile, then of the second (MTL = 2); CH of them in flight, each
+            // re-requested as soon as its MFMAs have consumed it (see the backward kernel)
+            constexpr int NF = MTL * CH;
+            const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+                A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP * 64, 0x00020000);
+            const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+                A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP * 64, 0x00020000);
+            const unsigned vin = (unsigned)(kfirst * 1024 + r * 64 + g4 * 16);
+            const unsigned vb0 = (m0 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
+            auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
+                return __builtin_bit_cast(f32x4, f < CH ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, min(f, ilast) * 1024, 16 /* sc1 */)
+                                                        : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, min(f - CH, ilast) * 1024, 16));
+            };
+            f32x4 a[CH];
 #pragma unroll
-            for (int mt = 0; mt < MTL; ++mt) {
-                const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    A.hyt + (((size_t)tp * A.nt16 + tile16 + mt) * A.ndir + dir) * tile_elems, 0, A.KP * 64, 0x00020000);
-                const bool ok = m0 + mt * 16 + r < nprev && !(A.dbg & 128);
-                const unsigned vbase = ok ? (unsigned)(kfirst * 1024 + r * 64 + g4 * 16) : 0x80000000u;
-#pragma unroll
-                for (int i = 0; i < CH; ++i)
-                    a[i][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, vbase, min(i, ilast) * 1024, 16 /* sc1 */));
-            }
+            for (int i = 0; i < CH; ++i) a[i] = fragment(i);
             prefetch();
             mark(3);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[MTL][NT];
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+            if (!(A.dbg & 64)) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if (kb0 + i < kb1 && !(A.dbg & 64)) {
+                for (int p0 = 0; p0 < NF; p0 += CH) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int i = 0; i < CH; ++i) {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][0][q], bq[i][nt][q], acc[0][nt], 0, 0, 0);
-                            if (MTL > 1 && mtiles > 1)
-                                acc[MTL - 1][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][MTL - 1][q], bq[i][nt][q], acc[MTL - 1][nt], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[p0 / CH][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][nt][q], acc[p0 / CH][nt], 0, 0, 0);
                         }
+                        if (p0 + i + CH < NF) a[i] = fragment(p0 + i + CH);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
@@ -679,12 +682,9 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
         const long long row0 = A.offs[t];
         const int tn = dir == 0 ? t + 1 : t - 1;     // processed in iteration s - 1
         const int tp = dir == 0 ? t - 1 : t + 1;     // forward-sense predecessor (c_{t-1})
-        int nnext = 0, npv = 0;
-        long long nrow0 = 0, prow0 = 0;
-        if (tn >= 0 && tn < A.T) {
-            nnext = min(A.bs[tn], nb);
-            nrow0 = A.offs[tn];
-        }
+        const int nnext = (tn >= 0 && tn < A.T) ? min(A.bs[tn], nb) : 0;
+        int npv = 0;
+        long long prow0 = 0;
         if (tp >= 0 && tp < A.T) {
             npv = min(A.bs[tp], nb);
             prow0 = A.offs[tp];
