@@ -154,3 +154,16 @@ def test_stateful_lstm_streams_like_the_reference_module():
     np.testing.assert_allclose(m(x.to(DEV)).detach().cpu().numpy(), want.detach().numpy(), atol=5e-6)
     m2 = StatefulLSTM(17, 20, bidirectional=True, save_states=False).to(DEV)
     assert m2(x.to(DEV)).shape == (3, 30, 40) and m2.states is None
+
+
+def test_random_configurations_vs_torch_cpu():
+    """scripts/fuzz_lstm.py: 16 random (B, T, H, I, layers, directions, ragged / equal lengths, initial
+    state) configurations - outputs, final states, input and parameter gradients against torch.nn.LSTM on
+    the CPU (covers partial row tiles, H not a multiple of 16, T = 1, tile-group launches)."""
+    import importlib.util
+    from pathlib import Path
+    path = Path(__file__).resolve().parent.parent / 'scripts' / 'fuzz_lstm.py'
+    spec = importlib.util.spec_from_file_location('fuzz_lstm', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(16, 7, verbose=False) < 2e-5
