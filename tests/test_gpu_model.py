@@ -180,6 +180,43 @@ def test_dc_loss_batched_full_size_vs_oracle():
     np.testing.assert_allclose(x.grad.cpu().numpy(), xt.grad.numpy(), atol=1e-9, rtol=2e-4)
 
 
+@pytest.mark.parametrize('E,K,F,lens', [
+    (24, 8, 40, [9, 9, 4]),        # the limits of the branch-free buffer-load kernels (E <= 24, K <= 8)
+    (25, 3, 33, [7, 5]),           # one past: generic kernels
+    (1, 1, 257, [3]),
+    (8, 2, 5, [20, 20, 20, 1]),    # rows of a tile spanning many time steps
+    (16, 4, 64, [6] * 5),          # equal lengths: no row_frames
+])
+def test_dc_loss_batched_shapes_vs_oracle(E, K, F, lens):
+    """dc_loss_batched on the model's (T, B, E, F) layout across both kernel families (fast: buffer loads
+    with out-of-range offsets for absent rows / columns; generic), value and gradient vs the fp64 oracle."""
+    from oracle import losses_np
+    from padertorch_amd.ops.losses import dc_loss_batched
+    rng = np.random.RandomState(E * 100 + K)
+    B, T = len(lens), max(lens)
+    emb = rng.standard_normal((T, B, E, F)).astype(np.float32)
+    tm = np.eye(K, dtype=np.float32)[rng.randint(0, K, (B, T, F))].transpose(0, 1, 3, 2).copy()
+    ref = [losses_np.deep_clustering_loss(emb[:l, b].transpose(0, 2, 1).reshape(-1, E),
+                                          tm[b, :l].transpose(0, 2, 1).reshape(-1, K)) for b, l in enumerate(lens)]
+    x = torch.from_numpy(emb).to(DEV).requires_grad_(True)
+    ld = None if len(set(lens)) == 1 else torch.tensor(lens, dtype=torch.int32, device=DEV)
+    loss, ex = dc_loss_batched(x, torch.from_numpy(tm).to(DEV), ld)
+    np.testing.assert_allclose(ex.cpu().numpy(), ref, rtol=3e-5)
+    loss.backward()
+    xt = torch.from_numpy(emb).double().requires_grad_(True)
+    tot = 0
+    for b, l in enumerate(lens):
+        X = xt[:l, b].permute(0, 2, 1).reshape(-1, E)
+        Tm = torch.from_numpy(tm[b, :l]).double().permute(0, 2, 1).reshape(-1, K)
+        N = X.shape[0]
+        tot = tot + (((X.t() @ X) ** 2).sum() - 2 * ((X.t() @ Tm) ** 2).sum() + ((Tm.t() @ Tm) ** 2).sum()) / N ** 2 / B
+    tot.backward()
+    g = x.grad.cpu().numpy()
+    np.testing.assert_allclose(g, xt.grad.numpy(), atol=1e-7 * max(1.0, float(np.abs(xt.grad.numpy()).max())), rtol=3e-4)
+    for b, l in enumerate(lens):
+        assert not g[l:, b].any()                      # padded frames get exactly zero
+
+
 def test_separate_vs_oracle():
     """Evaluation path (pit/evaluate.py:149-163) on the device vs numpy stft -> torch-CPU masks ->
     complex masking -> numpy istft."""
