@@ -588,10 +588,10 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
 }
 
 // Persistent backward-through-time: the mirror of lstm_fwd_persistent_kernel.  Workgroup tile =
-// 16 batch rows x 16 hidden units; its slice of W_hh^T (16 rows x 4H) stays in the registers of its
-// 16 wavefronts for all T steps; dgates rows are published write-through and chained by per-step
-// arrival counters per direction; the cell-state gradient of element (b, j) lives in a register of
-// the one thread that owns it for the whole sequence.
+// 16 (or 2 x 16) batch rows x 16 hidden units; its slice of W_hh^T (16 rows x 4H) stays in the registers
+// of its 8 (wide layers: 16) wavefronts for all T steps; dgates are published write-through in the
+// tile-major hand-off copy and chained by one slot per producer workgroup; the cell-state gradient and
+// the bias-gradient sums of element (b, j) live in registers of the one thread that owns it.
 struct LstmPersistBwdArgs {
     const float* gates;
     const float* c;
@@ -1041,10 +1041,10 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
     constexpr int NW = 16, CH = 10;
     PTMI_RETURN_IF((4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
-    // 1024-thread workgroups: one per CU must be resident.  Row tiles are independent recurrences, so a
-    // batch whose tiles do not fit at once runs as several launches over groups of tiles.
-    // A batch that needs more than one launch of 16-row chains runs as 32-row chains instead (8-wavefront
-    // workgroups, MTL = 2: one launch up to batch 64 at H = 600; per step ~7.5 us instead of 2 x 5.6).
+    // One workgroup per CU must be resident (at most 240 per launch).  Row tiles are independent recurrences,
+    // so a batch whose tiles do not fit at once runs as several launches over groups of tiles; before that,
+    // 16-row chains become 32-row chains (8-wavefront workgroups, MTL = 2: one launch up to batch 64 at
+    // H = 600; 7.5 us per step instead of 2 x 5.0).
     const int nx = (H + 15) / 16, nt16 = (max_batch + 15) / 16;
     PTMI_RETURN_IF((long long)nx * ndir > 240 || nx > kSlots, PTMI_E_UNSUPPORTED);
     const bool fits8 = (4 * H / 16 + 7) / 8 <= 19;
