@@ -78,7 +78,7 @@ def cpu_baseline(max_seconds=25.):
     frames = step()          # warm-up
     times = []
     t_all = time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_all) < max_seconds:
+    while len(times) < 16 and (time.perf_counter() - t_all) < max_seconds:        # ~12 s of CPU work
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
