@@ -15,7 +15,7 @@ dev = 'cuda:0'
 
 
 def one(it, rng, verbose):
-    H = int(rng.choice([4, 8, 24, 40, 100, 600]))
+    H = int(rng.choice([4, 8, 24, 40, 100, 600, 624, 1024]))    # 624: 16-wavefront backward; 1024: one launch per step
     B = int(rng.integers(1, 72 if H < 600 else 40))
     T = int(rng.integers(1, 40 if H < 600 else 12))
     I = int(rng.integers(1, 40))
