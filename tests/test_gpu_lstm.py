@@ -167,3 +167,54 @@ def test_random_configurations_vs_torch_cpu():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(16, 7, verbose=False) < 2e-5
+
+
+def test_full_size_properties(monkeypatch):
+    """BASELINE size (32 x 253 frames, 3 x BLSTM-600): properties that need no CPU reference.
+    (a) the persistent kernels and the one-launch-per-timestep kernels (independent implementations) agree;
+    (b) sequences are independent: the first 16 sequences alone (other tile shape: 16 x 8 units, one row tile)
+        give the same outputs and input gradients as inside the batch of 32 (16 x 12 units, two row tiles);
+    (c) time reversal: reversing every sequence and swapping the two directions' weights reverses the output."""
+    from padertorch_amd.ops import packed_lstm, lstm as L
+    monkeypatch.setattr(L, 'CHECK_PERSISTENT_ERRORS', True)
+    torch.manual_seed(3)
+    B, T, I, H = 32, 253, 257, 600
+    lstm = torch.nn.LSTM(I, H, 3, bidirectional=True).to(DEV)
+    xs = [torch.randn(T, I, device=DEV, requires_grad=True) for _ in range(B)]
+    g = torch.randn(T * B, 2 * H, device=DEV)
+
+    def run(seqs, gout):
+        for x in seqs:
+            x.grad = None
+        y = packed_lstm(lstm, pack_sequence(seqs)).data
+        (y * gout).sum().backward()
+        return y.detach(), [x.grad.clone() for x in seqs]
+
+    y, gx = run(xs, g)
+    # (a)
+    monkeypatch.setattr(L, 'PERSISTENT', False)
+    y2, gx2 = run(xs, g)
+    monkeypatch.setattr(L, 'PERSISTENT', True)
+    assert float((y - y2).abs().max()) < 2e-5
+    assert max(float((a - b).abs().max()) for a, b in zip(gx, gx2)) < 2e-4
+    # (b)
+    half = 16
+    yv, gv = y.view(T, B, 2 * H), g.view(T, B, 2 * H)
+    yh, gxh = run(xs[:half], gv[:, :half].reshape(T * half, 2 * H).contiguous())
+    assert float((yh.view(T, half, 2 * H) - yv[:, :half]).abs().max()) < 2e-5
+    assert max(float((a - b).abs().max()) for a, b in zip(gxh, gx[:half])) < 2e-4
+    # (c)
+    sd = lstm.state_dict()
+    swapped = torch.nn.LSTM(I, H, 3, bidirectional=True).to(DEV)
+    # layer l > 0 sees [h_fwd, h_bwd] of the layer below, which swap places too: permute the input columns
+    new = {}
+    for k, v in sd.items():
+        k2 = k[:-len('_reverse')] if k.endswith('_reverse') else k + '_reverse'
+        if k.startswith('weight_ih_l') and not k.startswith('weight_ih_l0'):
+            v = torch.cat([v[:, H:], v[:, :H]], 1)
+        new[k2] = v
+    swapped.load_state_dict(new)
+    with torch.no_grad():
+        yr = packed_lstm(swapped, pack_sequence([x.detach().flip(0) for x in xs[:8]])).data.view(T, 8, 2, H)
+        y8 = packed_lstm(lstm, pack_sequence([x.detach() for x in xs[:8]])).data.view(T, 8, 2, H)
+    assert float((yr.flip(0).flip(2) - y8).abs().max()) < 2e-5

@@ -131,3 +131,22 @@ def test_unit_norm_vs_oracle_and_torch(shape):
     np.testing.assert_allclose(yd.detach().cpu().numpy(), yt.detach().numpy(), rtol=2e-6, atol=1e-7)
     np.testing.assert_allclose(xd.grad.cpu().numpy(), norm_np.unit_norm_backward(g, x), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_unit_norm_full_size_properties():
+    """C5 embedding size (8 x 503 rows x 20 x 257): unit norms, idempotence, scale invariance, and a
+    gradient orthogonal to the output (d/dx of a function of x / |x| has no radial component)."""
+    import torch
+    from padertorch_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(8 * 503, 20, 257, device='cuda:0', requires_grad=True)
+    y = ops.unit_norm(x)
+    n = y.detach().square().sum(1).sqrt()
+    assert float((n - 1).abs().max()) < 1e-6
+    assert float((ops.unit_norm(y.detach()) - y.detach()).abs().max()) < 1e-6
+    assert float((ops.unit_norm(3.7 * x.detach()) - y.detach()).abs().max()) < 1e-6
+    g = torch.randn_like(y)
+    (y * g).sum().backward()
+    radial = (x.grad * x.detach()).sum(1)
+    assert float(radial.abs().max()) < 1e-4 * float(x.grad.abs().max()) * float(x.detach().abs().max()) * 20
