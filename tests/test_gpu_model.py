@@ -217,6 +217,28 @@ def test_dc_loss_batched_shapes_vs_oracle(E, K, F, lens):
         assert not g[l:, b].any()                      # padded frames get exactly zero
 
 
+def test_dc_loss_full_size_properties():
+    """C5 frame count per example (503 x 257 bins, E=20, K=3; 16 examples): the loss only sees X X^T and
+    T T^T, so it is invariant under a rotation of the embedding axis (with a covariant gradient) and under
+    a permutation of the target classes; the fused batch result is the mean of the per-example results."""
+    from padertorch_amd.ops.losses import dc_loss_batched
+    torch.manual_seed(2)
+    T, B, E, K, F = 503, 16, 20, 3, 257
+    x = torch.nn.functional.normalize(torch.randn(T, B, E, F, device=DEV), dim=2).requires_grad_(True)
+    tm = torch.nn.functional.one_hot(torch.randint(0, K, (B, T, F), device=DEV), K).permute(0, 1, 3, 2).float().contiguous()
+    loss, ex = dc_loss_batched(x, tm)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ex.mean().item(), rtol=1e-6)
+    q, _ = torch.linalg.qr(torch.randn(E, E, device=DEV))
+    x2 = torch.einsum('tbef,eg->tbgf', x.detach(), q).contiguous().requires_grad_(True)
+    loss2, ex2 = dc_loss_batched(x2, tm[:, :, [2, 0, 1]].contiguous())
+    loss2.backward()
+    np.testing.assert_allclose(ex2.cpu().numpy(), ex.detach().cpu().numpy(), rtol=2e-4)
+    g_rot = torch.einsum('tbef,eg->tbgf', x.grad, q)
+    scale = float(x.grad.abs().max())
+    assert float((x2.grad - g_rot).abs().max()) < 2e-4 * scale
+
+
 def test_separate_vs_oracle():
     """Evaluation path (pit/evaluate.py:149-163) on the device vs numpy stft -> torch-CPU masks ->
     complex masking -> numpy istft."""
