@@ -37,6 +37,12 @@
 #define PTMI_BWD_CA 5
 #endif
 
+// fragments of the forward K slice in flight per wavefront (us per step at B = 32 / 16 / 1: 5: 4.45 / 3.72 / 3.45,
+// 3: 4.44 / 3.62 / 3.54, 2: 4.32 / 3.54 / 3.43, 1: 4.41 / 3.59 / 3.37)
+#ifndef PTMI_FWD_CA
+#define PTMI_FWD_CA 2
+#endif
+
 namespace ptmi {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -493,9 +499,10 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
                 return __builtin_bit_cast(f32x4, f < CH ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, min(f, ilast) * 1024, 16 /* sc1 */)
                                                         : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, min(f - CH, ilast) * 1024, 16));
             };
-            f32x4 a[CH];
+            constexpr int CA = PTMI_FWD_CA < CH ? PTMI_FWD_CA : CH;      // fragments in flight
+            f32x4 a[CA];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) a[i] = fragment(i);
+            for (int i = 0; i < CA; ++i) a[i] = fragment(i);
             prefetch();
             mark(3);
             __builtin_amdgcn_sched_barrier(0);
@@ -506,16 +513,18 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
             if (!(A.dbg & 64)) {
 #pragma unroll
-                for (int p0 = 0; p0 < NF; p0 += CH) {
+                for (int p0 = 0; p0 < NF; p0 += CA) {
 #pragma unroll
-                    for (int i = 0; i < CH; ++i) {
+                    for (int i = 0; i < CA; ++i) {
+                        if (p0 + i < NF) {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
+                            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[p0 / CH][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][nt][q], acc[p0 / CH][nt], 0, 0, 0);
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[(p0 + i) / CH][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[(p0 + i) % CH][nt][q], acc[(p0 + i) / CH][nt], 0, 0, 0);
+                            }
+                            if (p0 + i + CA < NF) a[i] = fragment(p0 + i + CA);
                         }
-                        if (p0 + i + CH < NF) a[i] = fragment(p0 + i + CH);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
