@@ -337,7 +337,7 @@ __device__ __forceinline__ void dc_fast_load(DcFastRow<EX>& v, const DcArgs& A, 
 template <int EX>
 __global__ __launch_bounds__(256) void dc_gram_fast_kernel(const DcArgs A, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[kDcMaxD * kDcPitch];
-    __shared__ float red[4][32][33];
+    float (*red)[32][33] = reinterpret_cast<float (*)[32][33]>(lds);      // reuses the tile after the last MFMA (4 WGs / CU)
     const int b = blockIdx.x / A.nchunks;
     const int chunk = blockIdx.x - b * A.nchunks;
     const long long T_b = A.row_frames ? (long long)A.row_frames[b] : A.T;
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256) void dc_gram_fast_kernel(const DcArgs A, float
             }
         }
     }
+    __syncthreads();                                    // every wavefront is done with the last tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * h][c] = acc[r];
     __syncthreads();
