@@ -314,6 +314,31 @@ int ptmi_td_lincomb(const float* x, const float* y, const int32_t* lengths, cons
                     const float* coef_b, const float* coef_c, int64_t batch, int32_t K, int64_t T,
                     const int64_t* strides, float* out, ptmi_stream_t stream);
 
+/* ---- Dense layers: fp32 GEMM on the fp16 matrix cores (split operands) ----------------------------
+ * Replaces the library GEMMs behind torch.nn.LSTM's input projections and torch.nn.Linear in
+ * padertorch/contrib/examples/source_separation/pit/model.py:60-66,97-104 and contrib/tcl/dc.py:32-40,61-66
+ * (forward, input gradients, weight gradients).
+ *
+ * ptmi_absmax: out_bits[0] = float bits of max |x[r, c]| over a [rows, cols] fp32 matrix with row stride ld
+ * (device; zeroed and written on `stream`).  The GEMM derives the power-of-two operand scale from it.
+ *
+ * ptmi_gemm_split:  C[m, n] (+)= A B + bias  with fp32 operands and result,
+ *   a  device fp32: [m][k] with row stride lda when a_kmajor, else [k][m] (lda between consecutive k)
+ *   b  device fp32: [n][k] with row stride ldb when b_kmajor, else [k][n]
+ *   amax_a / amax_b  device words from ptmi_absmax over the WHOLE operand tensor, or NULL (operand within
+ *                    fp16's range as it is, e.g. |v| <= 1: scale 1)
+ *   bias   device fp32 [n] or NULL;  accumulate != 0: C += ...;  ldc row stride of C
+ *   products  3: every product as hi*hi + hi*lo + lo*hi of fp16 halves, fp32 accumulation (fp32-equivalent
+ *                result, see csrc/gemm.hip);  1: operands rounded to bf16, one product ("bf16 mode")
+ *   split_k   > 1: that many K ranges per output tile, each into its own slab of `workspace`
+ *             (ptmi_gemm_workspace_elems floats), summed in slab order by a second kernel (reproducible) */
+int ptmi_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* out_bits, ptmi_stream_t stream);
+int ptmi_gemm_split(const float* a, int32_t a_kmajor, int64_t lda, const uint32_t* amax_a, const float* b,
+                    int32_t b_kmajor, int64_t ldb, const uint32_t* amax_b, const float* bias, float* c, int64_t ldc,
+                    int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t products, int32_t split_k,
+                    float* workspace, ptmi_stream_t stream);
+int64_t ptmi_gemm_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k);
+
 #ifdef __cplusplus
 }
 #endif

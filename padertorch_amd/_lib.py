@@ -76,6 +76,10 @@ SIGNATURES = {
     'ptmi_lstm_plan_forward': (c_int, [c_void_p, _P]),
     'ptmi_lstm_plan_backward': (c_int, [c_void_p, _P]),
     'ptmi_lstm_plan_destroy': (None, [c_void_p]),
+    'ptmi_absmax': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    'ptmi_gemm_split': (c_int, [_P, c_int32, c_int64, _P, _P, c_int32, c_int64, _P, _P, _P, c_int64, c_int32, c_int32,
+                                c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'ptmi_gemm_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
 }
 
 _lib = None

@@ -108,7 +108,8 @@ class PermutationInvariantTrainingModel(base.Model):
             h, _ = self.blstm(h)                      # library LSTM (MIOpen)
 
         h_data = self.dropout_linear(h.data)
-        h_data = ops.linear.linear(self.linear1, h_data)      # (weight gradients may join ops.lstm.DEFER_WGRAD)
+        # BLSTM outputs lie in (-1, 1) (x 2 at most under dropout): no operand scaling pass for the split GEMM
+        h_data = ops.linear.linear(self.linear1, h_data, ops.gemm.UNIT_RANGE)
         h_data = self.relu(h_data)
         h_data = ops.linear.linear(self.linear2, h_data)
         h_data = self.output_activation(h_data)

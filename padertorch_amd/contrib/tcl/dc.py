@@ -55,7 +55,7 @@ class DeepClusteringModel(base.Model):
             h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
         else:
             h, _ = self.blstm(h)
-        h_data = ops.linear.linear(self.linear, h.data).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
+        h_data = ops.linear.linear(self.linear, h.data, ops.gemm.UNIT_RANGE).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
         # Hershey 2016 page 2 top right paragraph: Unit norm
         if h_data.is_cuda and h_data.dtype == torch.float32 and self.E <= 32:
             h_data = ops.unit_norm(h_data)            # one HIP pass forward, one backward (csrc/norm.hip)

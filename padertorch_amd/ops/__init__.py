@@ -7,6 +7,7 @@ from ._stft import STFT  # noqa: F401
 from .einsum import *  # noqa: F401,F403
 from .sequence import *  # noqa: F401,F403
 from .features import pit_features  # noqa: F401
+from . import gemm  # noqa: F401
 from . import lstm  # noqa: F401
 from . import linear  # noqa: F401
 from .lstm import packed_lstm  # noqa: F401

@@ -1,0 +1,147 @@
+"""fp32 matrix products on the fp16 matrix cores of the MI355X (``csrc/gemm.hip``).
+
+The dense layers of the hot path - the LSTM input projections and ``torch.nn.Linear`` layers of
+``padertorch/contrib/examples/source_separation/pit/model.py:60-66,97-104`` / ``contrib/tcl/dc.py:32-40`` and
+their input / weight gradients - are ``mm(x, y)`` calls here: fp32 tensors in, fp32 tensor out, every
+product evaluated as three fp16 products of the operands' (hi, lo) halves with fp32 accumulation, which
+is as close to the fp64 result as an exact fp32 GEMM (``tests/test_gpu_gemm.py``) at several times its
+speed (fp32 MFMA runs at 1/16 of the fp16 rate on this part).
+
+``PRODUCTS = 1`` switches every product to plain bf16 operands (BASELINE's "bf16" run of the model:
+reduced precision, reported as a delta, never the default).
+"""
+import torch
+
+from .. import _lib
+
+__all__ = ['mm', 'absmax', 'weight_absmax', 'UNIT_RANGE', 'PRODUCTS', 'ENABLED', 'usable']
+
+#: False: the dense layers go back to the BLAS library (torch.addmm / F.linear): the round-1 path, kept for A/B runs
+ENABLED = True
+
+#: 3 = split fp16 (fp32-equivalent), 1 = plain bf16 operands
+PRODUCTS = 3
+
+#: pass as ``amax_x`` / ``amax_y`` for operands known to lie in a range fp16 covers as it is (activations in
+#: [-1, 1], log-magnitude features): no scale, no reduction pass
+UNIT_RANGE = 'unit'
+
+_WEIGHT_AMAX = {}
+
+
+def absmax(x):
+    """Device word (int32 tensor [1]) holding the float bits of ``max |x|`` of a 2-D fp32 tensor with one unit stride."""
+    assert x.dim() == 2 and x.dtype == torch.float32
+    _lib.require_gpu(x)
+    lib = _lib.load()
+    out = torch.empty(1, dtype=torch.int32, device=x.device)
+    if x.stride(1) == 1 or x.shape[1] == 1:
+        rows, cols, ld = x.shape[0], x.shape[1], x.stride(0)
+    else:
+        assert x.stride(0) == 1, x.stride()
+        rows, cols, ld = x.shape[1], x.shape[0], x.stride(1)
+    ld = max(ld, cols)
+    _lib.check(lib.ptmi_absmax(x.data_ptr(), rows, cols, ld, out.data_ptr(), _lib.stream(x.device)), 'ptmi_absmax')
+    return out
+
+
+def weight_absmax(p):
+    """``absmax`` of a parameter, cached until the parameter is modified in place (optimizer step)."""
+    key = id(p)
+    hit = _WEIGHT_AMAX.get(key)
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+        return hit[2]
+    if len(_WEIGHT_AMAX) > 256:
+        _WEIGHT_AMAX.clear()
+    v = absmax(p.detach() if p.dim() == 2 else p.detach().reshape(-1, p.shape[-1]))
+    _WEIGHT_AMAX[key] = (p._version, p.data_ptr(), v)
+    return v
+
+
+def weights_absmax(params):
+    """``absmax`` over several parameters that are used as ONE operand (the two directions' ``weight_ih`` stacked)."""
+    params = tuple(params)
+    if len(params) == 1:
+        return weight_absmax(params[0])
+    key = tuple(id(p) for p in params)
+    sig = tuple((p._version, p.data_ptr()) for p in params)
+    hit = _WEIGHT_AMAX.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[2]
+    v = weight_absmax(params[0])
+    for p in params[1:]:
+        v = torch.maximum(v, weight_absmax(p))       # non-negative floats order like their bit patterns
+    _WEIGHT_AMAX[key] = (sig, None, v)
+    return v
+
+
+def usable(*tensors):
+    """The split GEMM applies: enabled, fp32 CUDA operands."""
+    return ENABLED and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+def _operand(t, reduce_first):
+    """(pointer, k-major flag, leading dimension) of a 2-D operand whose reduction axis is axis 1 (``x`` of
+    ``x @ y``, ``reduce_first`` False) or axis 0 (``y``)."""
+    red, other = (0, 1) if reduce_first else (1, 0)
+    if t.stride(red) == 1 and (t.stride(other) >= t.shape[red] or t.shape[other] == 1):
+        return t, 1, max(t.stride(other), t.shape[red])
+    if t.stride(other) == 1 and (t.stride(red) >= t.shape[other] or t.shape[red] == 1):
+        return t, 0, max(t.stride(red), t.shape[other])
+    t = t.contiguous()
+    return _operand(t, reduce_first)
+
+
+def auto_split_k(M, N, K):
+    """K ranges per output tile: weight-gradient shapes (few 128 x 128 tiles, K = all rows of the batch) are cut until
+    about two workgroups per CU exist; every range keeps at least 16 k-steps."""
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles >= 384:
+        return 1
+    return max(1, min(512 // tiles, K // 512, 8))
+
+
+def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, split_k=None, products=None):
+    """``out (+)= x @ y + bias`` for fp32 CUDA tensors ``x [M, K]``, ``y [K, N]`` (any strides with one unit stride:
+    transposed views and column blocks of wider matrices are consumed in place).
+
+    ``amax_x`` / ``amax_y``: device words from :func:`absmax` / :func:`weight_absmax` over the operand (computed here
+    when ``None``), or :data:`UNIT_RANGE`.  ``split_k``: K ranges per output tile (default: :func:`auto_split_k`).
+    """
+    assert x.dim() == 2 and y.dim() == 2 and x.shape[1] == y.shape[0], (x.shape, y.shape)
+    assert x.dtype == y.dtype == torch.float32, (x.dtype, y.dtype)
+    _lib.require_gpu(x, y, bias, out)
+    lib = _lib.load()
+    products = PRODUCTS if products is None else products
+    M, K = x.shape
+    N = y.shape[1]
+    x, a_kmajor, lda = _operand(x, False)
+    y, b_kmajor, ldb = _operand(y, True)
+    if out is None:
+        assert not accumulate
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, N) and (out.stride(1) == 1 or N == 1) and out.dtype == torch.float32, (out.shape, out.stride())
+    if M == 0 or N == 0:
+        return out
+    if K == 0:
+        if not accumulate:
+            out.zero_()
+            if bias is not None:
+                out += bias
+        return out
+    if products == 3:
+        ax = None if amax_x is UNIT_RANGE else (absmax(x) if amax_x is None else amax_x)
+        ay = None if amax_y is UNIT_RANGE else (absmax(y) if amax_y is None else amax_y)
+    else:
+        ax = ay = None
+    if bias is not None:
+        assert bias.shape == (N,) and bias.is_contiguous() and bias.dtype == torch.float32
+    ldc = max(out.stride(0), N)
+    split_k = int(split_k) if split_k else auto_split_k(M, N, K)
+    nws = int(lib.ptmi_gemm_workspace_elems(M, N, K, split_k))
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    _lib.check(_lib.timed(
+        'gemm_split', lib.ptmi_gemm_split, x.data_ptr(), a_kmajor, lda, _lib.ptr(ax), y.data_ptr(), b_kmajor, ldb,
+        _lib.ptr(ay), _lib.ptr(bias), out.data_ptr(), ldc, M, N, K, int(bool(accumulate)), products, split_k,
+        _lib.ptr(ws), _lib.stream(x.device)), 'ptmi_gemm_split')
+    return out

@@ -1,10 +1,16 @@
-"""``torch.nn.Linear`` forward whose weight gradient can join the side-stream accumulation of
-``ops.lstm.DEFER_WGRAD`` (the dense layers behind the BLSTM, ``pit/model.py:98-104``): their ``dW``
-GEMMs then run next to the last BLSTM layer's backward recurrence instead of in front of it.
-Same arithmetic as ``F.linear``; the fallback (flag off, no gradient buffers, evaluation) IS ``F.linear``.
+"""``torch.nn.Linear`` on the split-fp16 GEMM (``csrc/gemm.hip``), with the weight gradient joining the in-place
+side-stream accumulation of ``ops.lstm.DEFER_WGRAD``.
+
+The dense layers behind the BLSTM (``padertorch/contrib/examples/source_separation/pit/model.py:98-104``,
+``contrib/tcl/dc.py:38-40,62-66``): ``y = x W^T + b`` forward, ``dx = g W`` and ``dW += g^T x``, ``db += sum g``
+backward.  With ``DEFER_WGRAD`` (set by the Trainer when it owns flat gradient buffers) the weight gradient is
+accumulated straight into ``weight.grad`` on the weight-gradient stream, next to the last BLSTM layer's backward
+recurrence instead of in front of it; otherwise it is returned to autograd.  With ``ops.gemm.ENABLED = False`` (or
+non-fp32 / CPU tensors) this is ``module(x)``.
 """
 import torch
 
+from . import gemm as _gemm
 from . import lstm as _lstm
 
 __all__ = ['linear']
@@ -12,34 +18,50 @@ __all__ = ['linear']
 
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, module):
+    def forward(ctx, x, weight, bias, module, amax_x):
+        amax_w = _gemm.weight_absmax(module.weight)
+        amax_x = amax_x if amax_x is not None else _gemm.absmax(x)
         ctx.save_for_backward(x, weight)
         ctx.module = module
-        return torch.addmm(bias, x, weight.t())
+        ctx.amax = (amax_x, amax_w)
+        ctx.has_bias = bias is not None
+        return _gemm.mm(x, weight.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         mod = ctx.module
+        amax_x, amax_w = ctx.amax
         g = g.contiguous()
-        dx = g @ weight if ctx.needs_input_grad[0] else None
-        rows, n_out = g.shape
+        amax_g = _gemm.absmax(g)
+        dx = _gemm.mm(g, weight, amax_x=amax_g, amax_y=amax_w) if ctx.needs_input_grad[0] else None
+        in_place = (_lstm.DEFER_WGRAD and mod.weight.grad is not None and mod.weight.requires_grad
+                    and (not ctx.has_bias or mod.bias.grad is not None))
+        if not in_place:
+            dw = _gemm.mm(g.t(), x, amax_x=amax_g, amax_y=amax_x) if ctx.needs_input_grad[1] else None
+            db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+            return dx, dw, db, None, None
         main = torch.cuda.current_stream(x.device)
-        safe = _lstm.WGRAD_SIDE_STREAM and _lstm.gemm_keys_safe((_lstm.wgrad_key(x.shape[1], n_out, rows),))
-        side = _lstm._wgrad_stream(x.device) if safe else main
-        side.wait_stream(main)
+        side = _lstm._wgrad_stream(x.device) if _lstm.WGRAD_SIDE_STREAM else main
+        if side is not main:
+            side.wait_stream(main)
+        else:
+            main.wait_stream(_lstm._wgrad_stream(x.device))
         with torch.cuda.stream(side):
-            mod.weight.grad.addmm_(g.t(), x)
-            mod.bias.grad.add_(g.sum(0))
-        for t in (g, x):
-            t.record_stream(side)
-        return dx, None, None, None
+            _gemm.mm(g.t(), x, out=mod.weight.grad, accumulate=True, amax_x=amax_g, amax_y=amax_x)
+            if ctx.has_bias:
+                mod.bias.grad.add_(g.sum(0))
+        if side is not main:
+            for t in (g, x, amax_g) + ((amax_x,) if torch.is_tensor(amax_x) else ()):
+                t.record_stream(side)
+        if _lstm.GRAD_READY_HOOK is not None:
+            _lstm.GRAD_READY_HOOK([mod.weight] + ([mod.bias] if ctx.has_bias else []))
+        return dx, None, None, None, None
 
 
-def linear(module: torch.nn.Linear, x):
-    """``module(x)`` for a 2-D ``x``."""
-    if (_lstm.DEFER_WGRAD and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and module.bias is not None
-            and module.weight.grad is not None and module.bias.grad is not None
-            and module.weight.requires_grad and x.dtype == torch.float32):
-        return _LinearFn.apply(x, module.weight, module.bias, module)
+def linear(module: torch.nn.Linear, x, x_range=None):
+    """``module(x)`` for a 2-D ``x``.  ``x_range=ops.gemm.UNIT_RANGE`` when ``x`` is known to lie in a range fp16
+    covers without scaling (e.g. LSTM outputs); by default its maximum is measured."""
+    if x.dim() == 2 and _gemm.usable(x, module.weight):
+        return _LinearFn.apply(x, module.weight, module.bias, module, x_range)
     return module(x)

@@ -19,6 +19,7 @@ import torch
 from torch.nn.utils.rnn import PackedSequence
 
 from .. import _lib
+from . import gemm as _gemm
 
 __all__ = ['packed_lstm']
 
@@ -155,6 +156,9 @@ CHECK_PERSISTENT_ERRORS = False
 #: starts over five configurations ran clean); every other shape accumulates on the main stream.
 #: ``sync_deferred()`` must run before anything reads the gradients (the Trainer does).
 DEFER_WGRAD = False
+#: called with the list of parameters whose gradients have just been accumulated in place (the data-parallel
+#: Trainer issues the layer's all-reduce from it; autograd's post-accumulate hooks do not fire for in-place writes)
+GRAD_READY_HOOK = None
 #: False: the deferred accumulation runs on the current stream (same GEMM shapes, no overlap; used by the
 #: one-off GEMM tuning, which must not time kernels next to a running recurrence)
 WGRAD_SIDE_STREAM = True
@@ -296,7 +300,7 @@ class _LstmLayerFn(torch.autograd.Function):
     """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None):
+    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False):
         lib = _lib.load()
         ndir, G, H = w_hh.shape
         assert G == 4 * H
@@ -318,10 +322,20 @@ class _LstmLayerFn(torch.autograd.Function):
             ctx.save_for_backward(x, w_ih, w_hh)
             ctx.lease = lease
             ctx.ext = None
+            ctx.gemm = None
             if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
                 lease.release()
         else:
-            gates = torch.addmm(bias, x, w_ih.t())
+            use_gemm = _gemm.usable(x, w_ih)
+            # operand ranges of the split GEMM: the layer input is taken as it is when it is a hidden state (|h| < 1,
+            # a dropout scale aside), measured otherwise; the stacked weights' maximum is cached per optimizer step
+            amax_x = (_gemm.UNIT_RANGE if x_unit else _gemm.absmax(x)) if use_gemm else None
+            amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
+                      if use_gemm else None)
+            if use_gemm:
+                gates = _gemm.mm(x, w_ih.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
+            else:
+                gates = torch.addmm(bias, x, w_ih.t())
             if stateful:        # h0 W_hh^T enters the pre-activations of each sequence's first processed step
                 gv = gates.view(meta.rows, ndir, G)
                 for d in range(ndir):
@@ -362,6 +376,7 @@ class _LstmLayerFn(torch.autograd.Function):
                     meta.max_batch, H, KP, ndir, st), 'ptmi_lstm_forward')
             ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
             ctx.lease = None
+            ctx.gemm = (amax_x, amax_w) if use_gemm else None
         ctx.meta = meta
         ctx.params = params
         if stateful:
@@ -417,31 +432,57 @@ class _LstmLayerFn(torch.autograd.Function):
                     'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0), dhy.data_ptr(),
                     w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
                     meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
-        dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
+        gm = ctx.gemm
+        if gm is not None:
+            amax_x, amax_w = gm
+            amax_dg = _gemm.absmax(dg)          # one scale for the whole gate-gradient tensor (both directions)
+            dx = _gemm.mm(dg, w_ih, amax_x=amax_dg, amax_y=amax_w) if ctx.needs_input_grad[0] else None
+        else:
+            dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         params = ctx.params
         if DEFER_WGRAD and lease is None and params is not None and all(p.grad is not None for ps in params for p in ps):
             # weight gradients on the side stream, accumulated in place (see DEFER_WGRAD)
             main = torch.cuda.current_stream(x.device)
-            use_side = WGRAD_SIDE_STREAM and _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None)
+            # the split GEMM kernels never wait for sibling workgroups: always safe next to a persistent recurrence;
+            # library kernels only when their shape is pinned to a rocBLAS solution
+            use_side = WGRAD_SIDE_STREAM and (gm is not None or
+                                              _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
             side = _wgrad_stream(x.device) if use_side else main
-            side.wait_stream(main)
+            if use_side:
+                side.wait_stream(main)
+            else:
+                main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
             with torch.cuda.stream(side):
                 for d, ((p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev)) in enumerate(zip(
                         params, _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H))):
-                    p_wih.grad.addmm_(dgd.t(), x)
-                    p_whh.grad.addmm_(dgd.t(), h_prev)
+                    if gm is not None:
+                        _gemm.mm(dgd.t(), x, out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=amax_x)
+                        _gemm.mm(dgd.t(), h_prev, out=p_whh.grad, accumulate=True, amax_x=amax_dg,
+                                 amax_y=_gemm.UNIT_RANGE if h0 is None else None)
+                    else:
+                        p_wih.grad.addmm_(dgd.t(), x)
+                        p_whh.grad.addmm_(dgd.t(), h_prev)
                     db_d = dgd.sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
                     p_bih.grad.add_(db_d)
                     p_bhh.grad.add_(db_d)
-            for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel) if v is not None):
-                t.record_stream(side)           # keep the operands alive until the side stream is done
-            return dx, None, None, None, None, None, None, None
-        dw_ih = dg.t() @ x                                            # [ndir*4H, I]
+            if use_side:
+                for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel, amax_dg if gm is not None else None)
+                                             if v is not None and torch.is_tensor(v)):
+                    t.record_stream(side)           # keep the operands alive until the side stream is done
+            if GRAD_READY_HOOK is not None:
+                GRAD_READY_HOOK([p for ps in params for p in ps])
+            return (dx,) + (None,) * 8
         db = dg.sum(0) if db_kernel is None else db_kernel
-        dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
+        if gm is not None:
+            dw_ih = _gemm.mm(dg.t(), x, amax_x=amax_dg, amax_y=amax_x)
+            dw_hh = torch.stack([_gemm.mm(a.t(), b, amax_x=amax_dg, amax_y=_gemm.UNIT_RANGE if h0 is None else None)
+                                 for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
+        else:
+            dw_ih = dg.t() @ x                                            # [ndir*4H, I]
+            dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
         if lease is not None:
             lease.release()
-        return dx, dw_ih, db, dw_hh, None, None, None, None
+        return (dx, dw_ih, db, dw_hh) + (None,) * 5
 
 
 def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
@@ -503,12 +544,12 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             sl = slice(layer * ndir, (layer + 1) * ndir)
             h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
-            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params)
+            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0)
             hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
             h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:
-            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params)
+            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0)
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
     out = PackedSequence(h, packed.batch_sizes)

@@ -16,8 +16,9 @@ gradients into GPU 0 on EVERY micro-step, driven by GIL-bound python threads.  H
 owns one MI355X (``torch.distributed``, backend "nccl" = RCCL over xGMI): of every group of W
 consecutive examples rank j takes the j-th (as trainer.py:357-359,413-419 hands example j to
 device j), gradients accumulate locally in one flat fp32 bucket over ``virtual_minibatch_size // W``
-micro-steps and are exchanged by ONE ``all_reduce(SUM)`` per optimizer step - a sum, not a mean,
-like the reference's ``gather(...).sum()`` (:426-428).  Every rank then applies the identical
+micro-steps and are exchanged ONCE per optimizer step by ``all_reduce(SUM)`` - a sum, not a mean, like the
+reference's ``gather(...).sum()`` (:426-428) - issued per layer bucket (:class:`GradBuckets`) during the last
+micro-step's backward pass, so that the 94 MB of xGMI traffic run under the remaining backward kernels.  Every rank then applies the identical
 clip + Adam, so replicas stay bit-identical without any parameter broadcast after step 0.  A rank
 without an example in the last partial group contributes zeros (:408).
 """
@@ -61,6 +62,74 @@ class _Summary:
             self.data[kind].update(review.get(kind, {}))
 
 
+class GradBuckets:
+    """Layer-aligned slices of the flat gradient buffer and their all-reduce schedule.
+
+    A bucket = the parameters of one top-level module (one layer of an ``nn.LSTM``), contiguous in the flat
+    buffer.  ``ready(params)`` is called when gradients are final (autograd's post-accumulate hooks, or the
+    in-place accumulation of ``ops.lstm`` / ``ops.linear``); a bucket is reduced once all its parameters are
+    ready AND every later bucket has been issued: all ranks - also one that ran no backward pass because the
+    last group of examples was short - issue the collectives in the same order (last bucket first).
+    """
+
+    def __init__(self, model, flat_grads):
+        import re
+        flat = flat_grads.flat
+        names = {id(p): n for n, p in model.named_parameters()}
+        self.flat = flat
+        self.buckets = []          # [start, end, number of parameters]
+        self.bucket_of = {}
+        last_key, off = None, 0
+        for p in flat_grads.params:
+            name = names.get(id(p), '')
+            m = re.search(r'_l(\d+)(_reverse)?$', name)
+            key = (name.split('.')[0], m.group(1) if m else None)
+            if key != last_key:
+                self.buckets.append([off, off, 0])
+                last_key = key
+            b = self.buckets[-1]
+            b[1] = off + p.numel()
+            b[2] += 1
+            self.bucket_of[id(p)] = len(self.buckets) - 1
+            off += p.numel()
+        self.reset()
+
+    def reset(self):
+        self.count = [0] * len(self.buckets)
+        self.next = len(self.buckets) - 1        # buckets are issued last to first
+        self.works = []
+        self.active = False                      # True during the last micro-step of an optimizer step
+
+    def ready(self, params, stream=None):
+        if not self.active:
+            return
+        for p in params:
+            i = self.bucket_of.get(id(p))
+            if i is not None:
+                self.count[i] += 1
+        self._issue(stream, everything=False)
+
+    def _issue(self, stream, everything):
+        while self.next >= 0 and (everything or self.count[self.next] >= self.buckets[self.next][2]):
+            start, end, _ = self.buckets[self.next]
+            seg = self.flat[start:end]
+            if seg.is_cuda and stream is not None:
+                # the collective has to wait for the accumulations on BOTH the main and the weight-gradient stream
+                stream.wait_stream(torch.cuda.current_stream(seg.device))
+                with torch.cuda.stream(stream):
+                    self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, async_op=True))
+            self.next -= 1
+
+    def finish(self):
+        """Issue what is left (in order) and make the current stream / the host wait for every bucket."""
+        self._issue(None, everything=True)
+        for w in self.works:
+            w.wait()
+        self.reset()
+
+
 class Trainer:
     def __init__(
             self,
@@ -74,6 +143,7 @@ class Trainer:
             virtual_minibatch_size=1,
             overlap_wgrad=True,
             deferred_checks=False,
+            overlap_allreduce=True,
     ):
         if not isinstance(model, torch.nn.Module):
             raise TypeError('Expect that the model is a subclass from padertorch.Module.\n'
@@ -97,6 +167,11 @@ class Trainer:
         #: (fused optimizers' ``found_inf``), so a non-finite step still leaves the parameters untouched and
         #: raises the reference's RuntimeError -- one iteration late.  The host then runs ahead of the GPU.
         self.deferred_checks = deferred_checks
+        #: data parallel: the gradient bucket of a layer is all-reduced as soon as that layer's gradients of the LAST
+        #: micro-step of the optimizer step are complete, under the rest of the backward pass (False: one all-reduce
+        #: of the whole flat buffer in optimizer_step)
+        self.overlap_allreduce = overlap_allreduce
+        self._buckets = None
         self._pending = []           # [(what, event, host tensor, context, optimizer step)]
         self._opt_step = 0
         self._bad = None             # device flag: a loss of the current optimizer step is not finite
@@ -166,6 +241,7 @@ class Trainer:
         _lstm.DEFER_WGRAD = bool(self.overlap_wgrad) and self._flat.flat.is_cuda
         if _lstm.DEFER_WGRAD:
             _lstm.warm_side_stream(self._flat.flat.device)
+        hooks = self.enable_bucketed_allreduce()
 
         try:
             train_iterable = None
@@ -177,6 +253,8 @@ class Trainer:
                     train_iterable = iter(train_dataset)
                 optimize = True
                 for minibatch_index in range(self.virtual_minibatch_size // W):
+                    if self._buckets is not None:
+                        self._buckets.active = minibatch_index + 1 == self.virtual_minibatch_size // W
                     t0 = time.perf_counter()
                     group = list(itertools.islice(train_iterable, W))
                     self._time('time_per_data_loading', t0)
@@ -209,6 +287,10 @@ class Trainer:
         except StopTraining:
             pass
         finally:
+            for h in hooks:
+                h.remove()
+            _lstm.GRAD_READY_HOOK = None
+            self._buckets = None
             _lstm.sync_deferred()
             _lstm.DEFER_WGRAD = defer_before
             opt = self.optimizer.optimizer
@@ -293,7 +375,10 @@ class Trainer:
         _lstm.sync_deferred()          # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
         if self.world_size > 1:
             t0 = time.perf_counter()
-            dist.all_reduce(self._flat.flat, op=dist.ReduceOp.SUM)
+            if self._buckets is not None:
+                self._buckets.finish()             # buckets not yet issued + wait for all of them
+            else:
+                dist.all_reduce(self._flat.flat, op=dist.ReduceOp.SUM)
             self._time('time_per_all_reduce', t0)
         summary = self.clip_grad({})
         for i, param_group in enumerate(self.optimizer.optimizer.param_groups):
@@ -473,6 +558,22 @@ class Trainer:
         return str(log_dir / 'error_state_*.pth')
 
     # ------------------------------------------------------------------ data parallel
+    def enable_bucketed_allreduce(self):
+        """Data parallel with ``overlap_allreduce``: build the layer buckets over the flat gradient buffer and hook
+        them to gradient completion.  Returns the autograd hook handles (``train`` removes them)."""
+        from ..ops import lstm as _lstm
+        if self.world_size <= 1 or not self.overlap_allreduce or self._flat is None:
+            self._buckets = None
+            return []
+        self._buckets = buckets = GradBuckets(self.model, self._flat)
+        side = _lstm._wgrad_stream(self._flat.flat.device) if self._flat.flat.is_cuda else None
+
+        def on_grad(p):
+            buckets.ready((p,), side)
+
+        _lstm.GRAD_READY_HOOK = lambda params: buckets.ready(params, side)
+        return [p.register_post_accumulate_grad_hook(on_grad) for p in self._flat.params]
+
     def _broadcast_parameters(self):
         """Step-0 sync: every rank starts from rank 0's weights and buffers."""
         with torch.no_grad():

@@ -1,0 +1,83 @@
+"""Split-fp16 GEMM (csrc/gemm.hip, through the C ABI) against fp64: the result must be as close to the exact
+product as an fp32 GEMM is.  Error measure: |C - C64| / (|A| @ |B|) (error relative to the magnitude of the terms
+of each dot product), the same measure as scripts/mb/split_mfma_accuracy.hip."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU test on a box without GPU'
+    return torch.device('cuda:0')
+
+
+def _err(c, a, b):
+    ref = a.double() @ b.double()
+    mag = a.double().abs() @ b.double().abs()
+    return float(((c.double() - ref).abs() / mag.clamp_min(1e-300)).max())
+
+
+SHAPES = [(1, 1, 1), (5, 3, 2), (128, 128, 32), (130, 257, 33), (257, 130, 514), (300, 514, 1200), (1012, 1200, 257),
+          (2024, 4800, 1200), (8096, 1200, 600)]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_all_layouts_vs_fp64(M, N, K, ta, tb):
+    from padertorch_amd.ops import gemm
+    dev = _dev()
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N * 3 + K + ta * 2 + tb)
+    a = (torch.rand(M, K, generator=g) * 2 - 1).to(dev)
+    b = (0.05 * torch.randn(K, N, generator=g)).to(dev)
+    xa = a.t().contiguous().t() if ta else a          # [M, K] view of [K][M] storage
+    xb = b.t().contiguous().t() if tb else b          # [K, N] view of [N][K] storage
+    c = gemm.mm(xa, xb)
+    e = _err(c, a, b)
+    e32 = _err(a @ b, a, b)
+    assert e < 4e-7, (e, e32)
+
+
+def test_wide_dynamic_range_bias_accumulate_views():
+    """Gradient-like operand (values over many octaves, tiny overall scale), bias, accumulation into a strided output,
+    operands that are column blocks of wider matrices, split-K."""
+    from padertorch_amd.ops import gemm
+    dev = _dev()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    M, N, K = 700, 260, 2400
+    wide = (1e-6 * (torch.rand(M, 2 * K, generator=g) * 2 - 1) * torch.exp(8 * (torch.rand(M, 2 * K, generator=g) * 2 - 1))).to(dev)
+    a = wide[:, K:]                                   # column block, row stride 2K
+    w = (0.05 * torch.randn(K, N, generator=g)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev) * 1e-6
+    c = gemm.mm(a, w, bias=bias)
+    ref = a.double() @ w.double() + bias.double()
+    mag = a.double().abs() @ w.double().abs() + bias.double().abs()
+    e32 = float((((a @ w + bias).double() - ref).abs() / mag).max())
+    assert float(((c.double() - ref).abs() / mag).max()) < max(4e-7, 2 * e32), e32
+    # weight-gradient form: out[N, M] += w^T-like reduction over the rows, into a view of a flat buffer
+    flat = torch.zeros(N * M + 5, device=dev)
+    out = flat[5:].view(N, M)
+    out.fill_(1e-7)
+    x = (torch.rand(K, N, generator=g) * 2 - 1).to(dev)
+    dg = wide[:K, :M] if wide.shape[0] >= K else None
+    assert dg is None
+    dg = (1e-5 * torch.randn(K, M, generator=g)).to(dev)
+    for split in (1, 4):
+        out.fill_(1e-7)
+        gemm.mm(x.t(), dg, out=out, accumulate=True, split_k=split)
+        ref = x.double().t() @ dg.double() + 1e-7
+        mag = x.double().abs().t() @ dg.double().abs() + 1e-7
+        assert float(((out.double() - ref).abs() / mag).max()) < 4e-7, split
+    assert float(flat[:5].abs().max()) == 0.
+
+
+def test_bf16_mode_is_reduced_precision():
+    from padertorch_amd.ops import gemm
+    dev = _dev()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    a = (torch.rand(300, 640, generator=g) * 2 - 1).to(dev)
+    b = (0.05 * torch.randn(640, 200, generator=g)).to(dev)
+    c = gemm.mm(a, b, products=1)
+    ref = (a.bfloat16().double() @ b.bfloat16().double())
+    assert float((c.double() - ref).abs().max()) < 1e-4            # bf16 operands, fp32 accumulation
+    assert 1e-6 < _err(c, a, b) < 5e-3
