@@ -1,27 +1,39 @@
 #!/usr/bin/env python3
 """Benchmark of the PIT mask-estimation training step on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched by torchrun)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--dry]
+
+``--gpus N`` with N > 1 launches itself as N ranks (``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1``, one rank per GPU over RCCL); when it is already running under
+torchrun (RANK / WORLD_SIZE set) it is one of those ranks.
 
 Metric (BASELINE.json): training frames/s = mixture STFT frames through ONE full optimizer step
 (on-device STFT feature front-end from HBM-resident waveforms -> BLSTM mask estimator forward ->
-PIT review -> backward -> [RCCL all-reduce(sum)] -> global-norm clip -> Adam), whole job.
-Workload = BASELINE.json configs[1]: 2-speaker synthetic 8 kHz mixtures, batch 32 per GPU,
-4 s each (T = 253 frames/example, 8096 frames/step/GPU), PIT model defaults (3xBLSTM-600, K=2,
-23 480 914 parameters), STFT 512/128.  One micro-step per rank per optimizer step (weak scaling).
+PIT review -> backward -> [RCCL all-reduce(sum), per layer bucket under the backward pass] -> global-norm
+clip -> Adam), whole job.  Default workload = BASELINE.json configs[1]: 2-speaker synthetic 8 kHz mixtures,
+batch 32 per GPU, 4 s each (T = 253 frames/example, 8096 frames/step/GPU), PIT model defaults (3xBLSTM-600,
+K=2, 23 480 914 parameters), STFT 512/128; one micro-step per rank per optimizer step (weak scaling).
+Other configurations of BASELINE.json (parity / scaling cases, not the default line):
+  c3  PIT, batch 64, 16 kHz;  c4  c3 with 4 micro-steps per rank per optimizer step (the reference's
+  virtual_minibatch_size = 4 x devices);  c5  deep-clustering model, K = 3, batch 64, 16 kHz.
 
 The JSON line also carries
-  roofline     : the kernel family with the most GPU time per step (the BLSTM recurrence), its
-                 algorithmic flops / HIP-event time of its launches inside the timed steps against the
-                 fp32 MFMA peak; other_kernels lists every other hand-written kernel of the step the
-                 same way (the STFT front-end: 6676 B per mixture frame at K=2, SURVEY.md section 8d,
-                 against the 8 TB/s HBM3E peak);
-  cpu_baseline : the oracle's torch-CPU port of the reference step (oracle/torch_ref.py) timed on
-                 this box's host cores on a bounded sample (rank 0, N=1 only).
+  roofline        the kernel family with the most GPU time per step, HIP-event time of its launches inside the
+                  timed steps against the peak that bounds it; other_kernels lists every other hand-written
+                  kernel family of the step the same way;
+  cpu_baseline    the oracle's torch-CPU port of the reference step (oracle/torch_ref.py) timed on this box's host
+                  cores on a bounded sample (rank 0, N = 1 only), at 1 thread, 16 threads and all cores;
+  ms_per_step_sync_checks   the same step with the reference's two host syncs per step (loss / grad-norm checks
+                  in the step they belong to; the default defers them by one step, see Trainer.deferred_checks);
+  ms_per_step_h2d the same step with the waveform batch starting in (pinned) host memory;
+  rccl            (N > 1) world size, bucket layout and the time of a blocking all-reduce of the flat gradient buffer.
+``--dry`` (no GPU needed; used by the CPU test suite): the same launcher, process group (gloo), gradient buckets
+and JSON line around a stub step.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 from pathlib import Path
@@ -30,209 +42,368 @@ REPO = Path(__file__).resolve().parent
 if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-FS = 8000
-SECONDS = 4
-BATCH = 32
-K = 2
 SIZE, SHIFT = 512, 128
+SECONDS = 4
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 dense peak (MI355X_MICROARCH.md)
-FEATURE_BYTES_PER_FRAME = 3 * SHIFT * 4 + (1 + 2 * K) * (SIZE // 2 + 1) * 4   # 6676 B at K=2
-PIT_LOSS_BYTES_PER_FRAME = (1 + 3 * K) * (SIZE // 2 + 1) * 4                  # 7196 B at K=2
+FP16_MFMA_PEAK_TFLOPS = 2500.  # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md)
 LOSS_WEIGHTS = dict(pit_ips_loss=1., pit_mse_loss=0.)      # pit/train.py:68-71
 
+CONFIGS = {
+    'c2': dict(model='pit', batch=32, fs=8000, K=2, micro=1,
+               label='BASELINE configs[1]: PIT mask estimator (3xBLSTM-600, K=2, 23.5M params)'),
+    'c3': dict(model='pit', batch=64, fs=16000, K=2, micro=1,
+               label='BASELINE configs[2]: PIT mask estimator, batch 64, 16 kHz'),
+    'c4': dict(model='pit', batch=64, fs=16000, K=2, micro=4,
+               label='BASELINE configs[3]: PIT mask estimator, batch 64 per GPU, 16 kHz, 4 micro-steps per rank per '
+                     'optimizer step (virtual_minibatch_size = 4 x GPUs)'),
+    'c5': dict(model='dc', batch=64, fs=16000, K=3, micro=1,
+               label='BASELINE configs[4]: deep-clustering model (2xBLSTM-600, E=20), K=3, batch 64, 16 kHz'),
+}
 
-def synthetic_batch(seed, batch, n, device):
-    """K sources 0.1*N(0,1) fp32, mixture = sum (seeded, on device)."""
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c2')
+    ap.add_argument('--dry', action='store_true', help='launcher / process group / buckets / JSON line around a stub step (CPU, gloo)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the sync-checks / host-to-device / all-reduce side measurements')
+    ap.add_argument('--library-gemms', action='store_true',
+                    help='dense layers on the BLAS library (TunableOp selections of padertorch_amd/tuned) instead of csrc/gemm.hip')
+    ap.add_argument('--bf16', action='store_true', help='plain bf16 operands in the dense layers (reduced precision; reports the delta)')
+    ap.add_argument('--sync-checks', action='store_true',
+                    help='loss / grad-norm finiteness checks in the step they belong to (two host syncs per step, '
+                         'the reference behaviour) instead of Trainer(deferred_checks=True)')
+    ap.add_argument('--no-overlap', action='store_true',
+                    help='LSTM weight gradients through autograd on the main stream (ops.lstm.DEFER_WGRAD off)')
+    ap.add_argument('--no-overlap-allreduce', action='store_true', help='one all-reduce of the flat buffer in optimizer_step')
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """``python bench.py --gpus N`` -> N ranks under torch.distributed.run (replaces this process)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def synthetic_batch(seed, batch, K, n, device):
+    """K sources 0.1*N(0,1) fp32, mixture = sum (seeded)."""
+    import torch
     g = torch.Generator(device='cpu').manual_seed(seed)
     s = 0.1 * torch.randn(batch, K, n, generator=g)
     return dict(y=s.sum(1).to(device), s=s.to(device), num_samples=[n] * batch)
 
 
-def cpu_baseline(max_seconds=25.):
-    """Reference algorithm (oracle/torch_ref.py: conv1d STFT, nn.LSTM on PackedSequence, python-loop
-    pit_loss, clip + Adam) on the host cores, bounded sample: batch 4 x 4 s (1012 frames / step)."""
+def cpu_baseline(max_seconds=12.):
+    """Reference algorithm (oracle/torch_ref.py: conv1d STFT, nn.LSTM on PackedSequence, python-loop pit_loss, clip +
+    Adam) on the host cores, bounded sample: batch 4 x 4 s at 8 kHz (1012 frames / step), at three thread counts
+    (the reference's README recommends OMP_NUM_THREADS=1, pit/README.md:15; the small LSTM GEMMs run fastest on a few
+    cores of a many-core host).  ``value`` = the best of them."""
+    import numpy as np
+    import torch
     from oracle import torch_ref
-    # many-core hosts: the small LSTM GEMMs of this model run fastest on a few cores (the reference
-    # README even recommends OMP_NUM_THREADS=1, pit/README.md:15); use 16 threads, state it.
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    torch.manual_seed(0)
-    model = torch_ref.PITModelRef()
-    opt = torch.optim.Adam(model.parameters())
-    stft = torch_ref.ConvSTFT(SIZE, SHIFT)
-    b = 4
-    g = torch.Generator().manual_seed(1)
-    s = [0.1 * torch.randn(K, FS * SECONDS, generator=g) for _ in range(b)]
-    y = [x.sum(0) for x in s]
+    fs, K, b = 8000, 2, 4
+    variants = []
+    ncpu = os.cpu_count() or 1
+    for threads in sorted({1, min(16, ncpu), ncpu}):
+        torch.set_num_threads(threads)
+        torch.manual_seed(0)
+        model = torch_ref.PITModelRef()
+        opt = torch.optim.Adam(model.parameters())
+        stft = torch_ref.ConvSTFT(SIZE, SHIFT)
+        g = torch.Generator().manual_seed(1)
+        s = [0.1 * torch.randn(K, fs * SECONDS, generator=g) for _ in range(b)]
+        y = [x.sum(0) for x in s]
 
-    def step():
-        with torch.no_grad():
-            feats = torch_ref.features_from_waveforms(stft, s, y)
-        torch_ref.train_step(model, opt, [feats], LOSS_WEIGHTS, 1.)
-        return sum(feats['num_frames'])
+        def step():
+            with torch.no_grad():
+                feats = torch_ref.features_from_waveforms(stft, s, y)
+            torch_ref.train_step(model, opt, [feats], LOSS_WEIGHTS, 1.)
+            return sum(feats['num_frames'])
 
-    frames = step()          # warm-up
-    times = []
-    t_all = time.perf_counter()
-    while len(times) < 16 and (time.perf_counter() - t_all) < max_seconds:        # ~12 s of CPU work
-        t0 = time.perf_counter()
-        step()
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    return dict(value=frames / med, unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'batch {b} x {SECONDS} s @ {FS} Hz ({frames} frames/step), PIT defaults fp32, '
-                       f'{len(times)} timed steps after 1 warm-up, median {med:.3f} s/step, '
-                       f'os.cpu_count()={os.cpu_count()}')
+        frames = step()          # warm-up
+        times = []
+        t_all = time.perf_counter()
+        while len(times) < 12 and (time.perf_counter() - t_all) < max_seconds:
+            t0 = time.perf_counter()
+            step()
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        variants.append(dict(cores=threads, value=frames / med, steps=len(times), s_per_step=med))
+    best = max(variants, key=lambda v: v['value'])
+    return dict(value=best['value'], unit='frames/s', cores=best['cores'], kind='port',
+                sample=f'batch {b} x {SECONDS} s @ {fs} Hz ({frames} frames/step), PIT defaults fp32, median of up to 12 '
+                       f'timed steps (<= {max_seconds:.0f} s) after 1 warm-up per thread count, os.cpu_count()={ncpu}',
+                variants=variants)
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch from the committed PMC passes (profiles/r1_pmc_traffic.json: rocprofv3
-    FETCH_SIZE / WRITE_SIZE in separate passes of this same command, FETCH_SIZE doubled as the
-    MI355X guide prescribes for gfx950).  None when no measurement is committed."""
+    """HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: rocprofv3 FETCH_SIZE /
+    WRITE_SIZE in separate passes of this same command, FETCH_SIZE doubled as the MI355X guide prescribes for
+    gfx950).  None when no measurement is committed."""
     f = REPO / 'profiles' / 'pmc_traffic.json'
     if not f.exists():
         return None
     return json.loads(f.read_text()).get(kernel, {}).get('hbm_bytes_per_launch')
 
 
+def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
+    """One entry per hand-written kernel family seen in the timed steps: HIP-event time of every launch (events
+    recorded on the launch stream around the C-ABI call), algorithmic bytes or flops per launch."""
+    import numpy as np
+    by_name = {}
+    for name, a, b in timers:
+        by_name.setdefault(name, []).append(a.elapsed_time(b))
+    K, B = cfg['K'], cfg['batch']
+    F = SIZE // 2 + 1
+    T = frames_per_step // B
+    fpl = frames_per_step            # frames one launch processes (one micro-step)
+    rec_flop = 2.0 * 2 * B * hidden * 4 * hidden * T          # both directions, one layer, one pass
+    feature_bytes = (3 * SHIFT * 4 + (1 + 2 * K) * F * 4) * fpl if K == 2 else ((1 + K) * SHIFT * 4 + (1 + 2 * K) * F * 4) * fpl
+    pit_bytes = (1 + 3 * K) * F * 4 * fpl
+    spec = {
+        'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end)', 'hbm', feature_bytes),
+        'pit_pairwise_sse': ('pit_pairwise_kernel (PIT mse+ips pairwise SSE)', 'hbm', pit_bytes),
+        'pit_backward': ('pit_backward_kernel (d loss / d mask)', 'hbm', pit_bytes + K * F * 4 * fpl),
+        'lstm_forward': ('lstm_fwd_persistent_kernel (BLSTM recurrence, one launch per layer)', 'mfma32', rec_flop),
+        'lstm_backward': ('lstm_bwd_persistent_kernel (BLSTM backward-through-time, one launch per layer)', 'mfma32', rec_flop),
+    }
+    kernels = []
+    gemm = {}
+    for n, v in by_name.items():
+        if n.startswith('gemm_split:'):          # gemm_split:MxNxK:products
+            dims, products = n.split(':')[1:3]
+            M, N, Kd = (int(x) for x in dims.split('x'))
+            e = gemm.setdefault(int(products), dict(flop=0., ms=0., launches=0))
+            e['flop'] += 2.0 * M * N * Kd * len(v)
+            e['ms'] += float(np.sum(v))
+            e['launches'] += len(v)
+            continue
+        if n not in spec:
+            continue
+        label, bound, work = spec[n]
+        ms = float(np.mean(v))
+        if bound == 'hbm':
+            achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
+        else:
+            achieved, peak, unit = work / (ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s'
+        e = dict(kernel=label, bound='hbm' if bound == 'hbm' else 'mfma', achieved=achieved, peak=peak, unit=unit,
+                 frac=achieved / peak, traffic=measured_traffic(n), avg_launch_ms=ms,
+                 launches_per_step=len(v) / steps, ms_per_step=float(np.sum(v)) / steps)
+        if bound == 'hbm':
+            e['algorithmic_bytes_per_launch'] = work
+        else:
+            e['algorithmic_flop_per_launch'] = work
+            e['us_per_timestep'] = ms * 1e3 / T
+        kernels.append(e)
+    for products, e in gemm.items():
+        achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
+        peak = FP16_MFMA_PEAK_TFLOPS / products
+        kernels.append(dict(
+            kernel=f'gemm_split_kernel (dense layers: LSTM input projections, linears, input / weight gradients; '
+                   f'{products} fp16 MFMA product(s) per fp32 product)' if products == 3 else
+                   'gemm_split_kernel (dense layers, plain bf16 operands)',
+            bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=None,
+            peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = '
+                      f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream)',
+            avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
+            algorithmic_flop_per_step=e['flop'] / steps))
+    kernels.sort(key=lambda e: -e['ms_per_step'])
+    return kernels
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--default-gemms', action='store_true', help='library default GEMM kernel selection')
-    ap.add_argument('--sync-checks', action='store_true',
-                    help='loss / grad-norm finiteness checks in the step they belong to (two host syncs per step, '
-                         'the reference behaviour) instead of Trainer(deferred_checks=True)')
-    ap.add_argument('--no-overlap', action='store_true',
-                    help='LSTM weight gradients through autograd on the main stream (ops.lstm.DEFER_WGRAD off)')
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(args)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 through torchrun)'
-    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    cfg = CONFIGS[args.config]
+    if args.dry:
+        device = torch.device('cpu')
+        backend = 'gloo'
+    else:
+        assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (--dry for the launcher check on CPU)'
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
+        backend = 'nccl'
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=device)
+        if args.dry:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=device)
 
     import padertorch_amd as pt
-    from padertorch_amd.contrib.examples.source_separation.pit.model import \
-        PermutationInvariantTrainingModel
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
+    from padertorch_amd.ops import gemm as _gemm
+    from padertorch_amd.ops import lstm as _lstm
 
     torch.manual_seed(0)
-    if not args.default_gemms:
-        # library GEMMs (input projections, linears, weight gradients): committed TunableOp selections
-        # for these shapes (padertorch_amd/tuned/, see padertorch_amd/tuning.py); same arithmetic,
-        # better hipBLASLt / rocBLAS kernels (fp32: 65-70 % -> 85-91 % of the MFMA peak)
-        from padertorch_amd import tuning
-        tuning.use_tuned_gemms()
-    model = PermutationInvariantTrainingModel()          # defaults: F=257, 3 x BLSTM-600, K=2
+    if args.library_gemms:
+        _gemm.ENABLED = False
+        if not args.dry:
+            from padertorch_amd import tuning
+            tuning.use_tuned_gemms()
+    if args.bf16:
+        _gemm.PRODUCTS = 1
+    micro = cfg['micro']
+    model = PermutationInvariantTrainingModel() if cfg['model'] == 'pit' else DeepClusteringModel()
     trainer = pt.Trainer(model, f'/tmp/ptmi_bench_{rank}', pt.optimizer.Adam(gradient_clipping=1.),
-                         loss_weights=LOSS_WEIGHTS, virtual_minibatch_size=world,
-                         deferred_checks=not args.sync_checks)
+                         loss_weights=LOSS_WEIGHTS if cfg['model'] == 'pit' else None,
+                         virtual_minibatch_size=world * micro, deferred_checks=not args.sync_checks,
+                         overlap_allreduce=not args.no_overlap_allreduce)
     trainer.to(device)
     trainer._flat = trainer.optimizer.use_flat_grads()
     if world > 1:
         trainer._broadcast_parameters()
+    hooks = trainer.enable_bucketed_allreduce()
+    buckets = trainer._buckets
     model.train()
-    from padertorch_amd.ops import lstm as _lstm
-    _lstm.DEFER_WGRAD = not args.no_overlap      # what Trainer.train() sets (side stream only for rocBLAS-pinned shapes)
-    if _lstm.DEFER_WGRAD:
-        _lstm.warm_side_stream(device)
+    if not args.dry:
+        _lstm.DEFER_WGRAD = not args.no_overlap      # what Trainer.train() sets
+        if _lstm.DEFER_WGRAD:
+            _lstm.warm_side_stream(device)
 
-    n = FS * SECONDS
-    data = synthetic_batch(1000 + rank, BATCH, n, device)
-    frames_per_step = None
+    n = cfg['fs'] * SECONDS
+    K = cfg['K']
+    frames_per_micro = cfg['batch'] * ((n + 2 * (SIZE - SHIFT) - SIZE + SHIFT - 1) // SHIFT + 1)      # fading='full', pad
     from padertorch_amd import _lib
 
-    def step(timed):
-        nonlocal frames_per_step
-        # the STFT feature front-end is part of the step; inside the timed region every launch of
-        # a ptmi kernel is bracketed by HIP events on the stream it runs on (torch's current stream)
-        _lib.KERNEL_TIMERS = timers if timed else None
-        feats = pt.ops.pit_features(data['y'], data['s'], data['num_samples'])
-        frames_per_step = sum(feats['num_frames'])
-        loss, _, _, _ = trainer.train_step(model, feats, device)
-        loss.backward()
-        trainer.optimizer_step()
+    if args.dry:
+        data = None
+        nparam = trainer._flat.flat.numel()
 
-    timers = []
+        def step(timed, source=None):
+            # stub backward: every rank's gradient = rank + 1 everywhere, announced layer by layer (last bucket first)
+            for m in range(micro):
+                if buckets is not None:
+                    buckets.active = m + 1 == micro
+                trainer._flat.flat.add_(float(rank + 1))
+                if buckets is not None:
+                    for p in reversed(trainer._flat.params):
+                        buckets.ready((p,), None)
+            expect = micro * world * (world + 1) / 2.
+            if world > 1:
+                if buckets is not None:
+                    buckets.finish()
+                else:
+                    dist.all_reduce(trainer._flat.flat)
+            got = trainer._flat.flat
+            assert float(got.min()) == float(got.max()) == expect, (float(got.min()), float(got.max()), expect)
+            trainer._flat.flat.zero_()
+    else:
+        data = synthetic_batch(1000 + rank, cfg['batch'], K, n, device)
+        timers = []
+
+        def features(src):
+            feats = pt.ops.pit_features(src['y'], src['s'], src['num_samples'])
+            if cfg['model'] == 'pit':
+                return feats
+            X = feats['X_abs'].padded                                  # [B, T, K, F]: ideal binary masks as targets
+            target = torch.nn.functional.one_hot(X.argmax(2), K).permute(0, 1, 3, 2).to(torch.float32)
+            return dict(Y_abs=feats['Y_abs'], target_mask=list(target.unbind(0)), num_frames=feats['num_frames'])
+
+        def step(timed, source=None):
+            # the STFT feature front-end is part of the step; inside the timed region every launch of a ptmi kernel is
+            # bracketed by HIP events on the stream it runs on
+            _lib.KERNEL_TIMERS = timers if timed else None
+            for m in range(micro):
+                if buckets is not None:
+                    buckets.active = m + 1 == micro
+                src = data
+                if source is not None:        # waveforms start in pinned host memory
+                    src = dict(y=source['y'].to(device, non_blocking=True), s=source['s'].to(device, non_blocking=True),
+                               num_samples=source['num_samples'])
+                feats = features(src)
+                assert sum(feats['num_frames']) == frames_per_micro, (sum(feats['num_frames']), frames_per_micro)
+                loss, _, _, _ = trainer.train_step(model, feats, device)
+                loss.backward()
+            trainer.optimizer_step()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        if not args.dry:
+            torch.cuda.synchronize()
+
+    def timed_loop(nsteps, timed=False, source=None):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step(timed, source)
+        if not args.dry:
+            trainer._check_pending(flush=True)       # the last step's staged loss / grad-norm checks (deferred_checks)
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
     for _ in range(args.warmup):
         step(False)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    trainer._check_pending(flush=True)       # the last step's staged loss / grad-norm checks (deferred_checks)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed = timed_loop(args.steps, timed=True)
     _lib.KERNEL_TIMERS = None
+    frames_per_step = frames_per_micro * micro
+
+    extras = {}
+    if not args.dry and not args.no_extras:
+        nx = max(5, min(args.steps, 50))
+        if not args.sync_checks:
+            # the reference's semantics: loss and gradient norm cross to the host in the step they belong to
+            opt = trainer.optimizer.optimizer
+            opt.found_inf, trainer._bad = None, None
+            trainer.deferred_checks = False
+            for _ in range(3):
+                step(False)
+            extras['ms_per_step_sync_checks'] = timed_loop(nx) / nx * 1e3
+            trainer.deferred_checks = True
+        host = dict(y=data['y'].cpu().pin_memory(), s=data['s'].cpu().pin_memory(), num_samples=data['num_samples'])
+        for _ in range(3):
+            step(False, host)
+        extras['ms_per_step_h2d'] = timed_loop(nx, source=host) / nx * 1e3
+        extras['h2d_bytes_per_step'] = int((host['y'].numel() + host['s'].numel()) * 4 * micro)
+    rccl = None
+    if world > 1:
+        flat = trainer._flat.flat
+        reps = 2 if args.dry else 10
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        sync()
+        ar_ms = (time.perf_counter() - t0) / reps * 1e3
+        flat.zero_()
+        nbytes = flat.numel() * 4
+        rccl = dict(world_size=dist.get_world_size(), backend=backend, overlap_allreduce=buckets is not None,
+                    buckets=[b[1] - b[0] for b in buckets.buckets] if buckets is not None else [flat.numel()],
+                    flat_gradient_bytes=nbytes, blocking_all_reduce_ms=ar_ms,
+                    bus_bandwidth_gbs=2. * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9,
+                    time_per_all_reduce_host_ms=trainer.timer.get('time_per_all_reduce', 0.) / max(1, trainer._opt_step) * 1e3)
+
     if rank == 0:
-        by_name = {}
-        for name, a, b in timers:
-            by_name.setdefault(name, []).append(a.elapsed_time(b))
-        # One entry per hand-written kernel family seen in the timed steps: HIP-event time of every
-        # launch (events recorded on the launch stream around the C-ABI call), algorithmic bytes or
-        # flops per launch (SURVEY.md section 8d figures x the frames one launch processes).
-        Hh, T = model.blstm.hidden_size, frames_per_step // BATCH
-        rec_flop = 2.0 * 2 * BATCH * Hh * 4 * Hh * T          # both directions, one layer, one pass
-        F = SIZE // 2 + 1
-        spec = {
-            'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end)', 'hbm',
-                             FEATURE_BYTES_PER_FRAME * frames_per_step, 'pit_features'),
-            'pit_pairwise_sse': ('pit_pairwise_kernel<2> (PIT mse+ips pairwise SSE)', 'hbm',
-                                 PIT_LOSS_BYTES_PER_FRAME * frames_per_step, 'pit_pairwise_sse'),
-            'pit_backward': ('pit_backward_kernel (d loss / d mask)', 'hbm',
-                             (PIT_LOSS_BYTES_PER_FRAME + K * F * 4) * frames_per_step, 'pit_backward'),
-            'lstm_forward': ('lstm_fwd_persistent_kernel (BLSTM recurrence, one launch per layer)', 'mfma',
-                             rec_flop, 'lstm_fwd_persistent'),
-            'lstm_backward': ('lstm_bwd_persistent_kernel (BLSTM backward-through-time, one launch per layer)',
-                              'mfma', rec_flop, 'lstm_bwd_persistent'),
-        }
-        kernels = []
-        for n, v in by_name.items():
-            if n not in spec:
-                continue
-            label, bound, work, traffic_key = spec[n]
-            ms = float(np.mean(v))
-            if bound == 'hbm':
-                achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
-            else:
-                achieved, peak, unit = work / (ms * 1e-3) / 1e12, FP32_MFMA_PEAK_TFLOPS, 'TFLOP/s'
-            e = dict(kernel=label, bound=bound, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                     traffic=measured_traffic(traffic_key), avg_launch_ms=ms,
-                     launches_per_step=len(v) / args.steps, ms_per_step=float(np.sum(v)) / args.steps)
-            if bound == 'hbm':
-                e['algorithmic_bytes_per_launch'] = work
-            else:
-                e['algorithmic_flop_per_launch'] = work
-                e['us_per_timestep'] = ms * 1e3 / T
-            kernels.append(e)
-        # the dominant kernel = the family with the most GPU time per step.  At this workload that is
-        # the BLSTM recurrence: exact-fp32 matrix-core work against the 157.3 TFLOP/s fp32 MFMA peak,
-        # bound by the per-timestep dependency chain (DESIGN.md 3.3), not by the matrix cores.
-        kernels.sort(key=lambda e: -e['ms_per_step'])
-        dominant, other = kernels[0], kernels[1:]
         out = {
-            'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)',
+            'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)' if args.config == 'c2' else
+                      f'training frames/sec ({cfg["model"].upper()}, {K}-spk {cfg["fs"] // 1000} kHz)',
             'value': frames_per_step * world * args.steps / elapsed,
             'unit': 'frames/s',
             'n_gpus': world,
@@ -242,27 +413,38 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32',
+            'dtype': 'bf16' if args.bf16 else 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': f'BASELINE configs[1]: PIT mask estimator (3xBLSTM-600, K=2, 23.5M params), '
-                            f'{BATCH} x {SECONDS} s 2-spk {FS} Hz mixtures per GPU '
-                            f'({frames_per_step} frames/step/GPU), STFT {SIZE}/{SHIFT} on device, '
-                            f'full optimizer step (Adam, clip 1)',
-                'global_batch': BATCH * world,
+                'workload': f'{cfg["label"]}, {cfg["batch"]} x {SECONDS} s {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
+                            f'micro-step ({frames_per_micro} frames), {micro} micro-step(s) per optimizer step, STFT '
+                            f'{SIZE}/{SHIFT} on device, full optimizer step (Adam, clip 1)',
+                'global_batch': cfg['batch'] * world * micro,
                 'frames_per_step': frames_per_step * world,
                 'parallelism': f'dp{world}',
-                'blstm': 'HIP recurrence (csrc/lstm.hip)' if model.hip_blstm else 'torch.nn.LSTM (MIOpen)',
-                'gemms': 'library defaults' if args.default_gemms else 'hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)',
+                'blstm': 'HIP recurrence (csrc/lstm.hip)',
+                'gemms': ('hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)' if args.library_gemms else
+                          'csrc/gemm.hip, plain bf16 operands (reduced precision)' if args.bf16 else
+                          'csrc/gemm.hip: fp32 in/out, 3 fp16 MFMA products per product (fp32-equivalent accuracy)'),
                 'host_checks': 'same step (2 syncs)' if args.sync_checks else 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)',
-                'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence (rocBLAS-pinned shapes)',
+                'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',
             },
-            'roofline': dominant,
-            'other_kernels': other,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if args.dry:
+            out['dry'] = True
+            out['roofline'] = None
+        else:
+            kernels = kernel_report(timers, args.steps, cfg, frames_per_micro, model.blstm.hidden_size, micro)
+            out['roofline'] = kernels[0] if kernels else None
+            out['other_kernels'] = kernels[1:]
+        out.update(extras)
+        if rccl is not None:
+            out['rccl'] = rccl
+        if world == 1 and not args.no_cpu_baseline and not args.dry:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
+    for h in hooks:
+        h.remove()
     if world > 1:
         dist.destroy_process_group()
 

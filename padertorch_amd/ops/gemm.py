@@ -141,7 +141,7 @@ def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, sp
     nws = int(lib.ptmi_gemm_workspace_elems(M, N, K, split_k))
     ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
     _lib.check(_lib.timed(
-        'gemm_split', lib.ptmi_gemm_split, x.data_ptr(), a_kmajor, lda, _lib.ptr(ax), y.data_ptr(), b_kmajor, ldb,
+        f'gemm_split:{M}x{N}x{K}:{products}', lib.ptmi_gemm_split, x.data_ptr(), a_kmajor, lda, _lib.ptr(ax), y.data_ptr(), b_kmajor, ldb,
         _lib.ptr(ay), _lib.ptr(bias), out.data_ptr(), ldc, M, N, K, int(bool(accumulate)), products, split_k,
         _lib.ptr(ws), _lib.stream(x.device)), 'ptmi_gemm_split')
     return out

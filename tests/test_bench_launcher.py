@@ -1,0 +1,44 @@
+"""``python bench.py --gpus 2`` launches itself as two ranks (torch.distributed.run, 127.0.0.1) - here in --dry mode on
+CPU with gloo: the same launcher, process group, layer buckets of the flat gradient buffer, all-reduce schedule and
+JSON line as on the GPUs, around a stub step whose summed gradients are checked on every rank."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _run(*extra):
+    env = dict(os.environ, OMP_NUM_THREADS='4')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--dry', '--steps', '2', '--warmup', '1', *extra],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_self_launch_two_ranks_bucketed_allreduce():
+    out = _run('--gpus', '2')
+    assert out['n_gpus'] == 2 and out['dry'] is True and out['steps'] == 2
+    assert out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 64
+    r = out['rccl']
+    assert r['world_size'] == 2 and r['overlap_allreduce'] is True
+    # PIT model: three BLSTM layers and two linears -> five layer buckets covering all 23 480 914 parameters
+    assert len(r['buckets']) == 5 and sum(r['buckets']) == 23480914 and r['flat_gradient_bytes'] == 4 * 23480914
+    assert out['value'] > 0 and out['unit'] == 'frames/s'
+
+
+def test_c4_micro_steps_single_allreduce_per_optimizer_step():
+    out = _run('--gpus', '2', '--config', 'c4', '--no-overlap-allreduce')
+    assert out['config']['global_batch'] == 64 * 2 * 4 and out['rccl']['overlap_allreduce'] is False
+    assert out['config']['frames_per_step'] == 2 * 4 * 64 * 503
+
+
+def test_single_process_dry():
+    out = _run()
+    assert out['n_gpus'] == 1 and 'rccl' not in out
