@@ -199,12 +199,18 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* c0, cons
  * workgroups hand to each other, ptmi_lstm_flags_elems(T, ndir, max_batch) arrival counters (zeroed by
  * the call) and, as the LAST 8 words, the error words (non-zero after the call = a bounded spin ran
  * out).  KP must be H rounded up to 16.  Returns PTMI_E_UNSUPPORTED when the configuration cannot be
- * kept resident (caller falls back to ptmi_lstm_forward). */
+ * kept resident (caller falls back to ptmi_lstm_forward).
+ * The default kernels (csrc/lstm_split.hip; ptmi_lstm_split_enabled() != 0) evaluate h W_hh^T as three fp16 MFMA
+ * products of (hi, lo) operand halves with fp32 accumulation (fp32-equivalent result); w_hh_amax = device word
+ * from ptmi_absmax over w_hh_pad (NULL: |W_hh| within fp16's range as it is).  The backward kernel splits into
+ * bf16 halves (no scale) and leaves max |dgates| (float bits) in the word right behind the bias gradient.
+ * PTMI_LSTM_F32=1 in the environment selects the exact-fp32 MFMA kernels of round 1. */
 int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch);
+int ptmi_lstm_split_enabled(void);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
-                                 const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
-                                 int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,
-                                 ptmi_stream_t stream);
+                                 const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                 uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
+                                 int32_t ndir, ptmi_stream_t stream);
 
 /* Persistent backward-through-time (mirror of ptmi_lstm_forward_persistent; same results as
  * ptmi_lstm_backward; no dc_state scratch: the cell-state gradient stays in registers).  `flags` is a device

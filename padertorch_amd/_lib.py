@@ -67,7 +67,8 @@ SIGNATURES = {
     'ptmi_unit_norm_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_void_p]),
     'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
     'ptmi_lstm_scratch_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
-    'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
+    'ptmi_lstm_split_enabled': (c_int, []),
+    'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                              c_int32, _P]),
     'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
                                               c_int32, _P]),

@@ -74,7 +74,7 @@ class PermutationInvariantTrainingModel(base.Model):
 
     def prepare_batch(self, batch):
         """Waveforms -> features on the device when the batch does not carry them yet."""
-        if 'Y_abs' in batch:
+        if 'Y_abs' in batch or 'y' not in batch:
             return batch
         feats = ops.pit_features(batch['y'], batch.get('s'), batch.get('num_samples'))
         out = dict(batch)

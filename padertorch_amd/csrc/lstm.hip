@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "lstm_common.h"
 
 // fragments of the backward K slice in flight per wavefront (8-wavefront kernel, see HALF there)
 #ifndef PTMI_BWD_CA
@@ -44,8 +45,6 @@
 #endif
 
 namespace ptmi {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Per-direction bookkeeping of ONE timestep, computed on the host and passed as kernel arguments
 // (a scalar load of batch_sizes[t] / offsets[t] from memory costs a cold round trip per launch).
@@ -68,17 +67,6 @@ struct LstmArgs {
     const float* c0;   // [ndir, max_batch, H] initial cell state of every sequence, or null (= 0)
     int max_batch;
 };
-
-// Gate non-linearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, about 1 ulp each): they
-// sit on the serial chain of every time step, where the library expf / tanhf / IEEE division cost about
-// 0.4 us per step.  Absolute error < 2e-7 (checked against torch's CPU LSTM in tests/test_gpu_lstm.py).
-__device__ __forceinline__ float sigmoidf_(float x) {
-    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
-}
-__device__ __forceinline__ float tanhf_(float x) {
-    const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));       // exp(-2|x|)
-    return copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
-}
 
 // One forward timestep.  grid = (ceil(H / JT), ndir, ceil(maxB / 32)), NW * 64 threads.
 // Workgroup tile: 32 batch rows x (4 gates x JT hidden units) = 32 x NC outputs, NC = 4 JT (16 or 32).
@@ -335,51 +323,6 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(const LstmBwdArg
 // observed, so no stale copy can exist in any cache.  The two directions use separate counters and
 // drift freely.  Every workgroup must be resident (checked on the host against 256 CUs x 2);
 // every spin is bounded and reports through an error word instead of hanging.
-struct LstmPersistArgs {
-    float* gx;
-    float* hy;
-    float* c;
-    const float* w;
-    const int32_t* bs;       // device [T]
-    const int64_t* offs;     // device [T]
-    unsigned* flags;         // device [ndir][row tiles][kSlots] hand-off slots + 8 error words, zeroed per call
-    int T, H, KP, ndir;
-    unsigned expected;       // producer workgroups per chain (direction x row tile)
-    unsigned max_polls;
-    int hy_bytes;
-    unsigned err_off;        // index of the error words in flags
-    int dbg;                 // PTMI_LSTM_DBG timing ablations (16: no poll, 32: no drain, 64: no MFMA, 128: no operand loads)
-    int tile0, ntiles;       // first row tile of this launch / row tiles of the whole batch
-    const float* c0;         // [ndir, max_batch, H] initial cell state or null
-    int max_batch;
-    float* hyt;              // tile-major copy of hy for the hand-off: [T][16-row tile][dir][KP / 16][16 rows][16]
-    int nt16;                // 16-row tiles of the whole batch
-};
-
-// Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has
-// finished (a plain write-through store: no read-modify-write, no two producers on one address); a
-// consumer reads all slots of its chain with one or two loads per lane and goes on when every one of them
-// has reached the step it needs.  (First form: 8 sharded arrival counters per step; the ~6 atomic adds
-// queueing on each shard were part of every step's chain.)
-constexpr int kSlots = 128;          // slots per chain = most producer workgroups a chain may have
-
-__device__ __forceinline__ bool wait_arrivals(const unsigned* slots, unsigned producers, unsigned step,
-                                              unsigned max_polls, unsigned* err) {
-    const unsigned lane = threadIdx.x & 63;
-    for (unsigned it = 0; it < max_polls; ++it) {
-        unsigned v = lane < producers ? __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
-        if (producers > 64) {
-            const unsigned w = lane + 64 < producers
-                                   ? __hip_atomic_load(slots + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
-            v = min(v, w);
-        }
-        if (__all(v >= step)) return true;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return false;
-}
-
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // MTL = 16-row M tiles per workgroup.  Row tiles are independent recurrences: each has its own
@@ -428,6 +371,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
     unsigned* const err = A.flags + A.err_off;
     const int bl = tid / JT, u = tid - bl * JT;
     const int b = m0 + bl;
+    bool alive = true;                           // false once a wait has run out: no further spinning
     float pre_n[4] = {0.f, 0.f, 0.f, 0.f};       // input pre-activations of the step about to run
     float c_reg = 0.f;                           // cell state of (b, u) after the previous step
     unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
@@ -476,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         if (!has_rec) prefetch();
         if (has_rec) {
             mark(0);
-            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
             mark(1);
             __syncthreads();
             mark(2);
@@ -601,54 +545,6 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
 // of its 8 (wide layers: 16) wavefronts for all T steps; dgates are published write-through in the
 // tile-major hand-off copy and chained by one slot per producer workgroup; the cell-state gradient and
 // the bias-gradient sums of element (b, j) live in registers of the one thread that owns it.
-struct LstmPersistBwdArgs {
-    const float* gates;
-    const float* c;
-    const float* dhy;
-    const float* wt;
-    float* dg;
-    const int32_t* bs;
-    const int64_t* offs;
-    unsigned* flags;
-    int T, H, ndir;
-    unsigned expected;
-    unsigned max_polls;
-    int dg_bytes;
-    unsigned err_off;
-    int tile0, ntiles;   // first 16-row tile of this launch / tiles of the whole batch
-    int dbg;             // PTMI_LSTM_DBG timing ablations (as in the forward kernel)
-    const float* c0;
-    int max_batch;
-    int nx, nt, span;    // 1-D grid: unit tiles, row tiles of this launch, XCDs per chain (0: plain order)
-    float* dgt;          // tile-major copy of dgates for the hand-off: [T][16-row tile][dir][4H / 16][16 rows][16]
-    int nt16;            // 16-row tiles of the whole batch
-    float* dbias;        // [ndir][4H] sum of dgates over all rows (zeroed by the host call, accumulated atomically)
-};
-
-// Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)
-// exchanges its operand rows among its own workgroups every step; they are written through one XCD's L2
-// and read over the fabric by the others, which is what bounds the hand-off at batch >= 16.  With
-// `span` = 8 / chains XCDs per chain, a chain's workgroups sit on `span` neighbouring XCDs instead of all
-// eight, so 1/span of what a workgroup reads is local.  Returns false for the padding workgroups.
-__device__ __forceinline__ bool chain_tile(int nx, int nt, int span, int* x, int* y, int* dir) {
-    const int L = blockIdx.x;
-    int chain;
-    if (span > 0) {
-        const int xcd = L & 7;
-        chain = xcd / span;
-        *x = (L >> 3) * span + (xcd - chain * span);
-        if (*x >= nx) return false;
-    } else {
-        *x = L % nx;
-        chain = L / nx;
-    }
-    *y = chain % nt;
-    *dir = chain / nt;
-    return true;
-}
-
-// MTL = 16-row tiles per workgroup (2: a batch of 64 stays ONE launch of 32-row chains; the weights in
-// registers serve both tiles, the second tile's operands are requested while the first one multiplies).
 template <int NW, int CH, int MTL = 1>
 __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
     int bx, by, dir;
@@ -682,6 +578,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
     unsigned* const err = A.flags + A.err_off;
     const int bl = (tid >> 4) & (MR - 1), jl = tid & 15;
     const int b = m0 + bl, j = n0 + jl;
+    bool alive = true;         // false once a wait has run out: no further spinning
     float dc_state = 0.f;      // d loss / d c of (b, j) flowing to the next (earlier) step
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;      // bias gradient: this thread's dgates summed over time
 
@@ -714,7 +611,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
         }
         if (has_rec) {
-            if (wave == 0 && !(A.dbg & 16)) wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
             __syncthreads();
             // The operand comes from the TILE-MAJOR copy: one load instruction of a wavefront = one 16 x 16
             // tile = 1 KB of consecutive bytes (8 full cache lines; from the row-major dgates it would be
@@ -899,6 +796,19 @@ static int enqueue_backward(const float* gates, const float* c, const float* c0,
 
 using namespace ptmi;
 
+// compute units of the current device (the residency limits of the persistent kernels derive from it)
+static int cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 // A plan = the forward and backward time loops over FIXED buffers, captured once as hipGraphs.
 // Replaying a graph costs one host call and the per-kernel dispatch overhead inside a graph is
 // lower than 2 x T eager launches (measured 7.2 vs 9.4 us per forward step at B = 32, H = 600).
@@ -964,21 +874,27 @@ static int64_t lstm_tile_elems(int32_t T, int32_t ndir, int32_t max_batch, int32
 }
 
 int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward) {
-    return lstm_tile_elems(T, ndir, max_batch, backward ? 4 * H : (H + 15) / 16 * 16) + (backward ? (int64_t)ndir * 4 * H : 0) +
-           ptmi_lstm_flags_elems(T, ndir, max_batch);
+    // [tile-major hand-off copy (columns rounded up to 32) | backward: bias gradient [ndir][4H] + 8 words (word 0: max
+    // |dgates| as float bits) | hand-off slots | 8 error words]
+    return lstm_tile_elems(T, ndir, max_batch, backward ? (4 * H + 31) / 32 * 32 : (H + 31) / 32 * 32) +
+           (backward ? (int64_t)ndir * 4 * H + 8 : 0) + ptmi_lstm_flags_elems(T, ndir, max_batch);
 }
 
+int ptmi_lstm_split_enabled(void) { return getenv("PTMI_LSTM_F32") ? 0 : 1; }
+
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
-                                 const int32_t* batch_sizes_dev, const int64_t* offsets_dev, uint32_t* flags,
-                                 int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP, int32_t ndir,
-                                 ptmi_stream_t stream) {
+                                 const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                 uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
+                                 int32_t ndir, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !hy || !c || !w_hh_pad || !batch_sizes_dev || !offsets_dev || !flags, PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
     constexpr int NW = 8, CH = 5;
     // the resident W slice must fit CH K-blocks per wavefront; all workgroups must be co-resident
     // (512-thread workgroups at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2)
-    PTMI_RETURN_IF((KP / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    const int KP32 = (H + 31) / 32 * 32;
+    const bool split = ptmi_lstm_split_enabled() && (KP32 / 32 + NW - 1) / NW <= 3;      // split kernels: <= 3 k blocks of 32 per wavefront
+    PTMI_RETURN_IF(!split && (KP / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
     // 16-row workgroups (two interleaved chains per 32 rows) while all of them stay co-resident
     // (512 threads at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2), else 32-row workgroups
     const int jx8 = (H + 7) / 8;
@@ -989,14 +905,18 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     //   5.4; 16 x 16 on 152: 5.8; 32 x 8: 6.6; 16 x 8 with 300 workgroups sharing CUs: 8.3);
     //   B > 32: 32 x 12 (B = 64: 32 x 16 8.8, 32 x 8 11.6).
     int jt = max_batch <= 16 ? 8 : 12, mtl = max_batch <= 32 ? 1 : 2;
-    if (jt == 12 && (long long)((H + 11) / 12) * ndir > 256) jt = 16;      // wide tiles: one workgroup per CU
-    if (jt == 16 && (long long)((H + 15) / 16) * ndir > 256) jt = 8;
-    if (const char* v = getenv("PTMI_LSTM_JT")) jt = atoi(v) == 16 ? 16 : (atoi(v) == 12 ? 12 : 8);
+    if (jt == 12 && (long long)((H + 11) / 12) * ndir > cu_count()) jt = 16;      // wide tiles: one workgroup per CU
+    if (jt == 16 && (long long)((H + 15) / 16) * ndir > cu_count()) jt = 8;
+    if (const char* v = getenv("PTMI_LSTM_JT")) {
+        const int q = atoi(v);
+        jt = (q == 16 || q == 12 || (split && (q == 20 || q == 24))) ? q : 8;
+    }
     if (const char* v = getenv("PTMI_LSTM_MTL")) mtl = atoi(v) == 1 ? 1 : 2;
     const bool small = mtl == 1, wide = jt >= 12;
     const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
     const int jx = wide ? (H + jt - 1) / jt : jx8;
-    const int cap = wide ? 256 : 448;     // 12/16-unit tiles need the whole register file: one workgroup per CU
+    const int cus = cu_count();
+    const int cap = wide ? cus : cus * 7 / 4;     // 12/16-unit tiles need the whole register file: one workgroup per CU
     PTMI_RETURN_IF((long long)jx * ndir > cap || jx > kSlots, PTMI_E_UNSUPPORTED);
     // row tiles are independent recurrences: a batch whose tiles do not all fit runs as several launches
     const int per_launch = std::min(ntiles, cap / (jx * ndir));
@@ -1004,18 +924,24 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     // scratch = [tile-major hy | arrival counters | 8 error words]; only the counters need zeroing
     PTMI_RETURN_IF(KP != (H + 15) / 16 * 16, PTMI_E_UNSUPPORTED);
     float* const hyt = reinterpret_cast<float*>(flags);
-    flags += lstm_tile_elems(T, ndir, max_batch, KP);
+    flags += lstm_tile_elems(T, ndir, max_batch, KP32);
     hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
                       (unsigned)jx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
-                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch, hyt, (max_batch + 15) / 16};
+                      getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch, hyt, (max_batch + 15) / 16,
+                      w_hh_amax, KP32};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
         const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt), block(NW * 64);
-        const bool one_per_cu = (long long)jx * ndir * nt <= 256;
+        const bool one_per_cu = (long long)jx * ndir * nt <= cus;
+        if (split) {
+            int rc = launch_fwd_split(A, jt, small, one_per_cu, grid, st);
+            if (rc) return rc;
+            continue;
+        }
         if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1, true>), grid, block, 0, st, A);
         else if (jt == 12 && small)
@@ -1049,33 +975,39 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
     constexpr int NW = 16, CH = 10;
-    PTMI_RETURN_IF((4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    const int G32 = (4 * H + 31) / 32 * 32;
+    const bool split = ptmi_lstm_split_enabled() && (G32 / 32 + 7) / 8 <= 10;           // split kernel: <= 10 k blocks of 32 per wavefront
+    PTMI_RETURN_IF(!split && (4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    const int resident = cu_count() - 16;     // one workgroup per CU, with a margin
     // One workgroup per CU must be resident (at most 240 per launch).  Row tiles are independent recurrences,
     // so a batch whose tiles do not fit at once runs as several launches over groups of tiles; before that,
     // 16-row chains become 32-row chains (8-wavefront workgroups, MTL = 2: one launch up to batch 64 at
     // H = 600; 7.5 us per step instead of 2 x 5.0).
     const int nx = (H + 15) / 16, nt16 = (max_batch + 15) / 16;
-    PTMI_RETURN_IF((long long)nx * ndir > 240 || nx > kSlots, PTMI_E_UNSUPPORTED);
-    const bool fits8 = (4 * H / 16 + 7) / 8 <= 19;
-    int mtl = (nt16 > 240 / (nx * ndir) && fits8) ? 2 : 1;
+    PTMI_RETURN_IF((long long)nx * ndir > resident || nx > kSlots, PTMI_E_UNSUPPORTED);
+    const bool fits8 = split || (4 * H / 16 + 7) / 8 <= 19;
+    int mtl = (nt16 > resident / (nx * ndir) && fits8) ? 2 : 1;
     if (const char* v = getenv("PTMI_LSTM_BWD_MTL")) mtl = (atoi(v) == 2 && fits8) ? 2 : 1;
     const int ntiles = (nt16 + mtl - 1) / mtl;
-    const int per_launch = std::min(ntiles, 240 / (nx * ndir));
+    const int per_launch = std::min(ntiles, resident / (nx * ndir));
     const long long dg_bytes = rows * ndir * 4 * H * 4;
     PTMI_RETURN_IF(dg_bytes > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // scratch = [tile-major dgates | bias gradient [ndir][4H] | arrival counters | 8 error words];
     // the bias gradient and the counters are zeroed here (one memset)
     float* const dgt = reinterpret_cast<float*>(flags);
-    flags += lstm_tile_elems(T, ndir, max_batch, 4 * H);
+    flags += lstm_tile_elems(T, ndir, max_batch, G32);
     float* const dbias = reinterpret_cast<float*>(flags);
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(ndir * 4 * H + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
+    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
     if (e != hipSuccess) return (int)e;
     flags += ndir * 4 * H;
+    uint32_t* const dg_amax = flags;
+    flags += 8;
     LstmPersistBwdArgs A{gates, c, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, T, H, ndir,
                          (unsigned)nx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)dg_bytes,
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
-                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16, dbias};
+                         getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16, dbias,
+                         split ? dg_amax : nullptr, G32};
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
@@ -1084,6 +1016,11 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
         A.nt = nt;
         A.span = (chains <= 8 && 8 % chains == 0 && !getenv("PTMI_LSTM_NO_XCD")) ? 8 / chains : 0;
         const unsigned nwg = A.span ? (unsigned)((nx + A.span - 1) / A.span * 8) : (unsigned)(nx * chains);
+        if (split) {
+            int rc = launch_bwd_split(A, mtl, nwg, st);
+            if (rc) return rc;
+            continue;
+        }
         if (mtl == 2)
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19, 2>), dim3(nwg), dim3(512), 0, st, A);
         else if (!getenv("PTMI_LSTM_BWD16") && fits8)    // 8 wavefronts x 19 K blocks; 16 x 10 (128 VGPRs per lane, spills) only for wider layers

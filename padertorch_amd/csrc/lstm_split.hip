@@ -1,0 +1,538 @@
+// Persistent (B)LSTM recurrence kernels with split 16-bit MFMA products (gfx950).
+//
+// Same launches, hand-off protocol (write-through tile-major copy, one slot per producer workgroup, bounded polls),
+// layouts and results as lstm_{fwd,bwd}_persistent_kernel in lstm.hip (the recurrence of torch.nn.LSTM on a
+// PackedSequence: padertorch/contrib/examples/source_separation/pit/model.py:60-66,97, contrib/tcl/dc.py:32-34,61).
+// What changes is how the per-step matrix product is evaluated.  fp32 MFMA (v_mfma_f32_16x16x4_f32) runs at 1/16 of the
+// 16-bit rate; the product h_{t-1} W_hh^T (dgates_{t+1} W_hh in the backward pass) is the longest single item of
+// every step's serial chain (60 / 76 MFMAs of 32 cycles per wavefront).  Here
+//   forward   h in (-1, 1) is handed on as fp16 (hi, lo) halves of 2^10 h, W_hh lives in registers as fp16 halves of
+//             2^(13-e) W (e = exponent of max |W_hh|, device word from ptmi_absmax), and the product is
+//             hi*hi + hi*lo + lo*hi in one fp32 accumulator (v_mfma_f32_16x16x32_f16: 9 x 3 MFMAs of ~17 cycles per
+//             wavefront): as close to the fp64 product as the exact-fp32 chain (scripts/mb/split_mfma_accuracy.hip);
+//   backward  dgates have no bound known before they are computed, so their halves are bf16 (fp32's range, no scale;
+//             error <= 7e-7 of sum |a b|, v_mfma_f32_16x16x32_bf16), W_hh^T likewise.
+// The tile-major hand-off copy keeps its size and its access pattern: a "tile" is now 16 rows x 32 k of 16-bit values
+// (1 KB, one buffer_load_dwordx4 per lane), two planes (hi, lo) per 32-wide k block; a producer lane trades one half
+// with its neighbour lane so that it still issues ONE 4-byte write-through store per value.
+#include "lstm_common.h"
+
+namespace ptmi {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+
+constexpr float kHScale = 1024.f;       // forward: h is handed on as halves of 2^10 h (lo stays normal down to |h| = 2^-13)
+
+__device__ __forceinline__ float pow2_scale(const unsigned* amax_bits) {
+    if (!amax_bits) return 1.f;
+    const unsigned e = (*amax_bits >> 23) & 0xffu;
+    if (e == 0u || e == 0xffu) return 1.f;
+    return __uint_as_float((unsigned)(127 + 13 + 127 - (int)e) << 23);
+}
+
+// 16-bit (hi, lo) halves of one value, as bit patterns
+template <bool BF16>
+__device__ __forceinline__ void split1(float v, unsigned* hi, unsigned* lo) {
+    if (BF16) {
+        const __bf16 h = (__bf16)v;
+        const __bf16 l = (__bf16)(v - (float)h);
+        *hi = __builtin_bit_cast(unsigned short, h);
+        *lo = __builtin_bit_cast(unsigned short, l);
+    } else {
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        *hi = __builtin_bit_cast(unsigned short, h);
+        *lo = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
+// 8 consecutive values -> the (hi, lo) MFMA operand registers of one lane
+template <bool BF16>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4* hi, uint4* lo) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split1<BF16>(v[e], &h[e], &l[e]);
+    *hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    *lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+template <bool BF16>
+__device__ __forceinline__ f32x4 mma16(const uint4 a, const uint4 b, const f32x4 c) {
+    if (BF16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+// One value of a producer lane -> its 4-byte store into the (hi, lo) planes.  Lanes 2i and 2i+1 own neighbouring
+// columns c, c+1 (c even): the even lane stores {hi_c, hi_c+1} into the hi plane, the odd lane {lo_c, lo_c+1} into the
+// lo plane.  Must be executed by both lanes of a pair (the exchange is a wave-level shuffle).  Returns the word and
+// sets *plane.
+template <bool BF16>
+__device__ __forceinline__ unsigned pair_word(float v, int lane, int* plane) {
+    unsigned hi, lo;
+    split1<BF16>(v, &hi, &lo);
+    const bool odd = lane & 1;
+    const unsigned send = odd ? hi : lo;                               // what the neighbour stores
+    const unsigned recv = (unsigned)__shfl_xor((int)send, 1);
+    *plane = odd ? 1 : 0;
+    return odd ? (recv | (lo << 16)) : (hi | (recv << 16));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward.  Template parameters as lstm_fwd_persistent_kernel; CB = 32-wide k blocks per wavefront (K = KP32 split
+// evenly over the NW wavefronts).
+template <int JT, int NW, int CB, int MTL, int OCC>
+__global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const LstmPersistArgs A) {
+    constexpr int NC = 4 * JT;
+    constexpr int NT = NC / 16;
+    constexpr int MR = 16 * MTL;
+    const int dir = blockIdx.y;
+    const int j0 = blockIdx.x * JT;
+    const int m0 = (A.tile0 + blockIdx.z) * MR;
+    const int H = A.H, G = 4 * H;
+    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, r = lane & 15;
+    __shared__ float red[NW][MR][NC + 1];
+
+    // this wavefront's k blocks (32 wide): an even split of the KP32 / 32 blocks
+    const int nblk = A.KP32 >> 5;
+    const int base = nblk / NW, extra = nblk - base * NW;
+    const int kb0 = __builtin_amdgcn_readfirstlane(wave * base + min(wave, extra));
+    const int nbw = __builtin_amdgcn_readfirstlane(base + (wave < extra ? 1 : 0));        // <= CB (host checked)
+    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));
+    const int ilast = __builtin_amdgcn_readfirstlane(max(nbw - 1, 0));
+    const float ws = pow2_scale(A.w_amax);
+    const float inv = 1.f / (ws * kHScale);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // resident slice of W_hh as fp16 halves: lane (gate column r of tile nt, k group g4) holds k = 32 (kb0 + i) + 8 g4 ..
+    uint4 bh[CB][NT], bl[CB][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cidx = nt * 16 + r;
+        const int gate = cidx / JT, uu = cidx - gate * JT;
+        const bool bv = j0 + uu < H;
+        const float* bp = A.w + ((long long)dir * G + gate * H + (bv ? j0 + uu : 0)) * A.KP;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int k = (kb0 + i) * 32 + g4 * 8;
+            const bool in = bv && i < nbw;
+            const f32x4 w0 = (in && k + 4 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 4 <= A.KP ? k : 0)) : zero;
+            const f32x4 w1 = (in && k + 8 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 8 <= A.KP ? k + 4 : 0)) : zero;
+            const float v[8] = {w0[0] * ws, w0[1] * ws, w0[2] * ws, w0[3] * ws, w1[0] * ws, w1[1] * ws, w1[2] * ws, w1[3] * ws};
+            split8<false>(v, &bh[i][nt], &bl[i][nt]);
+        }
+    }
+    const size_t tile_elems = (size_t)A.KP32 * 16;       // floats per (time, 16-row tile, direction): 2 halves per value
+    const int tile16 = (A.tile0 + blockIdx.z) * MTL;
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * kSlots;
+    unsigned* const err = A.flags + A.err_off;
+    const int bl_ = tid / JT, u = tid - bl_ * JT;
+    const int b = m0 + bl_;
+    bool alive = true;
+    float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_reg = 0.f;
+    {
+        const int t0 = dir == 0 ? 0 : A.T - 1;
+        if (tid < MR * JT && b < A.bs[t0] && j0 + u < H) {
+            const float* np = A.gx + (A.offs[t0] + b) * ld_g + (long long)dir * G + j0 + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
+        }
+    }
+
+    for (int s = 0; s < A.T; ++s) {
+        const int t = dir == 0 ? s : A.T - 1 - s;
+        const int nb = A.bs[t];
+        const long long row0 = A.offs[t];
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int nprev = (tp >= 0 && tp < A.T) ? min(A.bs[tp], nb) : 0;
+        const bool has_rec = nprev > m0;
+        const bool act = tid < MR * JT && b < nb && j0 + u < H;
+        float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
+        float cprev = 0.f;
+        float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
+        if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
+        const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
+        const bool more = s + 1 < A.T;
+        const int nb1 = more ? A.bs[t1] : 0;
+        const long long row1 = more ? A.offs[t1] : 0;
+        auto prefetch = [&]() {
+            if (tid < MR * JT && b < nb1 && j0 + u < H && !(A.dbg & 256)) {
+                const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
+            }
+        };
+        if (!has_rec) prefetch();
+        if (has_rec) {
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            __syncthreads();
+            if (act && b < nprev) cprev = c_reg;
+            // fragments: (row tile mt, k block i, plane p); one 1 KB tile per load instruction
+            constexpr int NF = MTL * CB * 2;
+            const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+                A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
+            const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+                A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
+            const unsigned vin = (unsigned)(kfirst * 2048 + r * 64 + g4 * 16);
+            const unsigned vb0 = (m0 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
+            auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
+                const int mt = f / (2 * CB), rem = f - mt * 2 * CB, i = rem >> 1, p = rem & 1;
+                return mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, (min(i, ilast) * 2 + p) * 1024, 16 /* sc1 */)
+                               : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, (min(i, ilast) * 2 + p) * 1024, 16);
+            };
+            uint4 a[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) a[f] = __builtin_bit_cast(uint4, fragment(f));
+            prefetch();
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[MTL][NT];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+            if (!(A.dbg & 64)) {
+#pragma unroll
+                for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                    for (int i = 0; i < CB; ++i) {
+                        const uint4 ah = a[(mt * CB + i) * 2], al = a[(mt * CB + i) * 2 + 1];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(al, bh[i][nt], acc[mt][nt]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bl[i][nt], acc[mt][nt]);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bh[i][nt], acc[mt][nt]);
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            __syncthreads();
+            if (tid < MR * JT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cidx = q * JT + u;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += red[w][bl_][cidx];
+                    pre[q] += sum * inv;
+                }
+            }
+        }
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
+        if (act) {
+            ig = sigmoidf_(pre[0]);
+            fg = sigmoidf_(pre[1]);
+            gg = tanhf_(pre[2]);
+            og = sigmoidf_(pre[3]);
+            c_reg = fg * cprev + ig * gg;
+            h = og * tanhf_(c_reg);
+        }
+        // hand-off copy: the (hi, lo) planes of this step's tile, written through; lanes 2i / 2i+1 trade one half
+        {
+            int plane;
+            const unsigned word = pair_word<false>(h * kHScale, lane, &plane);
+            if (act) {
+                const int ce = (j0 + u) & ~1;
+                unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
+                __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16 + (bl_ & 15)) * 32 + (ce & 31)) / 2, word, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (j0 < H && j0 + JT >= H) {                     // owner of the last unit: zero the padding columns H .. KP32-1
+            const int pw2 = (A.KP32 - H) >> 1;           // pairs per row and plane
+            for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
+                const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = H + 2 * (rem - plane * pw2);
+                if (m0 + rl < nb) {
+                    unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
+                    __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16 + (rl & 15)) * 32 + (ce & 31)) / 2, 0u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(myflags + blockIdx.x, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (act) {                                        // nobody in this launch reads these
+            gp[0] = ig;
+            gp[H] = fg;
+            gp[2 * H] = gg;
+            gp[3 * H] = og;
+            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
+            A.c[o] = c_reg;
+            A.hy[o] = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward-through-time.  8 wavefronts, CB = 32-wide k blocks of K = 4H per wavefront (even split), CAB blocks in
+// flight per wavefront (re-requested as soon as their MFMAs have consumed them, as in lstm_bwd_persistent_kernel).
+template <int NW, int CB, int MTL>
+__global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
+    int bx, by, dir;
+    if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
+    const int n0 = bx * 16;
+    constexpr int MR = 16 * MTL;
+    const int m0 = (A.tile0 + by) * MR;
+    const int tile16 = (A.tile0 + by) * MTL;
+    const int H = A.H, G = 4 * H;
+    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, r = lane & 15;
+    __shared__ float red[NW][MR][17];
+
+    const int nblk = A.G32 >> 5;
+    const int base = nblk / NW, extra = nblk - base * NW;
+    const int kb0 = __builtin_amdgcn_readfirstlane(wave * base + min(wave, extra));
+    const int nbw = __builtin_amdgcn_readfirstlane(base + (wave < extra ? 1 : 0));        // <= CB (host checked)
+    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));
+    const int ilast = __builtin_amdgcn_readfirstlane(max(nbw - 1, 0));
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    // resident slice of W_hh^T as bf16 halves: lane (hidden unit n0 + r, k group g4)
+    uint4 bh[CB], bl[CB];
+    {
+        const bool bv = n0 + r < H;
+        const float* bp = A.wt + ((long long)dir * H + (bv ? n0 + r : 0)) * G;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int k = (kb0 + i) * 32 + g4 * 8;
+            const bool in = bv && i < nbw;
+            const f32x4 w0 = (in && k + 4 <= G) ? *reinterpret_cast<const f32x4*>(bp + (k + 4 <= G ? k : 0)) : zero;
+            const f32x4 w1 = (in && k + 8 <= G) ? *reinterpret_cast<const f32x4*>(bp + (k + 8 <= G ? k + 4 : 0)) : zero;
+            const float v[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+            split8<true>(v, &bh[i], &bl[i]);
+        }
+    }
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * kSlots;
+    unsigned* const err = A.flags + A.err_off;
+    const int bl_ = (tid >> 4) & (MR - 1), jl = tid & 15;
+    const int b = m0 + bl_, j = n0 + jl;
+    const size_t tile_elems = (size_t)A.G32 * 16;          // floats per (time, 16-row tile, direction)
+    bool alive = true;
+    float dc_state = 0.f;
+    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;
+    float amax = 0.f;                                      // max |dgates| this thread has produced
+
+    for (int s = 0; s < A.T; ++s) {
+        const int t = dir == 0 ? A.T - 1 - s : s;
+        const int nb = A.bs[t];
+        const long long row0 = A.offs[t];
+        const int tn = dir == 0 ? t + 1 : t - 1;
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int nnext = (tn >= 0 && tn < A.T) ? min(A.bs[tn], nb) : 0;
+        int npv = 0;
+        long long prow0 = 0;
+        if (tp >= 0 && tp < A.T) {
+            npv = min(A.bs[tp], nb);
+            prow0 = A.offs[tp];
+        }
+        const bool has_rec = nnext > m0;
+        const bool act = tid < 16 * MR && b < nb && j < H;
+        float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cprev = 0.f;
+        const long long oh = (row0 + b) * ld_h + dir * H + j;
+        const long long og_ = (row0 + b) * ld_g + (long long)dir * G + j;
+        if (act) {
+            dh = A.dhy[oh];
+            ig = A.gates[og_];
+            fg = A.gates[og_ + H];
+            gg = A.gates[og_ + 2 * H];
+            og = A.gates[og_ + 3 * H];
+            cn = A.c[oh];
+            if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
+            else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
+        }
+        if (has_rec) {
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            __syncthreads();
+            const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * tile_elems;
+            const unsigned vin = (unsigned)(kfirst * 2048 + r * 64 + g4 * 16);
+            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, A.G32 * 64, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(tbase + (MTL > 1 ? (size_t)A.ndir * tile_elems : 0)), 0, A.G32 * 64, 0x00020000);
+            const unsigned vb0 = (m0 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
+            constexpr int NB = MTL * CB;                    // k blocks of the first row tile, then of the second
+            constexpr int CAB = 3 < NB ? 3 : NB;            // blocks in flight
+            auto fragment = [&](int blk, int p) {           // compile-time constants after unrolling
+                const int mt = blk / CB, i = blk - mt * CB;
+                return __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, vb0, (min(i, ilast) * 2 + p) * 1024, 16 /* sc1 */)
+                                                         : __builtin_amdgcn_raw_buffer_load_b128(rs1, vb1, (min(i, ilast) * 2 + p) * 1024, 16));
+            };
+            uint4 ah[CAB], al[CAB];
+#pragma unroll
+            for (int i = 0; i < CAB; ++i) {
+                ah[i] = fragment(i, 0);
+                al[i] = fragment(i, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // one accumulator per product kind: three consecutive MFMAs never wait for each other's result
+            f32x4 acc3[MTL][3];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc3[mt][k] = zero;
+#pragma unroll
+            for (int p0 = 0; p0 < NB; p0 += CAB) {
+#pragma unroll
+                for (int i = 0; i < CAB; ++i) {
+                    const int blk = p0 + i;
+                    if (blk < NB) {
+                        if (!(A.dbg & 64)) {
+                            acc3[blk / CB][0] = mma16<true>(al[i], bh[blk % CB], acc3[blk / CB][0]);
+                            acc3[blk / CB][1] = mma16<true>(ah[i], bl[blk % CB], acc3[blk / CB][1]);
+                            acc3[blk / CB][2] = mma16<true>(ah[i], bh[blk % CB], acc3[blk / CB][2]);
+                        }
+                        if (blk + CAB < NB) {
+                            ah[i] = fragment(blk + CAB, 0);
+                            al[i] = fragment(blk + CAB, 1);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][r] = (acc3[mt][0][q] + acc3[mt][1][q]) + acc3[mt][2][q];
+            __syncthreads();
+            if (tid < 16 * MR && b < nnext) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += red[w][bl_][jl];
+                dh += sum;
+            }
+        }
+        float gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f;
+        if (act) {
+            float dc = b < nnext ? dc_state : 0.f;
+            const float tc = tanhf_(cn);
+            const float d_o = dh * tc;
+            dc += dh * og * (1.f - tc * tc);
+            const float d_i = dc * gg;
+            const float d_g = dc * ig;
+            const float d_f = dc * cprev;
+            dc_state = dc * fg;
+            gi = d_i * ig * (1.f - ig);
+            gf = d_f * fg * (1.f - fg);
+            gc = d_g * (1.f - gg * gg);
+            go = d_o * og * (1.f - og);
+            sb0 += gi;
+            sb1 += gf;
+            sb2 += gc;
+            sb3 += go;
+            amax = fmaxf(fmaxf(amax, fmaxf(fabsf(gi), fabsf(gf))), fmaxf(fabsf(gc), fabsf(go)));
+            float* dgp = A.dg + og_;                  // row-major: what the weight / input gradient GEMMs read
+            dgp[0] = gi;
+            dgp[H] = gf;
+            dgp[2 * H] = gc;
+            dgp[3 * H] = go;
+        }
+        // hand-off copy: bf16 (hi, lo) planes, written through; lanes 2i / 2i+1 (columns c, c+1) trade one half
+        {
+            int plane;
+            const unsigned w0 = pair_word<true>(gi, lane, &plane);
+            const unsigned w1 = pair_word<true>(gf, lane, &plane);
+            const unsigned w2 = pair_word<true>(gc, lane, &plane);
+            const unsigned w3 = pair_word<true>(go, lane, &plane);
+            if (act) {
+                unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
+                const int je = j & ~1;
+                const int rowoff = (bl_ & 15) * 32;
+                const unsigned ws_[4] = {w0, w1, w2, w3};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ce = g * H + je;
+                    __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16) * 32 + rowoff + (ce & 31)) / 2, ws_[g], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (A.G32 != G && n0 + 16 >= H && n0 < H) {       // owner of the last unit tile: zero the padding columns 4H .. G32-1
+            const int pw2 = (A.G32 - G) >> 1;
+            for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
+                const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = G + 2 * (rem - plane * pw2);
+                if (m0 + rl < nb) {
+                    unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
+                    __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16 + (rl & 15)) * 32 + (ce & 31)) / 2, 0u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // bias gradient = sum of dgates over all rows; max |dgates| for the GEMMs that follow (operand scale)
+    float* const fold = &red[0][0][0];
+    __syncthreads();
+    if (tid < 16 * MR) {
+        fold[(0 * MR + bl_) * 16 + jl] = sb0;
+        fold[(1 * MR + bl_) * 16 + jl] = sb1;
+        fold[(2 * MR + bl_) * 16 + jl] = sb2;
+        fold[(3 * MR + bl_) * 16 + jl] = sb3;
+    }
+    __syncthreads();
+    if (tid < 64 && n0 + jl < H) {
+        const int g = tid >> 4;
+        float sum = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < MR; ++rr) sum += fold[(g * MR + rr) * 16 + jl];
+        atomicAdd(A.dbias + (size_t)dir * G + g * H + n0 + jl, sum);
+    }
+    unsigned m = __float_as_uint(amax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0 && m != 0u && A.dg_amax) atomicMax(A.dg_amax, min(m, 0x7f7fffffu));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st) {
+    constexpr int NW = 8, CB = 3;
+    const dim3 block(NW * 64);
+    const bool wide = jt >= 12;
+    if (jt == 20 && small)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 1, 1>), grid, block, 0, st, A);
+    else if (jt == 20)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 2, 1>), grid, block, 0, st, A);
+    else if (jt == 24 && small)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<24, NW, CB, 1, 1>), grid, block, 0, st, A);
+    else if (jt == 12 && small)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 1, 1>), grid, block, 0, st, A);
+    else if (wide && small)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 1, 1>), grid, block, 0, st, A);
+    else if (jt == 12)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 2, 1>), grid, block, 0, st, A);
+    else if (wide)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 2, 1>), grid, block, 0, st, A);
+    else if (small && one_per_cu)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 1, 1>), grid, block, 0, st, A);
+    else if (small)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 1, 2>), grid, block, 0, st, A);
+    else if (one_per_cu)
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 2, 1>), grid, block, 0, st, A);
+    else
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 2, 2>), grid, block, 0, st, A);
+    return launch_status();
+}
+
+int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
+    if (mtl == 2)
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2>), dim3(nwg), dim3(512), 0, st, A);
+    else
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1>), dim3(nwg), dim3(512), 0, st, A);
+    return launch_status();
+}
+
+}  // namespace ptmi

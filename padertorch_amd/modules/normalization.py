@@ -207,113 +207,114 @@ def normalize(x, gamma, beta, statistics_axis, batch_axis, sequence_axis, sequen
                             shift, scale, eps)
 
 
+def _axes(data_format, letters):
+    """Positions of the axis ``letters`` in ``data_format`` (both case-insensitive)."""
+    fmt = data_format.lower()
+    return tuple(fmt.index(a.lower()) for a in letters)
+
+
+def _stat_shape(shape, rank, keep=None, drop=None):
+    """Broadcastable statistics / parameter shape: the sizes of the ``keep`` axes (all others 1), or ``shape`` with the
+    ``drop`` axes set to 1.  Every size that stays must be known."""
+    if keep is not None:
+        out = [shape[ax] if ax in keep else 1 for ax in range(rank)]
+    else:
+        out = [1 if ax in drop else shape[ax] for ax in range(rank)]
+    assert all(d is not None for d in out), (shape, out)
+    return out
+
+
 class Normalization(nn.Module):
-    """Same arguments and state as the reference class (``normalization.py:8-188``)."""
+    """Masked normalisation layer with the arguments, parameters (``gamma``, ``beta``), buffers
+    (``num_tracked_values``, ``running_mean``, ``running_power``) and semantics of the reference class
+    (``padertorch/modules/normalization.py:8-262``): statistics over ``statistics_axis`` of the valid part of every
+    sequence, learnable scale / shift along ``independent_axis``; when the batch axis is among the statistics axes,
+    running statistics are tracked during training (exponentially with ``momentum``, cumulatively with
+    ``momentum=None``) and used in evaluation.  The arithmetic runs in ``csrc/norm.hip`` (``normalize`` above)."""
 
     def __init__(self, data_format='bcft', shape=None, *, statistics_axis='bft', independent_axis='c',
                  batch_axis='b', sequence_axis='t', shift=True, scale=True, eps: float = 1e-5, momentum=0.95):
         super().__init__()
+        rank = len(data_format)
         self.data_format = data_format.lower()
-        self.batch_axis = None if batch_axis is None else data_format.index(batch_axis.lower())
-        self.sequence_axis = None if sequence_axis is None else data_format.index(sequence_axis.lower())
-        self.statistics_axis = tuple([data_format.index(ax.lower()) for ax in statistics_axis])
-        self.shift = shift
-        self.scale = scale
-        self.eps = eps
-        self.track_running_stats = batch_axis in statistics_axis
-        if self.track_running_stats:
-            reduced_shape = [*shape]
-            for ax in self.statistics_axis:
-                reduced_shape[ax] = 1
-            assert not any([d is None for d in reduced_shape])
-            self.register_buffer('num_tracked_values', torch.zeros(reduced_shape))
-            if shift:
-                self.register_buffer('running_mean', torch.zeros(reduced_shape))
-            else:
-                self.register_parameter('running_mean', None)
-            if scale:
-                self.register_buffer('running_power', torch.ones(reduced_shape))
-            else:
-                self.register_parameter('running_power', None)
-        else:
-            self.register_parameter('num_tracked_values', None)
-            self.register_parameter('running_mean', None)
-            self.register_parameter('running_power', None)
-        self.momentum = momentum
-        if independent_axis is not None:
-            reduced_shape = len(data_format) * [1]
-            for ax in independent_axis:
-                ax = data_format.index(ax.lower())
-                assert shape[ax] is not None, shape[ax]
-                reduced_shape[ax] = shape[ax]
-            self.gamma = nn.Parameter(torch.ones(reduced_shape), requires_grad=True) if scale else None
-            self.beta = nn.Parameter(torch.zeros(reduced_shape), requires_grad=True) if self.shift else None
-        else:
-            self.gamma = None
-            self.beta = None
+        self.batch_axis, = _axes(data_format, batch_axis) if batch_axis is not None else (None,)
+        self.sequence_axis, = _axes(data_format, sequence_axis) if sequence_axis is not None else (None,)
+        self.statistics_axis = _axes(data_format, statistics_axis)
+        self.shift, self.scale, self.eps, self.momentum = shift, scale, eps, momentum
         self.frozen_stats = False
+        # running statistics exist iff the statistics are shared across the batch
+        self.track_running_stats = batch_axis in statistics_axis
+        state = _stat_shape(shape, rank, drop=self.statistics_axis) if self.track_running_stats else None
+        for name, wanted, fill in (('num_tracked_values', True, 0.), ('running_mean', shift, 0.), ('running_power', scale, 1.)):
+            if state is not None and wanted:
+                self.register_buffer(name, torch.full(state, fill))
+            else:
+                self.register_parameter(name, None)
+        self.gamma = self.beta = None
+        if independent_axis is not None:
+            per_channel = _stat_shape(shape, rank, keep=_axes(data_format, independent_axis))
+            if scale:
+                self.gamma = nn.Parameter(torch.ones(per_channel))
+            if shift:
+                self.beta = nn.Parameter(torch.zeros(per_channel))
 
     @property
     def running_var(self):
-        n = torch.clip(self.num_tracked_values, min=2)
-        running_var = self.running_power
+        """Unbiased running variance (at least ``eps``) from the tracked power, mean and count."""
+        var = self.running_power
         if self.shift:
-            running_var = n / (n - 1) * running_var - self.running_mean ** 2
-        running_var = torch.clamp(running_var, min=0.)
-        running_var = running_var + self.eps
-        return running_var
+            n = self.num_tracked_values.clamp(min=2)
+            var = var * (n / (n - 1)) - self.running_mean.square()
+        return var.clamp(min=0.) + self.eps
 
     def reset_running_stats(self):
-        if self.track_running_stats:
-            self.num_tracked_values.zero_()
-            if self.shift:
-                self.running_mean.zero_()
-            if self.scale:
-                self.running_power.fill_(1)
+        if not self.track_running_stats:
+            return
+        self.num_tracked_values.zero_()
+        if self.shift:
+            self.running_mean.zero_()
+        if self.scale:
+            self.running_power.fill_(1)
+
+    def _set_trainable(self, flag):
+        for p in self.parameters():
+            p.requires_grad = flag
 
     def freeze(self, freeze_stats=True):
-        for param in self.parameters():
-            param.requires_grad = False
+        self._set_trainable(False)
         self.frozen_stats = freeze_stats
 
     def unfreeze(self):
-        for param in self.parameters():
-            param.requires_grad = True
+        self._set_trainable(True)
         self.frozen_stats = False
 
     def forward(self, x, sequence_lengths=None):
-        if (self.training and not self.frozen_stats) or not self.track_running_stats:
-            x, mean, power, n_values = normalize(
-                x, gamma=self.gamma, beta=self.beta, statistics_axis=self.statistics_axis,
-                batch_axis=self.batch_axis, sequence_axis=self.sequence_axis, sequence_lengths=sequence_lengths,
-                shift=self.shift, scale=self.scale, eps=self.eps)
-            if self.track_running_stats:
-                self._update_running_stats(mean, power, n_values)
-        else:
-            x = self._running_norm(x, sequence_lengths)
-        return x
+        use_batch_statistics = not self.track_running_stats or (self.training and not self.frozen_stats)
+        if not use_batch_statistics:
+            return self._running_norm(x, sequence_lengths)
+        y, mean, power, n_values = normalize(x, self.gamma, self.beta, self.statistics_axis, self.batch_axis,
+                                             self.sequence_axis, sequence_lengths, self.shift, self.scale, self.eps)
+        if self.track_running_stats:
+            self._update_running_stats(mean, power, n_values)
+        return y
 
     def _update_running_stats(self, mean, power, n_values):
+        """``running <- m running + (1 - m) new`` with ``m = momentum``, or the share of the values seen before this
+        batch when ``momentum`` is ``None`` (cumulative average)."""
         self.num_tracked_values += n_values.detach()
-        if self.momentum is None:
-            momentum = 1 - n_values / self.num_tracked_values.detach()
-        else:
-            momentum = self.momentum
-        if self.shift:
-            self.running_mean *= momentum
-            self.running_mean += (1 - momentum) * mean.detach()
-        if self.scale:
-            self.running_power *= momentum
-            self.running_power += (1 - momentum) * power.detach()
+        keep = self.momentum if self.momentum is not None else 1 - n_values / self.num_tracked_values.detach()
+        for wanted, running, new in ((self.shift, self.running_mean, mean), (self.scale, self.running_power, power)):
+            if wanted:
+                running.mul_(keep).add_((1 - keep) * new.detach())
 
     def _running_norm(self, x, sequence_lengths):
         mean = self.running_mean.detach() if self.shift else None
-        rstd = torch.rsqrt(self.running_var.detach() + self.eps) if self.scale else None   # (eps twice, like :238)
+        rstd = torch.rsqrt(self.running_var.detach() + self.eps) if self.scale else None   # eps enters twice, as in the reference (:238)
         return _RunningNorm.apply(x, self.gamma, self.beta, mean, rstd, self.statistics_axis, self.batch_axis,
                                   self.sequence_axis, sequence_lengths)
 
     def inverse(self, x, sequence_lengths=None):
-        """``normalization.py:248-262`` (torch ops: not on the training path)."""
+        """Undo the running-statistics normalisation (reference ``:248-262``; plain torch ops, not on the training path)."""
         if not self.track_running_stats:
             raise NotImplementedError
         if self.beta is not None:
@@ -321,13 +322,13 @@ class Normalization(nn.Module):
         if self.gamma is not None:
             x = x / self.gamma
         if self.scale:
-            x = torch.sqrt(self.running_var.detach() + self.eps) * x
+            x = x * torch.sqrt(self.running_var.detach() + self.eps)
         if self.shift:
             x = x + self.running_mean.detach()
-        if sequence_lengths is not None:
-            from ..ops.sequence.mask import compute_mask
-            x = x * compute_mask(x, sequence_lengths, self.batch_axis, self.sequence_axis)
-        return x
+        if sequence_lengths is None:
+            return x
+        from ..ops.sequence.mask import compute_mask
+        return x * compute_mask(x, sequence_lengths, self.batch_axis, self.sequence_axis)
 
 
 class InputNormalization(Normalization):

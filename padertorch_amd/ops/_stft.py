@@ -275,9 +275,25 @@ class STFT:
         return ceil(frames) if self._pad else int(np.floor(frames))
 
     def sample_index_to_frame_index(self, sample_index):
-        raise NotImplementedError(
-            'paderbox.sample_index_to_stft_frame_index is third-party, absent from the reference '
-            'tree and not pinned by any reference test (SURVEY.md section 8c: parity unpinned).')
+        """Index of the frame that represents ``sample_index`` best: the last frame whose window centre
+        (``start + window_length // 2``) is not behind the sample, at least 0; with fading the frame grid starts
+        ``pad_left`` samples before the signal.
+
+        The reference defers to ``paderbox.transform.module_stft.sample_index_to_stft_frame_index``
+        (``_stft.py:281-293``), which is third-party, absent from the reference tree and exercised by no reference
+        test: this restates its published behaviour (``[f(i, 8, 1, fading=None) for i in range(12)] ==
+        [0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7]``; fading adds the ``ceil(pad / shift)`` frames in front) and its
+        parity to paderbox is UNPINNED, like the mel filterbank."""
+        lead = 0
+        if self._fading not in (None, False):
+            pad_left = self.window_length - self.shift
+            if self._fading == 'half':
+                pad_left //= 2
+            lead = -(-pad_left // self.shift)
+        centre = self.window_length // 2
+        if isinstance(sample_index, np.ndarray):
+            return np.maximum((sample_index - centre) // self.shift, 0).astype(np.int64) + lead
+        return max((int(sample_index) - centre) // self.shift, 0) + lead
 
     def frames_to_samples(self, frames):
         """paderbox ``_stft_frames_to_samples(frames, window_length, shift, fading)``."""

@@ -359,9 +359,12 @@ class _LstmLayerFn(torch.autograd.Function):
             if PERSISTENT:
                 flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 0)),
                                     dtype=torch.int32, device=x.device)
+                # split-precision recurrence: the scale of W_hh's fp16 halves comes from its maximum (cached per optimizer step)
+                amax_whh = (_gemm.weights_absmax([ps[1] for ps in params]) if params is not None else _gemm.absmax(
+                    w_pad.view(-1, KP))) if lib.ptmi_lstm_split_enabled() else None
                 rc = _lib.timed(
                     'lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(),
-                    c.data_ptr(), _lib.ptr(c0), w_pad.data_ptr(), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
+                    c.data_ptr(), _lib.ptr(c0), w_pad.data_ptr(), _lib.ptr(amax_whh), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
                     flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, KP, ndir, st)
                 if rc not in (0, -2):
                     _lib.check(rc, 'ptmi_lstm_forward_persistent')
@@ -387,7 +390,7 @@ class _LstmLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dhy, _dc=None):
         meta, lease = ctx.meta, ctx.lease
-        h0 = c0 = db_kernel = None
+        h0 = c0 = db_kernel = amax_kernel = None
         lib = _lib.load()
         st = _lib.stream(dhy.device)
         if lease is not None:
@@ -424,8 +427,11 @@ class _LstmLayerFn(torch.autograd.Function):
                     if CHECK_PERSISTENT_ERRORS:
                         check_errors()
                     # the kernel also summed dgates over the rows: [ndir * 4H] floats in front of the counters
-                    nflags = int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch))
+                    # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]
+                    nflags = int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)) + 8
                     db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
+                    if lib.ptmi_lstm_split_enabled():
+                        amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
             if rc == -2:
                 dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
                 _lib.check(_lib.timed(
@@ -435,7 +441,8 @@ class _LstmLayerFn(torch.autograd.Function):
         gm = ctx.gemm
         if gm is not None:
             amax_x, amax_w = gm
-            amax_dg = _gemm.absmax(dg)          # one scale for the whole gate-gradient tensor (both directions)
+            # one scale for the whole gate-gradient tensor (both directions): the backward kernel tracked its maximum
+            amax_dg = amax_kernel if amax_kernel is not None else _gemm.absmax(dg)
             dx = _gemm.mm(dg, w_ih, amax_x=amax_dg, amax_y=amax_w) if ctx.needs_input_grad[0] else None
         else:
             dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
@@ -552,6 +559,10 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0)
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
+    if not (torch.is_grad_enabled() and h.requires_grad):
+        # inference: nobody will run Trainer.clip_grad (which reads the watchdog words of the persistent kernels during
+        # training) - check them here, so that results of a timed-out launch are never returned silently
+        check_errors()
     out = PackedSequence(h, packed.batch_sizes)
     if want_state:
         return out, (torch.stack(h_n), torch.stack(c_n))

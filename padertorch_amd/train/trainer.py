@@ -203,7 +203,7 @@ class Trainer:
         self.validation_iterator = validation_iterator
         self.validation_metric = metric
         self.validation_maximize = maximize
-        self._best = None
+        self._best = None          # a resume restores it from the checkpoint (load_state_dict runs after this)
 
     def to(self, device):
         self.model.to(device)
@@ -228,6 +228,8 @@ class Trainer:
             assert not self.checkpoint_dir.exists() or not any(self.checkpoint_dir.iterdir()), \
                 f'A checkpoint directory already exists ({self.checkpoint_dir}); use resume=True'
             self.iteration, self.epoch = 0, 0
+            for trigger in (self.summary_trigger, self.checkpoint_trigger, self.stop_trigger):
+                trigger.set_last(-1, -1)
         self.model.train()
         self.to(device)
         W = self.world_size
@@ -269,6 +271,7 @@ class Trainer:
                     elif minibatch_index == 0:
                         self._pre_step()
                     if self.rank < len(group):
+                        self._collective_loss_check = W > 1 and not self.deferred_checks
                         loss, example, model_output, review = self.train_step(
                             self.model, group[self.rank], device)
                         self.train_summary.update(review)
@@ -277,6 +280,8 @@ class Trainer:
                         loss.backward(retain_graph=False)
                         self._time('time_per_backward', t0)
                         del loss
+                    elif W > 1 and not self.deferred_checks:
+                        self._all_ranks_finite(True)      # takes part in the other ranks' loss check
                     # else: idle rank of a partial last group: contributes zero gradient (:408)
                 if optimize:
                     t0 = time.perf_counter()
@@ -365,6 +370,8 @@ class Trainer:
             with torch.no_grad():
                 for example in validation_iterator:
                     yield self.validation_step(self.model, example, self.device)
+            from ..ops import lstm as _lstm
+            _lstm.check_errors()        # the watchdog words of the persistent LSTM kernels (nothing else reads them here)
         finally:
             self.model.train(train_end_time)
 
@@ -500,7 +507,14 @@ class Trainer:
             loss_value = loss.item()
         review['scalars']['loss'] = loss_value
         assert loss.dim() == 0, loss
-        if not np.isfinite(loss_value):
+        finite = bool(np.isfinite(loss_value))
+        if getattr(self, '_collective_loss_check', False) and self.model.training:
+            # data parallel: every rank learns about a non-finite loss on ANY rank before the next collective, so that
+            # all of them raise instead of one raising and the others blocking in the gradient all-reduce
+            everyone = self._all_ranks_finite(finite)
+            if finite and not everyone:
+                raise RuntimeError('The loss of another rank is not finite (see its error state).')
+        if not finite:
             path = self.log_error_state({'state_dict': self.state_dict(), 'review': review})
             raise RuntimeError(f'The loss ({loss_value}) is not finite.\n'
                                f'See error states (model, example, model_out and review) in {path}.')
@@ -574,6 +588,13 @@ class Trainer:
         _lstm.GRAD_READY_HOOK = lambda params: buckets.ready(params, side)
         return [p.register_post_accumulate_grad_hook(on_grad) for p in self._flat.params]
 
+    def _all_ranks_finite(self, mine):
+        """Logical AND of ``mine`` over all ranks (one tiny all-reduce)."""
+        dev = self._flat.flat.device if self._flat is not None else 'cpu'
+        flag = torch.tensor([0. if mine else 1.], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return float(flag.item()) == 0.
+
     def _broadcast_parameters(self):
         """Step-0 sync: every rank starts from rank 0's weights and buffers."""
         with torch.no_grad():
@@ -591,13 +612,26 @@ class Trainer:
     def state_dict(self):
         """trainer.py:789-810."""
         return dict(model=self.model.state_dict(), iteration=self.iteration, epoch=self.epoch,
-                    optimizer=self.optimizer.state_dict() if self.optimizer.optimizer else None)
+                    optimizer=self.optimizer.state_dict() if self.optimizer.optimizer else None,
+                    # the reference's key for hook states (trainer.py:800-810), empty: the fixed hooks of this Trainer keep
+                    # their state under their own key, so that the reference Trainer can resume from this file
+                    hooks={},
+                    ptmi_hooks=dict(best=getattr(self, '_best', None), validation_metric=self.validation_metric,
+                                    validation_maximize=getattr(self, 'validation_maximize', False)))
 
     def load_state_dict(self, state_dict):
         self.model.load_state_dict(state_dict['model'])
         if state_dict.get('optimizer') is not None:
             self.optimizer.load_state_dict(state_dict['optimizer'])
         self.iteration, self.epoch = state_dict['iteration'], state_dict['epoch']
+        hooks = state_dict.get('ptmi_hooks')
+        if hooks is not None:                           # best-checkpoint tracking continues across a resume
+            self._best = hooks.get('best')
+            self.validation_metric = hooks.get('validation_metric', self.validation_metric)
+            self.validation_maximize = hooks.get('validation_maximize', getattr(self, 'validation_maximize', False))
+        # like the reference after a resume (trainer.py:845-851): the triggers have already fired for this iteration
+        for trigger in (self.summary_trigger, self.checkpoint_trigger, self.stop_trigger):
+            trigger.set_last(self.iteration, self.epoch)
 
     def save_checkpoint(self, checkpoint_path=None):
         """``ckpt_{iteration}.pth`` + relative symlink ``ckpt_latest.pth`` (trainer.py:812-828)."""
@@ -637,12 +671,13 @@ class Trainer:
         backup = copy.deepcopy(self.state_dict())
         saved = (self.storage_dir, self.iteration, self.epoch, self.stop_trigger, self.checkpoint_trigger,
                  self.summary_trigger, self.validation_iterator, self.summaries)
+        saved_validation = (self.validation_metric, getattr(self, 'validation_maximize', False), getattr(self, '_best', None))
         records = []
         try:
             for run in range(2):
                 with tempfile.TemporaryDirectory() as tmp:
-                    self.load_state_dict(copy.deepcopy(backup))
-                    self.optimizer.set_parameters(self.model.parameters())
+                    self.optimizer.set_parameters(self.model.parameters())      # fresh optimizer object ...
+                    self.load_state_dict(copy.deepcopy(backup))                 # ... then the saved state (Adam moments, step)
                     self.storage_dir = Path(tmp)
                     self.stop_trigger = EndTrigger(2, 'iteration')
                     self.checkpoint_trigger = IntervalTrigger(2, 'iteration')
@@ -671,10 +706,11 @@ class Trainer:
                 assert not torch.equal(v.detach().cpu(), a['params'][k].cpu()), \
                     f'parameter {k} did not change (zero gradient?)'
         finally:
-            self.load_state_dict(backup)
             self.optimizer.set_parameters(self.model.parameters())
+            self.load_state_dict(backup)
             (self.storage_dir, self.iteration, self.epoch, self.stop_trigger, self.checkpoint_trigger,
              self.summary_trigger, self.validation_iterator, self.summaries) = saved
+            self.validation_metric, self.validation_maximize, self._best = saved_validation
         for k, v in self.model.state_dict().items():
             assert torch.equal(v.cpu(), backup['model'][k].cpu()), k
         print('Successfully finished test run')

@@ -7,6 +7,10 @@
 // mode 1  chain c = the workgroups that FIND THEMSELVES on XCD c (HW_REG_XCC_ID + a ticket per XCD), payload and flag
 //         stored PLAIN (they stay in that XCD's L2), read with sc1 loads (bypass the CU's L1, served by the shared L2)
 // mode 2  placement of mode 1, stores of mode 0
+// mode 3  mode 1 with PLAIN payload loads (every address is written once and first read after its flag: no stale copy)
+// mode 4  reduce-scatter (backward form): every workgroup writes P slices of 16 x JT partial sums (one per consumer),
+//         reads its slice from all P producers; placement and flavours of mode 3
+// mode 5  mode 4 with write-through stores and sc1 loads, chain members spread over all XCDs
 // Every consumer checks every word it reads against the value the producer must have written (stale data = error).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -42,7 +46,7 @@ extern "C" __global__ __launch_bounds__(256) void chain_kernel(const Args A) {
     __syncthreads();
     const unsigned ticket = sh[0];
     int chain, idx;
-    if (A.mode == 0) {
+    if (A.mode == 0 || A.mode == 5) {
         chain = blockIdx.x / A.P;
         idx = blockIdx.x % A.P;
     } else {
@@ -52,9 +56,11 @@ extern "C" __global__ __launch_bounds__(256) void chain_kernel(const Args A) {
     const bool live = chain < A.nchains && idx < A.P;
     if (tid == 0) A.info[blockIdx.x] = xcc | (ticket << 8) | ((live ? 1u : 0u) << 20);
     if (!live) return;
-    const bool wt = A.mode != 1;                     // write-through stores
+    const bool wt = A.mode == 0 || A.mode == 2 || A.mode == 5;      // write-through stores
+    const bool plain_ld = A.mode == 3 || A.mode == 4;
+    const bool rs = A.mode >= 4;
     unsigned* const myflags = A.flags + chain * 64;
-    const size_t tile_elems = (size_t)A.KB * 256;
+    const size_t tile_elems = A.mode >= 4 ? (size_t)A.P * A.P * 16 * A.JT : (size_t)A.KB * 256;
     const int g4 = lane >> 4, r = lane & 15;
     const int per = (A.KB + 3) / 4, kb0 = wave * per, kb1 = min(A.KB, kb0 + per);
     float sink = 0.f;
@@ -88,12 +94,28 @@ extern "C" __global__ __launch_bounds__(256) void chain_kernel(const Args A) {
             __syncthreads();
             mark(1);
             const float* tbase = A.hbuf + ((size_t)(s - 1) * A.nchains + chain) * tile_elems;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, (int)(tile_elems * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, (int)(tile_elems * 4), 0x00020000);
             f32x4 a[10];
+            if (!rs) {
 #pragma unroll
-            for (int i = 0; i < 10; ++i) {
-                const int kb = min(kb0 + i, kb1 - 1);
-                a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)(kb * 1024 + r * 64 + g4 * 16), 0, 16 /* sc1 */));
+                for (int i = 0; i < 10; ++i) {
+                    const int kb = min(kb0 + i, kb1 - 1);
+                    const unsigned off = (unsigned)(kb * 1024 + r * 64 + g4 * 16);
+                    a[i] = plain_ld ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 0))
+                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 16 /* sc1 */));
+                }
+            } else {
+                // slab layout [producer][consumer][16 rows][JT] floats; this workgroup = consumer idx: its slice of producer p is
+                // 16 * JT contiguous floats; 256 threads x 10 float4 cover P * 16 * JT floats (host: P * 16 * JT <= 10240)
+                const int slice = 16 * A.JT;             // floats
+#pragma unroll
+                for (int i = 0; i < 10; ++i) {
+                    const int e4 = (i * 256 + tid);      // float4 index over [P][slice / 4]
+                    const int p = e4 / (slice / 4), w4 = e4 - p * (slice / 4);
+                    const unsigned off = p < A.P ? (unsigned)((((size_t)p * A.P + idx) * slice + 4 * w4) * 4) : 0x80000000u;
+                    a[i] = plain_ld ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 0))
+                                    : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_, off, 0, 16));
+                }
             }
             if (A.phases) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             mark(2);
@@ -103,8 +125,15 @@ extern "C" __global__ __launch_bounds__(256) void chain_kernel(const Args A) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     sink += a[i][q];
-                    const int unit = kb * 16 + g4 * 4 + q;
-                    if (A.check && unit < A.H && a[i][q] != val(s - 1, chain, r, unit)) ++bad;
+                    if (A.check) {
+                        if (!rs) {
+                            const int unit = kb * 16 + g4 * 4 + q;
+                            if (unit < A.H && a[i][q] != val(s - 1, chain, r, unit)) ++bad;
+                        } else {
+                            const int slice = 16 * A.JT, e4 = i * 256 + tid, p = e4 / (slice / 4), w4 = e4 - p * (slice / 4);
+                            if (p < A.P && a[i][q] != val(s - 1, chain, p, idx * slice + 4 * w4 + q)) ++bad;
+                        }
+                    }
                 }
             }
             for (int w = 0; w < A.work; ++w) __builtin_amdgcn_s_sleep(1);      // stand-in for the step's MFMA work (64 cycles each)
@@ -112,15 +141,27 @@ extern "C" __global__ __launch_bounds__(256) void chain_kernel(const Args A) {
             __syncthreads();
             mark(4);
         }
-        // produce this workgroup's JT units of all 16 rows
+        // produce
         float* tq = A.hbuf + ((size_t)s * A.nchains + chain) * tile_elems;
-        for (int e = tid; e < 16 * A.JT; e += 256) {
-            const int row = e / A.JT, u = idx * A.JT + (e - row * A.JT);
-            if (u < A.H) {
-                float* p = tq + (u >> 4) * 256 + row * 16 + (u & 15);
-                const float v = val(s, chain, row, u) + (sink == 12345.678f ? 1.f : 0.f);
-                if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else *p = v;
+        if (!rs) {          // this workgroup's JT units of all 16 rows
+            for (int e = tid; e < 16 * A.JT; e += 256) {
+                const int row = e / A.JT, u = idx * A.JT + (e - row * A.JT);
+                if (u < A.H) {
+                    float* p = tq + (u >> 4) * 256 + row * 16 + (u & 15);
+                    const float v = val(s, chain, row, u) + (sink == 12345.678f ? 1.f : 0.f);
+                    if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else *p = v;
+                }
+            }
+        } else {            // partial sums for every consumer: P * 16 * JT floats, 16-byte stores
+            const int slice = 16 * A.JT, total4 = A.P * slice / 4;
+            const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(tq, 0, (int)(tile_elems * 4), 0x00020000);
+            for (int e4 = tid; e4 < total4; e4 += 256) {
+                const int c = e4 / (slice / 4), w4 = e4 - c * (slice / 4);
+                f32x4 v;
+                for (int q = 0; q < 4; ++q) v[q] = val(s, chain, idx, c * slice + 4 * w4 + q) + (sink == 12345.678f ? 1.f : 0.f);
+                const unsigned off = (unsigned)((((size_t)idx * A.P + c) * slice + 4 * w4) * 4);
+                if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws_, off, 0, 16); else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws_, off, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -163,8 +204,8 @@ int main(int argc, char** argv) {
     A.phases = argc > 10 ? atoi(argv[10]) : 0;
     A.H = 600;
     A.KB = 38;
-    if (A.mode == 0) grid = A.nchains * A.P;
-    const size_t hb = (size_t)A.T * A.nchains * A.KB * 256 * 4;
+    if (A.mode == 0 || A.mode == 5) grid = A.nchains * A.P;
+    const size_t hb = (size_t)A.T * A.nchains * (A.mode >= 4 ? (size_t)A.P * A.P * 16 * A.JT : (size_t)A.KB * 256) * 4;
     CK(hipMalloc(&A.hbuf, hb));
     CK(hipMalloc(&A.flags, 8 * 64 * 4));
     CK(hipMalloc(&A.tickets, 8 * 4));

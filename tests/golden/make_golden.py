@@ -23,6 +23,8 @@ Fixtures:
   g9_norm.npz             modules/normalization.py: normalize() outputs + reference-autograd gradients over
                           a grid of formats / axes / shift / scale / lengths; Normalization and
                           InputNormalization training steps + eval; SimpleMaskEstimator forward / loss / grads
+  g10_summary_data.npz    summary/tbx_utils.py mask_to_image / stft_to_image / spectrogram_to_image over batch_first x colour x
+                          origin; data/batch.py Sorter and data/utils.py collate_fn results
   g8_logmel.npz           contrib/je/modules/features.py MelTransform (forward / inverse / maxima) and
                           the extractor front-end (stacked pt.ops.STFT -> power -> MelTransform); the
                           filterbank comes from the shim's restatement of paderbox.get_fbanks (parity
@@ -513,10 +515,52 @@ def g9():
     np.savez_compressed(HERE / 'g9_norm.npz', **out)
 
 
+def g10():
+    """summary/tbx_utils.py image helpers (grayscale and viridis), data/batch.py Sorter, data/utils.py collate_fn."""
+    import warnings
+    from padertorch.summary.tbx_utils import mask_to_image, stft_to_image, spectrogram_to_image
+    from padertorch.data.batch import Sorter
+    from padertorch.data.utils import collate_fn
+    rng = np.random.RandomState(10)
+    out, cases = {}, []
+    mask = rng.rand(7, 3, 5).astype(np.float32) * 1.2 - 0.1            # some values outside [0, 1]
+    spec = (rng.randn(7, 3, 5) + 1j * rng.randn(7, 3, 5)).astype(np.complex64) * np.exp(3 * rng.randn(7, 3, 5)).astype(np.float32)
+    out['mask'], out['spec'] = mask, spec
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for bf in (False, True):
+            for color in (None, 'viridis'):
+                for origin in ('lower', 'upper'):
+                    key = f'bf{int(bf)}_{color}_{origin}'
+                    cases.append(dict(key=key, batch_first=bf, color=color, origin=origin))
+                    m = mask.transpose(1, 0, 2) if bf else mask
+                    z = spec.transpose(1, 0, 2) if bf else spec
+                    out[f'{key}/mask3'] = mask_to_image(m, bf, color, origin)
+                    out[f'{key}/mask2'] = mask_to_image(mask[:, 1], bf, color, origin)
+                    out[f'{key}/stft3'] = stft_to_image(z, bf, color, origin)
+                    out[f'{key}/stft2_60'] = stft_to_image(spec[:, 2], bf, color, origin, 60)
+                    out[f'{key}/abs3'] = stft_to_image(np.abs(z), bf, color, origin)
+                    out[f'{key}/pow_lin'] = spectrogram_to_image(np.abs(z) ** 2, bf, color, origin, log=False)
+    out['cases'] = np.array(json.dumps(cases))
+    # structural helpers: results as JSON (the doctest inputs of data/batch.py:141-143 and data/utils.py:31-40 + a ragged one)
+    batch = [{'value': x, 'num_samples': n} for x, n in [(5, 10), (1, 30), (3, 20), (2, 20)]]
+    structural = dict(
+        sorter_value=[list(map(dict, [Sorter('value')(batch)][0]))][0],
+        sorter_default=list(Sorter()(batch)),
+        sorter_ascending=list(Sorter('value', reverse=False)(batch)),
+        collate_flat=collate_fn([{'a': 1}, {'a': 2}]),
+        collate_tuple=collate_fn(({'a': 1}, {'a': 2})),
+        collate_tuple_is_tuple=isinstance(collate_fn(({'a': 1}, {'a': 2}))['a'], tuple),
+        collate_nested=collate_fn([{'a': {'b': [1, 2]}}, {'a': {'b': [3, 4]}}]),
+    )
+    out['structural'] = np.array(json.dumps(structural))
+    np.savez_compressed(HERE / 'g10_summary_data.npz', **out)
+
+
 if __name__ == '__main__':
     assert os.path.isdir('/root/reference'), 'run in the build container'
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
         if only and fn.__name__ not in only:
             continue
         fn()

@@ -1,0 +1,100 @@
+"""Host-side helpers around the step: summary images (``padertorch/summary/tbx_utils.py:61-157,219-271``), ``Sorter``
+(``data/batch.py:133-158``), ``collate_fn`` (``data/utils.py:21-69``), frame bookkeeping - against the golden g10
+produced by the real reference and the literal answers of the reference's doctests."""
+import dataclasses
+import json
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from padertorch_amd.data import Sorter, collate_fn
+from padertorch_amd.summary import mask_to_image, spectrogram_to_image, stft_to_image
+
+
+@pytest.fixture(scope='module')
+def g10():
+    from conftest import GOLDEN
+    d = dict(np.load(GOLDEN / 'g10_summary_data.npz', allow_pickle=False))
+    d['cases'] = json.loads(str(d['cases']))
+    d['structural'] = json.loads(str(d['structural']))
+    return d
+
+
+def test_images_match_reference_over_all_options(g10):
+    mask, spec = g10['mask'], g10['spec']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for c in g10['cases']:
+            bf, color, origin, key = c['batch_first'], c['color'], c['origin'], c['key']
+            m = mask.transpose(1, 0, 2) if bf else mask
+            z = spec.transpose(1, 0, 2) if bf else spec
+            got = {
+                'mask3': mask_to_image(torch.from_numpy(np.ascontiguousarray(m)), bf, color, origin),
+                'mask2': mask_to_image(mask[:, 1], bf, color, origin),
+                'stft3': stft_to_image(torch.from_numpy(np.ascontiguousarray(z)), bf, color, origin),
+                'stft2_60': stft_to_image(spec[:, 2], bf, color, origin, 60),
+                'abs3': stft_to_image(np.abs(z), bf, color, origin),
+                'pow_lin': spectrogram_to_image(np.abs(z) ** 2, bf, color, origin, log=False),
+            }
+            for name, img in got.items():
+                ref = g10[f'{key}/{name}']
+                assert img.shape == ref.shape and img.dtype == ref.dtype, (key, name, img.shape, ref.shape, img.dtype)
+                np.testing.assert_array_equal(img, ref, err_msg=f'{key}/{name}')
+
+
+def test_image_doctest_answers_and_signature():
+    data = np.array([1, 0.004, 0.003, 0.001_05, 0.001])[:, None]           # tbx_utils.py:140-146
+    np.testing.assert_array_equal(np.squeeze(stft_to_image(data, color=None)), [255, 10, 0, 0, 0])
+    np.testing.assert_array_equal(np.squeeze(stft_to_image(data, color=None, visible_dB=60)), [255, 51, 40, 1, 0])
+    x = torch.rand(6, 2, 4)                                                  # (frames, batch, features)
+    assert mask_to_image(x).shape == (1, 4, 6)                               # grayscale by default
+    assert mask_to_image(x, True).shape == (1, 4, 2)                         # second positional argument = batch_first: x[0]
+    assert stft_to_image(x).shape == (4, 4, 6)                               # viridis RGBA by default
+    with pytest.raises(ValueError):
+        mask_to_image(x, None)
+    with pytest.warns(UserWarning):
+        mask_to_image(x * 3)
+
+
+def test_mask_estimator_images_only_with_snapshot():
+    """The review renders images (device -> host copies) only when create_snapshot is set; the images are the FIRST
+    example, features on the y axis (reference add_images calls the helpers with batch_first=True)."""
+    from padertorch_amd.contrib.examples.speech_enhancement.mask_estimator.model import SimpleMaskEstimator
+    out = dict(speech_mask_prediction=torch.rand(3, 11, 17), noise_mask_prediction=torch.rand(3, 11, 17))
+    batch = dict(observation_abs=torch.rand(3, 11, 17))
+    images = SimpleMaskEstimator.add_images(batch, out)
+    assert set(images) == {'speech_mask', 'observed_stft', 'noise_mask'}
+    assert images['speech_mask'].shape == (1, 17, 11) and images['observed_stft'].shape == (4, 17, 11)
+    np.testing.assert_array_equal(images['speech_mask'], mask_to_image(out['speech_mask_prediction'][0]))
+
+
+def test_sorter_and_collate_match_reference(g10):
+    st = g10['structural']
+    batch = [{'value': x, 'num_samples': n} for x, n in [(5, 10), (1, 30), (3, 20), (2, 20)]]
+    assert Sorter('value')([{'value': x} for x in [5, 1, 3, 2]]) == ({'value': 5}, {'value': 3}, {'value': 2}, {'value': 1})
+    assert list(Sorter('value')(batch)) == st['sorter_value']
+    assert list(Sorter()(batch)) == st['sorter_default']                       # by num_samples, descending, stable
+    assert list(Sorter('value', reverse=False)(batch)) == st['sorter_ascending']
+    assert isinstance(Sorter()(batch), tuple)
+    assert collate_fn([{'a': 1}, {'a': 2}]) == st['collate_flat'] == {'a': [1, 2]}
+    assert collate_fn(({'a': 1}, {'a': 2})) == {'a': (1, 2)} and st['collate_tuple_is_tuple']
+    assert collate_fn([{'a': {'b': [1, 2]}}, {'a': {'b': [3, 4]}}]) == st['collate_nested']
+    Point = dataclasses.make_dataclass('Point', ['x', 'y'])                    # data/utils.py:42-49
+    assert collate_fn([Point(1, 2), Point(3, 4)]) == Point([1, 3], [2, 4])
+    assert collate_fn((Point(1, 2), Point(3, 4))) == Point((1, 3), (2, 4))
+    with pytest.raises(AssertionError):
+        collate_fn([{'a': 1}, {'b': 2}])
+
+
+def test_sample_index_to_frame_index():
+    from padertorch_amd.ops import STFT
+    st = STFT(8, 1, fading=None)
+    assert [st.sample_index_to_frame_index(i) for i in range(12)] == [0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7]
+    st = STFT(512, 128, fading='full')
+    f = st.sample_index_to_frame_index(np.array([0, 255, 256, 1000]))
+    np.testing.assert_array_equal(f, np.array([0, 0, 0, 5]) + 3)
+    # consistent with the frame count: the last sample of a signal maps to an existing frame
+    for n in (600, 4000, 32000):
+        assert st.sample_index_to_frame_index(n - 1) < st.samples_to_frames(n)

@@ -113,7 +113,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _dp_worker(rank, world, port, g6_path, n_examples, out_dir):
+def _dp_worker(rank, world, port, g6_path, n_examples, out_dir, overlap=True, poison_rank=None):
     import json
     torch.set_num_threads(1)
     g6 = dict(np.load(g6_path, allow_pickle=False))
@@ -126,23 +126,36 @@ def _dp_worker(rank, world, port, g6_path, n_examples, out_dir):
             for p in model.parameters():
                 p.add_(1.)
     exs = (_examples(g6) * 2)[:n_examples]
+    if poison_rank is not None:           # the example rank `poison_rank` sees in the second group carries a NaN
+        ex = exs[2 + poison_rank]
+        ex['Y_abs'] = [a.copy() for a in ex['Y_abs']]
+        ex['Y_abs'][0][0, 0] = np.nan
     t = pt.Trainer(model, os.path.join(out_dir, f'r{rank}'), pt.optimizer.Adam(gradient_clipping=1.),
                    loss_weights=LW, summary_trigger=(1000, 'iteration'),
                    checkpoint_trigger=(1000, 'iteration'), stop_trigger=(1, 'epoch'),
-                   virtual_minibatch_size=2)
-    t.train(exs, device='cpu')
-    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f'sd{rank}.pth'))
+                   virtual_minibatch_size=2, overlap_allreduce=overlap)
+    if poison_rank is None:
+        t.train(exs, device='cpu')
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f'sd{rank}.pth'))
+    else:
+        try:
+            t.train(exs, device='cpu')
+            outcome = 'finished'
+        except RuntimeError as e:
+            outcome = str(e).split('\n')[0]
+        with open(os.path.join(out_dir, f'outcome{rank}.txt'), 'w') as f:
+            f.write(outcome)
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_examples', [8, 7])
-def test_data_parallel_gloo_matches_single_process(g6, tmp_path, n_examples):
+@pytest.mark.parametrize('n_examples,overlap', [(8, True), (7, True), (7, False)])
+def test_data_parallel_gloo_matches_single_process(g6, tmp_path, n_examples, overlap):
     """W=2 ranks x 1 micro-step == 1 process x virtual_minibatch_size=2: gradients are SUMMED (no
     averaging), replicas end bit-identical, and a partial last group (7 examples) works."""
     import torch.multiprocessing as mp
     from conftest import GOLDEN
     port = _free_port()
-    mp.spawn(_dp_worker, args=(2, port, str(GOLDEN / 'g6_models.npz'), n_examples, str(tmp_path)),
+    mp.spawn(_dp_worker, args=(2, port, str(GOLDEN / 'g6_models.npz'), n_examples, str(tmp_path), overlap),
              nprocs=2, join=True)
     sd0 = torch.load(tmp_path / 'sd0.pth')
     sd1 = torch.load(tmp_path / 'sd1.pth')
@@ -157,3 +170,45 @@ def test_data_parallel_gloo_matches_single_process(g6, tmp_path, n_examples):
     assert t.iteration == 4
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(sd0[k].numpy(), v.numpy(), atol=2e-6, err_msg=k)
+
+
+def test_data_parallel_non_finite_loss_raises_on_every_rank(g6, tmp_path):
+    """Sync checks, W = 2: a NaN loss on ONE rank makes BOTH raise (nobody is left blocking in the all-reduce)."""
+    import torch.multiprocessing as mp
+    from conftest import GOLDEN
+    mp.spawn(_dp_worker, args=(2, _free_port(), str(GOLDEN / 'g6_models.npz'), 8, str(tmp_path), True, 1),
+             nprocs=2, join=True)
+    out = [(tmp_path / f'outcome{r}.txt').read_text() for r in range(2)]
+    assert 'not finite' in out[1] and 'not finite' in out[0], out
+
+
+def test_grad_buckets_follow_layers_and_issue_last_first(g6):
+    from padertorch_amd.train.trainer import GradBuckets
+    model = _model(g6)
+    opt = pt.optimizer.Adam(1.)
+    opt.set_parameters(model.parameters())
+    flat = opt.use_flat_grads()
+    b = GradBuckets(model, flat)
+    # 2 BLSTM layers (8 parameters each) + linear1 + linear2, contiguous and complete
+    assert [n for _, _, n in b.buckets] == [8, 8, 2, 2]
+    assert b.buckets[0][0] == 0 and b.buckets[-1][1] == flat.flat.numel()
+    assert all(b.buckets[i][1] == b.buckets[i + 1][0] for i in range(3))
+    assert b.next == 3 and not b.active
+
+
+def test_resume_restores_best_and_does_not_refire_triggers(g6, tmp_path):
+    exs = _examples(g6)
+    kw = dict(loss_weights=LW, summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1, 'iteration'), virtual_minibatch_size=1)
+    a = pt.Trainer(_model(g6), tmp_path, pt.optimizer.Adam(1.), stop_trigger=(2, 'iteration'), **kw)
+    a.register_validation_hook(exs[:1])
+    a.train(exs, device='cpu')
+    best = a._best
+    assert best is not None
+    ckpt = torch.load(tmp_path / 'checkpoints' / 'ckpt_latest.pth', weights_only=False)
+    assert ckpt['hooks'] == {} and ckpt['ptmi_hooks']['best'] == best       # 'hooks' stays loadable by the reference Trainer
+    mtime = (tmp_path / 'checkpoints' / 'ckpt_2.pth').stat().st_mtime_ns
+    b = pt.Trainer(_model(g6), tmp_path, pt.optimizer.Adam(1.), stop_trigger=(2, 'iteration'), **kw)
+    b.register_validation_hook(exs[:1])
+    b.train(exs, resume=True, device='cpu')            # already at the stop iteration: nothing to do
+    assert b._best == best
+    assert (tmp_path / 'checkpoints' / 'ckpt_2.pth').stat().st_mtime_ns == mtime      # not validated / saved again
