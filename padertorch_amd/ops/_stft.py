@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from .. import _lib
+from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 
 __all__ = ['STFT']
 
@@ -83,40 +84,33 @@ def _to_f32(x):
     return x.contiguous()
 
 
+def _geom_list(st):
+    g = st._geom
+    return [g.size, g.shift, g.window_length, g.pad_left, g.pad_right, g.pad]
+
+
 class _StftFn(torch.autograd.Function):
-    """[rows, T] float32 -> [rows, frames, F, 2] (interleaved) or [rows, frames, 2F] (concat)."""
+    """[rows, T] float32 -> [rows, frames, F, 2] (interleaved) or [rows, frames, 2F] (concat); kernels:
+    ``torch.ops.ptmi.stft_forward`` and, as its adjoint, ``torch.ops.ptmi.istft_forward``."""
 
     @staticmethod
     def forward(ctx, x, st, layout, row_samples):
         _lib.require_gpu(x)
-        lib = _lib.load()
         tb = st._tables.get(x.device)
-        rows, T = x.shape
-        frames = st._frames_for(T)
-        F = st.size // 2 + 1
-        shape = (rows, frames, F, 2) if layout == 0 else (rows, frames, 2 * F)
-        out = torch.empty(shape, dtype=torch.float32, device=x.device)
-        _lib.check(_lib.timed(
-            'stft_forward', lib.ptmi_stft_forward, x.data_ptr(), rows, x.stride(0), T, _lib.ptr(row_samples), tb['window'].data_ptr(),
-            tb['twiddle'].data_ptr(), st._geom, frames, layout, 1.0, out.data_ptr(),
-            _lib.stream(x.device)), 'ptmi_stft_forward')
+        T = x.shape[1]
+        out = torch.ops.ptmi.stft_forward(x, row_samples, tb['window'], tb['twiddle'], _geom_list(st), st._frames_for(T), layout,
+                                          1.0, 'stft_forward')
         ctx.st, ctx.layout, ctx.T = st, layout, T
         return out
 
     @staticmethod
     def backward(ctx, g):
         st, T = ctx.st, ctx.T
-        g = g.contiguous()
-        lib = _lib.load()
         tb = st._tables.get(g.device)
-        rows, frames = g.shape[0], g.shape[1]
-        dx = torch.empty((rows, T), dtype=torch.float32, device=g.device)
         # adjoint of (frame, window, one-sided DFT) = hermitian inverse with doubled DC/Nyquist,
         # window w/2, overlap-add, cut the fading pad and anything right of the row.
-        _lib.check(lib.ptmi_istft_forward(
-            g.data_ptr(), rows, frames, None, tb['window_adj'].data_ptr(), tb['twiddle'].data_ptr(),
-            st._geom, ctx.layout, 2.0, st._geom.pad_left, T, T, dx.data_ptr(),
-            _lib.stream(g.device)), 'ptmi_istft_forward(adjoint)')
+        dx = torch.ops.ptmi.istft_forward(g.contiguous(), tb['window_adj'], tb['twiddle'], _geom_list(st), ctx.layout, 2.0,
+                                          st._geom.pad_left, T, '')
         return dx, None, None, None
 
 
@@ -126,35 +120,22 @@ class _IstftFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, spec, st, layout):
         _lib.require_gpu(spec)
-        lib = _lib.load()
         tb = st._tables.get(spec.device)
-        rows, frames = spec.shape[0], spec.shape[1]
-        n = int(lib.ptmi_istft_num_samples(st._geom, frames))
-        out = torch.empty((rows, max(n, 0)), dtype=torch.float32, device=spec.device)
-        if n > 0:
-            _lib.check(_lib.timed(
-                'istft_forward', lib.ptmi_istft_forward, spec.data_ptr(), rows, frames, None, tb['syn'].data_ptr(), tb['twiddle'].data_ptr(),
-                st._geom, layout, 1.0, st._geom.pad_left, n, n, out.data_ptr(),
-                _lib.stream(spec.device)), 'ptmi_istft_forward')
+        frames = spec.shape[1]
+        n = int(_lib.load().ptmi_istft_num_samples(st._geom, frames))
+        out = torch.ops.ptmi.istft_forward(spec, tb['syn'], tb['twiddle'], _geom_list(st), layout, 1.0, st._geom.pad_left, n,
+                                           'istft_forward')
         ctx.st, ctx.layout, ctx.frames = st, layout, frames
         return out
 
     @staticmethod
     def backward(ctx, g):
         st, frames = ctx.st, ctx.frames
-        g = g.contiguous()
-        lib = _lib.load()
         tb = st._tables.get(g.device)
-        rows, n = g.shape
-        F = st.size // 2 + 1
-        shape = (rows, frames, F, 2) if ctx.layout == 0 else (rows, frames, 2 * F)
-        ds = torch.empty(shape, dtype=torch.float32, device=g.device)
         # adjoint of (hermitian inverse, window, overlap-add, cut) = forward STFT of the gradient
         # with window 2*syn and halved, real-only DC/Nyquist bins.
-        _lib.check(lib.ptmi_stft_forward(
-            g.data_ptr(), rows, g.stride(0), n, None, tb['syn_adj'].data_ptr(),
-            tb['twiddle'].data_ptr(), st._geom, frames, ctx.layout, 0.5, ds.data_ptr(),
-            _lib.stream(g.device)), 'ptmi_stft_forward(adjoint)')
+        ds = torch.ops.ptmi.stft_forward(g.contiguous(), None, tb['syn_adj'], tb['twiddle'], _geom_list(st), frames, ctx.layout,
+                                         0.5, '')
         return ds, None, None
 
 

@@ -10,6 +10,7 @@ directly in HBM - the H2D copy shrinks from (1+2K) feature maps to (1+K) wavefor
 import torch
 
 from .. import _lib
+from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 from ._stft import STFT
 from .sequence.pack_module import PaddedList
 
@@ -66,19 +67,9 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None):
     ragged = any(n != N for n in num_samples)
     ns_dev = torch.tensor(num_samples, dtype=torch.int32, device=dev) if ragged else None
     tb = stft._tables.get(dev)
-    Y_abs = torch.empty((B, T, F), dtype=torch.float32, device=dev)
-    X_abs = cos_pd = None
-    if K:
-        X_abs = torch.empty((B, T, K, F), dtype=torch.float32, device=dev)
-        cos_pd = torch.empty((B, T, K, F), dtype=torch.float32, device=dev)
-    rc = _lib.timed(
-        'pit_features', lib.ptmi_pit_features, y.data_ptr(), _lib.ptr(s), B, K, N, N, _lib.ptr(ns_dev), tb['window'].data_ptr(),
-        tb['twiddle'].data_ptr(), stft._geom, T, Y_abs.data_ptr(), _lib.ptr(X_abs), _lib.ptr(cos_pd),
-        _lib.stream(dev))
-    if rc == -2:
-        raise NotImplementedError(
-            f'pit_features needs a power-of-two STFT size in 64..2048 (got {stft.size})')
-    _lib.check(rc, 'ptmi_pit_features')
+    g = stft._geom
+    Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features(
+        y, s, ns_dev, tb['window'], tb['twiddle'], [g.size, g.shift, g.window_length, g.pad_left, g.pad_right, g.pad], T)
     fl = torch.tensor(frames, dtype=torch.int32, device=dev) if ragged else None
     out = dict(Y_abs=PaddedList(Y_abs, frames, True, fl), num_frames=frames)
     if K:

@@ -13,6 +13,7 @@ reduced precision, reported as a delta, never the default).
 import torch
 
 from .. import _lib
+from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 
 __all__ = ['mm', 'absmax', 'weight_absmax', 'UNIT_RANGE', 'PRODUCTS', 'ENABLED', 'usable']
 
@@ -33,16 +34,12 @@ def absmax(x):
     """Device word (int32 tensor [1]) holding the float bits of ``max |x|`` of a 2-D fp32 tensor with one unit stride."""
     assert x.dim() == 2 and x.dtype == torch.float32
     _lib.require_gpu(x)
-    lib = _lib.load()
-    out = torch.empty(1, dtype=torch.int32, device=x.device)
     if x.stride(1) == 1 or x.shape[1] == 1:
         rows, cols, ld = x.shape[0], x.shape[1], x.stride(0)
     else:
         assert x.stride(0) == 1, x.stride()
         rows, cols, ld = x.shape[1], x.shape[0], x.stride(1)
-    ld = max(ld, cols)
-    _lib.check(lib.ptmi_absmax(x.data_ptr(), rows, cols, ld, out.data_ptr(), _lib.stream(x.device)), 'ptmi_absmax')
-    return out
+    return torch.ops.ptmi.absmax(x, rows, cols, max(ld, cols))
 
 
 def weight_absmax(p):
@@ -111,7 +108,6 @@ def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, sp
     assert x.dim() == 2 and y.dim() == 2 and x.shape[1] == y.shape[0], (x.shape, y.shape)
     assert x.dtype == y.dtype == torch.float32, (x.dtype, y.dtype)
     _lib.require_gpu(x, y, bias, out)
-    lib = _lib.load()
     products = PRODUCTS if products is None else products
     M, K = x.shape
     N = y.shape[1]
@@ -136,12 +132,6 @@ def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, sp
         ax = ay = None
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous() and bias.dtype == torch.float32
-    ldc = max(out.stride(0), N)
     split_k = int(split_k) if split_k else auto_split_k(M, N, K)
-    nws = int(lib.ptmi_gemm_workspace_elems(M, N, K, split_k))
-    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
-    _lib.check(_lib.timed(
-        f'gemm_split:{M}x{N}x{K}:{products}', lib.ptmi_gemm_split, x.data_ptr(), a_kmajor, lda, _lib.ptr(ax), y.data_ptr(), b_kmajor, ldb,
-        _lib.ptr(ay), _lib.ptr(bias), out.data_ptr(), ldc, M, N, K, int(bool(accumulate)), products, split_k,
-        _lib.ptr(ws), _lib.stream(x.device)), 'ptmi_gemm_split')
+    torch.ops.ptmi.gemm_split_(out, x, a_kmajor, lda, ax, y, b_kmajor, ldb, ay, bias, M, N, K, bool(accumulate), products, split_k)
     return out

@@ -1,0 +1,256 @@
+"""The HIP kernels of the hot path as registered torch custom ops (``torch.ops.ptmi.*``).
+
+Every op is a thin CUDA-dispatch-key implementation over one entry point (or a fixed pair) of the C ABI in
+``include/ptmi.h`` / ``libptmi.so``: tensors in, tensors out, launch on torch's current stream.  They carry no
+autograd formula of their own: the differentiable operators (``ops.STFT``, ``ops.pit_features``, ``ops.gemm.mm``,
+``ops.packed_lstm``, the loss functions) are ``torch.autograd.Function`` s whose forward and backward call these ops, so
+a forward kernel and its hand-written adjoint kernel stay paired.  There is no CPU implementation: calling an op
+with CPU tensors fails in the dispatcher (``NotImplementedError: ... 'CPU' backend``).
+
+    torch.ops.ptmi.stft_forward            ptmi_stft_forward                  (padertorch/ops/_stft.py:103-174)
+    torch.ops.ptmi.istft_forward           ptmi_istft_forward                 (_stft.py:176-263)
+    torch.ops.ptmi.pit_features            ptmi_pit_features                  (pit/data.py:49-77)
+    torch.ops.ptmi.pit_loss_forward        ptmi_pit_pairwise_sse + _assign    (ops/losses/source_separation.py:34-312)
+    torch.ops.ptmi.pit_loss_backward       ptmi_pit_backward
+    torch.ops.ptmi.dc_loss_forward / _backward     ptmi_dc_loss_*             (source_separation.py:13-31)
+    torch.ops.ptmi.unit_norm_forward / _backward   ptmi_unit_norm_*           (contrib/tcl/dc.py:70)
+    torch.ops.ptmi.lstm_recurrence_forward / _backward   ptmi_lstm_*_persistent, falling back to ptmi_lstm_forward / _backward
+                                                                              (torch.nn.LSTM in pit/model.py:60-66,97)
+    torch.ops.ptmi.absmax, torch.ops.ptmi.gemm_split_    ptmi_absmax, ptmi_gemm_split   (nn.LSTM input projections, nn.Linear)
+"""
+import ctypes
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .. import _lib
+
+_LIBRARY = torch.library.Library('ptmi', 'DEF')
+
+
+def _register(schema):
+    """``schema``: 'name(args) -> ret' in the dispatcher's schema language; the decorated function becomes the CUDA kernel."""
+    name = schema.split('(', 1)[0].strip()
+
+    def deco(fn):
+        _LIBRARY.define(schema)
+        _LIBRARY.impl(name, fn, 'CUDA')
+        return getattr(torch.ops.ptmi, name)
+    return deco
+
+
+def _geom(g: List[int]):
+    return _lib.StftGeom(*[int(v) for v in g])
+
+
+# ------------------------------------------------------------------------------------------------ STFT front-end
+@_register('stft_forward(Tensor x, Tensor? row_samples, Tensor window, Tensor twiddle, int[] geom, int frames, int layout, '
+           'float edge_scale, str timer) -> Tensor')
+def stft_forward(x, row_samples, window, twiddle, geom, frames, layout, edge_scale, timer):
+    lib = _lib.load()
+    rows, T = x.shape
+    F = geom[0] // 2 + 1
+    shape = (rows, frames, F, 2) if layout == 0 else (rows, frames, 2 * F)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    g = _geom(geom)
+    args = (x.data_ptr(), rows, x.stride(0), T, _lib.ptr(row_samples), window.data_ptr(), twiddle.data_ptr(), g, frames,
+            layout, edge_scale, out.data_ptr(), _lib.stream(x.device))
+    rc = _lib.timed(timer, lib.ptmi_stft_forward, *args) if timer else lib.ptmi_stft_forward(*args)
+    _lib.check(rc, 'ptmi_stft_forward')
+    return out
+
+
+@_register('istft_forward(Tensor spec, Tensor window, Tensor twiddle, int[] geom, int layout, float edge_scale, int cut_left, '
+           'int out_samples, str timer) -> Tensor')
+def istft_forward(spec, window, twiddle, geom, layout, edge_scale, cut_left, out_samples, timer):
+    lib = _lib.load()
+    rows, frames = spec.shape[0], spec.shape[1]
+    out = torch.empty((rows, max(out_samples, 0)), dtype=torch.float32, device=spec.device)
+    if out_samples > 0:
+        args = (spec.data_ptr(), rows, frames, None, window.data_ptr(), twiddle.data_ptr(), _geom(geom), layout, edge_scale,
+                cut_left, out_samples, out_samples, out.data_ptr(), _lib.stream(spec.device))
+        rc = _lib.timed(timer, lib.ptmi_istft_forward, *args) if timer else lib.ptmi_istft_forward(*args)
+        _lib.check(rc, 'ptmi_istft_forward')
+    return out
+
+
+@_register('pit_features(Tensor y, Tensor? s, Tensor? num_samples, Tensor window, Tensor twiddle, int[] geom, int frames) '
+           '-> (Tensor, Tensor?, Tensor?)')
+def pit_features(y, s, num_samples, window, twiddle, geom, frames):
+    lib = _lib.load()
+    B, N = y.shape
+    K = s.shape[1] if s is not None else 0
+    F = geom[0] // 2 + 1
+    dev = y.device
+    Y_abs = torch.empty((B, frames, F), dtype=torch.float32, device=dev)
+    X_abs = cos_pd = None
+    if K:
+        X_abs = torch.empty((B, frames, K, F), dtype=torch.float32, device=dev)
+        cos_pd = torch.empty((B, frames, K, F), dtype=torch.float32, device=dev)
+    rc = _lib.timed('pit_features', lib.ptmi_pit_features, y.data_ptr(), _lib.ptr(s), B, K, N, N, _lib.ptr(num_samples),
+                    window.data_ptr(), twiddle.data_ptr(), _geom(geom), frames, Y_abs.data_ptr(), _lib.ptr(X_abs),
+                    _lib.ptr(cos_pd), _lib.stream(dev))
+    if rc == -2:
+        raise NotImplementedError(f'pit_features needs a power-of-two STFT size in 64..2048 (got {geom[0]})')
+    _lib.check(rc, 'ptmi_pit_features')
+    return Y_abs, X_abs, cos_pd
+
+
+# ------------------------------------------------------------------------------------------------ losses
+@_register('pit_loss_forward(Tensor est, Tensor? obs, Tensor tgt, Tensor? scale, Tensor? row_frames, int B, int T, int K, int F, '
+           'int[] strides) -> (Tensor, Tensor, Tensor, Tensor)')
+def pit_loss_forward(est, obs, tgt, scale, row_frames, B, T, K, F, strides):
+    lib = _lib.load()
+    dev = est.device
+    nvar = 2 if scale is not None else 1
+    ws = torch.empty(int(lib.ptmi_pit_workspace_elems(B, T, K, F)), dtype=torch.float64, device=dev)
+    sse = torch.empty((B, nvar, K, K), dtype=torch.float64, device=dev)
+    st = _lib.stream(dev)
+    _lib.check(_lib.timed('pit_pairwise_sse', lib.ptmi_pit_pairwise_sse, est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(),
+                          _lib.ptr(scale), B, T, _lib.strides6(*strides), K, F, _lib.ptr(row_frames), ws.data_ptr(),
+                          sse.data_ptr(), st), 'ptmi_pit_pairwise_sse')
+    loss = torch.empty(nvar, dtype=torch.float32, device=dev)
+    perm = torch.empty((B, nvar, K), dtype=torch.int32, device=dev)
+    ex_loss = torch.empty((B, nvar), dtype=torch.float32, device=dev)
+    _lib.check(lib.ptmi_pit_assign(sse.data_ptr(), B, nvar, K, F, T, _lib.ptr(row_frames), loss.data_ptr(), perm.data_ptr(),
+                                   ex_loss.data_ptr(), st), 'ptmi_pit_assign')
+    return loss, perm, ex_loss, sse
+
+
+@_register('pit_loss_backward(Tensor est, Tensor? obs, Tensor tgt, Tensor? scale, Tensor perm, Tensor g_loss, Tensor? row_frames, '
+           'int B, int T, int K, int F, int[] strides) -> Tensor')
+def pit_loss_backward(est, obs, tgt, scale, perm, g_loss, row_frames, B, T, K, F, strides):
+    lib = _lib.load()
+    nvar = 2 if scale is not None else 1
+    # the kernel writes every (b, t < T) row, zero for the padded frames t >= T_b
+    grad = torch.empty_strided(est.shape, est.stride(), dtype=est.dtype, device=est.device)
+    _lib.check(_lib.timed('pit_backward', lib.ptmi_pit_backward, est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale),
+                          perm.data_ptr(), g_loss.data_ptr(), B, T, _lib.strides6(*strides), K, F, nvar, _lib.ptr(row_frames),
+                          grad.data_ptr(), _lib.stream(est.device)), 'ptmi_pit_backward')
+    return grad
+
+
+@_register('dc_loss_forward(Tensor x, Tensor t, Tensor? row_frames, int B, int T, int E, int K, int F, int[] strides) '
+           '-> (Tensor, Tensor, Tensor)')
+def dc_loss_forward(x, t, row_frames, B, T, E, K, F, strides):
+    lib = _lib.load()
+    dev = x.device
+    ws = torch.empty(int(lib.ptmi_dc_workspace_elems(B, T, F)), dtype=torch.float32, device=dev)
+    gram = torch.empty((B, 32, 32), dtype=torch.float64, device=dev)
+    ex_loss = torch.empty(B, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    _lib.check(_lib.timed('dc_loss_forward', lib.ptmi_dc_loss_forward, x.data_ptr(), t.data_ptr(), B, T, _lib.strides8(*strides),
+                          E, K, F, _lib.ptr(row_frames), ws.data_ptr(), gram.data_ptr(), ex_loss.data_ptr(), loss.data_ptr(),
+                          _lib.stream(dev)), 'ptmi_dc_loss_forward')
+    return loss, ex_loss, gram
+
+
+@_register('dc_loss_backward(Tensor x, Tensor t, Tensor gram, Tensor g_loss, Tensor? row_frames, int B, int T, int E, int K, int F, '
+           'int[] strides, bool zero_fill) -> Tensor')
+def dc_loss_backward(x, t, gram, g_loss, row_frames, B, T, E, K, F, strides, zero_fill):
+    lib = _lib.load()
+    dx = torch.zeros_like(x, memory_format=torch.preserve_format) if zero_fill \
+        else torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+    _lib.check(_lib.timed('dc_loss_backward', lib.ptmi_dc_loss_backward, x.data_ptr(), t.data_ptr(), gram.data_ptr(),
+                          g_loss.data_ptr(), B, T, _lib.strides8(*strides), E, K, F, _lib.ptr(row_frames), dx.data_ptr(),
+                          _lib.stream(x.device)), 'ptmi_dc_loss_backward')
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ dense layers
+@_register('absmax(Tensor x, int rows, int cols, int ld) -> Tensor')
+def absmax(x, rows, cols, ld):
+    out = torch.empty(1, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().ptmi_absmax(x.data_ptr(), rows, cols, ld, out.data_ptr(), _lib.stream(x.device)), 'ptmi_absmax')
+    return out
+
+
+@_register('gemm_split_(Tensor(a!) out, Tensor x, int a_kmajor, int lda, Tensor? amax_x, Tensor y, int b_kmajor, int ldb, '
+           'Tensor? amax_y, Tensor? bias, int M, int N, int K, bool accumulate, int products, int split_k) -> ()')
+def gemm_split_(out, x, a_kmajor, lda, amax_x, y, b_kmajor, ldb, amax_y, bias, M, N, K, accumulate, products, split_k):
+    lib = _lib.load()
+    nws = int(lib.ptmi_gemm_workspace_elems(M, N, K, split_k))
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
+    _lib.check(_lib.timed(f'gemm_split:{M}x{N}x{K}:{products}', lib.ptmi_gemm_split, x.data_ptr(), a_kmajor, lda,
+                          _lib.ptr(amax_x), y.data_ptr(), b_kmajor, ldb, _lib.ptr(amax_y), _lib.ptr(bias), out.data_ptr(),
+                          max(out.stride(0), N), M, N, K, int(accumulate), products, split_k, _lib.ptr(ws),
+                          _lib.stream(x.device)), 'ptmi_gemm_split')
+
+
+# ------------------------------------------------------------------------------------------------ unit norm
+@_register('unit_norm_forward(Tensor x, float eps) -> (Tensor, Tensor)')
+def unit_norm_forward(x, eps):
+    N, E, F = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty((N, F), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.timed('unit_norm_forward', _lib.load().ptmi_unit_norm_forward, _lib.ptr(x), _lib.ptr(y), _lib.ptr(inv),
+                          N, E, F, eps, _lib.stream(x.device)), 'ptmi_unit_norm_forward')
+    return y, inv
+
+
+@_register('unit_norm_backward(Tensor gy, Tensor y, Tensor inv, float eps) -> Tensor')
+def unit_norm_backward(gy, y, inv, eps):
+    N, E, F = y.shape
+    dx = torch.empty_like(y)
+    _lib.check(_lib.timed('unit_norm_backward', _lib.load().ptmi_unit_norm_backward, _lib.ptr(gy), _lib.ptr(y), _lib.ptr(inv),
+                          _lib.ptr(dx), N, E, F, eps, _lib.stream(y.device)), 'ptmi_unit_norm_backward')
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------ (B)LSTM recurrence
+@_register('lstm_recurrence_forward(Tensor(a!) gates, Tensor(b!) hy, Tensor? c0, Tensor w_hh_pad, Tensor? w_amax, Tensor bs_dev, '
+           'Tensor offs_dev, int bs_host, int offs_host, int T, int max_batch, int rows, int H, int KP, int ndir, bool persistent) '
+           '-> (Tensor, Tensor?)')
+def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, KP, ndir,
+                            persistent):
+    """gates: pre-activations in, activations out (in place); hy: output rows (a view into the caller's padded buffer).
+    Returns (c, scratch): scratch = the persistent kernel's flag / hand-off buffer (its last 8 words are the watchdog
+    words), None when the one-launch-per-timestep kernels ran.  bs_host / offs_host: addresses of the HOST copies of the
+    batch-size / offset vectors (the per-step launcher takes them as kernel arguments)."""
+    lib = _lib.load()
+    dev = gates.device
+    st = _lib.stream(dev)
+    c = torch.empty((rows, ndir * H), dtype=torch.float32, device=dev)
+    rc = -2
+    flags = None
+    if persistent:
+        flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 0)), dtype=torch.int32, device=dev)
+        rc = _lib.timed('lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
+                        _lib.ptr(c0), w_hh_pad.data_ptr(), _lib.ptr(w_amax), bs_dev.data_ptr(), offs_dev.data_ptr(),
+                        flags.data_ptr(), T, max_batch, rows, H, KP, ndir, st)
+        if rc not in (0, -2):
+            _lib.check(rc, 'ptmi_lstm_forward_persistent')
+    if rc == -2:        # configuration not resident-able: one launch per timestep
+        flags = None
+        _lib.check(_lib.timed('lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                              w_hh_pad.data_ptr(), ctypes.c_void_p(bs_host), ctypes.c_void_p(offs_host), T, max_batch, H, KP, ndir,
+                              st), 'ptmi_lstm_forward')
+    return c, flags
+
+
+@_register('lstm_recurrence_backward(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor bs_dev, Tensor offs_dev, '
+           'int bs_host, int offs_host, int T, int max_batch, int rows, int H, int ndir, bool persistent) -> (Tensor, Tensor?)')
+def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, ndir, persistent):
+    """Returns (dgates, scratch): scratch as above; behind its tile-major copy it carries the bias gradient [ndir * 4H]
+    and, for the split kernels, the word with max |dgates| (see ``ops.lstm``)."""
+    lib = _lib.load()
+    dev = gates.device
+    st = _lib.stream(dev)
+    dg = torch.empty_like(gates)
+    rc = -2
+    flags = None
+    if persistent:
+        flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 1)), dtype=torch.int32, device=dev)
+        rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                        dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
+                        flags.data_ptr(), T, max_batch, rows, H, ndir, st)
+        if rc not in (0, -2):
+            _lib.check(rc, 'ptmi_lstm_backward_persistent')
+    if rc == -2:
+        flags = None
+        dcs = torch.empty((max_batch, ndir, H), dtype=torch.float32, device=dev)
+        _lib.check(_lib.timed('lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0), dhy.data_ptr(),
+                              w_hh_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), ctypes.c_void_p(bs_host), ctypes.c_void_p(offs_host),
+                              T, max_batch, H, ndir, st), 'ptmi_lstm_backward')
+    return dg, flags

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional
 
 from ... import _lib
+from .. import library  # noqa: F401  (registers torch.ops.ptmi.*)
 from . import regression
 
 __all__ = [
@@ -27,42 +28,26 @@ __all__ = [
 
 
 class _DcFn(torch.autograd.Function):
-    """Batch-mean deep-clustering loss from ONE streaming Gram pass (``ptmi_dc_loss_forward``)."""
+    """Batch-mean deep-clustering loss from ONE streaming Gram pass (``torch.ops.ptmi.dc_loss_forward`` / ``_backward``)."""
 
     @staticmethod
     def forward(ctx, x, t, row_frames, geom):
         B, T, E, K, F, xs, ts = geom
-        lib = _lib.load()
-        dev = x.device
-        ws = torch.empty(int(lib.ptmi_dc_workspace_elems(B, T, F)), dtype=torch.float32, device=dev)
-        gram = torch.empty((B, 32, 32), dtype=torch.float64, device=dev)
-        ex_loss = torch.empty(B, dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        strides = _lib.strides8(*xs, *ts)
-        _lib.check(_lib.timed(
-            'dc_loss_forward', lib.ptmi_dc_loss_forward, x.data_ptr(), t.data_ptr(), B, T, strides, E, K, F,
-            _lib.ptr(row_frames), ws.data_ptr(), gram.data_ptr(), ex_loss.data_ptr(), loss.data_ptr(),
-            _lib.stream(dev)), 'ptmi_dc_loss_forward')
+        strides = [*xs, *ts]
+        loss, ex_loss, gram = torch.ops.ptmi.dc_loss_forward(x, t, row_frames, B, T, E, K, F, strides)
         ctx.save_for_backward(x, t, row_frames, gram)
-        ctx.geom = geom
+        # inner-contiguous layouts: the backward kernel writes every (t < T, f) row, zeros past an example's
+        # length; the generic layout path touches valid rows only (its output has to start from zeros)
+        ctx.geom = (B, T, E, K, F, strides, row_frames is not None and not (xs[3] == 1 and ts[3] == 1))
         ctx.mark_non_differentiable(ex_loss)
         return loss[0], ex_loss
 
     @staticmethod
     def backward(ctx, g_loss, _g_ex):
         x, t, row_frames, gram = ctx.saved_tensors
-        B, T, E, K, F, xs, ts = ctx.geom
-        lib = _lib.load()
-        # inner-contiguous layouts: the kernel writes every (t < T, f) row, zeros past an example's
-        # length; the generic layout path touches valid rows only
-        inner = xs[3] == 1 and ts[3] == 1
-        dx = torch.zeros_like(x, memory_format=torch.preserve_format) if (row_frames is not None and not inner) \
-            else torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
-        gs = g_loss.to(torch.float32).reshape(1).contiguous()
-        _lib.check(_lib.timed(
-            'dc_loss_backward', lib.ptmi_dc_loss_backward, x.data_ptr(), t.data_ptr(), gram.data_ptr(),
-            gs.data_ptr(), B, T, _lib.strides8(*xs, *ts), E, K, F, _lib.ptr(row_frames), dx.data_ptr(),
-            _lib.stream(x.device)), 'ptmi_dc_loss_backward')
+        B, T, E, K, F, strides, zero_fill = ctx.geom
+        dx = torch.ops.ptmi.dc_loss_backward(x, t, gram, g_loss.to(torch.float32).reshape(1).contiguous(), row_frames,
+                                             B, T, E, K, F, strides, zero_fill)
         return dx, None, None, None
 
 
@@ -118,48 +103,26 @@ class _PitFn(torch.autograd.Function):
     """losses[nvar] = batch mean of min-permutation MSE for nvar in {mse, mse vs tgt*scale}.
 
     All tensors are addressed through (batch stride, time stride) so batch-major front-end buffers
-    and the time-major padded output of the packed BLSTM are consumed in place.
+    and the time-major padded output of the packed BLSTM are consumed in place.  Kernels:
+    ``torch.ops.ptmi.pit_loss_forward`` / ``pit_loss_backward``.
     """
 
     @staticmethod
     def forward(ctx, est, obs, tgt, scale, row_frames, geom):
         B, T, K, F, es, os_, ts = geom
-        lib = _lib.load()
-        dev = est.device
-        nvar = 2 if scale is not None else 1
-        nws = int(lib.ptmi_pit_workspace_elems(B, T, K, F))
-        ws = torch.empty(nws, dtype=torch.float64, device=dev)
-        sse = torch.empty((B, nvar, K, K), dtype=torch.float64, device=dev)
-        strides = _lib.strides6(es[0], es[1], os_[0], os_[1], ts[0], ts[1])
-        st = _lib.stream(dev)
-        _lib.check(_lib.timed(
-            'pit_pairwise_sse', lib.ptmi_pit_pairwise_sse, est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), B, T, strides, K, F,
-            _lib.ptr(row_frames), ws.data_ptr(), sse.data_ptr(), st), 'ptmi_pit_pairwise_sse')
-        loss = torch.empty(nvar, dtype=torch.float32, device=dev)
-        perm = torch.empty((B, nvar, K), dtype=torch.int32, device=dev)
-        ex_loss = torch.empty((B, nvar), dtype=torch.float32, device=dev)
-        _lib.check(lib.ptmi_pit_assign(
-            sse.data_ptr(), B, nvar, K, F, T, _lib.ptr(row_frames), loss.data_ptr(), perm.data_ptr(),
-            ex_loss.data_ptr(), st), 'ptmi_pit_assign')
+        strides = [es[0], es[1], os_[0], os_[1], ts[0], ts[1]]
+        loss, perm, ex_loss, sse = torch.ops.ptmi.pit_loss_forward(est, obs, tgt, scale, row_frames, B, T, K, F, strides)
         ctx.save_for_backward(est, obs, tgt, scale, row_frames, perm)
-        ctx.geom = geom
+        ctx.geom = (B, T, K, F, strides)
         ctx.mark_non_differentiable(perm, ex_loss, sse)
         return loss, perm, ex_loss, sse
 
     @staticmethod
     def backward(ctx, g_loss, _gp, _ge, _gs):
         est, obs, tgt, scale, row_frames, perm = ctx.saved_tensors
-        B, T, K, F, es, os_, ts = ctx.geom
-        lib = _lib.load()
-        nvar = 2 if scale is not None else 1
-        # the kernel writes every (b, t < T) row, zero for the padded frames t >= T_b
-        grad = torch.empty_strided(est.shape, est.stride(), dtype=est.dtype, device=est.device)
-        strides = _lib.strides6(es[0], es[1], os_[0], os_[1], ts[0], ts[1])
-        gs = g_loss.to(torch.float32).contiguous()
-        _lib.check(_lib.timed(
-            'pit_backward', lib.ptmi_pit_backward, est.data_ptr(), _lib.ptr(obs), tgt.data_ptr(), _lib.ptr(scale), perm.data_ptr(),
-            gs.data_ptr(), B, T, strides, K, F, nvar, _lib.ptr(row_frames), grad.data_ptr(),
-            _lib.stream(est.device)), 'ptmi_pit_backward')
+        B, T, K, F, strides = ctx.geom
+        grad = torch.ops.ptmi.pit_loss_backward(est, obs, tgt, scale, perm, g_loss.to(torch.float32).contiguous(), row_frames,
+                                                B, T, K, F, strides)
         return grad, None, None, None, None, None
 
 

@@ -20,6 +20,7 @@ from torch.nn.utils.rnn import PackedSequence
 
 from .. import _lib
 from . import gemm as _gemm
+from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 
 __all__ = ['packed_lstm']
 
@@ -354,29 +355,18 @@ class _LstmLayerFn(torch.autograd.Function):
                     if ndir > 1:
                         ext[pad + meta.rows:].view(pad, ndir, H)[:, 1] = h0[1]
             ctx.ext = ext if pad else None
-            c = torch.empty((meta.rows, ndir * H), dtype=torch.float32, device=x.device)
-            rc = -2
-            if PERSISTENT:
-                flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 0)),
-                                    dtype=torch.int32, device=x.device)
-                # split-precision recurrence: the scale of W_hh's fp16 halves comes from its maximum (cached per optimizer step)
-                amax_whh = (_gemm.weights_absmax([ps[1] for ps in params]) if params is not None else _gemm.absmax(
-                    w_pad.view(-1, KP))) if lib.ptmi_lstm_split_enabled() else None
-                rc = _lib.timed(
-                    'lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(),
-                    c.data_ptr(), _lib.ptr(c0), w_pad.data_ptr(), _lib.ptr(amax_whh), meta.bs_dev.data_ptr(), meta.offs_dev.data_ptr(),
-                    flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, KP, ndir, st)
-                if rc not in (0, -2):
-                    _lib.check(rc, 'ptmi_lstm_forward_persistent')
-                if rc == 0:
-                    _note_errors(flags)
-                    if CHECK_PERSISTENT_ERRORS:
-                        check_errors()
-            if rc == -2:        # configuration not resident-able: one launch per timestep
-                _lib.check(_lib.timed(
-                    'lstm_forward', lib.ptmi_lstm_forward, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
-                    _lib.ptr(c0), w_pad.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T,
-                    meta.max_batch, H, KP, ndir, st), 'ptmi_lstm_forward')
+            # split-precision recurrence: the scale of W_hh's fp16 halves comes from its maximum (cached per optimizer step)
+            amax_whh = None
+            if PERSISTENT and lib.ptmi_lstm_split_enabled():
+                amax_whh = (_gemm.weights_absmax([ps[1] for ps in params]) if params is not None
+                            else _gemm.absmax(w_pad.view(-1, KP)))
+            c, flags = torch.ops.ptmi.lstm_recurrence_forward(
+                gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
+                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT)
+            if flags is not None:
+                _note_errors(flags)
+                if CHECK_PERSISTENT_ERRORS:
+                    check_errors()
             ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
             ctx.lease = None
             ctx.gemm = (amax_x, amax_w) if use_gemm else None
@@ -411,33 +401,18 @@ class _LstmLayerFn(torch.autograd.Function):
             ndir, G, H = w_hh.shape
             dhy = dhy.contiguous()
             w_t = w_hh.transpose(1, 2).contiguous()                   # [ndir, H, 4H]
-            dg = torch.empty_like(gates)
-            rc = -2
-            if PERSISTENT:
-                flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)),
-                                    dtype=torch.int32, device=x.device)
-                rc = _lib.timed(
-                    'lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
-                    dhy.data_ptr(), w_t.data_ptr(), dg.data_ptr(), meta.bs_dev.data_ptr(),
-                    meta.offs_dev.data_ptr(), flags.data_ptr(), meta.T, meta.max_batch, meta.rows, H, ndir, st)
-                if rc not in (0, -2):
-                    _lib.check(rc, 'ptmi_lstm_backward_persistent')
-                if rc == 0:
-                    _note_errors(flags)
-                    if CHECK_PERSISTENT_ERRORS:
-                        check_errors()
-                    # the kernel also summed dgates over the rows: [ndir * 4H] floats in front of the counters
-                    # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]
-                    nflags = int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)) + 8
-                    db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
-                    if lib.ptmi_lstm_split_enabled():
-                        amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
-            if rc == -2:
-                dcs = torch.empty((meta.max_batch, ndir, H), dtype=torch.float32, device=x.device)
-                _lib.check(_lib.timed(
-                    'lstm_backward', lib.ptmi_lstm_backward, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0), dhy.data_ptr(),
-                    w_t.data_ptr(), dg.data_ptr(), dcs.data_ptr(), meta.bs_host.ctypes.data,
-                    meta.offs_host.ctypes.data, meta.T, meta.max_batch, H, ndir, st), 'ptmi_lstm_backward')
+            dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
+                gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
+                meta.T, meta.max_batch, meta.rows, H, ndir, PERSISTENT)
+            if flags is not None:
+                _note_errors(flags)
+                if CHECK_PERSISTENT_ERRORS:
+                    check_errors()
+                # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]
+                nflags = int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)) + 8
+                db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
+                if lib.ptmi_lstm_split_enabled():
+                    amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
         gm = ctx.gemm
         if gm is not None:
             amax_x, amax_w = gm

@@ -3,20 +3,17 @@
 import torch
 
 from .. import _lib
+from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 
 __all__ = ['unit_norm']
 
 
 class _UnitNormFn(torch.autograd.Function):
+    """Kernels: ``torch.ops.ptmi.unit_norm_forward`` / ``unit_norm_backward``."""
+
     @staticmethod
     def forward(ctx, x, eps):
-        lib = _lib.load()
-        N, E, F = x.shape
-        x = x.contiguous()
-        y = torch.empty_like(x)
-        inv = torch.empty((N, F), dtype=torch.float32, device=x.device)
-        _lib.check(_lib.timed('unit_norm_forward', lib.ptmi_unit_norm_forward, _lib.ptr(x), _lib.ptr(y), _lib.ptr(inv),
-                              N, E, F, eps, _lib.stream(x.device)), 'ptmi_unit_norm_forward')
+        y, inv = torch.ops.ptmi.unit_norm_forward(x.contiguous(), eps)
         ctx.save_for_backward(y, inv)
         ctx.eps = eps
         return y
@@ -24,13 +21,7 @@ class _UnitNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         y, inv = ctx.saved_tensors
-        lib = _lib.load()
-        N, E, F = y.shape
-        gy = gy.contiguous()
-        dx = torch.empty_like(y)
-        _lib.check(_lib.timed('unit_norm_backward', lib.ptmi_unit_norm_backward, _lib.ptr(gy), _lib.ptr(y), _lib.ptr(inv),
-                              _lib.ptr(dx), N, E, F, ctx.eps, _lib.stream(y.device)), 'ptmi_unit_norm_backward')
-        return dx, None
+        return torch.ops.ptmi.unit_norm_backward(gy.contiguous(), y, inv, ctx.eps), None
 
 
 def unit_norm(x, eps=1e-12):

@@ -62,3 +62,20 @@ def test_stft_argument_checks():
         STFT(512, 128, complex_representation='polar')
     with pytest.raises(AssertionError):
         STFT(512, 128, fading='quarter')
+
+
+def test_kernels_are_registered_torch_ops_without_a_cpu_kernel():
+    """The hot-path kernels are torch custom ops (torch.ops.ptmi.*) over the C ABI; they have a CUDA kernel only."""
+    import torch
+    import padertorch_amd  # noqa: F401  (registers the library)
+    names = {'stft_forward', 'istft_forward', 'pit_features', 'pit_loss_forward', 'pit_loss_backward', 'dc_loss_forward',
+             'dc_loss_backward', 'unit_norm_forward', 'unit_norm_backward', 'lstm_recurrence_forward',
+             'lstm_recurrence_backward', 'absmax', 'gemm_split_'}
+    for n in names:
+        op = getattr(torch.ops.ptmi, n)
+        assert op.default._schema.name == f'ptmi::{n}'
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f'ptmi::{n}', 'CUDA')
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'ptmi::{n}', 'CPU')
+    assert torch.ops.ptmi.gemm_split_.default._schema.arguments[0].alias_info.is_write      # out is written in place
+    with pytest.raises(NotImplementedError):
+        torch.ops.ptmi.absmax(torch.ones(2, 2), 2, 2, 2)                                    # CPU tensor: no kernel, no fallback

@@ -85,7 +85,12 @@ def test_simple_mask_estimator(g9):
     for k, p in me.named_parameters():
         want = g9[f'me/grad/{k}']
         assert np.abs(p.grad.cpu().numpy() - want).max() <= 2e-4 * max(np.abs(want).max(), 1e-3), k
-    assert set(review['images']) >= {'speech_mask', 'observed_stft', 'noise_mask'}
+    assert 'images' not in review                      # rendered only on request (a device -> host copy each)
+    me.create_snapshot = True
+    images = me.review(batch, me(batch))['images']
+    assert set(images) >= {'speech_mask', 'observed_stft', 'noise_mask'}
+    assert images['speech_mask'].shape == (1, 17, 11) and images['observed_stft'].shape[1:] == (17, 11)
+    me.create_snapshot = False
 
 
 def test_full_size_properties():
