@@ -4,6 +4,7 @@ The product path has NO CPU fallback: if the library is missing, or a tensor is 
 MI355X device, the ops raise instead of silently computing something else.
 """
 import ctypes
+import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p, POINTER
 from pathlib import Path
 
@@ -11,6 +12,8 @@ import torch
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / 'libptmi.so'
+if os.environ.get('PTMI_LIB'):            # A/B runs against another build of the same ABI (experiments only)
+    LIB_PATH = Path(os.environ['PTMI_LIB'])
 
 
 class StftGeom(ctypes.Structure):

@@ -15,6 +15,8 @@
 // The tile-major hand-off copy keeps its size and its access pattern: a "tile" is now 16 rows x 32 k of 16-bit values
 // (1 KB, one buffer_load_dwordx4 per lane), two planes (hi, lo) per 32-wide k block; a producer lane trades one half
 // with its neighbour lane so that it still issues ONE 4-byte write-through store per value.
+#include <stdlib.h>
+
 #include "lstm_common.h"
 
 namespace ptmi {
@@ -83,7 +85,7 @@ __device__ __forceinline__ unsigned pair_word(float v, int lane, int* plane) {
 // ---------------------------------------------------------------------------------------------------------------
 // Forward.  Template parameters as lstm_fwd_persistent_kernel; CB = 32-wide k blocks per wavefront (K = KP32 split
 // evenly over the NW wavefronts).
-template <int JT, int NW, int CB, int MTL, int OCC>
+template <int JT, int NW, int CB, int MTL, int OCC, bool PHASES = false>
 __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
@@ -132,6 +134,15 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     unsigned* const err = A.flags + A.err_off;
     const int bl_ = tid / JT, u = tid - bl_ * JT;
     const int b = m0 + bl_;
+    // PHASES (PTMI_LSTM_PHASES): thread 0 of workgroup (0, 0, 0) sums the 100 MHz clock per phase of a step (scripts/exp_lstm_phases.py)
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
+    auto mark = [&](int kk) {
+        if (PHASES && tid == 0) {
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            ph[kk] += now - ph_last;
+            ph_last = now;
+        }
+    };
     bool alive = true;
     float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
     float c_reg = 0.f;
@@ -144,7 +155,9 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         }
     }
 
+    if (PHASES && tid == 0) ph_last = __builtin_amdgcn_s_memrealtime();
     for (int s = 0; s < A.T; ++s) {
+        mark(11);
         const int t = dir == 0 ? s : A.T - 1 - s;
         const int nb = A.bs[t];
         const long long row0 = A.offs[t];
@@ -169,8 +182,11 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         };
         if (!has_rec) prefetch();
         if (has_rec) {
+            mark(0);
             if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            mark(1);
             __syncthreads();
+            mark(2);
             if (act && b < nprev) cprev = c_reg;
             // fragments: (row tile mt, k block i, plane p); one 1 KB tile per load instruction
             constexpr int NF = MTL * CB * 2;
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
 #pragma unroll
             for (int f = 0; f < NF; ++f) a[f] = __builtin_bit_cast(uint4, fragment(f));
             prefetch();
+            mark(3);
             __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[MTL][NT];
 #pragma unroll
@@ -216,7 +233,9 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            mark(4);
             __syncthreads();
+            mark(5);
             if (tid < MR * JT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -237,6 +256,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
             c_reg = fg * cprev + ig * gg;
             h = og * tanhf_(c_reg);
         }
+        mark(6);
         // hand-off copy: the (hi, lo) planes of this step's tile, written through; lanes 2i / 2i+1 trade one half
         {
             int plane;
@@ -259,8 +279,11 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
                 }
             }
         }
+        mark(7);
         if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mark(8);
         __syncthreads();
+        mark(9);
         if (tid == 0)
             __hip_atomic_store(myflags + blockIdx.x, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (act) {                                        // nobody in this launch reads these
@@ -272,13 +295,18 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
             A.c[o] = c_reg;
             A.hy[o] = h;
         }
+        mark(10);
+    }
+    if (PHASES && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        unsigned long long* out = reinterpret_cast<unsigned long long*>(A.hyt);
+        for (int kk = 0; kk < 12; ++kk) out[kk] = ph[kk];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward-through-time.  8 wavefronts, CB = 32-wide k blocks of K = 4H per wavefront (even split), CAB blocks in
 // flight per wavefront (re-requested as soon as their MFMAs have consumed them, as in lstm_bwd_persistent_kernel).
-template <int NW, int CB, int MTL>
+template <int NW, int CB, int MTL, int CABW>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
@@ -324,18 +352,31 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;
     float amax = 0.f;                                      // max |dgates| this thread has produced
 
+    // bookkeeping one step ahead (see the forward kernel): this step needs the batch sizes of time index t, of the one processed
+    // before (t_n) and of the one processed next (t_p = the forward-sense predecessor, for c_{t-1}); the latter is loaded
+    // one iteration early
+    auto tindex = [&](int step) { return dir == 0 ? A.T - 1 - step : step; };
+    int nb_c = A.bs[tindex(0)], nb_n = 0;                      // this step's / the previously processed time index
+    long long row_c = A.offs[tindex(0)];
+    int nb_f = A.T > 1 ? A.bs[tindex(1)] : 0;                  // the time index processed next
+    long long row_f = A.T > 1 ? A.offs[tindex(1)] : 0;
     for (int s = 0; s < A.T; ++s) {
-        const int t = dir == 0 ? A.T - 1 - s : s;
-        const int nb = A.bs[t];
-        const long long row0 = A.offs[t];
+        const int t = tindex(s);
+        const int nb = nb_c;
+        const long long row0 = row_c;
         const int tn = dir == 0 ? t + 1 : t - 1;
-        const int tp = dir == 0 ? t - 1 : t + 1;
-        const int nnext = (tn >= 0 && tn < A.T) ? min(A.bs[tn], nb) : 0;
-        int npv = 0;
-        long long prow0 = 0;
-        if (tp >= 0 && tp < A.T) {
-            npv = min(A.bs[tp], nb);
-            prow0 = A.offs[tp];
+        const int nnext = s > 0 ? min(nb_n, nb) : 0;
+        const bool has_p = s + 1 < A.T;
+        const int npv = has_p ? min(nb_f, nb) : 0;
+        const long long prow0 = has_p ? row_f : 0;
+        // rotate, and request the time index after the next one (first used in the NEXT iteration)
+        nb_n = nb;
+        nb_c = nb_f;
+        row_c = row_f;
+        {
+            const int t2 = tindex(min(s + 2, A.T - 1));       // clamped, unconditional (see the forward kernel)
+            nb_f = A.bs[t2];
+            row_f = A.offs[t2];
         }
         const bool has_rec = nnext > m0;
         const bool act = tid < 16 * MR && b < nb && j < H;
@@ -363,7 +404,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const unsigned vb0 = (m0 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
             const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
             constexpr int NB = MTL * CB;                    // k blocks of the first row tile, then of the second
-            constexpr int CAB = 3 < NB ? 3 : NB;            // blocks in flight
+            constexpr int CAB = CABW < NB ? CABW : NB;      // blocks in flight
             auto fragment = [&](int blk, int p) {           // compile-time constants after unrolling
                 const int mt = blk / CB, i = blk - mt * CB;
                 return __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, vb0, (min(i, ilast) * 2 + p) * 1024, 16 /* sc1 */)
@@ -432,11 +473,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             sb2 += gc;
             sb3 += go;
             amax = fmaxf(fmaxf(amax, fmaxf(fabsf(gi), fabsf(gf))), fmaxf(fabsf(gc), fabsf(go)));
-            float* dgp = A.dg + og_;                  // row-major: what the weight / input gradient GEMMs read
-            dgp[0] = gi;
-            dgp[H] = gf;
-            dgp[2 * H] = gc;
-            dgp[3 * H] = go;
         }
         // hand-off copy: bf16 (hi, lo) planes, written through; lanes 2i / 2i+1 (columns c, c+1) trade one half
         {
@@ -473,6 +509,13 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         __syncthreads();
         if (tid == 0)
             __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (act) {                                    // row-major dgates (what the GEMMs read): nobody in this launch waits for them
+            float* dgp = A.dg + og_;
+            dgp[0] = gi;
+            dgp[H] = gf;
+            dgp[2 * H] = gc;
+            dgp[3 * H] = go;
+        }
     }
     // bias gradient = sum of dgates over all rows; max |dgates| for the GEMMs that follow (operand scale)
     float* const fold = &red[0][0][0];
@@ -502,7 +545,9 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
     constexpr int NW = 8, CB = 3;
     const dim3 block(NW * 64);
     const bool wide = jt >= 12;
-    if (jt == 20 && small)
+    if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 1, 1, true>), grid, block, 0, st, A);
+    else if (jt == 20 && small)
         hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 1, 1>), grid, block, 0, st, A);
     else if (jt == 20)
         hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 2, 1>), grid, block, 0, st, A);
@@ -528,10 +573,16 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 }
 
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
+    const char* v = getenv("PTMI_LSTM_BWD_CAB");
+    const int cab = v ? atoi(v) : 3;
     if (mtl == 2)
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2>), dim3(nwg), dim3(512), 0, st, A);
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3>), dim3(nwg), dim3(512), 0, st, A);
+    else if (cab >= 10)
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 10>), dim3(nwg), dim3(512), 0, st, A);
+    else if (cab >= 5)
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 5>), dim3(nwg), dim3(512), 0, st, A);
     else
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1>), dim3(nwg), dim3(512), 0, st, A);
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3>), dim3(nwg), dim3(512), 0, st, A);
     return launch_status();
 }
 
