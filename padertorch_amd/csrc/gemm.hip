@@ -427,12 +427,14 @@ int ptmi_gemm_split(const float* a, int32_t a_kmajor, int64_t lda, const uint32_
         PTMI_RETURN_IF(!accumulate, PTMI_E_UNSUPPORTED);
         return PTMI_OK;
     }
-    auto aligned = [](const void* p, int64_t ld, int64_t inner) {
-        return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && (inner & 3) == 0;
+    // float4 granularity: base 16-byte aligned, leading dimension a multiple of 4, and the contiguous extent a multiple of 4
+    // (K of a k-major operand: surplus elements would enter the sums) - or, for a rows-contiguous operand, a leading
+    // dimension that covers the extent rounded up to 4 (the surplus elements exist in memory and only feed output
+    // rows / columns past M / N, which are never stored)
+    auto aligned = [](const void* p, int64_t ld, int64_t inner, bool kmajor) {
+        return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0 && ((inner & 3) == 0 || (!kmajor && ld >= ((inner + 3) & ~3LL)));
     };
-    // float4 granularity: the contiguous extent (K for k-major operands, rows otherwise) and the leading
-    // dimension must be multiples of 4, the base 16-byte aligned
-    const bool fast = aligned(a, lda, a_kmajor ? k : m) && aligned(b, ldb, b_kmajor ? k : n);
+    const bool fast = aligned(a, lda, a_kmajor ? k : m, a_kmajor) && aligned(b, ldb, b_kmajor ? k : n, b_kmajor);
     int splits = std::max(1, std::min<int>(split_k, (k + BK - 1) / BK));
     int ksplit = ((k + splits - 1) / splits + BK - 1) / BK * BK;
     splits = (k + ksplit - 1) / ksplit;

@@ -334,7 +334,16 @@ class _LstmLayerFn(torch.autograd.Function):
             amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
                       if use_gemm else None)
             if use_gemm:
-                gates = _gemm.mm(x, w_ih.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
+                # an input width that is not a multiple of 4 (F = 257) would send the projection and its weight gradient
+                # down the kernel's unaligned (scalar-load) path: zero-pad the reduction axis of both operands instead
+                kpad = -x.shape[1] % 4
+                if kpad:
+                    x_in = x
+                    x = torch.nn.functional.pad(x_in, (0, kpad))
+                    gates = _gemm.mm(x, torch.nn.functional.pad(w_ih, (0, kpad)).t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
+                    x = x[:, :x_in.shape[1]]                  # view with the padded row stride: what the backward pass multiplies
+                else:
+                    gates = _gemm.mm(x, w_ih.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
             else:
                 gates = torch.addmm(bias, x, w_ih.t())
             if stateful:        # h0 W_hh^T enters the pre-activations of each sequence's first processed step

@@ -11,21 +11,29 @@ import sys
 from pathlib import Path
 
 prof = Path(__file__).resolve().parent.parent / 'profiles'
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r1'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+# kernel name fragment -> key = the timer name bench.py files the kernel family under (_lib.timed)
 KEYS = {'pit_features_kernel': 'pit_features', 'pit_pairwise_kernel': 'pit_pairwise_sse',
-        'pit_backward_kernel': 'pit_backward', 'lstm_fwd_persistent_kernel': 'lstm_fwd_persistent',
-        'lstm_bwd_persistent_kernel': 'lstm_bwd_persistent', 'stft_fwd_kernel': 'stft_fwd',
+        'pit_backward_kernel': 'pit_backward', 'lstm_fwd_split_kernel': 'lstm_forward',
+        'lstm_bwd_split_kernel': 'lstm_backward', 'lstm_fwd_persistent_kernel': 'lstm_forward',
+        'lstm_bwd_persistent_kernel': 'lstm_backward', 'gemm_split_kernel': 'gemm_split', 'stft_fwd_kernel': 'stft_fwd',
         'istft_kernel': 'istft'}
 
 
 def parse(path, counter):
-    out, cur = {}, None
+    tot, cnt, cur, cur_line, dispatches = {}, {}, None, None, {}
     for line in path.read_text().splitlines():
         if not line.startswith(' '):
             cur = next((v for k, v in KEYS.items() if k in line), None)
+            cur_line = line
+            m = re.search(r'dispatches: (\d+)', line)
+            dispatches[cur_line] = int(m.group(1)) if m else 1
         elif cur and counter in line:
-            out[cur] = float(line.split()[-1])
-    return out
+            # several kernels may map to one family (template instances of the GEMM): dispatch-weighted mean
+            n = dispatches.get(cur_line, 1)
+            tot[cur] = tot.get(cur, 0.) + float(line.split()[-1]) * n
+            cnt[cur] = cnt.get(cur, 0) + n
+    return {k: tot[k] / cnt[k] for k in tot}
 
 
 fetch = parse(prof / f'{tag}_pmc_fetch_size.txt', 'FETCH_SIZE')

@@ -3,20 +3,29 @@
 #   bench line, rocprofv3 kernel trace of the same bench command, FETCH_SIZE / WRITE_SIZE PMC passes
 #   (separate runs, kernel-trace only), kernel micro-benchmarks.  Text summaries -> gpurun_out/p/.
 # usage: scripts/refresh_profiles.sh <round-tag>
-tag=${1:-r1}
+tag=${1:-r2}
 repo=$(pwd)
 out=$repo/gpurun_out/p
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 600 python $repo/bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
-rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o p -- python $repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/kt.log 2>&1 </dev/null
+timeout 900 python $repo/bench.py 2>/dev/null | tail -1 > $out/${tag}_bench.json
+rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o p -- python $repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /tmp/kt.log 2>&1 </dev/null
 db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
 if [ -n "$db" ]; then python $repo/scripts/profile_summary.py "$db" --top 40 > $out/${tag}_kernel_trace_bench.txt 2>&1 </dev/null; else tail -5 /tmp/kt.log > $out/${tag}_kernel_trace_bench.txt; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_$c.log 2>&1 </dev/null
+  rm -rf /tmp/pmc_$c; timeout 600 rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p -- python $repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /tmp/pmc_$c.log 2>&1 </dev/null
   db=$(find /tmp/pmc_$c -name "*.db" 2>/dev/null | head -1)
   lc=$(echo $c | tr A-Z a-z)
   if [ -n "$db" ]; then python $repo/scripts/profile_summary.py "$db" --pmc > $out/${tag}_pmc_$lc.txt 2>&1 </dev/null; else tail -5 /tmp/pmc_$c.log > $out/${tag}_pmc_$lc.txt; fi
 done
 timeout 600 python $repo/scripts/bench_kernels.py --big 2>/dev/null | grep '^{' > $out/${tag}_kernel_microbench.jsonl
+timeout 600 python $repo/scripts/bench_gemm.py 2>/dev/null | grep '^{' > $out/${tag}_gemm_microbench.jsonl
+# one step's kernels in start order (critical path) from the kernel trace
+db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
+[ -n "$db" ] && python $repo/scripts/step_timeline.py "$db" --min-us 25 > $out/${tag}_step_timeline.txt 2>&1 </dev/null
+# the other configurations and modes: one JSON line each
+( for cfg in c3 c4 c5; do timeout 900 python $repo/bench.py --config $cfg --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1; done
+  timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --library-gemms 2>/dev/null | tail -1
+  timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1
+  PTMI_LSTM_F32=1 timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
 ls -la $out

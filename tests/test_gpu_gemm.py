@@ -81,3 +81,28 @@ def test_bf16_mode_is_reduced_precision():
     ref = (a.bfloat16().double() @ b.bfloat16().double())
     assert float((c.double() - ref).abs().max()) < 1e-4            # bf16 operands, fp32 accumulation
     assert 1e-6 < _err(c, a, b) < 5e-3
+
+
+def test_padded_row_stride_views_take_the_aligned_path():
+    """The layer-0 shapes (F = 257): the projection multiplies zero-padded operands (K = 260), the weight gradient reads the
+    [rows, 257] view of the padded input (row stride 260) - also when that view ends exactly at its last valid element."""
+    from padertorch_amd.ops import gemm
+    dev = _dev()
+    g = torch.Generator(device='cpu').manual_seed(11)
+    rows, I, G = 1012, 257, 640
+    x = (torch.rand(rows, I, generator=g) * 3).to(dev)
+    w = (0.05 * torch.randn(G, I, generator=g)).to(dev)
+    dg = (1e-3 * torch.randn(rows, G, generator=g)).to(dev)
+    xp = torch.nn.functional.pad(x, (0, 3))
+    out = gemm.mm(xp, torch.nn.functional.pad(w, (0, 3)).t())
+    assert _err(out, x, w.t()) < 4e-7
+    xv = xp[:, :I]
+    assert xv.stride(0) == 260
+    dw = gemm.mm(dg.t(), xv, split_k=1)
+    assert _err(dw, dg.t(), x) < 4e-7
+    # a view whose storage ends with the last valid element (no padding behind the last row)
+    flat = torch.zeros((rows - 1) * 260 + I, device=dev)
+    tight = flat.as_strided((rows, I), (260, 1))
+    tight.copy_(x)
+    dw2 = gemm.mm(dg.t(), tight, split_k=1)
+    assert _err(dw2, dg.t(), x) < 4e-7
