@@ -194,6 +194,10 @@ class Trainer:
     def rank(self):
         return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
+    @staticmethod
+    def _dp_active():
+        return dist.is_available() and dist.is_initialized()
+
     def _time(self, key, t0):
         self.timer[key] = self.timer.get(key, 0.) + time.perf_counter() - t0
 
@@ -380,7 +384,7 @@ class Trainer:
         With W > 1 the flat gradient bucket is summed over all ranks first (one collective)."""
         from ..ops import lstm as _lstm
         _lstm.sync_deferred()          # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
-        if self.world_size > 1:
+        if self._dp_active():
             t0 = time.perf_counter()
             if self._buckets is not None:
                 self._buckets.finish()             # buckets not yet issued + wait for all of them
@@ -576,7 +580,9 @@ class Trainer:
         """Data parallel with ``overlap_allreduce``: build the layer buckets over the flat gradient buffer and hook
         them to gradient completion.  Returns the autograd hook handles (``train`` removes them)."""
         from ..ops import lstm as _lstm
-        if self.world_size <= 1 or not self.overlap_allreduce or self._flat is None:
+        # (a process group of ONE rank still takes the collective path: that is how the RCCL code is exercised on a
+        # single-GPU box, tests/test_gpu_model.py::test_trainer_rccl_path_world_size_1)
+        if not self._dp_active() or not self.overlap_allreduce or self._flat is None:
             self._buckets = None
             return []
         self._buckets = buckets = GradBuckets(self.model, self._flat)

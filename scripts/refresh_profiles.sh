@@ -8,7 +8,7 @@ repo=$(pwd)
 out=$repo/gpurun_out/p
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python $repo/bench.py 2>/dev/null | tail -1 > $out/${tag}_bench.json
+timeout 1200 python $repo/bench.py 2>/dev/null | tail -1 > $out/${tag}_bench.json
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt -o p -- python $repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > /tmp/kt.log 2>&1 </dev/null
 db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
 if [ -n "$db" ]; then python $repo/scripts/profile_summary.py "$db" --top 40 > $out/${tag}_kernel_trace_bench.txt 2>&1 </dev/null; else tail -5 /tmp/kt.log > $out/${tag}_kernel_trace_bench.txt; fi
@@ -28,4 +28,10 @@ db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --library-gemms 2>/dev/null | tail -1
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1
   PTMI_LSTM_F32=1 timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
+bash $repo/scripts/mb/run_mb.sh > /dev/null 2>&1
+for f in accuracy dispatch_probe handoff; do cp $repo/gpurun_out/mb/$f.txt $out/${tag}_mb_$f.txt 2>/dev/null; done
+timeout 600 python $repo/scripts/bf16_delta.py 2>/dev/null | tail -1 > $out/${tag}_bf16_delta.json
+timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' > $out/${tag}_lstm_us_per_step.txt
+PTMI_LSTM_F32=1 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' | sed 's/^/exact-fp32 kernels: /' >> $out/${tag}_lstm_us_per_step.txt
+timeout 300 python $repo/scripts/exp_lstm_phases.py > $out/${tag}_lstm_fwd_phases.txt 2>/dev/null
 ls -la $out

@@ -269,9 +269,11 @@ def test_smoke_entry():
     __graft_entry__.smoke()
 
 
-def test_trainer_rccl_path_world_size_1(g6, tmp_path):
-    """The RCCL data-parallel code path (process group 'nccl', flat-bucket all_reduce, step-0
-    broadcast) with world_size 1 on the GPU: must reproduce the single-process result exactly."""
+@pytest.mark.parametrize('overlap', [True, False])
+def test_trainer_rccl_path_world_size_1(g6, tmp_path, overlap):
+    """The RCCL data-parallel code path (process group 'nccl', step-0 broadcast, the layer buckets of the flat gradient
+    buffer all-reduced asynchronously behind the weight-gradient stream during the last micro-step's backward pass - or
+    one all-reduce in optimizer_step) with world_size 1 on the GPU: must reproduce the single-process result."""
     import os
     import socket
     import torch.distributed as dist
@@ -289,9 +291,19 @@ def test_trainer_rccl_path_world_size_1(g6, tmp_path):
                             device_id=torch.device(DEV))
     try:
         model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
-        t = pt.Trainer(model, tmp_path / 'dp', pt.optimizer.Adam(gradient_clipping=1.), **kw)
+        t = pt.Trainer(model, tmp_path / 'dp', pt.optimizer.Adam(gradient_clipping=1.), overlap_allreduce=overlap, **kw)
         assert t.world_size == 1 and t.rank == 0
-        t.train(exs, device=DEV)
+        issued = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda tensor, *a, **k: (issued.append(tensor.numel()), real(tensor, *a, **k))[1]
+        try:
+            t.train(exs, device=DEV)
+        finally:
+            dist.all_reduce = real
+        nflat = sum(p.numel() for p in model.parameters())
+        # 3 optimizer steps: per step the four layer buckets (last first), or the whole buffer once
+        per_step = [n for n in issued if n > 1][:4 if overlap else 1]
+        assert sum(per_step) == nflat and len([n for n in issued if n > 1]) == (12 if overlap else 3), issued
         # force the collective path once (world_size 1: all_reduce(SUM) is the identity)
         dist.all_reduce(t._flat.flat, op=dist.ReduceOp.SUM)
         t._broadcast_parameters()
