@@ -25,6 +25,8 @@
 // stages and two register stages: tile t+2 is in flight from memory while tile t is multiplied; the split + LDS writes of tile t+1
 // follow the MFMAs of tile t.  Split K (weight gradients: few output tiles, long K) writes one slab per K range and sums
 // the slabs in a fixed order in a second kernel (bitwise reproducible, no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ptmi {
@@ -51,6 +53,8 @@ struct GemmArgs {
     int ksplit;                 // K range per blockIdx.z (multiple of 32)
     float* workspace;           // split K: [splits][M][N] partial results
     long long a_bytes, b_bytes; // extents of the operand buffers (buffer-load bounds)
+    int dbg;                    // PTMI_GEMM_DBG timing ablations (results void): 1 no global loads after the first tile, 2 no LDS
+                                // writes after the first tile, 4 no MFMAs, 8 no fragment reads
 };
 
 constexpr int BM = 128, BN = 128, BK = 32, PITCH = 40;      // PITCH in halfs
@@ -244,11 +248,17 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
         _Float16* nxt = lds + (stage ^ 1) * 4 * PLANE;
         // no branches in here (one scheduling region): loads past the end of K return zeros, the last iteration's LDS
         // writes go to the stage nobody reads any more
-        LA.template load<FAST>(kbeg + (t + 2) * BK, kend, m0, G.M, tid, la);
-        LB.template load<FAST>(kbeg + (t + 2) * BK, kend, n0, G.N, tid, lb);
+        if (!(G.dbg & 1)) {
+            LA.template load<FAST>(kbeg + (t + 2) * BK, kend, m0, G.M, tid, la);
+            LB.template load<FAST>(kbeg + (t + 2) * BK, kend, n0, G.N, tid, lb);
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             uint4 ah[2], al[2], bh[2], bl[2];
+            if (G.dbg & 8) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) ah[i] = al[i] = bh[i] = bl[i] = make_uint4(t, tid, kk, i);
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int o = (wm * 64 + i * 32) * PITCH + frag + kk * 16;
@@ -260,6 +270,11 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
                 const int o = (wn * 64 + j * 32) * PITCH + frag + kk * 16;
                 bh[j] = *reinterpret_cast<const uint4*>(cur + 2 * PLANE + o);
                 if (PRODUCTS == 3) bl[j] = *reinterpret_cast<const uint4*>(cur + 3 * PLANE + o);
+            }
+            }
+            if (G.dbg & 4) {
+                asm volatile("" ::"v"(ah[0].x), "v"(al[1].y), "v"(bh[0].z), "v"(bl[1].w));
+                continue;
             }
             // small terms first, the hi x hi term last
             if (PRODUCTS == 3) {
@@ -277,8 +292,10 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = mma<PRODUCTS>(ah[i], bh[j], acc[i][j]);
         }
-        store_tile<A_KMAJOR, PRODUCTS>(nxt, nxt + PLANE, tid, ca, sa);
-        store_tile<B_KMAJOR, PRODUCTS>(nxt + 2 * PLANE, nxt + 3 * PLANE, tid, cb, sb);
+        if (!(G.dbg & 2)) {
+            store_tile<A_KMAJOR, PRODUCTS>(nxt, nxt + PLANE, tid, ca, sa);
+            store_tile<B_KMAJOR, PRODUCTS>(nxt + 2 * PLANE, nxt + 3 * PLANE, tid, cb, sb);
+        }
         // Issue order for the scheduler: the matrix pipe and the vector ALU are separate, and one 32 x 32 x 16 MFMA keeps
         // its pipe busy for 32 cycles = about 6 VALU issue slots of the same wavefront.  The split of tile t+1 (about 150
         // VALU instructions per wavefront and k-step) and its LDS writes are therefore dealt out between the MFMAs
@@ -313,6 +330,132 @@ __global__ __launch_bounds__(256, 2) void gemm_split_kernel(const GemmArgs G) {
     // C layout of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const float alpha = 1.f / (sa * sb);
     const bool slab = gridDim.z > 1;            // split K: this range's partial result goes to its own slab
+    float* const Cz = slab ? G.workspace + (long long)blockIdx.z * G.M * G.N : G.C;
+    const long long ldc = slab ? G.N : G.ldc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= G.N) continue;
+        const float bv = (G.bias && !slab) ? G.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = m0 + wm * 64 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                if (row < G.M) {
+                    float* c = Cz + (long long)row * ldc + col;
+                    const float v = acc[i][j][q] * alpha + bv;
+                    if (G.accumulate && !slab) *c += v;
+                    else *c = v;
+                }
+            }
+        }
+    }
+}
+
+// Wave-specialised form (the default): 8 wavefronts per workgroup, one CONSUMER (fragment reads + MFMAs of tile t) and one
+// PRODUCER (global loads of tile t+2, split + LDS writes of tile t+1) on every SIMD.  The matrix pipe and the vector ALU /
+// LDS / memory paths are separate units, but two workgroups of the kernel above fall into lock step on a CU (timing
+// ablations: skeleton 103 + loads 51 + split and LDS writes 77 + fragment reads 55 + MFMAs 140 ~ the measured 384 us of the
+// projection GEMM: nothing overlapped); with fixed roles the two kinds of work always belong to different wavefronts of
+// the same SIMD and overlap by construction.  One barrier per k-step hands LDS stage (t+1) & 1 from the producers to the
+// consumers and stage t & 1 back.
+template <bool A_KMAJOR, bool B_KMAJOR, bool FAST, int PRODUCTS>
+__global__ __launch_bounds__(512, 4) void gemm_split_ws_kernel(const GemmArgs G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* const lds = reinterpret_cast<_Float16*>(smem);          // [stage][A hi | A lo | B hi | B lo][128][PITCH]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave >= 4;
+    const int ntn = (G.N + BN - 1) / BN, ntm = (G.M + BM - 1) / BM;
+    const int total = ntm * ntn, chunk = (total + 7) >> 3;
+    const int L = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || L >= total) return;
+    const int band = L / (8 * ntn), rem = L - band * 8 * ntn;
+    const int band_rows = min(8, ntm - 8 * band);
+    const int tn = rem / band_rows, tm = 8 * band + rem - tn * band_rows;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.z * G.ksplit, kend = min(G.K, kbeg + G.ksplit);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    if (producer) {
+        const int ptid = threadIdx.x - 256;
+        const float sa = operand_scale(G.amax_a), sb = operand_scale(G.amax_b);
+        const TileLoader<A_KMAJOR> LA(G.A, G.lda, m0, G.M, G.a_bytes, ptid);
+        const TileLoader<B_KMAJOR> LB(G.B, G.ldb, n0, G.N, G.b_bytes, ptid);
+        f32x4 va0[4], vb0[4], va1[4], vb1[4];
+        LA.template load<FAST>(kbeg, kend, m0, G.M, ptid, va0);
+        LB.template load<FAST>(kbeg, kend, n0, G.N, ptid, vb0);
+        LA.template load<FAST>(kbeg + BK, kend, m0, G.M, ptid, va1);
+        LB.template load<FAST>(kbeg + BK, kend, n0, G.N, ptid, vb1);
+        store_tile<A_KMAJOR, PRODUCTS>(lds, lds + PLANE, ptid, va0, sa);
+        store_tile<B_KMAJOR, PRODUCTS>(lds + 2 * PLANE, lds + 3 * PLANE, ptid, vb0, sb);
+        __syncthreads();
+        // iteration t: request tile t+2 into the registers tile t came through, split tile t+1 into the other LDS stage
+        auto body = [&](int t, int stage, f32x4 (&la)[4], f32x4 (&lb)[4], f32x4 (&ca)[4], f32x4 (&cb)[4]) {
+            _Float16* nxt = lds + (stage ^ 1) * 4 * PLANE;
+            LA.template load<FAST>(kbeg + (t + 2) * BK, kend, m0, G.M, ptid, la);
+            LB.template load<FAST>(kbeg + (t + 2) * BK, kend, n0, G.N, ptid, lb);
+            store_tile<A_KMAJOR, PRODUCTS>(nxt, nxt + PLANE, ptid, ca, sa);
+            store_tile<B_KMAJOR, PRODUCTS>(nxt + 2 * PLANE, nxt + 3 * PLANE, ptid, cb, sb);
+            __syncthreads();
+        };
+        for (int t = 0; t < nk; t += 2) {
+            body(t, 0, va0, vb0, va1, vb1);
+            if (t + 1 < nk) body(t + 1, 1, va1, vb1, va0, vb0);
+        }
+        return;
+    }
+
+    // consumers: wavefront (wm, wn) owns the 64 x 64 block of the tile
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+    const int frag = (lane & 31) * PITCH + (lane >> 5) * 8;
+    __syncthreads();                                   // stage 0 is filled
+    __builtin_amdgcn_s_setprio(1);
+    for (int t = 0; t < nk; ++t) {
+        const _Float16* cur = lds + (t & 1) * 4 * PLANE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int o = (wm * 64 + i * 32) * PITCH + frag + kk * 16;
+                ah[i] = *reinterpret_cast<const uint4*>(cur + o);
+                if (PRODUCTS == 3) al[i] = *reinterpret_cast<const uint4*>(cur + PLANE + o);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = (wn * 64 + j * 32) * PITCH + frag + kk * 16;
+                bh[j] = *reinterpret_cast<const uint4*>(cur + 2 * PLANE + o);
+                if (PRODUCTS == 3) bl[j] = *reinterpret_cast<const uint4*>(cur + 3 * PLANE + o);
+            }
+            if (PRODUCTS == 3) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mma<PRODUCTS>(al[i], bh[j], acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = mma<PRODUCTS>(ah[i], bl[j], acc[i][j]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma<PRODUCTS>(ah[i], bh[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    const float alpha = 1.f / (operand_scale(G.amax_a) * operand_scale(G.amax_b));
+    const bool slab = gridDim.z > 1;
     float* const Cz = slab ? G.workspace + (long long)blockIdx.z * G.M * G.N : G.C;
     const long long ldc = slab ? G.N : G.ldc;
 #pragma unroll
@@ -383,6 +526,21 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 template <bool AK, bool BK_, int PRODUCTS>
 static int launch_gemm(const GemmArgs& G, bool fast, dim3 grid, hipStream_t st) {
     const size_t lds = (size_t)2 * 4 * PLANE * sizeof(_Float16);      // 81920 B: two workgroups per CU
+    static const bool ws = !(getenv("PTMI_GEMM_WS") && atoi(getenv("PTMI_GEMM_WS")) == 0);
+    if (ws && fast) {
+        auto k = gemm_split_ws_kernel<AK, BK_, true, PRODUCTS>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, st, G);
+        return launch_status();
+    }
+    if (ws) {
+        auto k = gemm_split_ws_kernel<AK, BK_, false, PRODUCTS>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(k, grid, dim3(512), lds, st, G);
+        return launch_status();
+    }
     if (fast) {
         auto k = gemm_split_kernel<AK, BK_, true, PRODUCTS>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -443,7 +601,8 @@ int ptmi_gemm_split(const float* a, int32_t a_kmajor, int64_t lda, const uint32_
     const long long a_bytes = ((long long)((a_kmajor ? m : k) - 1) * lda + (a_kmajor ? k : m)) * 4;
     const long long b_bytes = ((long long)((b_kmajor ? n : k) - 1) * ldb + (b_kmajor ? k : n)) * 4;
     PTMI_RETURN_IF(a_bytes >= 0x7fffffffLL || b_bytes >= 0x7fffffffLL, PTMI_E_UNSUPPORTED);
-    GemmArgs G{a, b, c, bias, amax_a, amax_b, m, n, k, lda, ldb, ldc, accumulate ? 1 : 0, ksplit, workspace, a_bytes, b_bytes};
+    GemmArgs G{a, b, c, bias, amax_a, amax_b, m, n, k, lda, ldb, ldc, accumulate ? 1 : 0, ksplit, workspace, a_bytes, b_bytes,
+               getenv("PTMI_GEMM_DBG") ? atoi(getenv("PTMI_GEMM_DBG")) : 0};
     const int tiles = ((m + BM - 1) / BM) * ((n + BN - 1) / BN);
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
     const int sel = (a_kmajor ? 2 : 0) | (b_kmajor ? 1 : 0);

@@ -10,6 +10,8 @@ speed (fp32 MFMA runs at 1/16 of the fp16 rate on this part).
 ``PRODUCTS = 1`` switches every product to plain bf16 operands (BASELINE's "bf16" run of the model:
 reduced precision, reported as a delta, never the default).
 """
+import os
+
 import torch
 
 from .. import _lib
@@ -91,11 +93,12 @@ def _operand(t, reduce_first):
 
 def auto_split_k(M, N, K):
     """K ranges per output tile: weight-gradient shapes (few 128 x 128 tiles, K = all rows of the batch) are cut until
-    about two workgroups per CU exist; every range keeps at least 16 k-steps."""
+    about two workgroups per CU exist (measured at the step's shapes: 2400 x 1200 x 8096 311 / 274 / 262 / 254 us with 1 / 2 / 4 / 8
+    ranges, 2400 x 600 x 8096 295 / 165 / 150 / 144); every range keeps at least 16 k-steps."""
     tiles = -(-M // 128) * -(-N // 128)
     if tiles >= 384:
         return 1
-    return max(1, min(512 // tiles, K // 512, 8))
+    return max(1, min(int(os.environ.get('PTMI_GEMM_SPLIT_TARGET', '512')) // tiles, K // 512, 8))
 
 
 def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, split_k=None, products=None):
