@@ -345,6 +345,30 @@ int ptmi_gemm_split(const float* a, int32_t a_kmajor, int64_t lda, const uint32_
                     float* workspace, ptmi_stream_t stream);
 int64_t ptmi_gemm_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer step on the Trainer's flat gradient bucket (csrc/optim.hip): replaces, on the step path of
+ * padertorch/train/trainer.py:512-532, torch.nn.utils.clip_grad_norm_ (padertorch/train/optimizer.py:35-42),
+ * torch.optim.Adam.step (padertorch/train/optimizer.py:79-90 -> :31-33) and zero_grad (:27-29).
+ *
+ * ptmi_grad_norm: norm_out[0] = 2-norm of flat[0:n] (device fp32; 16-byte aligned).  Reproducible: fixed
+ *   per-workgroup slices summed in double, folded in a fixed order.  workspace = device buffer of
+ *   ptmi_grad_norm_workspace_elems() doubles.
+ *
+ * ptmi_adam_flat: for every element i of the bucket (segment s = the parameter tensor it belongs to):
+ *     g = flat_grad[i] * min(1, max_norm / (norm[0] + 1e-6))          (norm == NULL: no clipping)
+ *     g += weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g
+ *     p -= (lr / (1 - beta1^t)) * (m / (sqrt(v) / sqrt(1 - beta2^t) + eps)),   t = step[0] + 1
+ *   i.e. torch.optim.Adam's arithmetic (amsgrad / maximize not supported); flat_grad[i] = 0 afterwards when
+ *   zero_grad != 0.  found_inf (device fp32 scalar or NULL) != 0 skips the update (gradients are still zeroed),
+ *   the semantics of torch's fused Adam.  segments = device int64 [nseg][3]: parameter pointer, first flat
+ *   index, element count, ascending and dense over [0, n).  exp_avg / exp_avg_sq: flat fp32 [n].  The caller
+ *   advances `step` (a device fp32 scalar) afterwards. */
+int64_t ptmi_grad_norm_workspace_elems(void);
+int ptmi_grad_norm(const float* flat, int64_t n, double* workspace, float* norm_out, ptmi_stream_t stream);
+int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const int64_t* segments, int32_t nseg, int64_t n,
+                   const float* norm, float max_norm, const float* found_inf, const float* step, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, int32_t zero_grad, ptmi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ with CPU tensors fails in the dispatcher (``NotImplementedError: ... 'CPU' backe
     torch.ops.ptmi.lstm_recurrence_forward / _backward   ptmi_lstm_*_persistent, falling back to ptmi_lstm_forward / _backward
                                                                               (torch.nn.LSTM in pit/model.py:60-66,97)
     torch.ops.ptmi.absmax, torch.ops.ptmi.gemm_split_    ptmi_absmax, ptmi_gemm_split   (nn.LSTM input projections, nn.Linear)
+    torch.ops.ptmi.grad_norm, torch.ops.ptmi.adam_flat_  ptmi_grad_norm, ptmi_adam_flat (train/optimizer.py:27-42, trainer.py:512-532)
 """
 import ctypes
 from typing import List, Optional, Tuple
@@ -176,6 +177,29 @@ def gemm_split_(out, x, a_kmajor, lda, amax_x, y, b_kmajor, ldb, amax_y, bias, M
                           _lib.ptr(amax_x), y.data_ptr(), b_kmajor, ldb, _lib.ptr(amax_y), _lib.ptr(bias), out.data_ptr(),
                           max(out.stride(0), N), M, N, K, int(accumulate), products, split_k, _lib.ptr(ws),
                           _lib.stream(x.device)), 'ptmi_gemm_split')
+
+
+# ------------------------------------------------------------------------------------------------ optimizer step
+@_register('grad_norm(Tensor flat) -> Tensor')
+def grad_norm(flat):
+    lib = _lib.load()
+    ws = torch.empty(int(lib.ptmi_grad_norm_workspace_elems()), dtype=torch.float64, device=flat.device)
+    out = torch.empty((), dtype=torch.float32, device=flat.device)
+    _lib.check(_lib.timed('grad_norm', lib.ptmi_grad_norm, flat.data_ptr(), flat.numel(), ws.data_ptr(), out.data_ptr(),
+                          _lib.stream(flat.device)), 'ptmi_grad_norm')
+    return out
+
+
+@_register('adam_flat_(Tensor(a!) flat_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor segments, Tensor(d!)[] params, '
+           'Tensor? norm, float max_norm, Tensor? found_inf, Tensor step, float lr, float beta1, float beta2, float eps, '
+           'float weight_decay, bool zero_grad) -> ()')
+def adam_flat_(flat_grad, exp_avg, exp_avg_sq, segments, params, norm, max_norm, found_inf, step, lr, beta1, beta2, eps,
+               weight_decay, zero_grad):
+    # `params` are the tensors the segment table points into (listed so that the dispatcher sees what is written)
+    _lib.check(_lib.timed('adam_flat', _lib.load().ptmi_adam_flat, flat_grad.data_ptr(), exp_avg.data_ptr(),
+                          exp_avg_sq.data_ptr(), segments.data_ptr(), segments.shape[0], flat_grad.numel(), _lib.ptr(norm),
+                          max_norm, _lib.ptr(found_inf), step.data_ptr(), lr, beta1, beta2, eps, weight_decay, int(zero_grad),
+                          _lib.stream(flat_grad.device)), 'ptmi_adam_flat')
 
 
 # ------------------------------------------------------------------------------------------------ unit norm

@@ -13,6 +13,7 @@
 """
 import ctypes
 import functools
+import os
 
 import numpy as np
 import torch
@@ -166,11 +167,20 @@ WGRAD_SIDE_STREAM = True
 _WGRAD_STREAMS = {}
 
 
-def _wgrad_stream(device):
+_WGRAD_STREAMS2 = {}
+#: experiment knob, default off: 2 = the reverse direction's weight-gradient GEMMs of the FIRST layer (whose input needs no
+#: gradient: only the optimizer follows, the step's tail) run on a second side stream, joined into the first one right
+#: away; 3 = of every layer.  Measured: 2 makes no difference (10.81-10.84 vs 10.84-10.85 ms per step: each GEMM already
+#: fills the chip), 3 is slower (11.3 vs 10.7 ms: more workgroups next to the following layer's recurrence).
+WGRAD_STREAMS = int(os.environ.get('PTMI_WGRAD_STREAMS', '1'))
+
+
+def _wgrad_stream(device, second=False):
     key = (device.type, device.index)
-    if key not in _WGRAD_STREAMS:
-        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _WGRAD_STREAMS[key]
+    pool = _WGRAD_STREAMS2 if second else _WGRAD_STREAMS
+    if key not in pool:
+        pool[key] = torch.cuda.Stream(device=device)
+    return pool[key]
 
 
 _SIDE_SAFE = {}
@@ -439,13 +449,18 @@ class _LstmLayerFn(torch.autograd.Function):
             use_side = WGRAD_SIDE_STREAM and (gm is not None or
                                               _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
             side = _wgrad_stream(x.device) if use_side else main
+            side2 = _wgrad_stream(x.device, True) if use_side and ndir > 1 and (
+                WGRAD_STREAMS > 2 or (WGRAD_STREAMS == 2 and not ctx.needs_input_grad[0])) else None
             if use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
             with torch.cuda.stream(side):
-                for d, ((p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev)) in enumerate(zip(
-                        params, _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H))):
+                operands = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
+            if side2 is not None:
+                side2.wait_stream(side)
+            for d, ((p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev)) in enumerate(zip(params, operands)):
+                with torch.cuda.stream(side2 if side2 is not None and d == 1 else side):
                     if gm is not None:
                         _gemm.mm(dgd.t(), x, out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=amax_x)
                         _gemm.mm(dgd.t(), h_prev, out=p_whh.grad, accumulate=True, amax_x=amax_dg,
@@ -460,6 +475,12 @@ class _LstmLayerFn(torch.autograd.Function):
                 for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel, amax_dg if gm is not None else None)
                                              if v is not None and torch.is_tensor(v)):
                     t.record_stream(side)           # keep the operands alive until the side stream is done
+                    if side2 is not None:
+                        t.record_stream(side2)
+                if side2 is not None:
+                    for _, h_prev in operands:
+                        h_prev.record_stream(side2)
+                    side.wait_stream(side2)
             if GRAD_READY_HOOK is not None:
                 GRAD_READY_HOOK([p for ps in params for p in ps])
             return (dx,) + (None,) * 8

@@ -4,7 +4,16 @@
 gradients of all parameters live in ONE flat fp32 bucket (:class:`FlatGrads`): the global-norm clip
 is a single reduction over it, ``zero_grad`` a single memset, and the data-parallel exchange a
 single RCCL ``all_reduce(SUM)`` (see ``trainer.py``).
+
+On a GPU :class:`Adam` runs the three of them as TWO passes over HBM (``csrc/optim.hip``,
+``torch.ops.ptmi.grad_norm`` / ``adam_flat_``): the reproducible 2-norm of the bucket, then clip scale +
+moment update + parameter update + zeroing of the bucket in one kernel (32 B per parameter instead of the
+~60 B of clip ``mul_`` + multi-tensor Adam + memset).  The moments are views into two flat buffers, the
+``torch.optim.Adam`` object keeps owning them (``state_dict`` / ``load_state_dict`` are torch's, i.e. the
+reference's checkpoint layout).
 """
+import os
+
 import torch
 from torch import optim
 
@@ -67,6 +76,11 @@ class Optimizer:
         self.check_if_set()
         return self.optimizer.step()
 
+    def step_and_zero_grad(self):
+        """``step()`` then ``zero_grad()`` (``trainer.py:523-524``); one kernel where a subclass can fuse them."""
+        self.step()
+        self.zero_grad()
+
     def clip_grad(self):
         """Global-norm clipping (``optimizer.py:31-42``); returns the unclipped norm (0-dim tensor)."""
         self.check_if_set()
@@ -105,18 +119,105 @@ class Optimizer:
 
 class Adam(Optimizer):
     optimizer_cls = optim.Adam
+    #: clip + update + zero_grad on the flat bucket by the kernels of ``csrc/optim.hip`` (GPU buckets only)
+    native = os.environ.get('PTMI_NATIVE_ADAM', '1') != '0'
 
     def __init__(self, gradient_clipping=1e10, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0, amsgrad=False):
         super().__init__(gradient_clipping, lr=lr, betas=betas, eps=eps,
                          weight_decay=weight_decay, amsgrad=amsgrad)
+        self._bound = None           # (flat exp_avg, flat exp_avg_sq, steps, segment table, keys) of the native path
+        self._norm = None            # 2-norm of the bucket from clip_grad(), applied by the next step()
 
     def set_parameters(self, parameters):
         self.parameters = tuple(parameters)
+        self._bound = None
         try:        # one fused multi-tensor kernel per step (the model moves to the GPU later)
             self.optimizer = self.optimizer_cls(self.parameters, fused=True, **self.optimizer_kwargs)
         except (RuntimeError, TypeError, ValueError):
             self.optimizer = self.optimizer_cls(self.parameters, **self.optimizer_kwargs)
+
+    # ---------------------------------------------------------------------------------- native path
+    def _native_ok(self):
+        fg = self.flat_grads
+        if not self.native or fg is None or not fg.flat.is_cuda or fg.flat.dtype != torch.float32 or not fg.intact():
+            return False
+        groups = self.optimizer.param_groups
+        if len(groups) != 1:
+            return False
+        g = groups[0]
+        return not (g.get('amsgrad') or g.get('maximize') or g.get('differentiable') or g.get('capturable'))
+
+    def _bind(self):
+        """Make every parameter's Adam state a view into flat buffers laid out like the gradient bucket (existing state -
+        a loaded checkpoint, earlier torch steps - is copied in)."""
+        fg, opt = self.flat_grads, self.optimizer
+        keys = tuple(p.data_ptr() for p in fg.params)
+        b = self._bound
+        if b is not None and b[4] == keys and b[0].device == fg.flat.device and all(
+                (st := opt.state.get(p)) is not None and st['exp_avg'].data_ptr() == b[0].data_ptr() + 4 * off
+                and st['exp_avg_sq'].data_ptr() == b[1].data_ptr() + 4 * off and st['step'].data_ptr() == b[2].data_ptr() + 4 * i
+                for i, (p, off) in enumerate(zip(fg.params, b[5]))):
+            return b
+        dev = fg.flat.device
+        m, v = torch.zeros_like(fg.flat), torch.zeros_like(fg.flat)
+        steps = torch.zeros(len(fg.params), dtype=torch.float32, device=dev)
+        offs, table, off = [], [], 0
+        for i, p in enumerate(fg.params):
+            n = p.numel()
+            st = opt.state.get(p)
+            if st:
+                m[off:off + n].copy_(st['exp_avg'].reshape(-1))
+                v[off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                steps[i:i + 1].copy_(torch.as_tensor(st['step'], dtype=torch.float32).reshape(1))
+            opt.state[p] = {'step': steps[i], 'exp_avg': m[off:off + n].view_as(p), 'exp_avg_sq': v[off:off + n].view_as(p)}
+            table.append((p.data_ptr(), off, n))
+            offs.append(off)
+            off += n
+        segs = torch.tensor(table, dtype=torch.int64).to(dev)
+        self._bound = (m, v, steps, segs, keys, offs)
+        return self._bound
+
+    def clip_grad(self):
+        """Global-norm clipping (``optimizer.py:31-42``); returns the unclipped norm (0-dim tensor).  On the native path
+        the scale ``min(1, clip / (norm + 1e-6))`` is applied to the gradients inside the next ``step()``."""
+        if not self._native_ok():
+            return super().clip_grad()
+        self._norm = torch.ops.ptmi.grad_norm(self.flat_grads.flat)
+        return self._norm
+
+    def _native_step(self, zero_grad):
+        m, v, steps, segs, _, _ = self._bind()
+        fg, opt = self.flat_grads, self.optimizer
+        g = opt.param_groups[0]
+        found = getattr(opt, 'found_inf', None)          # device flag set by the Trainer's deferred checks (fused Adam's protocol)
+        if found is not None and not (torch.is_tensor(found) and found.is_cuda):
+            found = None
+        torch.ops.ptmi.adam_flat_(fg.flat, m, v, segs, list(fg.params), self._norm, float(self.gradient_clipping),
+                                  None if found is None else found.reshape(1).float(), steps, float(g['lr']),
+                                  float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
+                                  bool(zero_grad))
+        if found is None:
+            steps.add_(1.0)
+        else:
+            steps.add_(1.0 - found.reshape(()).float())
+        self._norm = None
+
+    def step(self):
+        self.check_if_set()
+        if not self._native_ok():
+            return self.optimizer.step()
+        return self._native_step(zero_grad=False)
+
+    def step_and_zero_grad(self):
+        self.check_if_set()
+        if not self._native_ok():
+            return super().step_and_zero_grad()
+        return self._native_step(zero_grad=True)
+
+    def zero_grad(self):
+        self._norm = None
+        return super().zero_grad()
 
 
 class SGD(Optimizer):

@@ -394,8 +394,11 @@ class Trainer:
         summary = self.clip_grad({})
         for i, param_group in enumerate(self.optimizer.optimizer.param_groups):
             summary['scalars'][f'lr/param_group_{i}'] = param_group['lr']
-        self.optimizer.step()
-        self.optimizer.zero_grad()
+        if hasattr(self.optimizer, 'step_and_zero_grad'):
+            self.optimizer.step_and_zero_grad()        # Adam on a GPU bucket: clip + update + zeroing in one kernel
+        else:
+            self.optimizer.step()
+            self.optimizer.zero_grad()
         self._opt_step += 1
         return summary
 
