@@ -167,6 +167,8 @@ WGRAD_SIDE_STREAM = True
 _WGRAD_STREAMS = {}
 
 
+#: run BLSTM layers on per-parameter-version cached stacked weights where autograd does not need the concatenations
+CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
 _WGRAD_STREAMS2 = {}
 #: experiment knob, default off: 2 = the reverse direction's weight-gradient GEMMs of the FIRST layer (whose input needs no
 #: gradient: only the optimizer follows, the step's tail) run on a second side stream, joined into the first one right
@@ -307,11 +309,46 @@ def _acquire(meta, ndir, H, device):
     return _Lease(ws)
 
 
+_STACKED = {}
+
+
+def _stacked_weights(params, KP):
+    """The per-layer operand forms of a BLSTM layer's parameters - both directions' ``weight_ih`` stacked (and, for an
+    input width that is not a multiple of 4, zero-padded along the reduction axis), the summed biases, ``weight_hh``
+    stacked, padded to ``KP`` columns and transposed - cached until a parameter is modified (``_version`` / storage):
+    they change once per optimizer step, not per micro-step or layer call (six concatenation / padding / transposition
+    kernels per layer and pass, ~70 us of launch-bound work per layer of the B = 32 step).  Detached: only for calls
+    whose weight gradients do not travel through autograd (``DEFER_WGRAD`` path, or no graph at all)."""
+    key = tuple(id(p) for ps in params for p in ps)
+    sig = tuple((p._version, p.data_ptr()) for ps in params for p in ps)
+    hit = _STACKED.get(key)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    if len(_STACKED) > 64:
+        _STACKED.clear()
+    with torch.no_grad():
+        w_ih = torch.cat([ps[0] for ps in params], 0)
+        bias = torch.cat([ps[2] + ps[3] for ps in params], 0)
+        w_hh = torch.stack([ps[1] for ps in params], 0)
+        H = w_hh.shape[2]
+        kpad = -w_ih.shape[1] % 4
+        forms = {
+            'w_ih': w_ih, 'bias': bias, 'w_hh': w_hh,
+            'w_ih_kpad': torch.nn.functional.pad(w_ih, (0, kpad)) if kpad else None,
+            'w_pad': torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous(),
+            'w_t': w_hh.transpose(1, 2).contiguous(),
+        }
+    _STACKED[key] = (sig, forms)
+    return forms
+
+
 class _LstmLayerFn(torch.autograd.Function):
     """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False):
+    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False, anchor=None, forms=None):
+        # anchor: a Parameter of the layer when (w_ih, bias, w_hh) are the cached detached forms (`forms`), so that the
+        # node stays in the graph although none of its tensor inputs may require a gradient (first layer)
         lib = _lib.load()
         ndir, G, H = w_hh.shape
         assert G == 4 * H
@@ -350,7 +387,8 @@ class _LstmLayerFn(torch.autograd.Function):
                 if kpad:
                     x_in = x
                     x = torch.nn.functional.pad(x_in, (0, kpad))
-                    gates = _gemm.mm(x, torch.nn.functional.pad(w_ih, (0, kpad)).t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
+                    w_ih_k = forms['w_ih_kpad'] if forms is not None else torch.nn.functional.pad(w_ih, (0, kpad))
+                    gates = _gemm.mm(x, w_ih_k.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
                     x = x[:, :x_in.shape[1]]                  # view with the padded row stride: what the backward pass multiplies
                 else:
                     gates = _gemm.mm(x, w_ih.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
@@ -360,7 +398,10 @@ class _LstmLayerFn(torch.autograd.Function):
                 gv = gates.view(meta.rows, ndir, G)
                 for d in range(ndir):
                     gv[:, d].index_add_(0, meta.first_rows[d], h0[d] @ w_hh[d].t())
-            w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
+            if forms is not None:
+                w_pad = forms['w_pad']
+            else:
+                w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
             # equal-length batch: bs[0] rows of "state before the first step" (zero or h0) in front of and
             # behind the output rows, so that the backward pass reads h_{t-1} as a shifted view (no gather)
             pad = meta.bs0 if meta.equal_lengths else 0
@@ -391,6 +432,7 @@ class _LstmLayerFn(torch.autograd.Function):
             ctx.gemm = (amax_x, amax_w) if use_gemm else None
         ctx.meta = meta
         ctx.params = params
+        ctx.forms = forms
         if stateful:
             ctx.mark_non_differentiable(c)
             return hy, c
@@ -419,7 +461,7 @@ class _LstmLayerFn(torch.autograd.Function):
             x, w_ih, w_hh, gates, c, hy, h0, c0 = ctx.saved_tensors
             ndir, G, H = w_hh.shape
             dhy = dhy.contiguous()
-            w_t = w_hh.transpose(1, 2).contiguous()                   # [ndir, H, 4H]
+            w_t = ctx.forms['w_t'] if ctx.forms is not None else w_hh.transpose(1, 2).contiguous()      # [ndir, H, 4H]
             dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                 gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
                 meta.T, meta.max_batch, meta.rows, H, ndir, PERSISTENT)
@@ -441,7 +483,11 @@ class _LstmLayerFn(torch.autograd.Function):
         else:
             dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         params = ctx.params
-        if DEFER_WGRAD and lease is None and params is not None and all(p.grad is not None for ps in params for p in ps):
+        if ctx.forms is not None and not (params is not None and all(p.grad is not None for ps in params for p in ps)):
+            raise RuntimeError('packed_lstm: the forward pass ran on the cached stacked weights (in-place weight gradients), '
+                               'but a parameter of the layer has no .grad buffer any more')
+        if (DEFER_WGRAD or ctx.forms is not None) and lease is None and params is not None and all(
+                p.grad is not None for ps in params for p in ps):
             # weight gradients on the side stream, accumulated in place (see DEFER_WGRAD)
             main = torch.cuda.current_stream(x.device)
             # the split GEMM kernels never wait for sibling workgroups: always safe next to a persistent recurrence;
@@ -483,7 +529,7 @@ class _LstmLayerFn(torch.autograd.Function):
                     side.wait_stream(side2)
             if GRAD_READY_HOOK is not None:
                 GRAD_READY_HOOK([p for ps in params for p in ps])
-            return (dx,) + (None,) * 8
+            return (dx,) + (None,) * 10
         db = dg.sum(0) if db_kernel is None else db_kernel
         if gm is not None:
             dw_ih = _gemm.mm(dg.t(), x, amax_x=amax_dg, amax_y=amax_x)
@@ -494,7 +540,7 @@ class _LstmLayerFn(torch.autograd.Function):
             dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
         if lease is not None:
             lease.release()
-        return (dx, dw_ih, db, dw_hh) + (None,) * 5
+        return (dx, dw_ih, db, dw_hh) + (None,) * 7
 
 
 def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
@@ -546,22 +592,31 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     h_n, c_n = [], []
     h = data.contiguous()
     for layer in range(lstm.num_layers):
-        w_ih = torch.cat([getattr(lstm, f'weight_ih_l{layer}{s}') for s in sfx], 0)
-        bias = torch.cat([getattr(lstm, f'bias_ih_l{layer}{s}') + getattr(lstm, f'bias_hh_l{layer}{s}')
-                          for s in sfx], 0)
-        w_hh = torch.stack([getattr(lstm, f'weight_hh_l{layer}{s}') for s in sfx], 0)
         params = tuple((getattr(lstm, f'weight_ih_l{layer}{s}'), getattr(lstm, f'weight_hh_l{layer}{s}'),
                         getattr(lstm, f'bias_ih_l{layer}{s}'), getattr(lstm, f'bias_hh_l{layer}{s}')) for s in sfx)
+        # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
+        # runs on the cached stacked / padded / transposed forms of its parameters
+        graph = torch.is_grad_enabled() and any(p.requires_grad for ps in params for p in ps)
+        in_place = DEFER_WGRAD and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for ps in params for p in ps)
+        forms = anchor = None
+        if CACHE_STACKED_WEIGHTS and data.is_cuda and (not graph or in_place):
+            forms = _stacked_weights(params, (H + 15) // 16 * 16)
+            w_ih, bias, w_hh = forms['w_ih'], forms['bias'], forms['w_hh']
+            anchor = params[0][0] if graph else None
+        else:
+            w_ih = torch.cat([ps[0] for ps in params], 0)
+            bias = torch.cat([ps[2] + ps[3] for ps in params], 0)
+            w_hh = torch.stack([ps[1] for ps in params], 0)
         if want_state:
             sl = slice(layer * ndir, (layer + 1) * ndir)
             h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
-            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0)
+            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0, anchor, forms)
             hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
             h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:
-            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0)
+            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms)
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
     if not (torch.is_grad_enabled() and h.requires_grad):

@@ -197,6 +197,9 @@ class Adam(Optimizer):
                                   None if found is None else found.reshape(1).float(), steps, float(g['lr']),
                                   float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
                                   bool(zero_grad))
+        # the kernel wrote the parameters through raw pointers: tell autograd (and everything that caches per parameter
+        # version, e.g. the operand scales and stacked weights of ops.gemm / ops.lstm) that they changed
+        torch.autograd.graph.increment_version(fg.params)
         if found is None:
             steps.add_(1.0)
         else:

@@ -14,14 +14,14 @@ def main():
     ap.add_argument('db')
     ap.add_argument('--step', type=int, default=-2)
     ap.add_argument('--min-us', type=float, default=20.0)
-    ap.add_argument('--marker', default='multi_tensor_apply')
+    ap.add_argument('--marker', default='adam_flat_kernel|multi_tensor_apply', help="'|'-separated kernel name parts that end a step")
     args = ap.parse_args()
     cur = sqlite3.connect(args.db).cursor()
     cols = [d[1] for d in cur.execute('pragma table_info(kernels)')]
     qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
     sel = f'select name, start, end, {qcol or 0}, grid_x from kernels order by start'
     rows = cur.execute(sel).fetchall()
-    marks = [i for i, r in enumerate(rows) if args.marker in r[0]]
+    marks = [i for i, r in enumerate(rows) if any(m in r[0] for m in args.marker.split('|'))]
     # consecutive optimizer launches belong to one step: keep the last of each burst
     bursts = [m for k, m in enumerate(marks) if k + 1 == len(marks) or rows[marks[k + 1]][1] - rows[m][2] > 2e6]
     a, b = bursts[args.step - 1], bursts[args.step]
