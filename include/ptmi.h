@@ -206,6 +206,22 @@ int ptmi_lstm_backward(const float* gates, const float* c, const float* c0, cons
  * bf16 halves (no scale) and leaves max |dgates| (float bits) in the word right behind the bias gradient.
  * PTMI_LSTM_F32=1 in the environment selects the exact-fp32 MFMA kernels of round 1. */
 int64_t ptmi_lstm_flags_elems(int32_t T, int32_t ndir, int32_t max_batch);
+/* ptmi_lstm_weight_prep (csrc/lstm_prep.hip): the operand forms of ONE (bi)directional LSTM layer's parameters
+ * (torch.nn.LSTM layout, padertorch/contrib/examples/source_separation/pit/model.py:60-66) in one launch:
+ *   w_ih / w_hh / b_ih / b_hh  HOST arrays of ndir device pointers: [4H, I], [4H, H], [4H], [4H] per direction
+ *   w_ih_cat [ndir * 4H, Ipad]  stacked input weights, columns I .. Ipad-1 zero (Ipad >= I, e.g. I rounded up to 4)
+ *   bias     [ndir * 4H]        b_ih + b_hh
+ *   w_pad    [ndir, 4H, KP]     recurrent weights, columns H .. KP-1 zero (what ptmi_lstm_forward* take as w_hh_pad)
+ *   w_t      [ndir, H, 4H]      transposed recurrent weights (what ptmi_lstm_backward* take)
+ *   amax     [2] uint32         float bits of max |w_ih|, max |w_hh| over both directions (the words ptmi_gemm_split /
+ *                               ptmi_lstm_forward_persistent take as operand scales) */
+int ptmi_lstm_weight_prep(const float* const* w_ih, const float* const* w_hh, const float* const* b_ih,
+                          const float* const* b_hh, int32_t ndir, int32_t H, int32_t I, float* w_ih_cat, int32_t Ipad,
+                          float* bias, float* w_pad, int32_t KP, float* w_t, uint32_t* amax, ptmi_stream_t stream);
+/* ptmi_lstm_set_error_sink: `word` (device uint32, zeroed by the caller, alive as long as launches may run; NULL to
+ * unset) of the CURRENT device is incremented by every persistent launch whose bounded spin runs out (next to that
+ * launch's own error word in its scratch): ONE word for the host to watch instead of one per call. */
+int ptmi_lstm_set_error_sink(uint32_t* word);
 int ptmi_lstm_split_enabled(void);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
@@ -359,15 +375,17 @@ int64_t ptmi_gemm_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split
  *     g += weight_decay * p;  m += (1 - beta1) (g - m);  v = beta2 v + (1 - beta2) g g
  *     p -= (lr / (1 - beta1^t)) * (m / (sqrt(v) / sqrt(1 - beta2^t) + eps)),   t = step[0] + 1
  *   i.e. torch.optim.Adam's arithmetic (amsgrad / maximize not supported); flat_grad[i] = 0 afterwards when
- *   zero_grad != 0.  found_inf (device fp32 scalar or NULL) != 0 skips the update (gradients are still zeroed),
- *   the semantics of torch's fused Adam.  segments = device int64 [nseg][3]: parameter pointer, first flat
+ *   zero_grad != 0.  The update is SKIPPED (gradients are still zeroed) when found_inf (device fp32 scalar or NULL)
+ *   is non-zero - the semantics of torch's fused Adam -, when `finite` (device fp32 scalar or NULL, e.g. the sum of the
+ *   step's losses) or norm[0] is not finite; applied (device fp32 scalar or NULL) receives 1 / 0 = applied / skipped.  segments = device int64 [nseg][3]: parameter pointer, first flat
  *   index, element count, ascending and dense over [0, n).  exp_avg / exp_avg_sq: flat fp32 [n].  The caller
  *   advances `step` (a device fp32 scalar) afterwards. */
 int64_t ptmi_grad_norm_workspace_elems(void);
 int ptmi_grad_norm(const float* flat, int64_t n, double* workspace, float* norm_out, ptmi_stream_t stream);
 int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const int64_t* segments, int32_t nseg, int64_t n,
-                   const float* norm, float max_norm, const float* found_inf, const float* step, double lr, double beta1,
-                   double beta2, double eps, double weight_decay, int32_t zero_grad, ptmi_stream_t stream);
+                   const float* norm, float max_norm, const float* found_inf, const float* finite, float* applied,
+                   const float* step, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t zero_grad,
+                   ptmi_stream_t stream);
 
 #ifdef __cplusplus
 }

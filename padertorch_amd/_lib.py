@@ -70,6 +70,8 @@ SIGNATURES = {
     'ptmi_unit_norm_backward': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_float, c_void_p]),
     'ptmi_lstm_flags_elems': (c_int64, [c_int32, c_int32, c_int32]),
     'ptmi_lstm_scratch_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32]),
+    'ptmi_lstm_weight_prep': (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, _P]),
+    'ptmi_lstm_set_error_sink': (c_int, [_P]),
     'ptmi_lstm_split_enabled': (c_int, []),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                              c_int32, _P]),
@@ -86,7 +88,7 @@ SIGNATURES = {
     'ptmi_gemm_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_grad_norm_workspace_elems': (c_int64, []),
     'ptmi_grad_norm': (c_int32, [_P, c_int64, _P, _P, _P]),
-    'ptmi_adam_flat': (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_float, _P, _P, c_double, c_double, c_double,
+    'ptmi_adam_flat': (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, c_double, c_double, c_double,
                                  c_double, c_double, c_int32, _P]),
 }
 

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(c
         if (!has_rec) prefetch();
         if (has_rec) {
             mark(0);
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             mark(1);
             __syncthreads();
             mark(2);
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent
             else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
         }
         if (has_rec) {
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             __syncthreads();
             // The operand comes from the TILE-MAJOR copy: one load instruction of a wavefront = one 16 x 16
             // tile = 1 KB of consecutive bytes (8 full cache lines; from the row-major dgates it would be
@@ -840,6 +840,13 @@ static int capture_graph(hipGraphExec_t* exec, F&& enqueue) {
     return rc;
 }
 
+// Per-device word that counts timed-out persistent launches (set once by the host binding; see ptmi_lstm_set_error_sink).
+static unsigned* g_error_sink[64] = {};
+static unsigned* error_sink() {
+    int dev = 0;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? g_error_sink[dev] : nullptr;
+}
+
 extern "C" {
 
 int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad, const int32_t* batch_sizes,
@@ -878,6 +885,15 @@ int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int3
     // |dgates| as float bits) | hand-off slots | 8 error words]
     return lstm_tile_elems(T, ndir, max_batch, backward ? (4 * H + 31) / 32 * 32 : (H + 31) / 32 * 32) +
            (backward ? (int64_t)ndir * 4 * H + 8 : 0) + ptmi_lstm_flags_elems(T, ndir, max_batch);
+}
+
+int ptmi_lstm_set_error_sink(uint32_t* word) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    PTMI_RETURN_IF(dev < 0 || dev >= 64, PTMI_E_UNSUPPORTED);
+    g_error_sink[dev] = word;
+    return PTMI_OK;
 }
 
 int ptmi_lstm_split_enabled(void) { return getenv("PTMI_LSTM_F32") ? 0 : 1; }
@@ -932,6 +948,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
                       getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch, hyt, (max_batch + 15) / 16,
                       w_hh_amax, KP32};
+    A.err_sink = error_sink();
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
@@ -1008,6 +1025,7 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
                          (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8), 0, ntiles,
                          getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16, dbias,
                          split ? dg_amax : nullptr, G32};
+    A.err_sink = error_sink();
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);

@@ -39,6 +39,7 @@ struct LstmPersistArgs {
     int nt16;                // 16-row tiles of the whole batch
     const unsigned* w_amax;  // split kernels: float bits of max |W_hh| (device) or null
     int KP32;                // split kernels: H rounded up to 32
+    unsigned* err_sink = nullptr;   // per-device count of timed-out launches (ptmi_lstm_set_error_sink) or null
 };
 
 // Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has
@@ -52,7 +53,7 @@ constexpr int kSlots = 128;          // slots per chain = most producer workgrou
 // re-read every 256 polls); every later wait then returns at once, so a launch whose workgroups are not all
 // resident ends after ONE bounded spin per workgroup instead of one per time step.
 __device__ __forceinline__ bool wait_arrivals(const unsigned* slots, unsigned producers, unsigned step,
-                                              unsigned max_polls, unsigned* err) {
+                                              unsigned max_polls, unsigned* err, unsigned* sink = nullptr) {
     const unsigned lane = threadIdx.x & 63;
     for (unsigned it = 0; it < max_polls; ++it) {
         unsigned v = lane < producers ? __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0u;
@@ -65,7 +66,10 @@ __device__ __forceinline__ bool wait_arrivals(const unsigned* slots, unsigned pr
         if ((it & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
         __builtin_amdgcn_s_sleep(2);
     }
-    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (sink) atomicAdd(sink, 1u);          // the failure path only: what the host polls instead of every call's own word
+    }
     return false;
 }
 
@@ -93,6 +97,7 @@ struct LstmPersistBwdArgs {
     float* dbias;        // [ndir][4H] sum of dgates over all rows (zeroed by the host call, accumulated atomically)
     unsigned* dg_amax;   // split kernels: float bits of max |dgates| (zeroed by the host call, atomicMax)
     int G32;             // split kernels: 4H rounded up to 32
+    unsigned* err_sink = nullptr;   // as in LstmPersistArgs
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)

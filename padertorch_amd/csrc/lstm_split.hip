@@ -184,7 +184,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         if (!has_rec) prefetch();
         if (has_rec) {
             mark(0);
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             mark(1);
             __syncthreads();
             mark(2);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
         }
         if (has_rec) {
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err);
+            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             __syncthreads();
             const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * tile_elems;
             const unsigned vin = (unsigned)(kfirst * 2048 + r * 64 + g4 * 16);

@@ -28,6 +28,8 @@ struct AdamArgs {
     const float* norm;       // device scalar from pass 1, or NULL (no clipping)
     float max_norm;
     const float* found_inf;  // device scalar: != 0 skips the update (gradients are still zeroed), or NULL
+    const float* finite;     // device scalar: a NON-FINITE value skips the update as well (e.g. the sum of the step's losses), or NULL
+    float* applied;          // device scalar out: 1 when the update was applied, 0 when it was skipped, or NULL
     const float* step;       // device scalar: optimizer steps taken so far (this one is step + 1)
     double lr, beta1, beta2;  // bias corrections and lr / bc1 are evaluated in double, as torch does on the host
     float beta2f, omb1, omb2, eps, weight_decay;      // float(beta2), float(1 - beta1), float(1 - beta2)
@@ -99,7 +101,11 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
     if (threadIdx.x == 0) {
         seg_off[A.nseg] = A.n;
         AdamConsts c;
-        c.skip = A.found_inf != nullptr && A.found_inf[0] != 0.f;
+        // a non-finite norm always skips: nothing useful can come from such gradients (torch's fused Adam leaves that
+        // decision to the caller's found_inf; the Trainer used to compute it with four small kernels)
+        c.skip = (A.found_inf != nullptr && A.found_inf[0] != 0.f) || (A.finite != nullptr && !isfinite(A.finite[0])) ||
+                 (A.norm != nullptr && !isfinite(A.norm[0]));
+        if (blockIdx.x == 0 && A.applied != nullptr) A.applied[0] = c.skip ? 0.f : 1.f;
         const double t = (double)A.step[0] + 1.0;
         const double bc1 = 1.0 - pow(A.beta1, t), bc2 = 1.0 - pow(A.beta2, t);
         c.step_size = (float)(A.lr / bc1);
@@ -176,8 +182,8 @@ int ptmi_grad_norm(const float* flat, int64_t n, double* workspace, float* norm_
 }
 
 int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const int64_t* segments, int32_t nseg, int64_t n,
-                   const float* norm, float max_norm, const float* found_inf, const float* step, double lr, double beta1,
-                   double beta2, double eps, double weight_decay, int32_t zero_grad, ptmi_stream_t stream) {
+                   const float* norm, float max_norm, const float* found_inf, const float* finite, float* applied, const float* step,
+                   double lr, double beta1, double beta2, double eps, double weight_decay, int32_t zero_grad, ptmi_stream_t stream) {
     PTMI_RETURN_IF(flat_grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || segments == nullptr || step == nullptr,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(nseg < 1 || n < 1, PTMI_E_INVALID);
@@ -185,7 +191,7 @@ int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const in
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(flat_grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                      reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) != 0, PTMI_E_INVALID);
     AdamArgs A{flat_grad, exp_avg, exp_avg_sq, reinterpret_cast<const long long*>(segments), nseg, (long long)n, norm, max_norm,
-               found_inf, step, lr, beta1, beta2, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+               found_inf, finite, applied, step, lr, beta1, beta2, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                (float)weight_decay, zero_grad};
     const long long n4 = (n + 3) >> 2;
     const long long blocks = (n4 + 255) / 256;

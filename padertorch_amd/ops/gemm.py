@@ -74,6 +74,18 @@ def weights_absmax(params):
     return v
 
 
+def seed_weights_absmax(params, word):
+    """Enter an ``absmax`` word computed elsewhere (``ptmi_lstm_weight_prep``) for ``params`` used as one operand."""
+    params = tuple(params)
+    if len(_WEIGHT_AMAX) > 256:
+        _WEIGHT_AMAX.clear()
+    if len(params) == 1:
+        p = params[0]
+        _WEIGHT_AMAX[id(p)] = (p._version, p.data_ptr(), word)
+    else:
+        _WEIGHT_AMAX[tuple(id(p) for p in params)] = (tuple((p._version, p.data_ptr()) for p in params), None, word)
+
+
 def usable(*tensors):
     """The split GEMM applies: enabled, fp32 CUDA operands."""
     return ENABLED and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)

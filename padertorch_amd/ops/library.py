@@ -17,6 +17,7 @@ with CPU tensors fails in the dispatcher (``NotImplementedError: ... 'CPU' backe
     torch.ops.ptmi.lstm_recurrence_forward / _backward   ptmi_lstm_*_persistent, falling back to ptmi_lstm_forward / _backward
                                                                               (torch.nn.LSTM in pit/model.py:60-66,97)
     torch.ops.ptmi.absmax, torch.ops.ptmi.gemm_split_    ptmi_absmax, ptmi_gemm_split   (nn.LSTM input projections, nn.Linear)
+    torch.ops.ptmi.lstm_weight_prep                ptmi_lstm_weight_prep      (the nn.LSTM parameters' operand forms, once per optimizer step)
     torch.ops.ptmi.grad_norm, torch.ops.ptmi.adam_flat_  ptmi_grad_norm, ptmi_adam_flat (train/optimizer.py:27-42, trainer.py:512-532)
 """
 import ctypes
@@ -179,6 +180,24 @@ def gemm_split_(out, x, a_kmajor, lda, amax_x, y, b_kmajor, ldb, amax_y, bias, M
                           _lib.stream(x.device)), 'ptmi_gemm_split')
 
 
+# ------------------------------------------------------------------------------------------------ LSTM parameter forms
+@_register('lstm_weight_prep(Tensor[] w_ih, Tensor[] w_hh, Tensor[] b_ih, Tensor[] b_hh, int KP) -> '
+           '(Tensor, Tensor, Tensor, Tensor, Tensor)')
+def lstm_weight_prep(w_ih, w_hh, b_ih, b_hh, KP):
+    ndir, (G, I), H = len(w_ih), w_ih[0].shape, w_hh[0].shape[1]
+    dev = w_ih[0].device
+    Ipad = (I + 3) // 4 * 4
+    f32 = dict(dtype=torch.float32, device=dev)
+    w_ih_cat, bias = torch.empty((ndir * G, Ipad), **f32), torch.empty(ndir * G, **f32)
+    w_pad, w_t = torch.empty((ndir, G, KP), **f32), torch.empty((ndir, H, G), **f32)
+    amax = torch.empty(2, dtype=torch.int32, device=dev)
+    ptrs = [(ctypes.c_void_p * ndir)(*[t.data_ptr() for t in ts]) for ts in (w_ih, w_hh, b_ih, b_hh)]
+    _lib.check(_lib.timed('lstm_weight_prep', _lib.load().ptmi_lstm_weight_prep, *ptrs, ndir, H, I, w_ih_cat.data_ptr(), Ipad,
+                          bias.data_ptr(), w_pad.data_ptr(), KP, w_t.data_ptr(), amax.data_ptr(), _lib.stream(dev)),
+               'ptmi_lstm_weight_prep')
+    return w_ih_cat, bias, w_pad, w_t, amax
+
+
 # ------------------------------------------------------------------------------------------------ optimizer step
 @_register('grad_norm(Tensor flat) -> Tensor')
 def grad_norm(flat):
@@ -191,15 +210,18 @@ def grad_norm(flat):
 
 
 @_register('adam_flat_(Tensor(a!) flat_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor segments, Tensor(d!)[] params, '
-           'Tensor? norm, float max_norm, Tensor? found_inf, Tensor step, float lr, float beta1, float beta2, float eps, '
-           'float weight_decay, bool zero_grad) -> ()')
-def adam_flat_(flat_grad, exp_avg, exp_avg_sq, segments, params, norm, max_norm, found_inf, step, lr, beta1, beta2, eps,
+           'Tensor? norm, float max_norm, Tensor? found_inf, Tensor? finite, Tensor step, float lr, float beta1, float beta2, '
+           'float eps, float weight_decay, bool zero_grad) -> Tensor')
+def adam_flat_(flat_grad, exp_avg, exp_avg_sq, segments, params, norm, max_norm, found_inf, finite, step, lr, beta1, beta2, eps,
                weight_decay, zero_grad):
-    # `params` are the tensors the segment table points into (listed so that the dispatcher sees what is written)
+    # `params` are the tensors the segment table points into (listed so that the dispatcher sees what is written);
+    # returns the 0-dim fp32 "applied" flag (0: the update was skipped)
+    applied = torch.empty((), dtype=torch.float32, device=flat_grad.device)
     _lib.check(_lib.timed('adam_flat', _lib.load().ptmi_adam_flat, flat_grad.data_ptr(), exp_avg.data_ptr(),
                           exp_avg_sq.data_ptr(), segments.data_ptr(), segments.shape[0], flat_grad.numel(), _lib.ptr(norm),
-                          max_norm, _lib.ptr(found_inf), step.data_ptr(), lr, beta1, beta2, eps, weight_decay, int(zero_grad),
-                          _lib.stream(flat_grad.device)), 'ptmi_adam_flat')
+                          max_norm, _lib.ptr(found_inf), _lib.ptr(finite), applied.data_ptr(), step.data_ptr(), lr, beta1, beta2,
+                          eps, weight_decay, int(zero_grad), _lib.stream(flat_grad.device)), 'ptmi_adam_flat')
+    return applied
 
 
 # ------------------------------------------------------------------------------------------------ unit norm

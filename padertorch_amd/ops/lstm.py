@@ -248,27 +248,43 @@ def sync_deferred(device=None):
             torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(side)
 
 
-#: error words of the persistent kernels launched since the last check, per device: views of their
-#: flag buffers, folded into ONE small reduction when somebody asks (`error_word` / `check_errors`; the
-#: Trainer does so once per optimizer step)
-_ERR_FLAGS = {}
+#: ONE word per device that every persistent launch whose bounded spin runs out increments (``ptmi_lstm_set_error_sink``):
+#: the Trainer stages its value with the gradient norm once per optimizer step, ``check_errors`` reads it with a host
+#: sync.  (Round 1 kept a view of every call's own error word and folded them with four small torch kernels per check.)
+_ERR_SINK = {}      # (device type, index) -> [int32 device tensor [1], count the host has already reported]
 
 
-def _note_errors(flags):
-    views = _ERR_FLAGS.setdefault((flags.device.type, flags.device.index), [])
-    views.append(flags[-8:])
-    if len(views) >= 64:            # nobody is checking: fold, so the flag buffers can be recycled
-        views[:] = [torch.stack(views).ne(0).any().to(torch.int32).expand(8)]
+def _error_sink(device):
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    ent = _ERR_SINK.get(key)
+    if ent is None:
+        with torch.cuda.device(key[1]):
+            word = torch.zeros(1, dtype=torch.int32, device=device)
+            _lib.check(_lib.load().ptmi_lstm_set_error_sink(word.data_ptr()), 'ptmi_lstm_set_error_sink')
+        ent = _ERR_SINK[key] = [word, 0]
+    return ent
+
+
+def error_count(device):
+    """0-dim int32 DEVICE tensor: persistent LSTM launches on ``device`` that timed out so far (no kernel, no host sync:
+    the caller decides when the value crosses over and hands it to :func:`errors_since_last_report`)."""
+    return _error_sink(device)[0][0]
+
+
+def errors_since_last_report(device, count):
+    """``count``: a host copy of :func:`error_count`.  True when it is beyond what has been reported before."""
+    ent = _error_sink(device)
+    new = int(count) > ent[1]
+    ent[1] = max(ent[1], int(count))
+    return new
 
 
 def error_word(device):
-    """0-dim int32 DEVICE tensor, non-zero iff a bounded spin of a persistent LSTM kernel on `device` ran
-    out since the previous call (no host sync: the caller decides when the value crosses over)."""
-    device = torch.device(device)
-    views = _ERR_FLAGS.pop((device.type, device.index if device.index is not None else torch.cuda.current_device()), [])
-    if not views:
-        return torch.zeros((), dtype=torch.int32, device=device)
-    return torch.stack(views).ne(0).any().to(torch.int32)
+    """0-dim int32 DEVICE tensor, non-zero iff a bounded spin of a persistent LSTM kernel on ``device`` ran out and has
+    not been reported yet (no host sync)."""
+    ent = _error_sink(device)
+    return ent[0][0] - ent[1]
 
 
 def raise_timeout(device):
@@ -279,11 +295,11 @@ def raise_timeout(device):
 
 
 def check_errors():
-    """Raise if a bounded spin of a persistent LSTM kernel ran out since the last check (the
-    recurrence results are then invalid).  One small device-to-host copy per device."""
-    for key in list(_ERR_FLAGS):
+    """Raise if a bounded spin of a persistent LSTM kernel ran out since the last report (the recurrence results
+    are then invalid).  One 4-byte device-to-host copy per device that has run such a kernel."""
+    for key, ent in list(_ERR_SINK.items()):
         device = torch.device(key[0], key[1])
-        if int(error_word(device)) != 0:
+        if errors_since_last_report(device, int(ent[0])):
             raise_timeout(device)
 
 
@@ -327,17 +343,29 @@ def _stacked_weights(params, KP):
     if len(_STACKED) > 64:
         _STACKED.clear()
     with torch.no_grad():
-        w_ih = torch.cat([ps[0] for ps in params], 0)
-        bias = torch.cat([ps[2] + ps[3] for ps in params], 0)
-        w_hh = torch.stack([ps[1] for ps in params], 0)
-        H = w_hh.shape[2]
-        kpad = -w_ih.shape[1] % 4
-        forms = {
-            'w_ih': w_ih, 'bias': bias, 'w_hh': w_hh,
-            'w_ih_kpad': torch.nn.functional.pad(w_ih, (0, kpad)) if kpad else None,
-            'w_pad': torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous(),
-            'w_t': w_hh.transpose(1, 2).contiguous(),
-        }
+        p0 = params[0][0]
+        if p0.is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for ps in params for p in ps):
+            # one launch: every parameter is read once (csrc/lstm_prep.hip)
+            w_ih_k, bias, w_pad, w_t, amax = torch.ops.ptmi.lstm_weight_prep(
+                [ps[0].detach() for ps in params], [ps[1].detach() for ps in params], [ps[2].detach() for ps in params],
+                [ps[3].detach() for ps in params], KP)
+            I, H = p0.shape[1], params[0][1].shape[1]
+            forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t,
+                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None}
+            _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
+            _gemm.seed_weights_absmax([ps[1] for ps in params], amax[1:2])
+        else:
+            w_ih = torch.cat([ps[0] for ps in params], 0)
+            bias = torch.cat([ps[2] + ps[3] for ps in params], 0)
+            w_hh = torch.stack([ps[1] for ps in params], 0)
+            H = w_hh.shape[2]
+            kpad = -w_ih.shape[1] % 4
+            forms = {
+                'w_ih': w_ih, 'bias': bias, 'w_hh': w_hh,
+                'w_ih_kpad': torch.nn.functional.pad(w_ih, (0, kpad)) if kpad else None,
+                'w_pad': torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous(),
+                'w_t': w_hh.transpose(1, 2).contiguous(),
+            }
     _STACKED[key] = (sig, forms)
     return forms
 
@@ -420,11 +448,12 @@ class _LstmLayerFn(torch.autograd.Function):
             if PERSISTENT and lib.ptmi_lstm_split_enabled():
                 amax_whh = (_gemm.weights_absmax([ps[1] for ps in params]) if params is not None
                             else _gemm.absmax(w_pad.view(-1, KP)))
+            if PERSISTENT:
+                _error_sink(x.device)           # the word a timed-out launch reports to (set before the first launch)
             c, flags = torch.ops.ptmi.lstm_recurrence_forward(
                 gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
                 meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT)
             if flags is not None:
-                _note_errors(flags)
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
             ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
@@ -462,11 +491,12 @@ class _LstmLayerFn(torch.autograd.Function):
             ndir, G, H = w_hh.shape
             dhy = dhy.contiguous()
             w_t = ctx.forms['w_t'] if ctx.forms is not None else w_hh.transpose(1, 2).contiguous()      # [ndir, H, 4H]
+            if PERSISTENT:
+                _error_sink(dhy.device)
             dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                 gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
                 meta.T, meta.max_batch, meta.rows, H, ndir, PERSISTENT)
             if flags is not None:
-                _note_errors(flags)
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
                 # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]

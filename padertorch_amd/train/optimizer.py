@@ -128,6 +128,9 @@ class Adam(Optimizer):
                          weight_decay=weight_decay, amsgrad=amsgrad)
         self._bound = None           # (flat exp_avg, flat exp_avg_sq, steps, segment table, keys) of the native path
         self._norm = None            # 2-norm of the bucket from clip_grad(), applied by the next step()
+        #: device scalar (e.g. the sum of the step's losses) whose NON-finiteness makes the next native step skip the update,
+        #: next to a non-finite gradient norm; consumed by that step
+        self.skip_if_not_finite = None
 
     def set_parameters(self, parameters):
         self.parameters = tuple(parameters)
@@ -186,6 +189,7 @@ class Adam(Optimizer):
         self._norm = torch.ops.ptmi.grad_norm(self.flat_grads.flat)
         return self._norm
 
+    @torch.no_grad()
     def _native_step(self, zero_grad):
         m, v, steps, segs, _, _ = self._bind()
         fg, opt = self.flat_grads, self.optimizer
@@ -193,17 +197,17 @@ class Adam(Optimizer):
         found = getattr(opt, 'found_inf', None)          # device flag set by the Trainer's deferred checks (fused Adam's protocol)
         if found is not None and not (torch.is_tensor(found) and found.is_cuda):
             found = None
-        torch.ops.ptmi.adam_flat_(fg.flat, m, v, segs, list(fg.params), self._norm, float(self.gradient_clipping),
-                                  None if found is None else found.reshape(1).float(), steps, float(g['lr']),
-                                  float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
-                                  bool(zero_grad))
+        finite, self.skip_if_not_finite = self.skip_if_not_finite, None
+        if finite is not None:
+            finite = finite.detach().reshape(1).float()
+        applied = torch.ops.ptmi.adam_flat_(
+            fg.flat, m, v, segs, list(fg.params), self._norm, float(self.gradient_clipping),
+            None if found is None else found.reshape(1).float(), finite, steps, float(g['lr']), float(g['betas'][0]),
+            float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), bool(zero_grad))
         # the kernel wrote the parameters through raw pointers: tell autograd (and everything that caches per parameter
         # version, e.g. the operand scales and stacked weights of ops.gemm / ops.lstm) that they changed
         torch.autograd.graph.increment_version(fg.params)
-        if found is None:
-            steps.add_(1.0)
-        else:
-            steps.add_(1.0 - found.reshape(()).float())
+        steps.add_(applied)                               # a skipped step does not count (fused Adam's semantics)
         self._norm = None
 
     def step(self):

@@ -174,7 +174,7 @@ class Trainer:
         self._buckets = None
         self._pending = []           # [(what, event, host tensor, context, optimizer step)]
         self._opt_step = 0
-        self._bad = None             # device flag: a loss of the current optimizer step is not finite
+        self._loss_acc = None        # device scalar: sum of the losses of the current optimizer step (non-finite -> skip)
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
         self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)
         self.stop_trigger = EndTrigger.new(stop_trigger)
@@ -410,18 +410,25 @@ class Trainer:
         grad_norm = self.optimizer.clip_grad()
         if self._deferred(grad_norm):
             self._check_pending()                          # the PREVIOUS optimizer step's loss / norm / watchdog
-            bad = ~torch.isfinite(grad_norm)
-            if self._bad is not None:
-                bad, self._bad = bad | self._bad, None
+            loss_acc, self._loss_acc = self._loss_acc, None
             opt = self.optimizer.optimizer
-            found = bad.to(torch.float32)
-            if self.world_size > 1:                        # a rank-local non-finite loss skips the update everywhere
-                dist.all_reduce(found, op=dist.ReduceOp.MAX)
-            opt.found_inf, opt.grad_scale = found, None    # gates optimizer.step on the device
-            host = self._stage('grad_norm', torch.stack(
-                [grad_norm.detach().float(), _lstm.error_word(grad_norm.device).float()]), summary)
-            summary['scalars']['grad_norm'] = host[0]
-            summary['histograms']['grad_norm_'] = host[:1]
+            native = getattr(self.optimizer, '_native_ok', None)
+            if self.world_size == 1 and native is not None and native():
+                # the update kernel itself skips on a non-finite gradient norm or loss sum (csrc/optim.hip): no flag kernels
+                self.optimizer.skip_if_not_finite = loss_acc
+                opt.found_inf = None
+            else:
+                bad = ~torch.isfinite(grad_norm)
+                if loss_acc is not None:
+                    bad = bad | ~torch.isfinite(loss_acc)
+                found = bad.to(torch.float32)
+                if self.world_size > 1:                    # a rank-local non-finite loss skips the update everywhere
+                    dist.all_reduce(found, op=dist.ReduceOp.MAX)
+                opt.found_inf, opt.grad_scale = found, None    # gates optimizer.step on the device
+            host = self._stage('grad_norm', [grad_norm.detach().reshape(1), _lstm.error_count(grad_norm.device).reshape(1)],
+                               summary)
+            summary['scalars']['grad_norm'] = host[0][0]
+            summary['histograms']['grad_norm_'] = host[0]
             return summary
         grad_norm = float(grad_norm)                       # host sync
         _lstm.check_errors()                               # persistent-kernel watchdog words
@@ -487,7 +494,9 @@ class Trainer:
             for key, value in losses.items():
                 weight = loss_weights[key] if loss_weights is not None else 1.
                 if weight != 0:
-                    loss = loss + (weight * value)
+                    # 0. + 1 * value == value bit for bit: no kernels (forward or backward) for the trivial factors
+                    term = value if weight == 1 else weight * value
+                    loss = term if (isinstance(loss, float) and loss == 0.) else loss + term
                 review['scalars'][f'{key}_loss_weight'] = weight
             keys = list(losses)
             vals = torch.stack([losses[k].detach().reshape(()) for k in keys] + [loss.detach().reshape(())])
@@ -535,13 +544,20 @@ class Trainer:
                     and opt is not None and opt.defaults.get('fused'))
 
     def _stage(self, what, vals, context):
-        """Asynchronous device -> pinned host copy of a few scalars; ``_check_pending`` inspects them later."""
-        vals = vals.detach().to(torch.float32)
-        if what == 'loss':
-            bad = ~torch.isfinite(vals[-1])
-            self._bad = bad if self._bad is None else self._bad | bad
-        host = torch.empty(vals.shape, dtype=torch.float32, pin_memory=True)
-        host.copy_(vals, non_blocking=True)
+        """Asynchronous device -> pinned host copy of a few scalars (a tensor, or a list of tensors that each keep their
+        dtype); ``_check_pending`` inspects them later."""
+        if isinstance(vals, (list, tuple)):
+            host = []
+            for v in vals:
+                h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                h.copy_(v.detach(), non_blocking=True)
+                host.append(h)
+        else:
+            vals = vals.detach().to(torch.float32)
+            if what == 'loss':      # a non-finite loss makes the sum non-finite: what the optimizer update is gated on
+                self._loss_acc = vals[-1] if self._loss_acc is None else self._loss_acc + vals[-1]
+            host = torch.empty(vals.shape, dtype=torch.float32, pin_memory=True)
+            host.copy_(vals, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
         self._pending.append((what, event, host, context, self._opt_step))
@@ -558,12 +574,13 @@ class Trainer:
                 raise RuntimeError(f'The loss ({float(host[-1])}) is not finite.\n'
                                    f'See error states (model, example, model_out and review) in {path}.')
             if what == 'grad_norm':
-                if host[1] != 0:
-                    from ..ops import lstm as _lstm
+                from ..ops import lstm as _lstm
+                norm, timeouts = float(host[0][0]), int(host[1][0])
+                if _lstm.errors_since_last_report(self._flat.flat.device, timeouts):
                     _lstm.raise_timeout(self._flat.flat.device)
-                if not np.isfinite(float(host[0])):
+                if not np.isfinite(norm):
                     path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': context})
-                    raise RuntimeError(f'The grad_norm ({float(host[0])}) is not finite.\n'
+                    raise RuntimeError(f'The grad_norm ({norm}) is not finite.\n'
                                        f'See error states (model, example, model_out and review) in {path}.')
 
     def log_error_state(self, data_dict, folder='log'):

@@ -218,3 +218,49 @@ def test_full_size_properties(monkeypatch):
         yr = packed_lstm(swapped, pack_sequence([x.detach().flip(0) for x in xs[:8]])).data.view(T, 8, 2, H)
         y8 = packed_lstm(lstm, pack_sequence([x.detach() for x in xs[:8]])).data.view(T, 8, 2, H)
     assert float((yr.flip(0).flip(2) - y8).abs().max()) < 2e-5
+
+
+def test_timed_out_persistent_launch_is_reported(monkeypatch):
+    """A bounded spin that runs out (here: a poll budget of ONE) ends the launch, bumps the device's error word and
+    `check_errors` raises once; the next, normal launch is clean again."""
+    from padertorch_amd.ops import lstm as L
+    from padertorch_amd.ops import packed_lstm
+    from torch.nn.utils.rnn import pack_sequence
+    if not L.PERSISTENT:
+        pytest.skip('persistent kernels disabled')
+    torch.manual_seed(0)
+    lstm = torch.nn.LSTM(40, 200, 1, bidirectional=True).cuda()
+    xs = [torch.randn(100, 40, device='cuda') for _ in range(4)]
+    L.check_errors()                                      # nothing pending from earlier tests
+    monkeypatch.setenv('PTMI_LSTM_MAX_POLLS', '1')
+    with torch.no_grad(), pytest.raises(RuntimeError, match='timed out'):
+        packed_lstm(lstm, pack_sequence(xs))              # inference calls check the word themselves
+    monkeypatch.delenv('PTMI_LSTM_MAX_POLLS')
+    with torch.no_grad():
+        y = packed_lstm(lstm, pack_sequence(xs))
+    L.check_errors()
+    import copy
+    ref = copy.deepcopy(lstm).cpu()(pack_sequence([x.cpu() for x in xs]))[0].data
+    assert float((y.data.cpu() - ref).detach().abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('I,H,ndir', [(257, 600, 2), (1200, 600, 2), (40, 36, 1), (7, 20, 2)])
+def test_weight_prep_forms(I, H, ndir):
+    """ptmi_lstm_weight_prep: stacked / padded / transposed parameter forms and the two absmax words, bit for bit."""
+    import padertorch_amd.ops.library  # noqa: F401
+    torch.manual_seed(I + H)
+    G, KP = 4 * H, (H + 15) // 16 * 16
+    w_ih = [torch.randn(G, I, device='cuda') * 0.3 for _ in range(ndir)]
+    w_hh = [torch.randn(G, H, device='cuda') * 0.2 for _ in range(ndir)]
+    b_ih = [torch.randn(G, device='cuda') for _ in range(ndir)]
+    b_hh = [torch.randn(G, device='cuda') for _ in range(ndir)]
+    w_hh[-1][3, 5] = -7.5                                   # the maximum: negative, in the last direction
+    cat, bias, w_pad, w_t, amax = torch.ops.ptmi.lstm_weight_prep(w_ih, w_hh, b_ih, b_hh, KP)
+    Ipad = (I + 3) // 4 * 4
+    assert cat.shape == (ndir * G, Ipad) and w_pad.shape == (ndir, G, KP) and w_t.shape == (ndir, H, G)
+    assert torch.equal(cat[:, :I], torch.cat(w_ih, 0)) and float(cat[:, I:].abs().sum()) == 0
+    assert torch.equal(bias, torch.cat([a + b for a, b in zip(b_ih, b_hh)]))
+    assert torch.equal(w_pad[:, :, :H], torch.stack(w_hh)) and float(w_pad[:, :, H:].abs().sum()) == 0
+    assert torch.equal(w_t, torch.stack(w_hh).transpose(1, 2))
+    got = amax.view(torch.float32).cpu()
+    assert float(got[0]) == float(torch.cat(w_ih, 0).abs().max()) and float(got[1]) == 7.5

@@ -89,7 +89,10 @@ def test_step_without_zero_and_without_clip_call():
         np.testing.assert_array_equal(q.grad.cpu().numpy(), g.numpy())      # step() alone leaves the gradients
 
 
-def test_found_inf_skips_update_but_zeroes():
+@pytest.mark.parametrize('how', ['found_inf', 'nan_norm', 'inf_loss'])
+def test_skipped_update_leaves_parameters_but_zeroes(how):
+    """The three ways an update is skipped on the device: torch's found_inf flag, a non-finite gradient norm, a non-finite
+    value handed in by the Trainer (the sum of the step's losses)."""
     _, gpu = _models(2)
     opt = _native(gpu, gradient_clipping=1.0)
     for q, g in zip(gpu, _grads(0, 1.0)):
@@ -99,15 +102,40 @@ def test_found_inf_skips_update_but_zeroes():
     before = [q.detach().clone() for q in gpu]
     for q, g in zip(gpu, _grads(1, 1.0)):
         q.grad.copy_(g)
-    gpu[0].grad[0, 0] = float('nan')
+    if how == 'nan_norm':
+        gpu[0].grad[0, 0] = float('nan')
     norm = opt.clip_grad()
-    assert not np.isfinite(float(norm))
-    opt.optimizer.found_inf = (~torch.isfinite(norm)).float()
+    assert np.isfinite(float(norm)) == (how != 'nan_norm')
+    if how == 'found_inf':
+        opt.optimizer.found_inf = torch.ones((), device='cuda')
+    if how == 'inf_loss':
+        opt.skip_if_not_finite = torch.full((), float('inf'), device='cuda')
     opt.step_and_zero_grad()
     for q, b in zip(gpu, before):
         assert torch.equal(q.detach(), b)
     assert float(opt.flat_grads.flat.abs().max()) == 0.0
     assert all(float(opt.optimizer.state[q]['step']) == 1 for q in gpu)
+    # and the next, clean step is applied
+    opt.optimizer.found_inf = None
+    for q, g in zip(gpu, _grads(2, 1.0)):
+        q.grad.copy_(g)
+    opt.clip_grad()
+    opt.step_and_zero_grad()
+    assert all(float(opt.optimizer.state[q]['step']) == 2 for q in gpu)
+    assert not torch.equal(gpu[0].detach(), before[0])
+
+
+def test_step_bumps_parameter_versions():
+    """The kernel writes through raw pointers; caches keyed on Parameter._version (operand scales, stacked weights) rely on
+    the bump."""
+    _, gpu = _models(5)
+    opt = _native(gpu, gradient_clipping=1.0)
+    v0 = [q._version for q in gpu]
+    for q, g in zip(gpu, _grads(0, 1.0)):
+        q.grad.copy_(g)
+    opt.clip_grad()
+    opt.step_and_zero_grad()
+    assert all(q._version > v for q, v in zip(gpu, v0))
 
 
 def test_state_dict_round_trip_continues_identically():
