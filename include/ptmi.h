@@ -239,6 +239,17 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                   uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
                                   int32_t ndir, ptmi_stream_t stream);
+/* The same recurrence cut in time: processes the steps [s_begin, s_end) of the T processing steps (step s handles
+ * time index T-1-s in direction 0, s in direction 1).  Ranges must be launched in order on one stream with the same
+ * scratch; the first (s_begin == 0) zeroes it, dc_carry (device fp32 [ndir, max_batch, H]) takes the cell-state
+ * gradient across a cut.  After the range [0, s) the gate gradients of direction 0 are complete for time indices
+ * >= T - s and of direction 1 for time indices < s: their weight-gradient GEMMs can run under the next range.
+ * Split kernels only (PTMI_E_UNSUPPORTED otherwise). */
+int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, const float* c0, const float* dhy,
+                                        const float* w_hh_t, float* dgates, const int32_t* batch_sizes_dev,
+                                        const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
+                                        int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
+                                        int32_t s_end, ptmi_stream_t stream);
 
 /* Plans: the two time loops over FIXED buffers captured once as hipGraphs and replayed with one
  * host call each (same buffers / bookkeeping arguments as ptmi_lstm_forward / ptmi_lstm_backward;

@@ -987,14 +987,27 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                   uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
                                   int32_t ndir, ptmi_stream_t stream) {
+    return ptmi_lstm_backward_persistent_range(gates, c, c0, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, nullptr, T,
+                                               max_batch, rows, H, ndir, 0, T, stream);
+}
+
+int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, const float* c0, const float* dhy,
+                                        const float* w_hh_t, float* dgates, const int32_t* batch_sizes_dev,
+                                        const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
+                                        int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin, int32_t s_end,
+                                        ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || !dgates || !batch_sizes_dev || !offsets_dev || !flags,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
+    PTMI_RETURN_IF(s_begin < 0 || s_end > T || s_begin >= s_end, PTMI_E_INVALID);
+    const bool whole = s_begin == 0 && s_end == T;
+    PTMI_RETURN_IF(!whole && !dc_carry, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
     constexpr int NW = 16, CH = 10;
     const int G32 = (4 * H + 31) / 32 * 32;
     const bool split = ptmi_lstm_split_enabled() && (G32 / 32 + 7) / 8 <= 10;           // split kernel: <= 10 k blocks of 32 per wavefront
     PTMI_RETURN_IF(!split && (4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    PTMI_RETURN_IF(!split && !whole, PTMI_E_UNSUPPORTED);          // step ranges: split kernels only
     const int resident = cu_count() - 16;     // one workgroup per CU, with a margin
     // One workgroup per CU must be resident (at most 240 per launch).  Row tiles are independent recurrences,
     // so a batch whose tiles do not fit at once runs as several launches over groups of tiles; before that,
@@ -1015,8 +1028,10 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
     float* const dgt = reinterpret_cast<float*>(flags);
     flags += lstm_tile_elems(T, ndir, max_batch, G32);
     float* const dbias = reinterpret_cast<float*>(flags);
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
-    if (e != hipSuccess) return (int)e;
+    if (s_begin == 0) {         // a later range continues on the first one's counters, bias sums and maximum
+        hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
+        if (e != hipSuccess) return (int)e;
+    }
     flags += ndir * 4 * H;
     uint32_t* const dg_amax = flags;
     flags += 8;
@@ -1026,6 +1041,9 @@ int ptmi_lstm_backward_persistent(const float* gates, const float* c, const floa
                          getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16, dbias,
                          split ? dg_amax : nullptr, G32};
     A.err_sink = error_sink();
+    A.s_begin = s_begin;
+    A.s_end = s_end;
+    A.dc_carry = dc_carry;
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);

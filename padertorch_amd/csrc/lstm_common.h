@@ -98,6 +98,11 @@ struct LstmPersistBwdArgs {
     unsigned* dg_amax;   // split kernels: float bits of max |dgates| (zeroed by the host call, atomicMax)
     int G32;             // split kernels: 4H rounded up to 32
     unsigned* err_sink = nullptr;   // as in LstmPersistArgs
+    // split kernels: this launch runs the processing steps [s_begin, s_end) of the T steps (a recurrence cut into several
+    // launches lets the weight-gradient GEMMs of the finished time range start under the rest); the cell-state
+    // gradient crosses the cut through dc_carry [ndir][max_batch][H] (written when s_end < T, read when s_begin > 0)
+    int s_begin = 0, s_end = -1;
+    float* dc_carry = nullptr;
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)

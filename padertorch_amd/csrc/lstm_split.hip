@@ -358,11 +358,14 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     // before (t_n) and of the one processed next (t_p = the forward-sense predecessor, for c_{t-1}); the latter is loaded
     // one iteration early
     auto tindex = [&](int step) { return dir == 0 ? A.T - 1 - step : step; };
-    int nb_c = A.bs[tindex(0)], nb_n = 0;                      // this step's / the previously processed time index
-    long long row_c = A.offs[tindex(0)];
-    int nb_f = A.T > 1 ? A.bs[tindex(1)] : 0;                  // the time index processed next
-    long long row_f = A.T > 1 ? A.offs[tindex(1)] : 0;
-    for (int s = 0; s < A.T; ++s) {
+    const int s0 = A.s_begin, s1 = A.s_end < 0 ? A.T : A.s_end;        // this launch's range of processing steps
+    int nb_c = A.bs[tindex(s0)], nb_n = s0 > 0 ? A.bs[tindex(s0 - 1)] : 0;    // this step's / the previously processed time index
+    long long row_c = A.offs[tindex(s0)];
+    int nb_f = s0 + 1 < A.T ? A.bs[tindex(s0 + 1)] : 0;        // the time index processed next
+    long long row_f = s0 + 1 < A.T ? A.offs[tindex(s0 + 1)] : 0;
+    const bool carries = tid < 16 * MR && b < A.max_batch && j < H && A.dc_carry != nullptr;
+    if (s0 > 0 && carries) dc_state = A.dc_carry[((size_t)dir * A.max_batch + b) * H + j];
+    for (int s = s0; s < s1; ++s) {
         const int t = tindex(s);
         const int nb = nb_c;
         const long long row0 = row_c;
@@ -519,6 +522,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             dgp[3 * H] = go;
         }
     }
+    if (s1 < A.T && carries) A.dc_carry[((size_t)dir * A.max_batch + b) * H + j] = dc_state;
     // bias gradient = sum of dgates over all rows; max |dgates| for the GEMMs that follow (operand scale)
     float* const fold = &red[0][0][0];
     __syncthreads();

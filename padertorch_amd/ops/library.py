@@ -180,6 +180,22 @@ def gemm_split_(out, x, a_kmajor, lda, amax_x, y, b_kmajor, ldb, amax_y, bias, M
                           _lib.stream(x.device)), 'ptmi_gemm_split')
 
 
+@_register('lstm_recurrence_backward_range(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!) dg, '
+           'Tensor(b!) scratch, Tensor(c!) dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, int H, '
+           'int ndir, int s_begin, int s_end) -> bool')
+def lstm_recurrence_backward_range(gates, c, c0, dhy, w_hh_t, dg, scratch, dc_carry, bs_dev, offs_dev, T, max_batch, rows, H, ndir,
+                                   s_begin, s_end):
+    """The persistent backward recurrence over the processing steps [s_begin, s_end) (``ptmi_lstm_backward_persistent_range``;
+    ranges in order, same ``dg`` / ``scratch`` / ``dc_carry``).  False: the launch cannot be resident (nothing was run)."""
+    rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_range, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                    dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), scratch.data_ptr(),
+                    dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, _lib.stream(gates.device))
+    if rc == -2:
+        return False
+    _lib.check(rc, 'ptmi_lstm_backward_persistent_range')
+    return True
+
+
 # ------------------------------------------------------------------------------------------------ LSTM parameter forms
 @_register('lstm_weight_prep(Tensor[] w_ih, Tensor[] w_hh, Tensor[] b_ih, Tensor[] b_hh, int KP) -> '
            '(Tensor, Tensor, Tensor, Tensor, Tensor)')

@@ -169,20 +169,19 @@ _WGRAD_STREAMS = {}
 
 #: run BLSTM layers on per-parameter-version cached stacked weights where autograd does not need the concatenations
 CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
-_WGRAD_STREAMS2 = {}
-#: experiment knob, default off: 2 = the reverse direction's weight-gradient GEMMs of the FIRST layer (whose input needs no
-#: gradient: only the optimizer follows, the step's tail) run on a second side stream, joined into the first one right
-#: away; 3 = of every layer.  Measured: 2 makes no difference (10.81-10.84 vs 10.84-10.85 ms per step: each GEMM already
-#: fills the chip), 3 is slower (11.3 vs 10.7 ms: more workgroups next to the following layer's recurrence).
-WGRAD_STREAMS = int(os.environ.get('PTMI_WGRAD_STREAMS', '1'))
+#: launches per backward recurrence: > 1 cuts it into step ranges (``ptmi_lstm_backward_persistent_range``) so that the
+#: finished range's weight-gradient GEMMs start on the side stream under the next launch instead of after the whole layer.
+#: Measured at the B = 32 step (ms per step, two boxes): 1: 10.56 / 10.56, 2: 10.52 / 10.60, 3: 10.75 / 10.75 - the side
+#: stream's idle time during the last layer's recurrence is not free throughput: what the GEMMs gain by starting earlier,
+#: the recurrence next to them loses (5.8 instead of 5.0 us per step), plus ~30 us per extra launch.  Default 1.
+BWD_CHUNKS = int(os.environ.get('PTMI_LSTM_BWD_CHUNKS', '1'))
 
 
-def _wgrad_stream(device, second=False):
+def _wgrad_stream(device):
     key = (device.type, device.index)
-    pool = _WGRAD_STREAMS2 if second else _WGRAD_STREAMS
-    if key not in pool:
-        pool[key] = torch.cuda.Stream(device=device)
-    return pool[key]
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _WGRAD_STREAMS[key]
 
 
 _SIDE_SAFE = {}
@@ -489,22 +488,93 @@ class _LstmLayerFn(torch.autograd.Function):
         else:
             x, w_ih, w_hh, gates, c, hy, h0, c0 = ctx.saved_tensors
             ndir, G, H = w_hh.shape
+        gm, params = ctx.gemm, ctx.params
+        has_grads = params is not None and all(p.grad is not None for ps in params for p in ps)
+        if ctx.forms is not None and not has_grads:
+            raise RuntimeError('packed_lstm: the forward pass ran on the cached stacked weights (in-place weight gradients), '
+                               'but a parameter of the layer has no .grad buffer any more')
+        # weight gradients accumulated in place (see DEFER_WGRAD), on the side stream where that is safe: the split GEMM
+        # kernels never wait for sibling workgroups - always safe next to a persistent recurrence -, library kernels only
+        # when their shape is pinned to a rocBLAS solution
+        in_place = (DEFER_WGRAD or ctx.forms is not None) and lease is None and has_grads
+        use_side = in_place and WGRAD_SIDE_STREAM and (
+            gm is not None or _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
+        main = torch.cuda.current_stream(x.device) if in_place else None
+        side = _wgrad_stream(x.device) if use_side else main
+        operands = [None]
+
+        def wgrad_rows(dg, ranges, amax_dg):
+            """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`."""
+            with torch.cuda.stream(side):
+                if operands[0] is None:
+                    operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
+                for (p_wih, p_whh, _, _), (dgd, h_prev), (r0, r1) in zip(params, operands[0], ranges):
+                    if r1 <= r0:
+                        continue
+                    dgt = dgd[r0:r1].t()
+                    if gm is not None:
+                        _gemm.mm(dgt, x[r0:r1], out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=gm[0])
+                        _gemm.mm(dgt, h_prev[r0:r1], out=p_whh.grad, accumulate=True, amax_x=amax_dg,
+                                 amax_y=_gemm.UNIT_RANGE if h0 is None else None)
+                    else:
+                        p_wih.grad.addmm_(dgt, x[r0:r1])
+                        p_whh.grad.addmm_(dgt, h_prev[r0:r1])
+
+        todo = [(0, meta.rows)] * ndir                  # row ranges whose weight gradients are still to be accumulated
+        if lease is None:
             dhy = dhy.contiguous()
             w_t = ctx.forms['w_t'] if ctx.forms is not None else w_hh.transpose(1, 2).contiguous()      # [ndir, H, 4H]
             if PERSISTENT:
                 _error_sink(dhy.device)
-            dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
-                gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                meta.T, meta.max_batch, meta.rows, H, ndir, PERSISTENT)
+            dg = flags = None
+            T = meta.T
+            chunks = BWD_CHUNKS if (PERSISTENT and use_side and gm is not None and lib.ptmi_lstm_split_enabled()
+                                    and T >= 64 * BWD_CHUNKS) else 1
+            if chunks > 1:
+                # the recurrence in `chunks` launches over consecutive step ranges: the weight-gradient GEMMs of the time
+                # range a launch has finished run on the side stream under the next launch (ptmi_lstm_backward_persistent_range)
+                dg = torch.empty_like(gates)
+                flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
+                                    device=dhy.device)
+                carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device)
+                cuts = [T * i // chunks for i in range(chunks + 1)]
+                nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
+                amax_word = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
+                offs = [int(v) for v in meta.offs_host[:T]] + [meta.rows]
+
+                def launch(i):
+                    return torch.ops.ptmi.lstm_recurrence_backward_range(
+                        gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
+                        ndir, cuts[i], cuts[i + 1])
+                if launch(0):
+                    for i in range(1, chunks):
+                        snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
+                        done = torch.cuda.Event()
+                        done.record(main)
+                        side.wait_event(done)
+                        s0, s1 = cuts[i - 1], cuts[i]                # steps finished by the previous launch
+                        part = [(offs[T - s1], offs[T - s0]), (offs[s0], offs[s1])][:ndir]
+                        wgrad_rows(dg, part, snap)
+                        snap.record_stream(side)
+                        if not launch(i):
+                            raise RuntimeError('ptmi_lstm_backward_persistent_range: a later range was refused')
+                    s0 = cuts[chunks - 1]
+                    todo = [(offs[0], offs[T - s0]), (offs[s0], offs[T])][:ndir]
+                else:
+                    dg = flags = None                                # not resident: the one-call path decides
+            if dg is None:
+                dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
+                    gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
+                    T, meta.max_batch, meta.rows, H, ndir, PERSISTENT)
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
                 # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]
-                nflags = int(lib.ptmi_lstm_flags_elems(meta.T, ndir, meta.max_batch)) + 8
+                nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
                 db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
                 if lib.ptmi_lstm_split_enabled():
                     amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
-        gm = ctx.gemm
+        amax_dg = None
         if gm is not None:
             amax_x, amax_w = gm
             # one scale for the whole gate-gradient tensor (both directions): the backward kernel tracked its maximum
@@ -512,51 +582,21 @@ class _LstmLayerFn(torch.autograd.Function):
             dx = _gemm.mm(dg, w_ih, amax_x=amax_dg, amax_y=amax_w) if ctx.needs_input_grad[0] else None
         else:
             dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
-        params = ctx.params
-        if ctx.forms is not None and not (params is not None and all(p.grad is not None for ps in params for p in ps)):
-            raise RuntimeError('packed_lstm: the forward pass ran on the cached stacked weights (in-place weight gradients), '
-                               'but a parameter of the layer has no .grad buffer any more')
-        if (DEFER_WGRAD or ctx.forms is not None) and lease is None and params is not None and all(
-                p.grad is not None for ps in params for p in ps):
-            # weight gradients on the side stream, accumulated in place (see DEFER_WGRAD)
-            main = torch.cuda.current_stream(x.device)
-            # the split GEMM kernels never wait for sibling workgroups: always safe next to a persistent recurrence;
-            # library kernels only when their shape is pinned to a rocBLAS solution
-            use_side = WGRAD_SIDE_STREAM and (gm is not None or
-                                              _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
-            side = _wgrad_stream(x.device) if use_side else main
-            side2 = _wgrad_stream(x.device, True) if use_side and ndir > 1 and (
-                WGRAD_STREAMS > 2 or (WGRAD_STREAMS == 2 and not ctx.needs_input_grad[0])) else None
+        if in_place:
             if use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
+            wgrad_rows(dg, todo, amax_dg)
             with torch.cuda.stream(side):
-                operands = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
-            if side2 is not None:
-                side2.wait_stream(side)
-            for d, ((p_wih, p_whh, p_bih, p_bhh), (dgd, h_prev)) in enumerate(zip(params, operands)):
-                with torch.cuda.stream(side2 if side2 is not None and d == 1 else side):
-                    if gm is not None:
-                        _gemm.mm(dgd.t(), x, out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=amax_x)
-                        _gemm.mm(dgd.t(), h_prev, out=p_whh.grad, accumulate=True, amax_x=amax_dg,
-                                 amax_y=_gemm.UNIT_RANGE if h0 is None else None)
-                    else:
-                        p_wih.grad.addmm_(dgd.t(), x)
-                        p_whh.grad.addmm_(dgd.t(), h_prev)
-                    db_d = dgd.sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
+                for d, (_, _, p_bih, p_bhh) in enumerate(params):
+                    db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
                     p_bih.grad.add_(db_d)
                     p_bhh.grad.add_(db_d)
             if use_side:
-                for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel, amax_dg if gm is not None else None)
-                                             if v is not None and torch.is_tensor(v)):
+                for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
+                        + tuple(h_prev for _, h_prev in operands[0]):
                     t.record_stream(side)           # keep the operands alive until the side stream is done
-                    if side2 is not None:
-                        t.record_stream(side2)
-                if side2 is not None:
-                    for _, h_prev in operands:
-                        h_prev.record_stream(side2)
-                    side.wait_stream(side2)
             if GRAD_READY_HOOK is not None:
                 GRAD_READY_HOOK([p for ps in params for p in ps])
             return (dx,) + (None,) * 10

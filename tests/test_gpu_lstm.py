@@ -264,3 +264,40 @@ def test_weight_prep_forms(I, H, ndir):
     assert torch.equal(w_t, torch.stack(w_hh).transpose(1, 2))
     got = amax.view(torch.float32).cpu()
     assert float(got[0]) == float(torch.cat(w_ih, 0).abs().max()) and float(got[1]) == 7.5
+
+
+@pytest.mark.parametrize('lens', [[130] * 32, [200, 180, 180, 131, 77, 64, 3]])
+def test_in_place_weight_gradients_and_time_ranges(lens, monkeypatch):
+    """The Trainer's path - weight gradients accumulated in place on the side stream, the backward recurrence in 1, 2 or 3
+    launches over step ranges (ptmi_lstm_backward_persistent_range) with the finished range's weight-gradient GEMMs under
+    the next launch - against autograd through torch's CPU LSTM."""
+    import copy
+    from padertorch_amd.ops import lstm as L
+    from padertorch_amd.ops import packed_lstm
+    torch.manual_seed(len(lens))
+    I, H = 36, 600
+    ref = torch.nn.LSTM(I, H, 2, bidirectional=True)
+    xs = [torch.randn(n, I) for n in lens]
+    w = [torch.randn(n, 2 * H) for n in lens]
+    xr = [x.clone().requires_grad_() for x in xs]
+    out = ref(pack_sequence(xr))[0]
+    (out.data * pack_sequence(w).data).sum().backward()
+    want = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    monkeypatch.setattr(L, 'DEFER_WGRAD', True)
+    for chunks in (1, 2, 3):
+        monkeypatch.setattr(L, 'BWD_CHUNKS', chunks)
+        net = copy.deepcopy(ref).cuda()
+        for p in net.parameters():
+            p.grad = torch.zeros_like(p)
+        xg = [x.cuda().requires_grad_() for x in xs]
+        y = packed_lstm(net, pack_sequence(xg))
+        (y.data * pack_sequence([v.cuda() for v in w]).data).sum().backward()
+        L.sync_deferred()
+        torch.cuda.synchronize()
+        L.check_errors()
+        assert float((y.data.cpu() - out.data).abs().max()) < 2e-5
+        for a, b in zip(xg, xr):
+            assert float((a.grad.cpu() - b.grad).abs().max()) < 2e-4 * max(1.0, float(b.grad.abs().max()))
+        for k, p in net.named_parameters():
+            scale = max(1.0, float(want[k].abs().max()))
+            assert float((p.grad.cpu() - want[k]).abs().max()) < 3e-4 * scale, (chunks, k)
