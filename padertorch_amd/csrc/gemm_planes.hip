@@ -1,0 +1,248 @@
+// fp32-equivalent GEMM on operands that are ALREADY split into fp16 (hi, lo) planes in MFMA-fragment order.
+//
+// csrc/gemm.hip splits fp32 operands in registers on their way into LDS; that arithmetic (and, for operands whose reduction
+// axis is not contiguous, a 4 x 4 transpose in registers) is what bounds it, most of all in the weight-gradient form
+// dW = dg^T x where both operands are of that kind (165-175 fp32-equivalent TFLOP/s alone, half of that next to a
+// running recurrence).  Here the split happens ONCE per operand in a streaming pass (ptmi_pack_planes_t: read 4 B, write
+// 4 B per element, any source orientation), and the GEMM is a plain 16-bit one:
+//   operand X, R rows x K (reduction):  tiles [ceil(R / 16)][ceil(K / 32)][plane hi | lo][64 chunks of 16 B]
+//   chunk (k group g = 0..3, row r = 0..15) at slot 16 g + r = the 8 fp16 values X[16 t + r][32 kb + 8 g .. + 7]
+//   i.e. exactly the register image of one v_mfma_f32_16x16x32_f16 operand: a wavefront's LDS-DMA (global_load_lds, 16 B
+//   per lane) of a 1 KB plane tile lands lane-linear in LDS and ds_read_b128 at lane * 16 is the fragment (no bank
+//   conflicts, no VALU on the way); rows / k past the matrix are zero in the planes, so the loads need no bounds.
+// C (+)= (A B^T) / (s_a s_b) with a b = hi hi + hi lo + lo hi in one fp32 accumulator, as in csrc/gemm.hip (same accuracy).
+// Workgroup = 4 wavefronts, 128 x 128 tile (each 64 x 64 = 4 x 4 MFMA tiles), 32-wide k steps, two LDS stages of 32 KB
+// (two workgroups per CU), ONE barrier per k step, the 8 LDS-DMA pieces of the next stage dealt out between the MFMA
+// groups of the current one; split K through slabs summed in slab order (reproducible, no atomics, nobody waits for a
+// sibling workgroup: safe next to the persistent recurrence kernels).  Prototype + measurements: scripts/mb/gemm_planes.hip.
+#include <algorithm>
+
+#include "common.h"
+
+namespace ptmi {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int PBM = 128, PBN = 128;
+constexpr int FR = 64;                  // uint4 (16 B chunks) per plane tile
+
+// s = 2^(13 - e) for max|v| = m 2^e, 1 <= m < 2 (as csrc/gemm.hip::operand_scale; NULL / zero / non-finite maximum: 1)
+__device__ __forceinline__ float plane_scale(const unsigned* amax_bits) {
+    if (!amax_bits) return 1.f;
+    const unsigned e = (*amax_bits >> 23) & 0xffu;
+    if (e == 0u || e == 0xffu) return 1.f;
+    return __uint_as_float((unsigned)(127 + 13 + 127 - (int)e) << 23);
+}
+
+struct PlanesArgs {
+    const uint4* A;             // planes of the M-side operand
+    const uint4* B;             // planes of the N-side operand
+    float* C;
+    float* workspace;           // split K: [splits][M][N]
+    const unsigned* amax_a;
+    const unsigned* amax_b;
+    int M, N, KB;               // KB = k blocks of 32 in the planes
+    long long ldc;
+    int accumulate;
+    int kb_per_split;
+    int tiles_m, tiles_n;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G) {
+#if __HIP_DEVICE_COMPILE__          // (the host pass cannot parse the LDS-DMA builtin; it only needs the stub)
+    constexpr int PIECES = 32;      // plane tiles per stage: (8 row tiles + 8 column tiles) x 2 planes
+    __shared__ uint4 lds[2 * PIECES * FR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware tile order: workgroup id L runs on XCD L % 8; every XCD gets one contiguous range of tiles (row-major over
+    // [tiles_m][tiles_n]), so the workgroups an XCD runs at a time share operand panels through its L2
+    const int T = G.tiles_m * G.tiles_n;
+    const int q = T / 8, r8 = T % 8, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    if (idx >= (xcd < r8 ? q + 1 : q)) return;
+    const int tile = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+    const int tm = tile / G.tiles_n, tn = tile - tm * G.tiles_n;
+    const int kb0 = blockIdx.z * G.kb_per_split, kb1 = min(G.KB, kb0 + G.kb_per_split);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int rta = (G.M + 15) / 16, rtb = (G.N + 15) / 16;
+    const uint4* gsrc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = wave * 8 + i;                        // piece: 16 A pieces (row tile, plane), then 16 B pieces
+        const bool isa = f < 16;
+        const int rt = (f & 15) >> 1, p = f & 1;
+        const long long row_tile = min((long long)(isa ? tm : tn) * 8 + rt, (long long)(isa ? rta : rtb) - 1);
+        gsrc[i] = (isa ? G.A : G.B) + ((row_tile * G.KB + kb0) * 2 + p) * FR + lane;
+    }
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    if (kb0 < kb1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(gsrc[i], &lds[(wave * 8 + i) * FR], 16, 0, 0);
+    }
+    for (int kb = kb0; kb < kb1; ++kb) {
+        const int st = (kb - kb0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of stage `st` have landed
+        __builtin_amdgcn_s_barrier();                             // everybody's have; everybody is done reading stage st ^ 1
+        const uint4* sa = &lds[(st * PIECES + wm * 8) * FR + lane];
+        const uint4* sb = &lds[(st * PIECES + 16 + wn * 8) * FR + lane];
+        const bool more = kb + 1 < kb1;
+        h8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = __builtin_bit_cast(h8, sb[(j * 2 + 0) * FR]);
+            bl[j] = __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
+        }
+        h8 ah = __builtin_bit_cast(h8, sa[0]), al = __builtin_bit_cast(h8, sa[FR]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h8 nh = ah, nl = al;
+            if (i + 1 < 4) {
+                nh = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 0) * FR]);
+                nl = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
+            }
+            if (more) {         // two pieces of the next stage per MFMA group
+#pragma unroll
+                for (int pc = 2 * i; pc < 2 * i + 2; ++pc)
+                    __builtin_amdgcn_global_load_lds(gsrc[pc] + (long long)(kb + 1 - kb0) * 2 * FR,
+                                                     &lds[((st ^ 1) * PIECES + wave * 8 + pc) * FR], 16, 0, 0);
+            }
+            // D[n = 4 (lane >> 4) + e][m = lane & 15]: the MFMA's "a" operand is the B fragment, so a lane holds four
+            // consecutive columns of C; product kind outermost: 4 independent MFMAs between two on one accumulator
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? bl[j] : bh[j], p == 1 ? al : ah, acc[i][j], 0, 0, 0);
+            ah = nh;
+            al = nl;
+        }
+    }
+    const float inv = 1.f / (plane_scale(G.amax_a) * plane_scale(G.amax_b));
+    const bool slab = gridDim.z > 1;
+    float* const Cz = slab ? G.workspace + (long long)blockIdx.z * G.M * G.N : G.C;
+    const long long ldc = slab ? G.N : G.ldc;
+    const bool vec = (ldc & 3) == 0 && (reinterpret_cast<unsigned long long>(Cz) & 15) == 0;
+    const bool add = G.accumulate && !slab;
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = tm * PBM + wm * 64 + i * 16 + r;
+        if (m >= G.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
+            float* o = Cz + (long long)m * ldc + n;
+            const f4 v = acc[i][j] * inv;
+            if (vec && n + 3 < G.N) {
+                f4* o4 = reinterpret_cast<f4*>(o);
+                *o4 = add ? *o4 + v : v;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < G.N) o[e] = add ? o[e] + v[e] : v[e];
+            }
+        }
+    }
+#endif
+}
+
+// split K, second pass: C (+)= sum over the slabs in slab order (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long long ldc,
+                                                            int M, int N, int accumulate) {
+    const long long total = (long long)M * N;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / N), c = (int)(i - (long long)r * N);
+        float sum = 0.f;
+        for (int z = 0; z < splits; ++z) sum += ws[(long long)z * total + i];
+        float* o = C + (long long)r * ldc + c;
+        *o = accumulate ? *o + sum : sum;
+    }
+}
+
+// Source x[k][c] (row stride ld; the operand's ROWS are the columns c, its reduction axis the rows k) -> planes.
+// Workgroup: 32 k x 64 c; loads coalesced along c, a transpose through LDS, one 16 B chunk per thread and plane.
+__global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restrict__ x, long long krows, long long cols, long long ld,
+                                                            const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB) {
+    __shared__ float tile[32][65];
+    const int tid = threadIdx.x;
+    const long long kb = blockIdx.x, c0 = (long long)blockIdx.y * 64;
+    const float s = plane_scale(amax);
+    {
+        const int cx = tid & 63, ky = tid >> 6;             // 64 columns x 4 rows per pass
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const long long k = kb * 32 + ky + p * 4, c = c0 + cx;
+            tile[ky + p * 4][cx] = (k < krows && c < cols) ? x[k * ld + c] * s : 0.f;
+        }
+    }
+    __syncthreads();
+    // chunk of this thread: row tile rl = tid / 64 of the 4 in this block, k group g, row r
+    const int rl = tid >> 6, g = (tid >> 4) & 3, r = tid & 15;
+    const long long rt = blockIdx.y * 4 + rl;
+    if (rt * 16 >= ((cols + 15) / 16) * 16) return;
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float v = tile[g * 8 + e][rl * 16 + r];
+        hi[e] = (_Float16)v;                                  // round to nearest; v - hi is exact in fp32
+        lo[e] = (_Float16)(v - (float)hi[e]);
+    }
+    uint4* o = out + ((rt * KB + kb) * 2) * FR + g * 16 + r;
+    o[0] = __builtin_bit_cast(uint4, hi);
+    o[FR] = __builtin_bit_cast(uint4, lo);
+}
+
+}  // namespace ptmi
+
+using namespace ptmi;
+
+extern "C" {
+
+int64_t ptmi_planes_elems(int64_t rows, int64_t k) {
+    return ((rows + 15) / 16) * ((k + 31) / 32) * 2 * 512;          // fp16 values
+}
+
+int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
+                       ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!x || !out || k_rows < 1 || cols < 1 || ld < cols, PTMI_E_INVALID);
+    PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(out) & 15) != 0, PTMI_E_INVALID);
+    const long long KB = (k_rows + 31) / 32, cb = (cols + 63) / 64;
+    PTMI_RETURN_IF(cb > 65535, PTMI_E_UNSUPPORTED);
+    hipLaunchKernelGGL(pack_planes_t_kernel, dim3((unsigned)KB, (unsigned)cb), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       (long long)k_rows, (long long)cols, (long long)ld, amax, reinterpret_cast<uint4*>(out), KB);
+    return launch_status();
+}
+
+int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k) {
+    const int KB = (k + 31) / 32;
+    const int splits = std::max(1, std::min<int>(split_k, KB));
+    return splits > 1 ? (int64_t)splits * m * n : 0;
+}
+
+int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, float* c, int64_t ldc,
+                     int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
+    PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
+    const int KB = (k + 31) / 32;
+    int splits = std::max(1, std::min<int>(split_k, KB));
+    const int per = (KB + splits - 1) / splits;
+    splits = (KB + per - 1) / per;
+    PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
+    PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, m, n, KB,
+                 (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
+    const int tiles = G.tiles_m * G.tiles_n;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gemm_planes_kernel, dim3((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits), dim3(256), 0, st, G);
+    int rc = launch_status();
+    if (rc != PTMI_OK || splits == 1) return rc;
+    const long long total = (long long)m * n;
+    const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, m, n,
+                       accumulate ? 1 : 0);
+    return launch_status();
+}
+
+}  // extern "C"

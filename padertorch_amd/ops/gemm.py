@@ -86,6 +86,28 @@ def seed_weights_absmax(params, word):
         _WEIGHT_AMAX[tuple(id(p) for p in params)] = (tuple((p._version, p.data_ptr()) for p in params), None, word)
 
 
+#: weight-gradient GEMMs (both operands reduce over their OUTER axis) on pre-split fp16 planes (csrc/gemm_planes.hip)
+PLANES = os.environ.get('PTMI_GEMM_PLANES', '1') != '0'
+
+
+def pack_t(x, amax=None):
+    """``x [k, c]`` (fp32 CUDA, unit inner stride; any row stride) -> ``(planes, amax word or None)`` of the operand whose
+    rows are ``x``'s columns and whose reduction axis is ``k`` (``torch.ops.ptmi.pack_planes_t``).  ``amax``: the device
+    word from :func:`absmax` (measured here when ``None``) or :data:`UNIT_RANGE`."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32, (x.shape, x.stride(), x.dtype)
+    ax = None if amax is UNIT_RANGE else (absmax(x) if amax is None else amax)
+    return torch.ops.ptmi.pack_planes_t(x, ax), ax
+
+
+def mm_planes_(out, a, b, M, N, K, accumulate=False, split_k=None):
+    """``out [M, N] (+)= A B^T`` for operands ``a = (planes, amax)``, ``b = (planes, amax)`` from :func:`pack_t` (``A`` is
+    ``M x K``, ``B`` is ``N x K``): ``torch.ops.ptmi.gemm_planes_``."""
+    assert out.dim() == 2 and out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32, (out.shape, out.stride())
+    sk = auto_split_k(M, N, K) if split_k is None else int(split_k)
+    torch.ops.ptmi.gemm_planes_(out, a[0], a[1], b[0], b[1], M, N, K, bool(accumulate), sk)
+    return out
+
+
 def usable(*tensors):
     """The split GEMM applies: enabled, fp32 CUDA operands."""
     return ENABLED and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)

@@ -17,6 +17,7 @@ with CPU tensors fails in the dispatcher (``NotImplementedError: ... 'CPU' backe
     torch.ops.ptmi.lstm_recurrence_forward / _backward   ptmi_lstm_*_persistent, falling back to ptmi_lstm_forward / _backward
                                                                               (torch.nn.LSTM in pit/model.py:60-66,97)
     torch.ops.ptmi.absmax, torch.ops.ptmi.gemm_split_    ptmi_absmax, ptmi_gemm_split   (nn.LSTM input projections, nn.Linear)
+    torch.ops.ptmi.pack_planes_t, torch.ops.ptmi.gemm_planes_   ptmi_pack_planes_t, ptmi_gemm_planes   (weight-gradient GEMMs)
     torch.ops.ptmi.lstm_weight_prep                ptmi_lstm_weight_prep      (the nn.LSTM parameters' operand forms, once per optimizer step)
     torch.ops.ptmi.grad_norm, torch.ops.ptmi.adam_flat_  ptmi_grad_norm, ptmi_adam_flat (train/optimizer.py:27-42, trainer.py:512-532)
 """
@@ -238,6 +239,29 @@ def adam_flat_(flat_grad, exp_avg, exp_avg_sq, segments, params, norm, max_norm,
                           max_norm, _lib.ptr(found_inf), _lib.ptr(finite), applied.data_ptr(), step.data_ptr(), lr, beta1, beta2,
                           eps, weight_decay, int(zero_grad), _lib.stream(flat_grad.device)), 'ptmi_adam_flat')
     return applied
+
+
+# ------------------------------------------------------------------------------------------------ GEMM on split planes
+@_register('pack_planes_t(Tensor x, Tensor? amax) -> Tensor')
+def pack_planes_t(x, amax):
+    """x [k, c] (fp32, unit inner stride) -> fp16 (hi, lo) planes of the c x k operand (``ptmi_pack_planes_t``)."""
+    lib = _lib.load()
+    k, c = x.shape
+    out = torch.empty(int(lib.ptmi_planes_elems(c, k)), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.timed('pack_planes_t', lib.ptmi_pack_planes_t, x.data_ptr(), k, c, x.stride(0), _lib.ptr(amax), out.data_ptr(),
+                          _lib.stream(x.device)), 'ptmi_pack_planes_t')
+    return out
+
+
+@_register('gemm_planes_(Tensor(a!) out, Tensor a, Tensor? amax_a, Tensor b, Tensor? amax_b, int M, int N, int K, bool accumulate, '
+           'int split_k) -> ()')
+def gemm_planes_(out, a, amax_a, b, amax_b, M, N, K, accumulate, split_k):
+    lib = _lib.load()
+    nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
+    ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
+    _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}', lib.ptmi_gemm_planes, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
+                          _lib.ptr(amax_b), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k, _lib.ptr(ws),
+                          _lib.stream(out.device)), 'ptmi_gemm_planes')
 
 
 # ------------------------------------------------------------------------------------------------ unit norm

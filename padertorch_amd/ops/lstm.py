@@ -501,7 +501,7 @@ class _LstmLayerFn(torch.autograd.Function):
             gm is not None or _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
         main = torch.cuda.current_stream(x.device) if in_place else None
         side = _wgrad_stream(x.device) if use_side else main
-        operands = [None]
+        operands, xplanes = [None], {}
 
         def wgrad_rows(dg, ranges, amax_dg):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`."""
@@ -512,7 +512,18 @@ class _LstmLayerFn(torch.autograd.Function):
                     if r1 <= r0:
                         continue
                     dgt = dgd[r0:r1].t()
-                    if gm is not None:
+                    if gm is not None and _gemm.PLANES:
+                        # both operands reduce over the batch's rows (their outer axis): split them into fp16 planes once
+                        # (dg for two GEMMs, the layer input for both directions) and run the plain 16-bit GEMM
+                        k = r1 - r0
+                        dgp = _gemm.pack_t(dgd[r0:r1], amax_dg)
+                        key = (r0, r1)
+                        if key not in xplanes:
+                            xplanes[key] = _gemm.pack_t(x[r0:r1], gm[0])
+                        _gemm.mm_planes_(p_wih.grad, dgp, xplanes[key], G, x.shape[1], k, accumulate=True)
+                        _gemm.mm_planes_(p_whh.grad, dgp, _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None),
+                                         G, H, k, accumulate=True)
+                    elif gm is not None:
                         _gemm.mm(dgt, x[r0:r1], out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=gm[0])
                         _gemm.mm(dgt, h_prev[r0:r1], out=p_whh.grad, accumulate=True, amax_x=amax_dg,
                                  amax_y=_gemm.UNIT_RANGE if h0 is None else None)

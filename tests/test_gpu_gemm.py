@@ -106,3 +106,45 @@ def test_padded_row_stride_views_take_the_aligned_path():
     tight.copy_(x)
     dw2 = gemm.mm(dg.t(), tight, split_k=1)
     assert _err(dw2, dg.t(), x) < 4e-7
+
+
+@pytest.mark.parametrize('M,N,K,split,acc', [(2400, 1200, 8096, None, True), (2400, 600, 8096, 4, False), (2400, 257, 8096, None, True),
+                                             (100, 36, 70, 1, False), (129, 130, 31, 2, True), (16, 4, 3000, 3, False)])
+def test_planes_gemm_vs_fp64(M, N, K, split, acc):
+    """pack_planes_t + gemm_planes_ (the weight-gradient form: both operands reduce over their outer axis) against fp64,
+    with the bound of the in-register split GEMM; strided sources, odd sizes, split K, accumulation into a strided C."""
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(M + N + K)
+    big_a = torch.randn(K, M + 5, device='cuda') * 3.0                  # sources are column blocks of wider matrices
+    big_b = torch.randn(K, N + 3, device='cuda') * 0.02
+    a, b = big_a[:, 2:2 + M], big_b[:, 1:1 + N]
+    cbuf = torch.randn(M, N + 2, device='cuda')
+    c = cbuf[:, :N]
+    want = a.double().t() @ b.double() + (c.double() if acc else 0)
+    mag = a.double().abs().t() @ b.double().abs()
+    G.mm_planes_(c, G.pack_t(a), G.pack_t(b), M, N, K, accumulate=acc, split_k=split)
+    err = float(((c.double() - want).abs() / mag).max())
+    assert err < 4e-7, err
+    again = cbuf.clone()[:, :N]
+    # bitwise reproducible (slabs summed in order)
+    c2 = (torch.zeros(M, N, device='cuda') if not acc else None)
+    if c2 is not None:
+        G.mm_planes_(c2, G.pack_t(a), G.pack_t(b), M, N, K, split_k=split)
+        assert torch.equal(c2, again)
+
+
+def test_planes_pack_layout_and_unit_range():
+    """The plane layout is what csrc/gemm_planes.hip documents; UNIT_RANGE packs without a scale."""
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(0)
+    x = (torch.rand(70, 20, device='cuda') * 2 - 1)
+    planes, word = G.pack_t(x, G.UNIT_RANGE)
+    assert word is None
+    p = planes.view(2, 3, 2, 4, 16, 8).cpu().float()          # [row tile][k block][plane][k group][row][8]
+    xs = x.cpu()
+    for c in (0, 7, 19):
+        for k in (0, 31, 32, 69):
+            hi = p[c // 16, k // 32, 0, (k % 32) // 8, c % 16, k % 8]
+            lo = p[c // 16, k // 32, 1, (k % 32) // 8, c % 16, k % 8]
+            assert float(hi) == float(xs[k, c].half()) and abs(float(hi + lo) - float(xs[k, c])) < 2e-7
+    assert float(p[1, :, :, :, 4:, :].abs().sum()) == 0 and float(p[:, 2, :, 0, :, 6:].abs().sum()) == 0      # past the matrix
