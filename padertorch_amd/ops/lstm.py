@@ -327,7 +327,22 @@ def _acquire(meta, ndir, H, device):
 _STACKED = {}
 
 
-def _stacked_weights(params, KP):
+_PREP_STREAMS = {}
+
+
+def _prep_stream(device):
+    key = (device.type, device.index)
+    if key not in _PREP_STREAMS:
+        _PREP_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _PREP_STREAMS[key]
+
+
+def _stacked_stale(params):
+    hit = _STACKED.get(tuple(id(p) for ps in params for p in ps))
+    return hit is None or hit[0] != tuple((p._version, p.data_ptr()) for ps in params for p in ps)
+
+
+def _stacked_weights(params, KP, stream=None):
     """The per-layer operand forms of a BLSTM layer's parameters - both directions' ``weight_ih`` stacked (and, for an
     input width that is not a multiple of 4, zero-padded along the reduction axis), the summed biases, ``weight_hh``
     stacked, padded to ``KP`` columns and transposed - cached until a parameter is modified (``_version`` / storage):
@@ -344,13 +359,21 @@ def _stacked_weights(params, KP):
     with torch.no_grad():
         p0 = params[0][0]
         if p0.is_cuda and all(p.dtype == torch.float32 and p.is_contiguous() for ps in params for p in ps):
-            # one launch: every parameter is read once (csrc/lstm_prep.hip)
-            w_ih_k, bias, w_pad, w_t, amax = torch.ops.ptmi.lstm_weight_prep(
-                [ps[0].detach() for ps in params], [ps[1].detach() for ps in params], [ps[2].detach() for ps in params],
-                [ps[3].detach() for ps in params], KP)
+            # one launch: every parameter is read once (csrc/lstm_prep.hip); on `stream` when the caller prefetches the
+            # forms of later layers next to the first layer's work (consumers wait for forms['ready'])
+            main = torch.cuda.current_stream(p0.device)
+            with torch.cuda.stream(stream if stream is not None else main):
+                w_ih_k, bias, w_pad, w_t, amax = torch.ops.ptmi.lstm_weight_prep(
+                    [ps[0].detach() for ps in params], [ps[1].detach() for ps in params], [ps[2].detach() for ps in params],
+                    [ps[3].detach() for ps in params], KP)
             I, H = p0.shape[1], params[0][1].shape[1]
             forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t,
-                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None}
+                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None}
+            if stream is not None:
+                forms['ready'] = torch.cuda.Event()
+                forms['ready'].record(stream)
+                for t in (w_ih_k, bias, w_pad, w_t, amax):
+                    t.record_stream(main)          # allocated on the side stream's pool, used (and later freed) on the main one
             _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
             _gemm.seed_weights_absmax([ps[1] for ps in params], amax[1:2])
         else:
@@ -672,9 +695,23 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         assert h_all.shape == c_all.shape == (lstm.num_layers * ndir, meta.max_batch, H), (h_all.shape, meta.max_batch)
     h_n, c_n = [], []
     h = data.contiguous()
+    all_params = [tuple((getattr(lstm, f'weight_ih_l{layer}{s}'), getattr(lstm, f'weight_hh_l{layer}{s}'),
+                         getattr(lstm, f'bias_ih_l{layer}{s}'), getattr(lstm, f'bias_hh_l{layer}{s}')) for s in sfx)
+                  for layer in range(lstm.num_layers)]
+    flat_params = [p for ps_ in all_params for ps in ps_ for p in ps]
+    if (CACHE_STACKED_WEIGHTS and data.is_cuda and any(_stacked_stale(ps_) for ps_ in all_params)
+            and all(p.is_cuda and p.dtype == torch.float32 for p in flat_params)
+            and (not (torch.is_grad_enabled() and any(p.requires_grad for p in flat_params))
+                 or (DEFER_WGRAD and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for p in flat_params)))):
+        # after an optimizer step: the operand forms of ALL layers on a side stream, next to whatever the main stream is
+        # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
+        pre = _prep_stream(data.device)
+        pre.wait_stream(torch.cuda.current_stream(data.device))
+        for ps_ in all_params:
+            if _stacked_stale(ps_):
+                _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre)
     for layer in range(lstm.num_layers):
-        params = tuple((getattr(lstm, f'weight_ih_l{layer}{s}'), getattr(lstm, f'weight_hh_l{layer}{s}'),
-                        getattr(lstm, f'bias_ih_l{layer}{s}'), getattr(lstm, f'bias_hh_l{layer}{s}')) for s in sfx)
+        params = all_params[layer]
         # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
         # runs on the cached stacked / padded / transposed forms of its parameters
         graph = torch.is_grad_enabled() and any(p.requires_grad for ps in params for p in ps)
@@ -682,6 +719,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         forms = anchor = None
         if CACHE_STACKED_WEIGHTS and data.is_cuda and (not graph or in_place):
             forms = _stacked_weights(params, (H + 15) // 16 * 16)
+            if forms.get('ready') is not None:
+                torch.cuda.current_stream(data.device).wait_event(forms['ready'])
             w_ih, bias, w_hh = forms['w_ih'], forms['bias'], forms['w_hh']
             anchor = params[0][0] if graph else None
         else:
