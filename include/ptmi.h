@@ -382,16 +382,21 @@ int64_t ptmi_gemm_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split
  *   columns c and whose reduction axis is k: [ceil(cols / 16)][ceil(k_rows / 32)][hi | lo][64 chunks of 8 fp16]
  *   (ptmi_planes_elems(cols, k_rows) fp16 values, 16-byte aligned), every value scaled by 2^(13 - exponent(*amax))
  *   (amax: device word from ptmi_absmax or the backward recurrence; NULL: scale 1), zero past the matrix.
- * ptmi_gemm_planes:  C[m, n] (+)= sum_k A[m, k] B[n, k] / (scale_a scale_b)  with A, B as planes of m x k and n x k
+ * ptmi_pack_planes_n: the same planes from a source x[r][k] whose reduction axis is contiguous (rows x k, row stride ld):
+ *   activations and weights of the forward form x W^T.
+ * ptmi_gemm_planes:  C[m, n] (+)= sum_k A[m, k] B[n, k] / (scale_a scale_b) + bias[n]  with A, B as planes of m x k and n x k
  *   operands (same amax words as at packing), three fp16 MFMA products per product, fp32 accumulation;
  *   split_k > 1: that many k ranges, summed in order by a second kernel (workspace:
  *   ptmi_gemm_planes_workspace_elems floats). */
 int64_t ptmi_planes_elems(int64_t rows, int64_t k);
 int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
                        ptmi_stream_t stream);
+int ptmi_pack_planes_n(const float* x, int64_t rows, int64_t k, int64_t ld, const uint32_t* amax, uint16_t* out,
+                       ptmi_stream_t stream);
 int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k);
-int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, float* c, int64_t ldc,
-                     int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream);
+int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
+                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
+                     ptmi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer step on the Trainer's flat gradient bucket (csrc/optim.hip): replaces, on the step path of

@@ -42,6 +42,7 @@ struct PlanesArgs {
     float* workspace;           // split K: [splits][M][N]
     const unsigned* amax_a;
     const unsigned* amax_b;
+    const float* bias;          // [N] or null
     int M, N, KB;               // KB = k blocks of 32 in the planes
     long long ldc;
     int accumulate;
@@ -135,7 +136,12 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
         for (int j = 0; j < 4; ++j) {
             const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
             float* o = Cz + (long long)m * ldc + n;
-            const f4 v = acc[i][j] * inv;
+            f4 v = acc[i][j] * inv;
+            if (G.bias != nullptr && !slab) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < G.N) v[e] += G.bias[n + e];
+            }
             if (vec && n + 3 < G.N) {
                 f4* o4 = reinterpret_cast<f4*>(o);
                 *o4 = add ? *o4 + v : v;
@@ -151,12 +157,13 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
 
 // split K, second pass: C (+)= sum over the slabs in slab order (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long long ldc,
-                                                            int M, int N, int accumulate) {
+                                                            const float* __restrict__ bias, int M, int N, int accumulate) {
     const long long total = (long long)M * N;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / N), c = (int)(i - (long long)r * N);
         float sum = 0.f;
         for (int z = 0; z < splits; ++z) sum += ws[(long long)z * total + i];
+        if (bias) sum += bias[c];
         float* o = C + (long long)r * ldc + c;
         *o = accumulate ? *o + sum : sum;
     }
@@ -195,6 +202,39 @@ __global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restr
     o[FR] = __builtin_bit_cast(uint4, lo);
 }
 
+// Source x[r][k] (row stride ld, the reduction axis k contiguous) -> planes of the operand with rows r.  Workgroup: one
+// 16-row tile x 4 k blocks; a thread makes one chunk (8 consecutive k of one row: 32 B read, 2 x 16 B written).
+__global__ __launch_bounds__(256) void pack_planes_n_kernel(const float* __restrict__ x, long long rows, long long K, long long ld,
+                                                            const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB) {
+    const int tid = threadIdx.x;
+    const int r = tid >> 4, c = tid & 15;
+    const long long rt = blockIdx.y, kb = (long long)blockIdx.x * 4 + (c >> 2);
+    const int g = c & 3;
+    if (kb >= KB) return;
+    const float s = plane_scale(amax);
+    const long long row = rt * 16 + r, k0 = kb * 32 + g * 8;
+    float v[8];
+    const float* src = x + row * ld + k0;
+    if (row < rows && k0 + 8 <= K && ((reinterpret_cast<unsigned long long>(src) & 15) == 0)) {
+        const f4 a = *reinterpret_cast<const f4*>(src), b = *reinterpret_cast<const f4*>(src + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+        v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (row < rows && k0 + e < K) ? src[e] : 0.f;
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float w = v[e] * s;
+        hi[e] = (_Float16)w;
+        lo[e] = (_Float16)(w - (float)hi[e]);
+    }
+    uint4* o = out + ((rt * KB + kb) * 2) * FR + g * 16 + r;
+    o[0] = __builtin_bit_cast(uint4, hi);
+    o[FR] = __builtin_bit_cast(uint4, lo);
+}
+
 }  // namespace ptmi
 
 using namespace ptmi;
@@ -216,14 +256,26 @@ int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld,
     return launch_status();
 }
 
+int ptmi_pack_planes_n(const float* x, int64_t rows, int64_t k, int64_t ld, const uint32_t* amax, uint16_t* out,
+                       ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!x || !out || rows < 1 || k < 1 || ld < k, PTMI_E_INVALID);
+    PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(out) & 15) != 0, PTMI_E_INVALID);
+    const long long KB = (k + 31) / 32, rt = (rows + 15) / 16;
+    PTMI_RETURN_IF(rt > 65535, PTMI_E_UNSUPPORTED);
+    hipLaunchKernelGGL(pack_planes_n_kernel, dim3((unsigned)((KB + 3) / 4), (unsigned)rt), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       x, (long long)rows, (long long)k, (long long)ld, amax, reinterpret_cast<uint4*>(out), KB);
+    return launch_status();
+}
+
 int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k) {
     const int KB = (k + 31) / 32;
     const int splits = std::max(1, std::min<int>(split_k, KB));
     return splits > 1 ? (int64_t)splits * m * n : 0;
 }
 
-int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, float* c, int64_t ldc,
-                     int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream) {
+int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
+                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
+                     ptmi_stream_t stream) {
     PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
     const int KB = (k + 31) / 32;
@@ -231,7 +283,7 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
     const int per = (KB + splits - 1) / splits;
     splits = (KB + per - 1) / per;
     PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
-    PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, m, n, KB,
+    PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, bias, m, n, KB,
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
     const int tiles = G.tiles_m * G.tiles_n;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -240,7 +292,7 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
     if (rc != PTMI_OK || splits == 1) return rc;
     const long long total = (long long)m * n;
     const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, m, n,
+    hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
                        accumulate ? 1 : 0);
     return launch_status();
 }

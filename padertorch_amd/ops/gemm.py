@@ -99,13 +99,35 @@ def pack_t(x, amax=None):
     return torch.ops.ptmi.pack_planes_t(x, ax), ax
 
 
-def mm_planes_(out, a, b, M, N, K, accumulate=False, split_k=None):
+def pack_n(x, amax=None):
+    """``x [r, k]`` (reduction axis contiguous) -> ``(planes, amax word or None)`` of that ``r x k`` operand."""
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32, (x.shape, x.stride(), x.dtype)
+    ax = None if amax is UNIT_RANGE else (absmax(x) if amax is None else amax)
+    return torch.ops.ptmi.pack_planes_n(x, ax), ax
+
+
+def mm_planes_(out, a, b, M, N, K, accumulate=False, split_k=None, bias=None):
     """``out [M, N] (+)= A B^T`` for operands ``a = (planes, amax)``, ``b = (planes, amax)`` from :func:`pack_t` (``A`` is
     ``M x K``, ``B`` is ``N x K``): ``torch.ops.ptmi.gemm_planes_``."""
     assert out.dim() == 2 and out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32, (out.shape, out.stride())
     sk = auto_split_k(M, N, K) if split_k is None else int(split_k)
-    torch.ops.ptmi.gemm_planes_(out, a[0], a[1], b[0], b[1], M, N, K, bool(accumulate), sk)
+    torch.ops.ptmi.gemm_planes_(out, a[0], a[1], b[0], b[1], bias, M, N, K, bool(accumulate), sk)
     return out
+
+
+_WEIGHT_PLANES = {}
+
+
+def weight_planes(p):
+    """``pack_n`` of a 2-D parameter used as the ``W`` of ``x W^T``, cached until the parameter is modified."""
+    hit = _WEIGHT_PLANES.get(id(p))
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+        return hit[2]
+    if len(_WEIGHT_PLANES) > 64:
+        _WEIGHT_PLANES.clear()
+    v = pack_n(p.detach(), weight_absmax(p))
+    _WEIGHT_PLANES[id(p)] = (p._version, p.data_ptr(), v)
+    return v
 
 
 def usable(*tensors):

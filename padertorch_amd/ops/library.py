@@ -253,14 +253,26 @@ def pack_planes_t(x, amax):
     return out
 
 
-@_register('gemm_planes_(Tensor(a!) out, Tensor a, Tensor? amax_a, Tensor b, Tensor? amax_b, int M, int N, int K, bool accumulate, '
-           'int split_k) -> ()')
-def gemm_planes_(out, a, amax_a, b, amax_b, M, N, K, accumulate, split_k):
+@_register('pack_planes_n(Tensor x, Tensor? amax) -> Tensor')
+def pack_planes_n(x, amax):
+    """x [r, k] (fp32, unit inner stride) -> fp16 (hi, lo) planes of the r x k operand (``ptmi_pack_planes_n``)."""
+    lib = _lib.load()
+    r, k = x.shape
+    out = torch.empty(int(lib.ptmi_planes_elems(r, k)), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.timed('pack_planes_n', lib.ptmi_pack_planes_n, x.data_ptr(), r, k, x.stride(0), _lib.ptr(amax), out.data_ptr(),
+                          _lib.stream(x.device)), 'ptmi_pack_planes_n')
+    return out
+
+
+@_register('gemm_planes_(Tensor(a!) out, Tensor a, Tensor? amax_a, Tensor b, Tensor? amax_b, Tensor? bias, int M, int N, int K, '
+           'bool accumulate, int split_k) -> ()')
+def gemm_planes_(out, a, amax_a, b, amax_b, bias, M, N, K, accumulate, split_k):
     lib = _lib.load()
     nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
     ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
     _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}', lib.ptmi_gemm_planes, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
-                          _lib.ptr(amax_b), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k, _lib.ptr(ws),
+                          _lib.ptr(amax_b), _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k,
+                          _lib.ptr(ws),
                           _lib.stream(out.device)), 'ptmi_gemm_planes')
 
 

@@ -25,6 +25,11 @@ class _LinearFn(torch.autograd.Function):
         ctx.module = module
         ctx.amax = (amax_x, amax_w)
         ctx.has_bias = bias is not None
+        if _gemm.PLANES and x.stride(1) == 1:
+            # both operands as fp16 planes (the weight's cached per optimizer step): csrc/gemm_planes.hip
+            y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+            return _gemm.mm_planes_(y, _gemm.pack_n(x, amax_x), _gemm.weight_planes(module.weight), x.shape[0], weight.shape[0],
+                                    x.shape[1], bias=bias)
         return _gemm.mm(x, weight.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
 
     @staticmethod
@@ -48,7 +53,11 @@ class _LinearFn(torch.autograd.Function):
         else:
             main.wait_stream(_lstm._wgrad_stream(x.device))
         with torch.cuda.stream(side):
-            _gemm.mm(g.t(), x, out=mod.weight.grad, accumulate=True, amax_x=amax_g, amax_y=amax_x)
+            if _gemm.PLANES and x.stride(1) == 1:
+                _gemm.mm_planes_(mod.weight.grad, _gemm.pack_t(g, amax_g), _gemm.pack_t(x, amax_x), g.shape[1], x.shape[1],
+                                 x.shape[0], accumulate=True)
+            else:
+                _gemm.mm(g.t(), x, out=mod.weight.grad, accumulate=True, amax_x=amax_g, amax_y=amax_x)
             if ctx.has_bias:
                 mod.bias.grad.add_(g.sum(0))
         if side is not main:

@@ -366,13 +366,15 @@ def _stacked_weights(params, KP, stream=None):
                 w_ih_k, bias, w_pad, w_t, amax = torch.ops.ptmi.lstm_weight_prep(
                     [ps[0].detach() for ps in params], [ps[1].detach() for ps in params], [ps[2].detach() for ps in params],
                     [ps[3].detach() for ps in params], KP)
-            I, H = p0.shape[1], params[0][1].shape[1]
+                I, H = p0.shape[1], params[0][1].shape[1]
+                # fp16 planes of the stacked input weights (the W of x W^T on csrc/gemm_planes.hip)
+                planes = _gemm.pack_n(w_ih_k[:, :I], amax[0:1]) if _gemm.PLANES else None
             forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t,
-                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None}
+                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None, 'w_ih_planes': planes}
             if stream is not None:
                 forms['ready'] = torch.cuda.Event()
                 forms['ready'].record(stream)
-                for t in (w_ih_k, bias, w_pad, w_t, amax):
+                for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if planes is not None else ()):
                     t.record_stream(main)          # allocated on the side stream's pool, used (and later freed) on the main one
             _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
             _gemm.seed_weights_absmax([ps[1] for ps in params], amax[1:2])
@@ -430,7 +432,11 @@ class _LstmLayerFn(torch.autograd.Function):
             amax_x = (_gemm.UNIT_RANGE if x_unit else _gemm.absmax(x)) if use_gemm else None
             amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
                       if use_gemm else None)
-            if use_gemm:
+            if use_gemm and _gemm.PLANES and forms is not None and forms.get('w_ih_planes') is not None:
+                # both operands as fp16 planes: the input split once here, the stacked weights' planes come with the forms
+                gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
+                _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), forms['w_ih_planes'], meta.rows, ndir * G, x.shape[1], bias=bias)
+            elif use_gemm:
                 # an input width that is not a multiple of 4 (F = 257) would send the projection and its weight gradient
                 # down the kernel's unaligned (scalar-load) path: zero-pad the reduction axis of both operands instead
                 kpad = -x.shape[1] % 4

@@ -148,3 +148,19 @@ def test_planes_pack_layout_and_unit_range():
             lo = p[c // 16, k // 32, 1, (k % 32) // 8, c % 16, k % 8]
             assert float(hi) == float(xs[k, c].half()) and abs(float(hi + lo) - float(xs[k, c])) < 2e-7
     assert float(p[1, :, :, :, 4:, :].abs().sum()) == 0 and float(p[:, 2, :, 0, :, 6:].abs().sum()) == 0      # past the matrix
+
+
+@pytest.mark.parametrize('M,N,K,split', [(8096, 4800, 1200, None), (8096, 514, 1200, None), (300, 70, 257, 1), (17, 5, 33, 2)])
+def test_planes_forward_form_with_bias(M, N, K, split):
+    """x W^T + b with both operands packed from k-contiguous sources (pack_planes_n), odd K / N, strided x."""
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(M + N)
+    xb = torch.randn(M, K + 3, device='cuda') * 2.0
+    x = xb[:, :K]
+    w = torch.randn(N, K, device='cuda') * 0.05
+    b = torch.randn(N, device='cuda')
+    want = x.double() @ w.double().t() + b.double()
+    mag = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    y = torch.empty(M, N, device='cuda')
+    G.mm_planes_(y, G.pack_n(x), G.pack_n(w), M, N, K, split_k=split, bias=b)
+    assert float(((y.double() - want).abs() / mag).max()) < 4e-7
