@@ -201,13 +201,19 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
     kernels = []
     gemm = {}
     for n, v in by_name.items():
-        if n.startswith('gemm_split:'):          # gemm_split:MxNxK:products
-            dims, products = n.split(':')[1:3]
-            M, N, Kd = (int(x) for x in dims.split('x'))
-            e = gemm.setdefault(int(products), dict(flop=0., ms=0., launches=0))
+        if n.startswith('gemm_split:') or n.startswith('gemm_planes:'):          # gemm_split:MxNxK:products, gemm_planes:MxNxK
+            parts = n.split(':')
+            M, N, Kd = (int(x) for x in parts[1].split('x'))
+            e = gemm.setdefault(int(parts[2]) if len(parts) > 2 else 3, dict(flop=0., ms=0., launches=0, pack_ms=0., planes=0))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
             e['launches'] += len(v)
+            e['planes'] += len(v) if n.startswith('gemm_planes:') else 0
+            continue
+        if n.startswith('pack_planes'):          # the operand split passes of the planes GEMM: part of the dense layers' time
+            e = gemm.setdefault(3, dict(flop=0., ms=0., launches=0, pack_ms=0., planes=0))
+            e['ms'] += float(np.sum(v))
+            e['pack_ms'] += float(np.sum(v))
             continue
         if n not in spec:
             continue
@@ -235,13 +241,15 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
         kernels.append(dict(
-            kernel=f'gemm_split_kernel (dense layers: LSTM input projections, linears, input / weight gradients; '
-                   f'{products} fp16 MFMA product(s) per fp32 product)' if products == 3 else
-                   'gemm_split_kernel (dense layers, plain bf16 operands)',
+            kernel=f'gemm_planes_kernel / gemm_split_kernel (dense layers: LSTM input projections, linears and weight gradients on '
+                   f'pre-split fp16 planes incl. their pack passes, input gradients split in registers; {products} fp16 MFMA '
+                   f'products per fp32 product)' if products == 3 else 'gemm_split_kernel (dense layers, plain bf16 operands)',
             bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=measured_traffic('gemm_split'),
             peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = '
-                      f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream)',
+                      f'algorithmic 2MNK flop of all launches / their HIP-event time incl. the operand pack passes (main and '
+                      f'weight-gradient stream, i.e. next to the running recurrences)',
             avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
+            planes_launches_per_step=e['planes'] / steps, pack_ms_per_step=e['pack_ms'] / steps,
             algorithmic_flop_per_step=e['flop'] / steps))
     kernels.sort(key=lambda e: -e['ms_per_step'])
     return kernels
@@ -450,11 +458,13 @@ def main():
                 'global_batch': cfg['batch'] * world * micro,
                 'frames_per_step': frames_per_step * world,
                 'parallelism': f'dp{world}',
-                'blstm': 'HIP recurrence (csrc/lstm.hip)',
+                'blstm': 'HIP recurrence (csrc/lstm_split.hip)',
                 'gemms': ('hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)' if args.library_gemms else
                           'csrc/gemm.hip, plain bf16 operands (reduced precision)' if args.bf16 else
-                          'csrc/gemm.hip: fp32 in/out, 3 fp16 MFMA products per product (fp32-equivalent accuracy)'),
+                          'csrc/gemm_planes.hip (projections, linears, weight gradients: operands pre-split into fp16 planes) + '
+                          'csrc/gemm.hip (input gradients): fp32 in/out, 3 fp16 MFMA products per product (fp32-equivalent accuracy)'),
                 'host_checks': 'same step (2 syncs)' if args.sync_checks else 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)',
+                'optimizer': 'csrc/optim.hip: reproducible 2-norm + fused clip / Adam / zero_grad over the flat bucket',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',
             },
         }

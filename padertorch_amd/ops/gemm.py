@@ -90,6 +90,11 @@ def seed_weights_absmax(params, word):
 PLANES = os.environ.get('PTMI_GEMM_PLANES', '1') != '0'
 
 
+def planes_enabled():
+    """The planes GEMM exists in the fp32-equivalent (three-product) form only."""
+    return PLANES and PRODUCTS == 3
+
+
 def pack_t(x, amax=None):
     """``x [k, c]`` (fp32 CUDA, unit inner stride; any row stride) -> ``(planes, amax word or None)`` of the operand whose
     rows are ``x``'s columns and whose reduction axis is ``k`` (``torch.ops.ptmi.pack_planes_t``).  ``amax``: the device
@@ -127,6 +132,20 @@ def weight_planes(p):
         _WEIGHT_PLANES.clear()
     v = pack_n(p.detach(), weight_absmax(p))
     _WEIGHT_PLANES[id(p)] = (p._version, p.data_ptr(), v)
+    return v
+
+
+def weight_planes_t(p):
+    """``pack_t`` of a 2-D parameter ``W [out, in]`` used as the right operand of ``g W`` (rows = input features, reduction
+    over the outputs), cached until the parameter is modified."""
+    key = ('t', id(p))
+    hit = _WEIGHT_PLANES.get(key)
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+        return hit[2]
+    if len(_WEIGHT_PLANES) > 64:
+        _WEIGHT_PLANES.clear()
+    v = pack_t(p.detach(), weight_absmax(p))
+    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v)
     return v
 
 

@@ -25,7 +25,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.module = module
         ctx.amax = (amax_x, amax_w)
         ctx.has_bias = bias is not None
-        if _gemm.PLANES and x.stride(1) == 1:
+        if _gemm.planes_enabled() and x.stride(1) == 1:
             # both operands as fp16 planes (the weight's cached per optimizer step): csrc/gemm_planes.hip
             y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
             return _gemm.mm_planes_(y, _gemm.pack_n(x, amax_x), _gemm.weight_planes(module.weight), x.shape[0], weight.shape[0],
@@ -39,7 +39,14 @@ class _LinearFn(torch.autograd.Function):
         amax_x, amax_w = ctx.amax
         g = g.contiguous()
         amax_g = _gemm.absmax(g)
-        dx = _gemm.mm(g, weight, amax_x=amax_g, amax_y=amax_w) if ctx.needs_input_grad[0] else None
+        planes = _gemm.planes_enabled() and x.stride(1) == 1
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif planes:
+            dx = _gemm.mm_planes_(torch.empty_like(x, memory_format=torch.contiguous_format), _gemm.pack_n(g, amax_g),
+                                  _gemm.weight_planes_t(mod.weight), g.shape[0], weight.shape[1], weight.shape[0])
+        else:
+            dx = _gemm.mm(g, weight, amax_x=amax_g, amax_y=amax_w)
         in_place = (_lstm.DEFER_WGRAD and mod.weight.grad is not None and mod.weight.requires_grad
                     and (not ctx.has_bias or mod.bias.grad is not None))
         if not in_place:
@@ -53,7 +60,7 @@ class _LinearFn(torch.autograd.Function):
         else:
             main.wait_stream(_lstm._wgrad_stream(x.device))
         with torch.cuda.stream(side):
-            if _gemm.PLANES and x.stride(1) == 1:
+            if _gemm.planes_enabled() and x.stride(1) == 1:
                 _gemm.mm_planes_(mod.weight.grad, _gemm.pack_t(g, amax_g), _gemm.pack_t(x, amax_x), g.shape[1], x.shape[1],
                                  x.shape[0], accumulate=True)
             else:

@@ -368,7 +368,7 @@ def _stacked_weights(params, KP, stream=None):
                     [ps[3].detach() for ps in params], KP)
                 I, H = p0.shape[1], params[0][1].shape[1]
                 # fp16 planes of the stacked input weights (the W of x W^T on csrc/gemm_planes.hip)
-                planes = _gemm.pack_n(w_ih_k[:, :I], amax[0:1]) if _gemm.PLANES else None
+                planes = _gemm.pack_n(w_ih_k[:, :I], amax[0:1]) if _gemm.planes_enabled() else None
             forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t,
                      'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None, 'w_ih_planes': planes}
             if stream is not None:
@@ -432,7 +432,7 @@ class _LstmLayerFn(torch.autograd.Function):
             amax_x = (_gemm.UNIT_RANGE if x_unit else _gemm.absmax(x)) if use_gemm else None
             amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
                       if use_gemm else None)
-            if use_gemm and _gemm.PLANES and forms is not None and forms.get('w_ih_planes') is not None:
+            if use_gemm and _gemm.planes_enabled() and forms is not None and forms.get('w_ih_planes') is not None:
                 # both operands as fp16 planes: the input split once here, the stacked weights' planes come with the forms
                 gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
                 _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), forms['w_ih_planes'], meta.rows, ndir * G, x.shape[1], bias=bias)
@@ -541,7 +541,7 @@ class _LstmLayerFn(torch.autograd.Function):
                     if r1 <= r0:
                         continue
                     dgt = dgd[r0:r1].t()
-                    if gm is not None and _gemm.PLANES:
+                    if gm is not None and _gemm.planes_enabled():
                         # both operands reduce over the batch's rows (their outer axis): split them into fp16 planes once
                         # (dg for two GEMMs, the layer input for both directions) and run the plain 16-bit GEMM
                         k = r1 - r0
