@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Split-fp16 GEMM vs the library fp32 GEMM at the shapes of the PIT step (B = 32, T = 253: 8096 rows)."""
+"""Split-fp16 GEMMs (in-register split: csrc/gemm.hip; pre-split planes incl. their pack passes: csrc/gemm_planes.hip) vs
+the library fp32 GEMM at the shapes of the PIT step (B = 32, T = 253: 8096 rows)."""
 import json
 import sys
 from pathlib import Path
@@ -54,6 +55,20 @@ for name, M, N, K, form in [
         rec[f'split_us_k{sk}'] = t
         rec[f'split_tflops_k{sk}'] = flop / t / 1e6
     rec['auto_split'] = gemm.auto_split_k(M, N, K)
+    # planes GEMM: operands packed from the same sources (k-contiguous: pack_n, row-contiguous: pack_t)
+    if form == 'nt':
+        pa, pb = (lambda: gemm.pack_n(x, ax)), (lambda: gemm.pack_n(w, ay))
+    elif form == 'nn':
+        pa, pb = (lambda: gemm.pack_n(a, ax)), (lambda: gemm.pack_t(b, ay))
+    else:
+        pa, pb = (lambda: gemm.pack_t(dg, ax)), (lambda: gemm.pack_t(xx, ay))
+    A, Bp = pa(), pb()
+    t = timeit(lambda: gemm.mm_planes_(out, A, Bp, M, N, K))
+    rec['planes_us'] = t
+    rec['planes_tflops'] = flop / t / 1e6
+    rec['pack_a_us'], rec['pack_b_us'] = timeit(pa), timeit(pb)
+    ref = (a.double() @ b.double())
+    rec['planes_max_err_over_mag'] = float(((out.double() - ref).abs() / (a.double().abs() @ b.double().abs())).max())
     t = timeit(lambda: gemm.mm(a, b, out=out, products=1, split_k=1))
     rec['bf16_us'] = t
     rec['absmax_us'] = timeit(lambda: gemm.absmax(a))
