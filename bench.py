@@ -239,6 +239,8 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
                               'hand-off (poll + operand gather + drain), not by the matrix cores')
         kernels.append(e)
     for products, e in gemm.items():
+        if not e['launches']:
+            continue
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
         kernels.append(dict(

@@ -92,7 +92,7 @@ PLANES = os.environ.get('PTMI_GEMM_PLANES', '1') != '0'
 
 def planes_enabled():
     """The planes GEMM exists in the fp32-equivalent (three-product) form only."""
-    return PLANES and PRODUCTS == 3
+    return ENABLED and PLANES and PRODUCTS == 3
 
 
 def pack_t(x, amax=None):
