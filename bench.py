@@ -200,21 +200,23 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
                           'products)', 'mfma16x3', rec_flop),
     }
     kernels = []
-    gemm = {}
+    gemm, packs = {}, {}
     for n, v in by_name.items():
         if n.startswith('gemm_split:') or n.startswith('gemm_planes:'):          # gemm_split:MxNxK:products, gemm_planes:MxNxK
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
-            e = gemm.setdefault(int(parts[2]) if len(parts) > 2 else 3, dict(flop=0., ms=0., launches=0, pack_ms=0., planes=0))
+            key = ('planes', 3) if n.startswith('gemm_planes:') else ('split', int(parts[2]))
+            e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
             e['launches'] += len(v)
-            e['planes'] += len(v) if n.startswith('gemm_planes:') else 0
             continue
-        if n.startswith('pack_planes'):          # the operand split passes of the planes GEMM: part of the dense layers' time
-            e = gemm.setdefault(3, dict(flop=0., ms=0., launches=0, pack_ms=0., planes=0))
+        if n.startswith('pack_planes'):          # pack_planes_t:KxC / pack_planes_n:RxK: 4 B read + 4 B written per element
+            a_, b_ = (int(x) for x in n.split(':')[1].split('x'))
+            e = packs.setdefault('pack', dict(bytes=0., ms=0., launches=0))
+            e['bytes'] += 8.0 * a_ * b_ * len(v)
             e['ms'] += float(np.sum(v))
-            e['pack_ms'] += float(np.sum(v))
+            e['launches'] += len(v)
             continue
         if n not in spec:
             continue
@@ -238,22 +240,30 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
             e['peak_note'] = ('fp16/bf16 MFMA dense peak 2500 TFLOP/s / 3 products; the kernel is bound by the serial per-timestep '
                               'hand-off (poll + operand gather + drain), not by the matrix cores')
         kernels.append(e)
-    for products, e in gemm.items():
+    for (kind, products), e in gemm.items():
         if not e['launches']:
             continue
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
+        label = ('gemm_planes_kernel (LSTM input projections, linears, their input gradients and all weight gradients: operands '
+                 'pre-split into fp16 (hi, lo) planes, 3 fp16 MFMA products per fp32 product)' if kind == 'planes' else
+                 f'gemm_split_ws_kernel (LSTM input gradients: fp32 operands split in registers, {products} fp16 MFMA products per '
+                 f'fp32 product)' if products == 3 else 'gemm_split_ws_kernel (dense layers, plain bf16 operands)')
         kernels.append(dict(
-            kernel=f'gemm_planes_kernel / gemm_split_kernel (dense layers: LSTM input projections, linears and weight gradients on '
-                   f'pre-split fp16 planes incl. their pack passes, input gradients split in registers; {products} fp16 MFMA '
-                   f'products per fp32 product)' if products == 3 else 'gemm_split_kernel (dense layers, plain bf16 operands)',
-            bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=measured_traffic('gemm_split'),
+            kernel=label, bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak,
+            traffic=measured_traffic('gemm_' + kind),
             peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = '
-                      f'algorithmic 2MNK flop of all launches / their HIP-event time incl. the operand pack passes (main and '
-                      f'weight-gradient stream, i.e. next to the running recurrences)',
+                      f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream, i.e. '
+                      f'mostly next to a running recurrence)',
             avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
-            planes_launches_per_step=e['planes'] / steps, pack_ms_per_step=e['pack_ms'] / steps,
             algorithmic_flop_per_step=e['flop'] / steps))
+    for e in packs.values():
+        achieved = e['bytes'] / (e['ms'] * 1e-3) / 1e9
+        kernels.append(dict(
+            kernel='pack_planes_t_kernel / pack_planes_n_kernel (fp32 operand -> fp16 (hi, lo) planes in MFMA fragment order)',
+            bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=None,
+            avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
+            algorithmic_bytes_per_step=e['bytes'] / steps))
     kernels.sort(key=lambda e: -e['ms_per_step'])
     return kernels
 

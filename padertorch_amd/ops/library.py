@@ -248,7 +248,7 @@ def pack_planes_t(x, amax):
     lib = _lib.load()
     k, c = x.shape
     out = torch.empty(int(lib.ptmi_planes_elems(c, k)), dtype=torch.float16, device=x.device)
-    _lib.check(_lib.timed('pack_planes_t', lib.ptmi_pack_planes_t, x.data_ptr(), k, c, x.stride(0), _lib.ptr(amax), out.data_ptr(),
+    _lib.check(_lib.timed(f'pack_planes_t:{k}x{c}', lib.ptmi_pack_planes_t, x.data_ptr(), k, c, x.stride(0), _lib.ptr(amax), out.data_ptr(),
                           _lib.stream(x.device)), 'ptmi_pack_planes_t')
     return out
 
@@ -259,7 +259,7 @@ def pack_planes_n(x, amax):
     lib = _lib.load()
     r, k = x.shape
     out = torch.empty(int(lib.ptmi_planes_elems(r, k)), dtype=torch.float16, device=x.device)
-    _lib.check(_lib.timed('pack_planes_n', lib.ptmi_pack_planes_n, x.data_ptr(), r, k, x.stride(0), _lib.ptr(amax), out.data_ptr(),
+    _lib.check(_lib.timed(f'pack_planes_n:{r}x{k}', lib.ptmi_pack_planes_n, x.data_ptr(), r, k, x.stride(0), _lib.ptr(amax), out.data_ptr(),
                           _lib.stream(x.device)), 'ptmi_pack_planes_n')
     return out
 

@@ -16,7 +16,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
 KEYS = {'pit_features_kernel': 'pit_features', 'pit_pairwise_kernel': 'pit_pairwise_sse',
         'pit_backward_kernel': 'pit_backward', 'lstm_fwd_split_kernel': 'lstm_forward',
         'lstm_bwd_split_kernel': 'lstm_backward', 'lstm_fwd_persistent_kernel': 'lstm_forward',
-        'lstm_bwd_persistent_kernel': 'lstm_backward', 'gemm_split_kernel': 'gemm_split', 'stft_fwd_kernel': 'stft_fwd',
+        'lstm_bwd_persistent_kernel': 'lstm_backward', 'gemm_split_kernel': 'gemm_split', 'gemm_split_ws_kernel': 'gemm_split',
+        'gemm_planes_kernel': 'gemm_planes', 'stft_fwd_kernel': 'stft_fwd',
         'istft_kernel': 'istft'}
 
 

@@ -6,6 +6,7 @@ mkdir -p ../../gpurun_out/mb
 O=../../gpurun_out/mb
 ./split_mfma_accuracy > $O/accuracy.txt 2>&1
 ./xcd_dispatch_probe > $O/dispatch_probe.txt 2>&1
+{ timeout 120 ./gemm_planes; timeout 120 ./gemm_planes 8096 1200 4800; timeout 120 ./gemm_planes 8192 8192 4096; } > $O/gemm_planes.txt 2>&1
 {
 for c in 1 0; do
   # all-gather (forward form): spread over the XCDs (round-1 protocol), one XCD with sc1 / plain loads, 8 chains

@@ -29,7 +29,7 @@ db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1
   PTMI_LSTM_F32=1 timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
 bash $repo/scripts/mb/run_mb.sh > /dev/null 2>&1
-for f in accuracy dispatch_probe handoff; do cp $repo/gpurun_out/mb/$f.txt $out/${tag}_mb_$f.txt 2>/dev/null; done
+for f in accuracy dispatch_probe handoff gemm_planes; do cp $repo/gpurun_out/mb/$f.txt $out/${tag}_mb_$f.txt 2>/dev/null; done
 timeout 600 python $repo/scripts/bf16_delta.py 2>/dev/null | tail -1 > $out/${tag}_bf16_delta.json
 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' > $out/${tag}_lstm_us_per_step.txt
 PTMI_LSTM_F32=1 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' | sed 's/^/exact-fp32 kernels: /' >> $out/${tag}_lstm_us_per_step.txt
