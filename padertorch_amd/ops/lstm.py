@@ -169,6 +169,9 @@ _WGRAD_STREAMS = {}
 
 #: run BLSTM layers on per-parameter-version cached stacked weights where autograd does not need the concatenations
 CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
+#: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
+TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
+_WGRAD_DONE = {}
 #: launches per backward recurrence: > 1 cuts it into step ranges (``ptmi_lstm_backward_persistent_range``) so that the
 #: finished range's weight-gradient GEMMs start on the side stream under the next launch instead of after the whole layer.
 #: Measured at the B = 32 step (ms per step, two boxes): 1: 10.56 / 10.56, 2: 10.52 / 10.60, 3: 10.75 / 10.75 - the side
@@ -532,12 +535,14 @@ class _LstmLayerFn(torch.autograd.Function):
         side = _wgrad_stream(x.device) if use_side else main
         operands, xplanes = [None], {}
 
-        def wgrad_rows(dg, ranges, amax_dg):
-            """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`."""
-            with torch.cuda.stream(side):
-                if operands[0] is None:
-                    operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
-                for (p_wih, p_whh, _, _), (dgd, h_prev), (r0, r1) in zip(params, operands[0], ranges):
+        def wgrad_rows(dg, ranges, amax_dg, both_queues=False):
+            """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
+            (both_queues: the reverse direction on the main stream - see TAIL_ON_BOTH_QUEUES)."""
+            for d, ((p_wih, p_whh, _, _), (r0, r1)) in enumerate(zip(params, ranges)):
+                with torch.cuda.stream(main if both_queues and d == 1 else side):
+                    if operands[0] is None:
+                        operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
+                    dgd, h_prev = operands[0][d]
                     if r1 <= r0:
                         continue
                     dgt = dgd[r0:r1].t()
@@ -623,11 +628,33 @@ class _LstmLayerFn(torch.autograd.Function):
         else:
             dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         if in_place:
+            # the first layer's weight gradients are the step's tail (nothing but the optimizer follows): the reverse
+            # direction's pack passes and GEMMs on the otherwise idle main queue, next to the forward direction's on the side
+            # queue (small launches with ~12 us of dispatch gap between dependent kernels of one queue)
+            both = (TAIL_ON_BOTH_QUEUES and use_side and ndir > 1 and gm is not None and _gemm.planes_enabled()
+                    and not ctx.needs_input_grad[0] and todo[0] == (0, meta.rows))
+            if both:
+                for p in params[1][:2]:                       # earlier side-stream accumulations into the same .grad views
+                    ev = _WGRAD_DONE.get(id(p))
+                    if ev is not None:
+                        main.wait_event(ev)
+                operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
+                xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
             if use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
-            wgrad_rows(dg, todo, amax_dg)
+            wgrad_rows(dg, todo, amax_dg, both_queues=both)
+            if both:
+                side.wait_stream(main)                         # whoever orders itself after `side` sees both directions
+                for t in xplanes[todo[0]][:1]:
+                    t.record_stream(side)
+            if use_side:
+                done = torch.cuda.Event()
+                done.record(side)
+                for ps in params:
+                    for p in ps[:2]:
+                        _WGRAD_DONE[id(p)] = done
             with torch.cuda.stream(side):
                 for d, (_, _, p_bih, p_bhh) in enumerate(params):
                     db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
