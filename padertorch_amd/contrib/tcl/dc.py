@@ -34,34 +34,34 @@ class DeepClusteringModel(base.Model):
         self.blstm = torch.nn.LSTM(F, units, recurrent_layers, bidirectional=True)
         self.linear = torch.nn.Linear(2 * units, F * E)
 
+    #: feature transforms applied to the packed magnitudes ahead of the BLSTM (reference ``dc.py:48-57``)
+    _TRANSFORMS = {
+        'identity': lambda h: h,
+        'log1p': lambda h: ops.sequence.log1p(h),
+        'log': lambda h: ops.sequence.log(PackedSequence(h.data + 1e-10, h.batch_sizes)),
+    }
+
+    def _embed_rows(self, rows):
+        """Packed BLSTM outputs ``[tb, 2 units]`` -> unit-norm embeddings ``[tb, E, F]`` (Hershey 2016, p. 2)."""
+        e = ops.linear.linear(self.linear, rows, ops.gemm.UNIT_RANGE).view(-1, self.E, self.F)     # 'tb (e f) -> tb e f'
+        if e.is_cuda and e.dtype == torch.float32 and self.E <= 32:
+            return ops.unit_norm(e)                    # one HIP pass forward, one backward (csrc/norm.hip)
+        return torch.nn.functional.normalize(e, dim=-2)
+
     def forward(self, batch):
         """batch: dictionary with lists of tensors -> list of embeddings ``(T_b, E, F)``."""
-        h = ops.pack_sequence(batch['Y_abs'])
-
-        if self.input_feature_transform == 'identity':
-            pass
-        elif self.input_feature_transform == 'log1p':
-            h = ops.sequence.log1p(h)
-        elif self.input_feature_transform == 'log':
-            h = PackedSequence(h.data + 1e-10, h.batch_sizes)
-            h = ops.sequence.log(h)
-        else:
-            raise NotImplementedError(self.input_feature_transform)
-
-        _, F = h.data.size()
+        try:
+            transform = self._TRANSFORMS[self.input_feature_transform]
+        except KeyError:
+            raise NotImplementedError(self.input_feature_transform) from None
+        h = transform(ops.pack_sequence(batch['Y_abs']))
+        F = h.data.shape[1]
         assert F == self.F, f'self.F = {self.F} != F = {F}'
-
         if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
             h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
         else:
-            h, _ = self.blstm(h)
-        h_data = ops.linear.linear(self.linear, h.data, ops.gemm.UNIT_RANGE).view(-1, self.E, self.F)      # 'tb (e f) -> tb e f'
-        # Hershey 2016 page 2 top right paragraph: Unit norm
-        if h_data.is_cuda and h_data.dtype == torch.float32 and self.E <= 32:
-            h_data = ops.unit_norm(h_data)            # one HIP pass forward, one backward (csrc/norm.hip)
-        else:
-            h_data = torch.nn.functional.normalize(h_data, dim=-2)
-        return ops.unpack_sequence(PackedSequence(h_data, h.batch_sizes))
+            h = self.blstm(h)[0]
+        return ops.unpack_sequence(PackedSequence(self._embed_rows(h.data), h.batch_sizes))
 
     def review(self, batch, model_out):
         """Mean deep-clustering loss of the batch (reference ``dc.py:73-84``: per-example loop over

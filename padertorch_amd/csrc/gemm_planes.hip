@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
     const int tm = tile / G.tiles_n, tn = tile - tm * G.tiles_n;
     const int kb0 = blockIdx.z * G.kb_per_split, kb1 = min(G.KB, kb0 + G.kb_per_split);
     const int wm = wave >> 1, wn = wave & 1;
+    const float inv = 1.f / (plane_scale(G.amax_a) * plane_scale(G.amax_b));      // two dependent loads: long before their use
     const int rta = (G.M + 15) / 16, rtb = (G.N + 15) / 16;
     const uint4* gsrc[8];
 #pragma unroll
@@ -121,13 +122,29 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
             al = nl;
         }
     }
-    const float inv = 1.f / (plane_scale(G.amax_a) * plane_scale(G.amax_b));
     const bool slab = gridDim.z > 1;
     float* const Cz = slab ? G.workspace + (long long)blockIdx.z * G.M * G.N : G.C;
     const long long ldc = slab ? G.N : G.ldc;
     const bool vec = (ldc & 3) == 0 && (reinterpret_cast<unsigned long long>(Cz) & 15) == 0;
     const bool add = G.accumulate && !slab;
     const int r = lane & 15, g = lane >> 4;
+    // this lane's four bias groups (one per column tile j), all requested before any is used
+    f4 bv[4];
+    {
+        const bool bias_on = G.bias != nullptr && !slab;
+        const bool bvec = (reinterpret_cast<unsigned long long>(G.bias) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
+            bv[j] = f4{0.f, 0.f, 0.f, 0.f};
+            if (bias_on && bvec && n + 3 < G.N) {
+                bv[j] = *reinterpret_cast<const f4*>(G.bias + n);
+            } else if (bias_on) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = G.bias[min(n + e, G.N - 1)];
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = tm * PBM + wm * 64 + i * 16 + r;
@@ -136,12 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
         for (int j = 0; j < 4; ++j) {
             const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
             float* o = Cz + (long long)m * ldc + n;
-            f4 v = acc[i][j] * inv;
-            if (G.bias != nullptr && !slab) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < G.N) v[e] += G.bias[n + e];
-            }
+            const f4 v = acc[i][j] * inv + bv[j];
             if (vec && n + 3 < G.N) {
                 f4* o4 = reinterpret_cast<f4*>(o);
                 *o4 = add ? *o4 + v : v;
