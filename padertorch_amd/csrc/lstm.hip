@@ -941,7 +941,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     PTMI_RETURN_IF(KP != (H + 15) / 16 * 16, PTMI_E_UNSUPPORTED);
     float* const hyt = reinterpret_cast<float*>(flags);
     flags += lstm_tile_elems(T, ndir, max_batch, KP32);
-    hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
+    hipError_t e = zero_words_async(flags, (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
     if (e != hipSuccess) return (int)e;
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
                       (unsigned)jx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)hy_bytes,
@@ -955,7 +955,19 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
         const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt), block(NW * 64);
         const bool one_per_cu = (long long)jx * ndir * nt <= cus;
         if (split) {
-            int rc = launch_fwd_split(A, jt, small, one_per_cu, grid, st);
+            // one workgroup per CU: the workgroups of a chain (direction x row tile) on 8 / chains neighbouring XCDs, as in the
+            // backward kernel (a chain's hand-off rows and slots then live in the L2s of those XCDs only)
+            const int chains = ndir * nt;
+            A.span = (one_per_cu && chains <= 8 && 8 % chains == 0 && (jx + 8 / chains - 1) / (8 / chains) * 8 <= cus &&
+                      !getenv("PTMI_LSTM_FWD_NO_XCD")) ? 8 / chains : 0;
+            if (const char* v = getenv("PTMI_LSTM_FWD_SPAN")) {        // experiment: fewer XCDs per chain (the others stay idle)
+                const int sp = atoi(v);
+                if (A.span && sp >= 1 && sp <= A.span && (jx + sp - 1) / sp <= cus / 8) A.span = sp;
+            }
+            A.nx = jx;
+            A.nt = nt;
+            const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
+            int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st);
             if (rc) return rc;
             continue;
         }
@@ -1029,7 +1041,7 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
     flags += lstm_tile_elems(T, ndir, max_batch, G32);
     float* const dbias = reinterpret_cast<float*>(flags);
     if (s_begin == 0) {         // a later range continues on the first one's counters, bias sums and maximum
-        hipError_t e = hipMemsetAsync(flags, 0, sizeof(uint32_t) * (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
+        hipError_t e = zero_words_async(flags, (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
         if (e != hipSuccess) return (int)e;
     }
     flags += ndir * 4 * H;

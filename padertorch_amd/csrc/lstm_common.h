@@ -40,6 +40,9 @@ struct LstmPersistArgs {
     const unsigned* w_amax;  // split kernels: float bits of max |W_hh| (device) or null
     int KP32;                // split kernels: H rounded up to 32
     unsigned* err_sink = nullptr;   // per-device count of timed-out launches (ptmi_lstm_set_error_sink) or null
+    // split kernels, 1-D grid with the workgroups of a chain on `span` neighbouring XCDs (chain_tile below); span 0: the
+    // 3-D grid (unit tile, direction, row tile) in dispatch order
+    int nx = 0, nt = 0, span = 0;
 };
 
 // Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has
@@ -110,14 +113,14 @@ struct LstmPersistBwdArgs {
 // and read over the fabric by the others, which is what bounds the hand-off at batch >= 16.  With
 // `span` = 8 / chains XCDs per chain, a chain's workgroups sit on `span` neighbouring XCDs instead of all
 // eight, so 1/span of what a workgroup reads is local.  Returns false for the padding workgroups.
-__device__ __forceinline__ bool chain_tile(int nx, int nt, int span, int* x, int* y, int* dir) {
+__device__ __forceinline__ bool chain_tile(int nx, int nt, int span, int* x, int* y, int* dir, int nchains = 1 << 30) {
     const int L = blockIdx.x;
     int chain;
     if (span > 0) {
         const int xcd = L & 7;
         chain = xcd / span;
         *x = (L >> 3) * span + (xcd - chain * span);
-        if (*x >= nx) return false;
+        if (*x >= nx || chain >= nchains) return false;
     } else {
         *x = L % nx;
         chain = L / nx;

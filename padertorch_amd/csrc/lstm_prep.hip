@@ -139,7 +139,7 @@ extern "C" int ptmi_lstm_weight_prep(const float* const* w_ih, const float* cons
     A.tiles_h = (KP + 31) / 32;
     const int blocks_bias = (ndir * A.G + 255) / 256;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(amax, 0, 2 * sizeof(uint32_t), st);
+    hipError_t e = zero_words_async(amax, 2, st);
     if (e != hipSuccess) return (int)e;
     const unsigned grid = (unsigned)(A.blocks_ih + ndir * A.tiles_g * A.tiles_h + blocks_bias);
     hipLaunchKernelGGL(lstm_weight_prep_kernel, dim3(grid), dim3(256), 0, st, A);

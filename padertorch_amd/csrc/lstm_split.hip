@@ -90,9 +90,10 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
     constexpr int MR = 16 * MTL;
-    const int dir = blockIdx.y;
-    const int j0 = blockIdx.x * JT;
-    const int m0 = (A.tile0 + blockIdx.z) * MR;
+    int bx = blockIdx.x, bz = blockIdx.z, dir = blockIdx.y;
+    if (A.span > 0 && !chain_tile(A.nx, A.nt, A.span, &bx, &bz, &dir, A.ndir * A.nt)) return;
+    const int j0 = bx * JT;
+    const int m0 = (A.tile0 + bz) * MR;
     const int H = A.H, G = 4 * H;
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -130,12 +131,12 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         }
     }
     const size_t tile_elems = (size_t)A.KP32 * 16;       // floats per (time, 16-row tile, direction): 2 halves per value
-    const int tile16 = (A.tile0 + blockIdx.z) * MTL;
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * kSlots;
+    const int tile16 = (A.tile0 + bz) * MTL;
+    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + bz) * kSlots;
     unsigned* const err = A.flags + A.err_off;
     const int bl_ = tid / JT, u = tid - bl_ * JT;
     const int b = m0 + bl_;
-    // PHASES (PTMI_LSTM_PHASES): thread 0 of workgroup (0, 0, 0) sums the 100 MHz clock per phase of a step (scripts/exp_lstm_phases.py)
+    // PHASES (PTMI_LSTM_PHASES): thread 0 of every workgroup (written out by workgroup (0, 0, 0)) sums the 100 MHz clock per phase of a step (scripts/exp_lstm_phases.py)
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
     auto mark = [&](int kk) {
         if (PHASES && tid == 0) {
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         __syncthreads();
         mark(9);
         if (tid == 0)
-            __hip_atomic_store(myflags + blockIdx.x, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (act) {                                        // nobody in this launch reads these
             gp[0] = ig;
             gp[H] = fg;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         }
         mark(10);
     }
-    if (PHASES && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    if (PHASES && tid == 0 && bx == 0 && dir == 0 && bz == 0) {
         unsigned long long* out = reinterpret_cast<unsigned long long*>(A.hyt);
         for (int kk = 0; kk < 12; ++kk) out[kk] = ph[kk];
     }

@@ -171,6 +171,8 @@ _WGRAD_STREAMS = {}
 CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
 #: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
 TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
+#: the first layer's parameter forms on the main stream, the later layers' on the side stream (see packed_lstm)
+PREP_FIRST_ON_MAIN = os.environ.get('PTMI_PREP_MAIN', '1') != '0'
 _WGRAD_DONE = {}
 #: launches per backward recurrence: > 1 cuts it into step ranges (``ptmi_lstm_backward_persistent_range``) so that the
 #: finished range's weight-gradient GEMMs start on the side stream under the next launch instead of after the whole layer.
@@ -740,9 +742,12 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
         pre = _prep_stream(data.device)
         pre.wait_stream(torch.cuda.current_stream(data.device))
-        for ps_ in all_params:
-            if _stacked_stale(ps_):
+        for layer, ps_ in enumerate(all_params):
+            if _stacked_stale(ps_) and not (layer == 0 and PREP_FIRST_ON_MAIN):
                 _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre)
+        # the first layer's forms are needed at once: on the main queue itself (a cross-queue wait in front of the first
+        # projection was measured to cost the main queue 110-260 us; the later layers' forms are long done when their
+        # projection is reached, and a wait for a finished event costs nothing)
     for layer in range(lstm.num_layers):
         params = all_params[layer]
         # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
