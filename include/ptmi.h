@@ -223,6 +223,13 @@ int ptmi_lstm_weight_prep(const float* const* w_ih, const float* const* w_hh, co
  * launch's own error word in its scratch): ONE word for the host to watch instead of one per call. */
 int ptmi_lstm_set_error_sink(uint32_t* word);
 int ptmi_lstm_split_enabled(void);
+/* ptmi_lstm_handoff_cols: columns per direction (H resp. 4H rounded up to 32) of the 16-bit hand-off planes the persistent
+ * split kernels leave at the START of their scratch - forward (backward = 0): fp16 (hi, lo) halves of 2^10 h, backward: bf16
+ * halves of dgates -, as [T][16-row tile][direction][cols / 32][hi | lo][64 chunks of 8 values] in the fragment order of
+ * ptmi_gemm_planes: for a batch of equal-length sequences whose size is a multiple of 16 this IS the A operand
+ * (rows = packed rows, k = direction-major columns) of the dense GEMM that follows.  0: these kernels do not run for this H
+ * (PTMI_LSTM_F32, or a layer too wide for their register budget). */
+int32_t ptmi_lstm_handoff_cols(int32_t H, int32_t backward);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
@@ -397,6 +404,14 @@ int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_
 int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
                      int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
                      ptmi_stream_t stream);
+/* The bf16 flavour of the three calls above: the planes hold bf16 (hi, lo) halves, no operand scale (fp32's exponent range).
+ * It exists for the LSTM input gradient dx = dgates W_ih (torch.nn.LSTM backward inside pit/model.py:60-66): the persistent
+ * backward recurrence hands its gate gradients on as exactly such planes (its scratch, ptmi_lstm_handoff_cols), so the
+ * GEMM takes them as operand A as they lie and only W_ih is packed (once per optimizer step). */
+int ptmi_pack_planes_t_bf16(const float* x, int64_t k_rows, int64_t cols, int64_t ld, uint16_t* out, ptmi_stream_t stream);
+int ptmi_pack_planes_n_bf16(const float* x, int64_t rows, int64_t k, int64_t ld, uint16_t* out, ptmi_stream_t stream);
+int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
+                          int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer step on the Trainer's flat gradient bucket (csrc/optim.hip): replaces, on the step path of

@@ -73,6 +73,7 @@ SIGNATURES = {
     'ptmi_lstm_weight_prep': (c_int, [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32, _P, _P, c_int32, _P, _P, _P]),
     'ptmi_lstm_set_error_sink': (c_int, [_P]),
     'ptmi_lstm_split_enabled': (c_int, []),
+    'ptmi_lstm_handoff_cols': (c_int32, [c_int32, c_int32]),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                              c_int32, _P]),
     'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
@@ -93,6 +94,9 @@ SIGNATURES = {
     'ptmi_gemm_planes_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_pack_planes_n': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
     'ptmi_gemm_planes': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'ptmi_pack_planes_t_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    'ptmi_pack_planes_n_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    'ptmi_gemm_planes_bf16': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'ptmi_grad_norm_workspace_elems': (c_int64, []),
     'ptmi_grad_norm': (c_int32, [_P, c_int64, _P, _P, _P]),
     'ptmi_adam_flat': (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, c_double, c_double, c_double,

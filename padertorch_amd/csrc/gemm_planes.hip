@@ -22,6 +22,7 @@
 namespace ptmi {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int PBM = 128, PBN = 128;
@@ -50,6 +51,9 @@ struct PlanesArgs {
     int tiles_m, tiles_n;
 };
 
+// BF16: the planes hold bf16 halves (fp32's exponent range: no operand scale) - the backward recurrence's hand-off copy of the
+// gate gradients, whose range is not known before they are computed, and weights packed to match (csrc/lstm_split.hip)
+template <bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G) {
 #if __HIP_DEVICE_COMPILE__          // (the host pass cannot parse the LDS-DMA builtin; it only needs the stub)
     constexpr int PIECES = 32;      // plane tiles per stage: (8 row tiles + 8 column tiles) x 2 planes
@@ -117,7 +121,9 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
             for (int p = 0; p < 3; ++p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? bl[j] : bh[j], p == 1 ? al : ah, acc[i][j], 0, 0, 0);
+                    acc[i][j] = BF16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, p == 0 ? bl[j] : bh[j]),
+                                                                               __builtin_bit_cast(b8, p == 1 ? al : ah), acc[i][j], 0, 0, 0)
+                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? bl[j] : bh[j], p == 1 ? al : ah, acc[i][j], 0, 0, 0);
             ah = nh;
             al = nl;
         }
@@ -167,6 +173,30 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
 #endif
 }
 
+// 8 values -> their 16-bit (hi, lo) halves as one 16-byte chunk per plane (round to nearest; v - hi is exact in fp32)
+template <bool BF16>
+__device__ __forceinline__ void split_chunk(const float (&v)[8], uint4* hi_out, uint4* lo_out) {
+    if (BF16) {
+        b8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = (__bf16)v[e];
+            lo[e] = (__bf16)(v[e] - (float)hi[e]);
+        }
+        *hi_out = __builtin_bit_cast(uint4, hi);
+        *lo_out = __builtin_bit_cast(uint4, lo);
+    } else {
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            hi[e] = (_Float16)v[e];
+            lo[e] = (_Float16)(v[e] - (float)hi[e]);
+        }
+        *hi_out = __builtin_bit_cast(uint4, hi);
+        *lo_out = __builtin_bit_cast(uint4, lo);
+    }
+}
+
 // split K, second pass: C (+)= sum over the slabs in slab order (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long long ldc,
                                                             const float* __restrict__ bias, int M, int N, int accumulate) {
@@ -183,6 +213,7 @@ __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restr
 
 // Source x[k][c] (row stride ld; the operand's ROWS are the columns c, its reduction axis the rows k) -> planes.
 // Workgroup: 32 k x 64 c; loads coalesced along c, a transpose through LDS, one 16 B chunk per thread and plane.
+template <bool BF16>
 __global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restrict__ x, long long krows, long long cols, long long ld,
                                                             const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB) {
     __shared__ float tile[32][65];
@@ -202,20 +233,16 @@ __global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restr
     const int rl = tid >> 6, g = (tid >> 4) & 3, r = tid & 15;
     const long long rt = blockIdx.y * 4 + rl;
     if (rt * 16 >= ((cols + 15) / 16) * 16) return;
-    h8 hi, lo;
+    float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float v = tile[g * 8 + e][rl * 16 + r];
-        hi[e] = (_Float16)v;                                  // round to nearest; v - hi is exact in fp32
-        lo[e] = (_Float16)(v - (float)hi[e]);
-    }
+    for (int e = 0; e < 8; ++e) v[e] = tile[g * 8 + e][rl * 16 + r];
     uint4* o = out + ((rt * KB + kb) * 2) * FR + g * 16 + r;
-    o[0] = __builtin_bit_cast(uint4, hi);
-    o[FR] = __builtin_bit_cast(uint4, lo);
+    split_chunk<BF16>(v, o, o + FR);
 }
 
 // Source x[r][k] (row stride ld, the reduction axis k contiguous) -> planes of the operand with rows r.  Workgroup: one
 // 16-row tile x 4 k blocks; a thread makes one chunk (8 consecutive k of one row: 32 B read, 2 x 16 B written).
+template <bool BF16>
 __global__ __launch_bounds__(256) void pack_planes_n_kernel(const float* __restrict__ x, long long rows, long long K, long long ld,
                                                             const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB) {
     const int tid = threadIdx.x;
@@ -235,16 +262,10 @@ __global__ __launch_bounds__(256) void pack_planes_n_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (row < rows && k0 + e < K) ? src[e] : 0.f;
     }
-    h8 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float w = v[e] * s;
-        hi[e] = (_Float16)w;
-        lo[e] = (_Float16)(w - (float)hi[e]);
-    }
+    for (int e = 0; e < 8; ++e) v[e] *= s;
     uint4* o = out + ((rt * KB + kb) * 2) * FR + g * 16 + r;
-    o[0] = __builtin_bit_cast(uint4, hi);
-    o[FR] = __builtin_bit_cast(uint4, lo);
+    split_chunk<BF16>(v, o, o + FR);
 }
 
 }  // namespace ptmi
@@ -257,26 +278,56 @@ int64_t ptmi_planes_elems(int64_t rows, int64_t k) {
     return ((rows + 15) / 16) * ((k + 31) / 32) * 2 * 512;          // fp16 values
 }
 
-int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
+static int pack_t_impl(bool bf16, const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
                        ptmi_stream_t stream) {
     PTMI_RETURN_IF(!x || !out || k_rows < 1 || cols < 1 || ld < cols, PTMI_E_INVALID);
     PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(out) & 15) != 0, PTMI_E_INVALID);
     const long long KB = (k_rows + 31) / 32, cb = (cols + 63) / 64;
     PTMI_RETURN_IF(cb > 65535, PTMI_E_UNSUPPORTED);
-    hipLaunchKernelGGL(pack_planes_t_kernel, dim3((unsigned)KB, (unsigned)cb), dim3(256), 0, static_cast<hipStream_t>(stream), x,
-                       (long long)k_rows, (long long)cols, (long long)ld, amax, reinterpret_cast<uint4*>(out), KB);
+    const dim3 grid((unsigned)KB, (unsigned)cb);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bf16)
+        hipLaunchKernelGGL(pack_planes_t_kernel<true>, grid, dim3(256), 0, st, x, (long long)k_rows, (long long)cols, (long long)ld, amax,
+                           reinterpret_cast<uint4*>(out), KB);
+    else
+        hipLaunchKernelGGL(pack_planes_t_kernel<false>, grid, dim3(256), 0, st, x, (long long)k_rows, (long long)cols, (long long)ld, amax,
+                           reinterpret_cast<uint4*>(out), KB);
     return launch_status();
 }
 
-int ptmi_pack_planes_n(const float* x, int64_t rows, int64_t k, int64_t ld, const uint32_t* amax, uint16_t* out,
+static int pack_n_impl(bool bf16, const float* x, int64_t rows, int64_t k, int64_t ld, const uint32_t* amax, uint16_t* out,
                        ptmi_stream_t stream) {
     PTMI_RETURN_IF(!x || !out || rows < 1 || k < 1 || ld < k, PTMI_E_INVALID);
     PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(out) & 15) != 0, PTMI_E_INVALID);
     const long long KB = (k + 31) / 32, rt = (rows + 15) / 16;
     PTMI_RETURN_IF(rt > 65535, PTMI_E_UNSUPPORTED);
-    hipLaunchKernelGGL(pack_planes_n_kernel, dim3((unsigned)((KB + 3) / 4), (unsigned)rt), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       x, (long long)rows, (long long)k, (long long)ld, amax, reinterpret_cast<uint4*>(out), KB);
+    const dim3 grid((unsigned)((KB + 3) / 4), (unsigned)rt);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bf16)
+        hipLaunchKernelGGL(pack_planes_n_kernel<true>, grid, dim3(256), 0, st, x, (long long)rows, (long long)k, (long long)ld, amax,
+                           reinterpret_cast<uint4*>(out), KB);
+    else
+        hipLaunchKernelGGL(pack_planes_n_kernel<false>, grid, dim3(256), 0, st, x, (long long)rows, (long long)k, (long long)ld, amax,
+                           reinterpret_cast<uint4*>(out), KB);
     return launch_status();
+}
+
+int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
+                       ptmi_stream_t stream) {
+    return pack_t_impl(false, x, k_rows, cols, ld, amax, out, stream);
+}
+
+int ptmi_pack_planes_n(const float* x, int64_t rows, int64_t k, int64_t ld, const uint32_t* amax, uint16_t* out,
+                       ptmi_stream_t stream) {
+    return pack_n_impl(false, x, rows, k, ld, amax, out, stream);
+}
+
+int ptmi_pack_planes_t_bf16(const float* x, int64_t k_rows, int64_t cols, int64_t ld, uint16_t* out, ptmi_stream_t stream) {
+    return pack_t_impl(true, x, k_rows, cols, ld, nullptr, out, stream);
+}
+
+int ptmi_pack_planes_n_bf16(const float* x, int64_t rows, int64_t k, int64_t ld, uint16_t* out, ptmi_stream_t stream) {
+    return pack_n_impl(true, x, rows, k, ld, nullptr, out, stream);
 }
 
 int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k) {
@@ -285,9 +336,11 @@ int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_
     return splits > 1 ? (int64_t)splits * m * n : 0;
 }
 
-int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
-                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
-                     ptmi_stream_t stream) {
+}  // extern "C"
+
+static int gemm_planes_impl(bool bf16, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
+                            const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate,
+                            int32_t split_k, float* workspace, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
     const int KB = (k + 31) / 32;
@@ -299,7 +352,11 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
     const int tiles = G.tiles_m * G.tiles_n;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(gemm_planes_kernel, dim3((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits), dim3(256), 0, st, G);
+    const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
+    if (bf16)
+        hipLaunchKernelGGL(gemm_planes_kernel<true>, grid, dim3(256), 0, st, G);
+    else
+        hipLaunchKernelGGL(gemm_planes_kernel<false>, grid, dim3(256), 0, st, G);
     int rc = launch_status();
     if (rc != PTMI_OK || splits == 1) return rc;
     const long long total = (long long)m * n;
@@ -307,6 +364,19 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
     hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
                        accumulate ? 1 : 0);
     return launch_status();
+}
+
+extern "C" {
+
+int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
+                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
+                     ptmi_stream_t stream) {
+    return gemm_planes_impl(false, a, amax_a, b, amax_b, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
+}
+
+int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
+                          int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream) {
+    return gemm_planes_impl(true, a, nullptr, b, nullptr, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
 }
 
 }  // extern "C"

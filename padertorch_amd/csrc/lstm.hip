@@ -898,6 +898,16 @@ int ptmi_lstm_set_error_sink(uint32_t* word) {
 
 int ptmi_lstm_split_enabled(void) { return getenv("PTMI_LSTM_F32") ? 0 : 1; }
 
+int32_t ptmi_lstm_handoff_cols(int32_t H, int32_t backward) {
+    if (H < 1 || H % 4 != 0 || !ptmi_lstm_split_enabled()) return 0;
+    if (backward) {
+        const int G32 = (4 * H + 31) / 32 * 32;
+        return (G32 / 32 + 7) / 8 <= 10 ? G32 : 0;           // the rule of ptmi_lstm_backward_persistent_range
+    }
+    const int KP32 = (H + 31) / 32 * 32;
+    return (KP32 / 32 + 7) / 8 <= 3 ? KP32 : 0;              // the rule of ptmi_lstm_forward_persistent
+}
+
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,

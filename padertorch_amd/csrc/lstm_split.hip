@@ -12,9 +12,9 @@
 //             wavefront): as close to the fp64 product as the exact-fp32 chain (scripts/mb/split_mfma_accuracy.hip);
 //   backward  dgates have no bound known before they are computed, so their halves are bf16 (fp32's range, no scale;
 //             error <= 7e-7 of sum |a b|, v_mfma_f32_16x16x32_bf16), W_hh^T likewise.
-// The tile-major hand-off copy keeps its size and its access pattern: a "tile" is now 16 rows x 32 k of 16-bit values
-// (1 KB, one buffer_load_dwordx4 per lane), two planes (hi, lo) per 32-wide k block; a producer lane trades one half
-// with its neighbour lane so that it still issues ONE 4-byte write-through store per value.
+// The tile-major hand-off copy keeps its size: a "tile" is now 16 rows x 32 k of 16-bit values (1 KB, one
+// buffer_load_dwordx4 per lane) in MFMA-fragment order (handoff_index below), two planes (hi, lo) per 32-wide k block; a
+// producer lane trades one half with its neighbour lane so that it still issues ONE 4-byte write-through store per value.
 #include <stdlib.h>
 
 #include "lstm_common.h"
@@ -25,6 +25,15 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+
+// Hand-off planes: per (time, 16-row tile, direction) and 32-wide k block two 1 KB plane tiles (hi, lo) in the MFMA-fragment
+// order of csrc/gemm_planes.hip - the 16-byte chunk of (k group g = 0..3, row r) at slot 16 g + r holds the 8 values
+// [r][32 kb + 8 g ..] - so that lane l of a consumer wavefront reads its operand registers at l * 16 AND the dense GEMMs that
+// follow (next layer's projection, the input gradient) take the copy as their operand planes as it lies.
+// Index (in 16-bit values) of column `col` of row `row` in plane `plane` within one (time, tile, direction) block:
+__device__ __forceinline__ int handoff_index(int col, int plane, int row) {
+    return (((col >> 5) * 2 + plane) * 64 + ((col & 31) >> 3) * 16 + row) * 8 + (col & 7);
+}
 
 constexpr float kHScale = 1024.f;       // forward: h is handed on as halves of 2^10 h (lo stays normal down to |h| = 2^-13)
 
@@ -90,6 +99,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
     constexpr int MR = 16 * MTL;
+    constexpr int ACTW = (MR * JT + 63) / 64;        // wavefronts that own elements (and store); the others only multiply
+    constexpr bool WARM = ACTW < NW;                 // the last wavefront touches the input pre-activations two steps ahead
     int bx = blockIdx.x, bz = blockIdx.z, dir = blockIdx.y;
     if (A.span > 0 && !chain_tile(A.nx, A.nt, A.span, &bx, &bz, &dir, A.ndir * A.nt)) return;
     const int j0 = bx * JT;
@@ -148,6 +159,10 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     bool alive = true;
     float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
     float c_reg = 0.f;
+    constexpr int NWARM = (MR * 8 + 63) / 64;
+    float warm[NWARM];
+#pragma unroll
+    for (int i = 0; i < NWARM; ++i) warm[i] = 0.f;
     {
         const int t0 = dir == 0 ? 0 : A.T - 1;
         if (tid < MR * JT && b < A.bs[t0] && j0 + u < H) {
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
                 A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
             const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
                 A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
-            const unsigned vin = (unsigned)(kfirst * 2048 + r * 64 + g4 * 16);
+            const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
             const unsigned vb0 = (m0 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
             const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
             auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
@@ -235,6 +250,28 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            if (WARM && wave == NW - 1 && !(A.dbg & 1024)) {
+                // The owners request their input pre-activations one step ahead, behind their operand loads; from HBM those
+                // rows (written by the projection GEMM, long evicted) take longer than the rest of the step, and the step's
+                // write-through drain (vmcnt counts loads and stores alike) waited for them.  This wavefront owns no
+                // element and stores nothing: it touches the first and last word of every (row, gate) segment of the step
+                // AFTER the next one, so that the owners' requests hit this XCD's L2.  The values are never used; the sink
+                // keeps their registers reserved until the loads have come back.
+#pragma unroll
+                for (int i = 0; i < NWARM; ++i) asm volatile("" ::"v"(warm[i]));
+                const int s2 = s + 2;
+                if (s2 < A.T) {
+                    const int t2 = dir == 0 ? s2 : A.T - 1 - s2;
+                    const int nb2 = A.bs[t2];
+                    const float* base2 = A.gx + A.offs[t2] * ld_g + (long long)dir * G;
+                    const int jlast = min(j0 + JT, H) - 1;
+#pragma unroll
+                    for (int i = 0; i < NWARM; ++i) {
+                        const int e = lane + 64 * i, seg = e >> 1, rl = seg >> 2, q = seg & 3;
+                        if (e < MR * 8 && m0 + rl < nb2) warm[i] = base2[(long long)(m0 + rl) * ld_g + q * H + ((e & 1) ? jlast : j0)];
+                    }
+                }
+            }
             mark(4);
             __syncthreads();
             mark(5);
@@ -266,23 +303,23 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
             if (act) {
                 const int ce = (j0 + u) & ~1;
                 unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
-                __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16 + (bl_ & 15)) * 32 + (ce & 31)) / 2, word, __ATOMIC_RELAXED,
+                __hip_atomic_store(tq + handoff_index(ce, plane, bl_ & 15) / 2, word, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (j0 < H && j0 + JT >= H) {                     // owner of the last unit: zero the padding columns H .. KP32-1
             const int pw2 = (A.KP32 - H) >> 1;           // pairs per row and plane
-            for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
+            for (int e = tid; e < MR * pw2 * 2 && tid < ACTW * 64; e += ACTW * 64) {
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = H + 2 * (rem - plane * pw2);
                 if (m0 + rl < nb) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
-                    __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16 + (rl & 15)) * 32 + (ce & 31)) / 2, 0u, __ATOMIC_RELAXED,
+                    __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         }
         mark(7);
-        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(A.dbg & 32) && wave < ACTW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wavefronts that have stored
         mark(8);
         __syncthreads();
         mark(9);
@@ -403,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             __syncthreads();
             const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * tile_elems;
-            const unsigned vin = (unsigned)(kfirst * 2048 + r * 64 + g4 * 16);
+            const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
             const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, A.G32 * 64, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(tbase + (MTL > 1 ? (size_t)A.ndir * tile_elems : 0)), 0, A.G32 * 64, 0x00020000);
@@ -490,14 +527,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             if (act) {
                 unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
                 const int je = j & ~1;
-                const int rowoff = (bl_ & 15) * 32;
                 const unsigned ws_[4] = {w0, w1, w2, w3};
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ce = g * H + je;
-                    __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16) * 32 + rowoff + (ce & 31)) / 2, ws_[g], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
+                for (int g = 0; g < 4; ++g)
+                    __hip_atomic_store(tq + handoff_index(g * H + je, plane, bl_ & 15) / 2, ws_[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (A.G32 != G && n0 + 16 >= H && n0 < H) {       // owner of the last unit tile: zero the padding columns 4H .. G32-1
@@ -506,7 +539,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = G + 2 * (rem - plane * pw2);
                 if (m0 + rl < nb) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
-                    __hip_atomic_store(tq + ((((ce >> 5) * 2 + plane) * 16 + (rl & 15)) * 32 + (ce & 31)) / 2, 0u, __ATOMIC_RELAXED,
+                    __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
             }

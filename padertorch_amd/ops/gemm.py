@@ -149,6 +149,32 @@ def weight_planes_t(p):
     return v
 
 
+def stacked_planes_t_bf16(w, ndir, cols, key_params=None):
+    """bf16 planes of the right operand of ``dgates @ w`` for ``w [ndir * G, I]`` (the two directions' ``weight_ih`` stacked)
+    when ``dgates`` is taken from the backward recurrence's hand-off planes, whose k axis has ``cols >= G`` columns per
+    direction (``ptmi_lstm_handoff_cols``; the surplus is zero there): rows = input features, k = direction-major columns.
+    Cached per parameter version when ``key_params`` (the Parameters ``w`` was built from) are given."""
+    key = sig = None
+    if key_params is not None:
+        key = ('tb', cols) + tuple(id(q) for q in key_params)
+        sig = tuple((q._version, q.data_ptr()) for q in key_params)
+        hit = _WEIGHT_PLANES.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[2]
+        if len(_WEIGHT_PLANES) > 64:
+            _WEIGHT_PLANES.clear()
+    G = w.shape[0] // ndir
+    with torch.no_grad():
+        if cols != G:
+            wp = w.new_zeros((ndir, cols, w.shape[1]))
+            wp[:, :G] = w.view(ndir, G, -1)
+            w = wp.view(ndir * cols, -1)
+        planes = torch.ops.ptmi.pack_planes_bf16(w.detach().contiguous(), True)
+    if key is not None:
+        _WEIGHT_PLANES[key] = (sig, None, planes)
+    return planes
+
+
 def usable(*tensors):
     """The split GEMM applies: enabled, fp32 CUDA operands."""
     return ENABLED and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)

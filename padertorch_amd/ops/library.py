@@ -276,6 +276,34 @@ def gemm_planes_(out, a, amax_a, b, amax_b, bias, M, N, K, accumulate, split_k):
                           _lib.stream(out.device)), 'ptmi_gemm_planes')
 
 
+
+@_register('pack_planes_bf16(Tensor x, bool transposed) -> Tensor')
+def pack_planes_bf16(x, transposed):
+    """bf16 (hi, lo) planes, no scale (``ptmi_pack_planes_t_bf16`` / ``_n_bf16``): ``transposed`` - x [k, c], the operand's
+    rows are x's columns; else x [r, k]."""
+    lib = _lib.load()
+    a, b = x.shape
+    rows, k = (b, a) if transposed else (a, b)
+    out = torch.empty(int(lib.ptmi_planes_elems(rows, k)), dtype=torch.bfloat16, device=x.device)
+    fn = lib.ptmi_pack_planes_t_bf16 if transposed else lib.ptmi_pack_planes_n_bf16
+    _lib.check(_lib.timed(f'pack_planes_bf16:{a}x{b}', fn, x.data_ptr(), a, b, x.stride(0), out.data_ptr(), _lib.stream(x.device)),
+               'ptmi_pack_planes_bf16')
+    return out
+
+
+@_register('gemm_planes_bf16_(Tensor(a!) out, Tensor a, int a_offset, Tensor b, Tensor? bias, int M, int N, int K, bool accumulate, '
+           'int split_k) -> ()')
+def gemm_planes_bf16_(out, a, a_offset, b, bias, M, N, K, accumulate, split_k):
+    """``a``: any tensor whose storage holds the bf16 planes of the M x K operand from byte ``a_offset`` on (16-byte aligned) -
+    e.g. the scratch of the persistent backward recurrence (``ptmi_lstm_handoff_cols``)."""
+    lib = _lib.load()
+    nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
+    ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
+    _lib.check(_lib.timed(f'gemm_planes_bf16:{M}x{N}x{K}', lib.ptmi_gemm_planes_bf16, a.data_ptr() + a_offset, b.data_ptr(),
+                          _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k, _lib.ptr(ws),
+                          _lib.stream(out.device)), 'ptmi_gemm_planes_bf16')
+
+
 # ------------------------------------------------------------------------------------------------ unit norm
 @_register('unit_norm_forward(Tensor x, float eps) -> (Tensor, Tensor)')
 def unit_norm_forward(x, eps):

@@ -171,6 +171,8 @@ _WGRAD_STREAMS = {}
 CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
 #: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
 TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
+#: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
+DX_FROM_HANDOFF = os.environ.get('PTMI_DX_HANDOFF', '1') != '0'
 #: the first layer's parameter forms on the main stream, the later layers' on the side stream (see packed_lstm)
 PREP_FIRST_ON_MAIN = os.environ.get('PTMI_PREP_MAIN', '1') != '0'
 _WGRAD_DONE = {}
@@ -626,7 +628,18 @@ class _LstmLayerFn(torch.autograd.Function):
             amax_x, amax_w = gm
             # one scale for the whole gate-gradient tensor (both directions): the backward kernel tracked its maximum
             amax_dg = amax_kernel if amax_kernel is not None else _gemm.absmax(dg)
-            dx = _gemm.mm(dg, w_ih, amax_x=amax_dg, amax_y=amax_w) if ctx.needs_input_grad[0] else None
+            cols = int(lib.ptmi_lstm_handoff_cols(H, 1)) if (DX_FROM_HANDOFF and flags is not None and amax_kernel is not None) else 0
+            if not ctx.needs_input_grad[0]:
+                dx = None
+            elif cols and _gemm.planes_enabled() and meta.equal_lengths and meta.bs0 % 16 == 0:
+                # the recurrence has left its gate gradients as bf16 (hi, lo) planes in fragment order at the start of its
+                # scratch (the hand-off copy): for a batch of equal lengths they ARE operand A of dx = dgates W_ih
+                wplanes = _gemm.stacked_planes_t_bf16(w_ih, ndir, cols, None if params is None else [ps[0] for ps in params])
+                dx = torch.empty((meta.rows, w_ih.shape[1]), dtype=torch.float32, device=dg.device)
+                torch.ops.ptmi.gemm_planes_bf16_(dx, flags, 0, wplanes, None, meta.rows, w_ih.shape[1], ndir * cols, False,
+                                                 _gemm.auto_split_k(meta.rows, w_ih.shape[1], ndir * cols))
+            else:
+                dx = _gemm.mm(dg, w_ih, amax_x=amax_dg, amax_y=amax_w)
         else:
             dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         if in_place:

@@ -164,3 +164,26 @@ def test_planes_forward_form_with_bias(M, N, K, split):
     y = torch.empty(M, N, device='cuda')
     G.mm_planes_(y, G.pack_n(x), G.pack_n(w), M, N, K, split_k=split, bias=b)
     assert float(((y.double() - want).abs() / mag).max()) < 4e-7
+
+
+@pytest.mark.parametrize('M,N,K,split', [(8096, 1200, 4800, None), (300, 70, 257, 1), (17, 5, 33, 2)])
+def test_bf16_planes_gemm_vs_fp64(M, N, K, split):
+    """The bf16 flavour (no operand scale; what the LSTM input gradient runs on): A from a k-contiguous source, B = W^T from
+    a source whose reduction axis is the outer one, wide dynamic range, against fp64.  bf16 halves carry 16 mantissa bits:
+    the bound is that of the backward recurrence's own products (csrc/lstm_split.hip)."""
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device='cuda') * torch.logspace(-6, 2, K, device='cuda')
+    w = torch.randn(K, N, device='cuda') * 0.05
+    want = a.double() @ w.double()
+    mag = a.double().abs() @ w.double().abs()
+    pa = torch.ops.ptmi.pack_planes_bf16(a, False)
+    pw = torch.ops.ptmi.pack_planes_bf16(w, True)
+    from padertorch_amd.ops import gemm as G
+    y = torch.empty(M, N, device='cuda')
+    sk = G.auto_split_k(M, N, K) if split is None else split
+    torch.ops.ptmi.gemm_planes_bf16_(y, pa, 0, pw, None, M, N, K, False, sk)
+    err = float(((y.double() - want).abs() / mag).max())
+    assert err < 1.2e-5, err          # 2^-17 per product at worst (two 8-bit halves); sums of many terms average far below
+    y2 = torch.empty(M, N, device='cuda')
+    torch.ops.ptmi.gemm_planes_bf16_(y2, pa, 0, pw, None, M, N, K, False, sk)
+    assert torch.equal(y, y2)

@@ -301,3 +301,41 @@ def test_in_place_weight_gradients_and_time_ranges(lens, monkeypatch):
         for k, p in net.named_parameters():
             scale = max(1.0, float(want[k].abs().max()))
             assert float((p.grad.cpu() - want[k]).abs().max()) < 3e-4 * scale, (chunks, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T,H', [(32, 37, 600), (16, 20, 40), (64, 25, 600), (48, 9, 100)])
+def test_input_gradient_from_handoff_planes(B, T, H, monkeypatch):
+    """Equal-length batches whose size is a multiple of 16: dx = dgates W_ih runs on the bf16 planes GEMM straight from the
+    backward recurrence's hand-off copy (ops.lstm.DX_FROM_HANDOFF).  Same gradients as the in-register split GEMM on the
+    row-major dgates (both fp32-equivalent), and as torch's CPU LSTM."""
+    from padertorch_amd.ops import lstm as L
+    from padertorch_amd import _lib
+    if not _lib.load().ptmi_lstm_handoff_cols(H, 1):
+        pytest.skip('split recurrence kernels not active')
+    torch.manual_seed(B + T + H)
+    I = 2 * H
+    lstm = torch.nn.LSTM(I, H, 1, bidirectional=True).cuda()
+    xs = [torch.randn(T, I, device='cuda') * 0.5 for _ in range(B)]
+    w = torch.randn(T * B, 2 * H, device='cuda')
+
+    def run(flag):
+        monkeypatch.setattr(L, 'DX_FROM_HANDOFF', flag)
+        x = torch.nn.utils.rnn.pack_sequence(xs).data.clone().requires_grad_(True)
+        packed = torch.nn.utils.rnn.PackedSequence(x, torch.full((T,), B, dtype=torch.int64))
+        lstm.zero_grad()
+        y = L.packed_lstm(lstm, packed)
+        (y.data * w).sum().backward()
+        return x.grad.clone()
+
+    dx_planes = run(True)
+    dx_split = run(False)
+    scale = float(dx_split.abs().max())
+    assert float((dx_planes - dx_split).abs().max()) < 2e-5 * scale
+    # reference: torch CPU
+    ref = torch.nn.LSTM(I, H, 1, bidirectional=True)
+    ref.load_state_dict(lstm.state_dict())
+    xc = torch.nn.utils.rnn.pack_sequence([t.cpu() for t in xs]).data.clone().requires_grad_(True)
+    yc, _ = ref(torch.nn.utils.rnn.PackedSequence(xc, torch.full((T,), B, dtype=torch.int64)))
+    (yc.data * w.cpu()).sum().backward()
+    assert float((dx_planes.cpu() - xc.grad).abs().max()) < 1e-4 * scale
