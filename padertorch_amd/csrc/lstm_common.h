@@ -43,6 +43,7 @@ struct LstmPersistArgs {
     // split kernels, 1-D grid with the workgroups of a chain on `span` neighbouring XCDs (chain_tile below); span 0: the
     // 3-D grid (unit tile, direction, row tile) in dispatch order
     int nx = 0, nt = 0, span = 0;
+    int uniform = 0;         // split kernels: all sequences have the same length (bs[t] = max_batch, offs[t] = t max_batch)
 };
 
 // Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has
@@ -106,6 +107,7 @@ struct LstmPersistBwdArgs {
     // gradient crosses the cut through dc_carry [ndir][max_batch][H] (written when s_end < T, read when s_begin > 0)
     int s_begin = 0, s_end = -1;
     float* dc_carry = nullptr;
+    int uniform = 0;         // as in LstmPersistArgs
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)

@@ -111,6 +111,11 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
     __shared__ float red[NW][MR][NC + 1];
+    // batch size / first packed row of a time index: arithmetic for a batch of equal lengths (no scalar loads in front of
+    // every step's poll), the PackedSequence tables otherwise
+    const bool uniform = A.uniform != 0;
+    auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
+    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
 
     // this wavefront's k blocks (32 wide): an even split of the KP32 / 32 blocks
     const int nblk = A.KP32 >> 5;
@@ -165,8 +170,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     for (int i = 0; i < NWARM; ++i) warm[i] = 0.f;
     {
         const int t0 = dir == 0 ? 0 : A.T - 1;
-        if (tid < MR * JT && b < A.bs[t0] && j0 + u < H) {
-            const float* np = A.gx + (A.offs[t0] + b) * ld_g + (long long)dir * G + j0 + u;
+        if (tid < MR * JT && b < bs_at(t0) && j0 + u < H) {
+            const float* np = A.gx + (offs_at(t0) + b) * ld_g + (long long)dir * G + j0 + u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
         }
@@ -176,10 +181,10 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     for (int s = 0; s < A.T; ++s) {
         mark(11);
         const int t = dir == 0 ? s : A.T - 1 - s;
-        const int nb = A.bs[t];
-        const long long row0 = A.offs[t];
+        const int nb = bs_at(t);
+        const long long row0 = offs_at(t);
         const int tp = dir == 0 ? t - 1 : t + 1;
-        const int nprev = (tp >= 0 && tp < A.T) ? min(A.bs[tp], nb) : 0;
+        const int nprev = (tp >= 0 && tp < A.T) ? min(bs_at(tp), nb) : 0;
         const bool has_rec = nprev > m0;
         const bool act = tid < MR * JT && b < nb && j0 + u < H;
         float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
@@ -188,8 +193,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
         if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
         const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
         const bool more = s + 1 < A.T;
-        const int nb1 = more ? A.bs[t1] : 0;
-        const long long row1 = more ? A.offs[t1] : 0;
+        const int nb1 = more ? bs_at(t1) : 0;
+        const long long row1 = more ? offs_at(t1) : 0;
         auto prefetch = [&]() {
             if (tid < MR * JT && b < nb1 && j0 + u < H && !(A.dbg & 256)) {
                 const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
@@ -262,8 +267,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
                 const int s2 = s + 2;
                 if (s2 < A.T) {
                     const int t2 = dir == 0 ? s2 : A.T - 1 - s2;
-                    const int nb2 = A.bs[t2];
-                    const float* base2 = A.gx + A.offs[t2] * ld_g + (long long)dir * G;
+                    const int nb2 = bs_at(t2);
+                    const float* base2 = A.gx + offs_at(t2) * ld_g + (long long)dir * G;
                     const int jlast = min(j0 + JT, H) - 1;
 #pragma unroll
                     for (int i = 0; i < NWARM; ++i) {
@@ -359,6 +364,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
     __shared__ float red[NW][MR][17];
+    const bool uniform = A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
+    auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
+    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
 
     const int nblk = A.G32 >> 5;
     const int base = nblk / NW, extra = nblk - base * NW;
@@ -391,16 +399,19 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     float dc_state = 0.f;
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;
     float amax = 0.f;                                      // max |dgates| this thread has produced
+    // (Tried here as well: the forward kernel's L2 warm-up of the owners' cold loads - dhy, gates, c two steps ahead - by the
+    //  last wavefront.  4.52 instead of 4.09 us per step at B = 32: that wavefront carries a k slice of the product, and its
+    //  cold loads sit in front of its next operand loads in the in-order return queue.)
 
     // bookkeeping one step ahead (see the forward kernel): this step needs the batch sizes of time index t, of the one processed
     // before (t_n) and of the one processed next (t_p = the forward-sense predecessor, for c_{t-1}); the latter is loaded
     // one iteration early
     auto tindex = [&](int step) { return dir == 0 ? A.T - 1 - step : step; };
     const int s0 = A.s_begin, s1 = A.s_end < 0 ? A.T : A.s_end;        // this launch's range of processing steps
-    int nb_c = A.bs[tindex(s0)], nb_n = s0 > 0 ? A.bs[tindex(s0 - 1)] : 0;    // this step's / the previously processed time index
-    long long row_c = A.offs[tindex(s0)];
-    int nb_f = s0 + 1 < A.T ? A.bs[tindex(s0 + 1)] : 0;        // the time index processed next
-    long long row_f = s0 + 1 < A.T ? A.offs[tindex(s0 + 1)] : 0;
+    int nb_c = bs_at(tindex(s0)), nb_n = s0 > 0 ? bs_at(tindex(s0 - 1)) : 0;    // this step's / the previously processed time index
+    long long row_c = offs_at(tindex(s0));
+    int nb_f = s0 + 1 < A.T ? bs_at(tindex(s0 + 1)) : 0;        // the time index processed next
+    long long row_f = s0 + 1 < A.T ? offs_at(tindex(s0 + 1)) : 0;
     const bool carries = tid < 16 * MR && b < A.max_batch && j < H && A.dc_carry != nullptr;
     if (s0 > 0 && carries) dc_state = A.dc_carry[((size_t)dir * A.max_batch + b) * H + j];
     for (int s = s0; s < s1; ++s) {
@@ -418,8 +429,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         row_c = row_f;
         {
             const int t2 = tindex(min(s + 2, A.T - 1));       // clamped, unconditional (see the forward kernel)
-            nb_f = A.bs[t2];
-            row_f = A.offs[t2];
+            nb_f = bs_at(t2);
+            row_f = offs_at(t2);
         }
         const bool has_rec = nnext > m0;
         const bool act = tid < 16 * MR && b < nb && j < H;
@@ -587,6 +598,8 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
     const bool wide = jt >= 12;
     if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
         hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 1, 1, true>), grid, block, 0, st, A);
+    else if (jt == 16 && small && getenv("PTMI_LSTM_PHASES"))
+        hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 1, 1, true>), grid, block, 0, st, A);
     else if (jt == 20 && small)
         hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 1, 1>), grid, block, 0, st, A);
     else if (jt == 20)

@@ -171,6 +171,8 @@ _WGRAD_STREAMS = {}
 CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
 #: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
 TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
+#: side queue: a layer's weight-gradient GEMMs start behind its recurrence, not behind its input-gradient GEMM
+WGRAD_BEFORE_DX = os.environ.get('PTMI_WGRAD_EARLY', '0') != '0'      # measured neutral (8.75 = 8.75 ms): off
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
 DX_FROM_HANDOFF = os.environ.get('PTMI_DX_HANDOFF', '1') != '0'
 #: the first layer's parameter forms on the main stream, the later layers' on the side stream (see packed_lstm)
@@ -624,6 +626,12 @@ class _LstmLayerFn(torch.autograd.Function):
                 if lib.ptmi_lstm_split_enabled():
                     amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
         amax_dg = None
+        rec_done = None
+        if in_place and use_side and WGRAD_BEFORE_DX:
+            # the weight gradients need the gate gradients, not the input gradient that is computed next: the side queue may
+            # start them as soon as the recurrence is done, next to the input-gradient GEMM of the main queue
+            rec_done = torch.cuda.Event()
+            rec_done.record(main)
         if gm is not None:
             amax_x, amax_w = gm
             # one scale for the whole gate-gradient tensor (both directions): the backward kernel tracked its maximum
@@ -655,7 +663,9 @@ class _LstmLayerFn(torch.autograd.Function):
                         main.wait_event(ev)
                 operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
                 xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
-            if use_side:
+            if use_side and rec_done is not None and amax_kernel is not None and not both:
+                side.wait_event(rec_done)
+            elif use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
