@@ -94,7 +94,7 @@ __device__ __forceinline__ unsigned pair_word(float v, int lane, int* plane) {
 // ---------------------------------------------------------------------------------------------------------------
 // Forward.  Template parameters as lstm_fwd_persistent_kernel; CB = 32-wide k blocks per wavefront (K = KP32 split
 // evenly over the NW wavefronts).
-template <int JT, int NW, int CB, int MTL, int OCC, bool PHASES = false>
+template <int JT, int NW, int CB, int MTL, int OCC, bool PHASES = false, int CP = 16>
 __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
             const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
             auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
                 const int mt = f / (2 * CB), rem = f - mt * 2 * CB, i = rem >> 1, p = rem & 1;
-                return mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, (min(i, ilast) * 2 + p) * 1024, 16 /* sc1 */)
-                               : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, (min(i, ilast) * 2 + p) * 1024, 16);
+                return mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, (min(i, ilast) * 2 + p) * 1024, CP /* 16: sc1 */)
+                               : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, (min(i, ilast) * 2 + p) * 1024, CP);
             };
             uint4 a[NF];
 #pragma unroll
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward-through-time.  8 wavefronts, CB = 32-wide k blocks of K = 4H per wavefront (even split), CAB blocks in
 // flight per wavefront (re-requested as soon as their MFMAs have consumed them, as in lstm_bwd_persistent_kernel).
-template <int NW, int CB, int MTL, int CABW>
+template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
@@ -364,9 +364,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
     __shared__ float red[NW][MR][17];
-    const bool uniform = A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
-    auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
-    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
+    const bool uniform = UNI || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
+    auto bs_at = [&](int t) { if (UNI) return A.max_batch; return uniform ? A.max_batch : A.bs[t]; };
+    auto offs_at = [&](int t) { if (UNI) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
 
     const int nblk = A.G32 >> 5;
     const int base = nblk / NW, extra = nblk - base * NW;
@@ -434,19 +434,32 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         }
         const bool has_rec = nnext > m0;
         const bool act = tid < 16 * MR && b < nb && j < H;
-        float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cprev = 0.f;
+        // The saved activations of this thread's element: UNCONDITIONAL loads from clamped addresses in the wavefronts that own
+        // elements (a wave-uniform branch).  With `if (act) x = load` the compiler zero-initialises the destination registers at
+        // the loop head and, to protect them, waits there for every memory operation of the previous step (s_waitcnt
+        // vmcnt(0): the trailing row-major stores) BEFORE it issues these loads - cold HBM lines that need the whole step
+        // to arrive.  Values of threads without an element are never used.
+        float dh, ig, fg, gg, og, cn, cprev;
         const long long oh = (row0 + b) * ld_h + dir * H + j;
         const long long og_ = (row0 + b) * ld_g + (long long)dir * G + j;
-        if (act) {
-            dh = A.dhy[oh];
-            ig = A.gates[og_];
-            fg = A.gates[og_ + H];
-            gg = A.gates[og_ + 2 * H];
-            og = A.gates[og_ + 3 * H];
-            cn = A.c[oh];
-            if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
-            else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
+        if (__builtin_amdgcn_readfirstlane(wave) < (16 * MR) / 64 && !(A.dbg & 4096)) {        // scalar branch (4096: timing ablation)
+            const int bb = min(b, nb - 1), jj = min(j, H - 1);
+            const long long ohc = (row0 + bb) * ld_h + dir * H + jj;
+            const long long ogc = (row0 + bb) * ld_g + (long long)dir * G + jj;
+            dh = A.dhy[ohc];
+            ig = A.gates[ogc];
+            fg = A.gates[ogc + H];
+            gg = A.gates[ogc + 2 * H];
+            og = A.gates[ogc + 3 * H];
+            cn = A.c[ohc];
+            cprev = A.c[(prow0 + min(bb, max(npv - 1, 0))) * ld_h + dir * H + jj];
+        } else {        // never used: "defined" without an instruction (a zero store here is hoisted in front of the branch,
+                        // where it brings the wait back)
+            asm volatile("" : "=v"(dh), "=v"(ig), "=v"(fg), "=v"(gg), "=v"(og), "=v"(cn), "=v"(cprev));
         }
+        const bool has_prev_c = b < npv;
+        float c0v = 0.f;
+        if (A.c0 && act && !has_prev_c) c0v = A.c0[((long long)dir * A.max_batch + b) * H + j];
         if (has_rec) {
             if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             __syncthreads();
@@ -461,8 +474,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             constexpr int CAB = CABW < NB ? CABW : NB;      // blocks in flight
             auto fragment = [&](int blk, int p) {           // compile-time constants after unrolling
                 const int mt = blk / CB, i = blk - mt * CB;
-                return __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, vb0, (min(i, ilast) * 2 + p) * 1024, 16 /* sc1 */)
-                                                         : __builtin_amdgcn_raw_buffer_load_b128(rs1, vb1, (min(i, ilast) * 2 + p) * 1024, 16));
+                return __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, vb0, (min(i, ilast) * 2 + p) * 1024, CP /* 16: sc1 */)
+                                                         : __builtin_amdgcn_raw_buffer_load_b128(rs1, vb1, (min(i, ilast) * 2 + p) * 1024, CP));
             };
             uint4 ah[CAB], al[CAB];
 #pragma unroll
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             dc += dh * og * (1.f - tc * tc);
             const float d_i = dc * gg;
             const float d_g = dc * ig;
-            const float d_f = dc * cprev;
+            const float d_f = dc * (has_prev_c ? cprev : c0v);
             dc_state = dc * fg;
             gi = d_i * ig * (1.f - ig);
             gf = d_f * fg * (1.f - fg);
@@ -628,8 +641,14 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
     const char* v = getenv("PTMI_LSTM_BWD_CAB");
     const int cab = v ? atoi(v) : 3;
-    if (mtl == 2)
+    // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
+    const bool uni = A.uniform != 0 && !getenv("PTMI_LSTM_NO_UNI_T");
+    if (mtl == 2 && uni)
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true>), dim3(nwg), dim3(512), 0, st, A);
+    else if (mtl == 2)
         hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3>), dim3(nwg), dim3(512), 0, st, A);
+    else if (uni && cab < 5)
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, true>), dim3(nwg), dim3(512), 0, st, A);
     else if (cab >= 10)
         hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 10>), dim3(nwg), dim3(512), 0, st, A);
     else if (cab >= 5)
