@@ -202,10 +202,10 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
     kernels = []
     gemm, packs = {}, {}
     for n, v in by_name.items():
-        if n.startswith('gemm_split:') or n.startswith('gemm_planes:'):          # gemm_split:MxNxK:products, gemm_planes:MxNxK
+        if n.startswith(('gemm_split:', 'gemm_planes:', 'gemm_planes_bf16:')):          # gemm_split:MxNxK:products, gemm_planes[_bf16]:MxNxK
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
-            key = ('planes', 3) if n.startswith('gemm_planes:') else ('split', int(parts[2]))
+            key = ('planes', 3) if n.startswith('gemm_planes') else ('split', int(parts[2]))
             e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
@@ -246,7 +246,7 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
         label = ('gemm_planes_kernel (LSTM input projections, linears, their input gradients and all weight gradients: operands '
-                 'pre-split into fp16 (hi, lo) planes, 3 fp16 MFMA products per fp32 product)' if kind == 'planes' else
+                 'pre-split into fp16 (hi, lo) planes - bf16 planes straight from the backward recurrence for the LSTM input gradients -, 3 16-bit MFMA products per fp32 product)' if kind == 'planes' else
                  f'gemm_split_ws_kernel (LSTM input gradients: fp32 operands split in registers, {products} fp16 MFMA products per '
                  f'fp32 product)' if products == 3 else 'gemm_split_ws_kernel (dense layers, plain bf16 operands)')
         kernels.append(dict(
@@ -480,8 +480,9 @@ def main():
                 'blstm': 'HIP recurrence (csrc/lstm_split.hip)',
                 'gemms': ('hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)' if args.library_gemms else
                           'csrc/gemm.hip, plain bf16 operands (reduced precision)' if args.bf16 else
-                          'csrc/gemm_planes.hip (projections, linears, weight gradients: operands pre-split into fp16 planes) + '
-                          'csrc/gemm.hip (input gradients): fp32 in/out, 3 fp16 MFMA products per product (fp32-equivalent accuracy)'),
+                          'csrc/gemm_planes.hip: fp32 in / out, 3 16-bit MFMA products per product (fp32-equivalent accuracy); projections, '
+                          'linears and weight gradients on operands pre-split into fp16 planes, LSTM input gradients on the bf16 planes the '
+                          'backward recurrence hands on'),
                 'host_checks': 'same step (2 syncs)' if args.sync_checks else 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)',
                 'optimizer': 'csrc/optim.hip: reproducible 2-norm + fused clip / Adam / zero_grad over the flat bucket',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',
