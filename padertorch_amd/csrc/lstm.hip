@@ -981,6 +981,10 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
             A.nx = jx;
             A.nt = nt;
             const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
+            if (fwd_daf_applies(jt, small, one_per_cu) && t0 == 0) {       // every 16-bit value of the planes = 0xFFFF (no value can be)
+                int fe = daf_prefill(hyt, (size_t)lstm_tile_elems(T, ndir, max_batch, KP32), st);
+                if (fe) return fe;
+            }
             int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st);
             if (rc) return rc;
             continue;
@@ -1057,6 +1061,10 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
     if (s_begin == 0) {         // a later range continues on the first one's counters, bias sums and maximum
         hipError_t e = zero_words_async(flags, (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
         if (e != hipSuccess) return (int)e;
+    }
+    if (s_begin == 0 && split && bwd_daf_applies()) {       // data-as-flag hand-off: the planes start as the fill pattern
+        int fe = daf_prefill(dgt, (size_t)lstm_tile_elems(T, ndir, max_batch, G32), st);
+        if (fe) return fe;
     }
     flags += ndir * 4 * H;
     uint32_t* const dg_amax = flags;

@@ -17,6 +17,8 @@
 // producer lane trades one half with its neighbour lane so that it still issues ONE 4-byte write-through store per value.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "lstm_common.h"
 
 namespace ptmi {
@@ -33,6 +35,61 @@ typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
 // Index (in 16-bit values) of column `col` of row `row` in plane `plane` within one (time, tile, direction) block:
 __device__ __forceinline__ int handoff_index(int col, int plane, int row) {
     return (((col >> 5) * 2 + plane) * 64 + ((col & 31) >> 3) * 16 + row) * 8 + (col & 7);
+}
+
+// Data-as-flag hand-off (DAF kernels below): the planes are pre-filled with 0xFFFF in every 16-bit value - a NaN pattern no
+// conversion produces (they give the canonical 0x7E00 / 0x7FC0 forms) -, producers only issue their write-through stores,
+// consumers request their operand tiles and check every value they are going to use.
+constexpr unsigned kFill = 0xffffffffu;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+// running maximum over the unsigned 16-bit halves of a fragment (3 + 1 packed VALU operations)
+__device__ __forceinline__ unsigned fold_max16(const uint4 v, unsigned m) {
+    us2 x = __builtin_elementwise_max(__builtin_bit_cast(us2, v.x), __builtin_bit_cast(us2, v.y));
+    x = __builtin_elementwise_max(x, __builtin_bit_cast(us2, v.z));
+    x = __builtin_elementwise_max(x, __builtin_bit_cast(us2, v.w));
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, __builtin_bit_cast(us2, m)));
+}
+__device__ __forceinline__ bool has_fill(unsigned m) { return (m & 0xffffu) == 0xffffu || (m >> 16) == 0xffffu; }
+
+// A step's FIRST request is held back until `hold` ticks of the 100 MHz clock after the workgroup's previous barrier (the one
+// point of a step all its wavefronts share; the owners still have their activations and stores to do behind it, the others
+// do not): a request that arrives before the slowest producer's stores are visible is wasted, and every wasted 39 / 154 KB
+// round of every workgroup loads the fabric the stores travel on - without the hold the protocol was no faster than the
+// flags (3.27 vs 3.21 us per step).  `hold` adapts slowly and in step: a first request that still found the pattern adds 3
+// ticks at once; every 64th step every wavefront that has not failed since the last one takes 1 tick off (all at the same
+// step: with free-running per-wavefront probing some wavefront of the chain is always just trying a shorter wait, and the
+// whole chain pays its failed attempt).
+struct DafHold {
+    unsigned hold, failed;
+    unsigned long long ref;
+    __device__ __forceinline__ void mark() { ref = __builtin_amdgcn_s_memrealtime(); }
+    __device__ __forceinline__ void wait() const {
+        while ((unsigned)(__builtin_amdgcn_s_memrealtime() - ref) < hold) __builtin_amdgcn_s_sleep(1);
+    }
+    __device__ __forceinline__ void update(bool first_clean, int step, bool adapt) {
+        if (!adapt) return;
+        if (!first_clean) {
+            hold = min(hold + 3u, 1000u);
+            failed = 1u;
+        }
+        if ((step & 63) == 63) {
+            if (!failed && hold > 0u) --hold;
+            failed = 0u;
+        }
+    }
+};
+
+__global__ void fill_words_kernel(uint4* p, size_t n16, unsigned word) {
+    const uint4 v = make_uint4(word, word, word, word);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// host: fill `words` 32-bit words (a multiple of 4, 16-byte aligned) with the pattern
+int daf_prefill(void* p, size_t words, hipStream_t st) {
+    const size_t n16 = words / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 8192);
+    hipLaunchKernelGGL(fill_words_kernel, dim3(grid), dim3(256), 0, st, static_cast<uint4*>(p), n16, kFill);
+    return launch_status();
 }
 
 constexpr float kHScale = 1024.f;       // forward: h is handed on as halves of 2^10 h (lo stays normal down to |h| = 2^-13)
@@ -348,9 +405,217 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Forward, data-as-flag hand-off (experiment, PTMI_LSTM_DAF=1; 16-row chains, one workgroup per CU).
+// The protocol above costs every step two store round trips in series (the write-through drain, then the flag) and two
+// load round trips (the poll, then the operands).  Here the scratch planes are pre-filled with a pattern no value can
+// have (0xFFFF: a NaN in fp16), producers only issue their write-through stores, and a consumer wavefront requests its
+// operand tiles at once and again until none of their 16-bit values is the pattern: one store and one load round trip.
+// Every 4-byte word is written exactly once per launch and checked by the lane that uses it, so no ordering between
+// stores is assumed.  The partial sums are double-buffered in LDS (one barrier per step is left).
+template <int JT, int NW, int CB, int MTL>
+__global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPersistArgs A) {
+    constexpr int NC = 4 * JT;
+    constexpr int NT = NC / 16;
+    constexpr int MR = 16 * MTL;
+    constexpr int ACTW = (MR * JT + 63) / 64;
+    int bx = blockIdx.x, bz = blockIdx.z, dir = blockIdx.y;
+    if (A.span > 0 && !chain_tile(A.nx, A.nt, A.span, &bx, &bz, &dir, A.ndir * A.nt)) return;
+    const int j0 = bx * JT;
+    const int m0 = (A.tile0 + bz) * MR;
+    const int H = A.H, G = 4 * H;
+    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g4 = lane >> 4, r = lane & 15;
+    __shared__ float red[2][NW][MR][NC + 1];
+    const bool uniform = A.uniform != 0;
+    auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
+    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
+    const int nblk = A.KP32 >> 5;
+    const int base = nblk / NW, extra = nblk - base * NW;
+    const int kb0 = __builtin_amdgcn_readfirstlane(wave * base + min(wave, extra));
+    const int nbw = __builtin_amdgcn_readfirstlane(base + (wave < extra ? 1 : 0));
+    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));
+    const int ilast = __builtin_amdgcn_readfirstlane(max(nbw - 1, 0));
+    const float ws = pow2_scale(A.w_amax);
+    const float inv = 1.f / (ws * kHScale);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 bh[CB][NT], bl[CB][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int cidx = nt * 16 + r;
+        const int gate = cidx / JT, uu = cidx - gate * JT;
+        const bool bv = j0 + uu < H;
+        const float* bp = A.w + ((long long)dir * G + gate * H + (bv ? j0 + uu : 0)) * A.KP;
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int k = (kb0 + i) * 32 + g4 * 8;
+            const bool in = bv && i < nbw;
+            const f32x4 w0 = (in && k + 4 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 4 <= A.KP ? k : 0)) : zero;
+            const f32x4 w1 = (in && k + 8 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 8 <= A.KP ? k + 4 : 0)) : zero;
+            const float v[8] = {w0[0] * ws, w0[1] * ws, w0[2] * ws, w0[3] * ws, w1[0] * ws, w1[1] * ws, w1[2] * ws, w1[3] * ws};
+            split8<false>(v, &bh[i][nt], &bl[i][nt]);
+        }
+    }
+    const size_t tile_elems = (size_t)A.KP32 * 16;
+    const int tile16 = (A.tile0 + bz) * MTL;
+    unsigned* const err = A.flags + A.err_off;
+    const int bl_ = tid / JT, u = tid - bl_ * JT;
+    const int b = m0 + bl_;
+    bool alive = true;
+    float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_reg = 0.f;
+    {
+        const int t0 = dir == 0 ? 0 : A.T - 1;
+        if (tid < MR * JT && b < bs_at(t0) && j0 + u < H) {
+            const float* np = A.gx + (offs_at(t0) + b) * ld_g + (long long)dir * G + j0 + u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
+        }
+    }
+    DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : 100u, 0u, 0ull};      // (PTMI_LSTM_DBG bits 16-23: initial hold / 4)
+    const bool adapt = !(A.dbg & (1 << 24));
+    dd.mark();
+    for (int s = 0; s < A.T; ++s) {
+        const int t = dir == 0 ? s : A.T - 1 - s;
+        const int nb = bs_at(t);
+        const long long row0 = offs_at(t);
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const int nprev = (tp >= 0 && tp < A.T) ? min(bs_at(tp), nb) : 0;
+        const bool has_rec = nprev > m0;
+        const bool act = tid < MR * JT && b < nb && j0 + u < H;
+        float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
+        float cprev = 0.f;
+        float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
+        if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
+        const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
+        const bool more = s + 1 < A.T;
+        const int nb1 = more ? bs_at(t1) : 0;
+        const long long row1 = more ? offs_at(t1) : 0;
+        auto prefetch = [&]() {
+            if (tid < MR * JT && b < nb1 && j0 + u < H) {
+                const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
+            }
+        };
+        if (!has_rec) prefetch();
+        if (has_rec) {
+            if (act && b < nprev) cprev = c_reg;
+            constexpr int NF = MTL * CB * 2;                 // fragments: (row tile mt, k block i, plane p)
+            const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
+                A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
+            const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
+                A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
+            const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
+            const unsigned vb0 = m0 + r < nprev ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev) ? vin : 0x80000000u;
+            uint4 a[NF];
+            dd.wait();
+            unsigned polls = 0;
+            for (;;) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const int mt = f / (2 * CB), rem = f - mt * 2 * CB;
+                    a[f] = __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, (min(rem >> 1, ilast) * 2 + (rem & 1)) * 1024, 16)
+                                                             : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, (min(rem >> 1, ilast) * 2 + (rem & 1)) * 1024, 16));
+                }
+                unsigned m = 0u;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) m = fold_max16(a[f], m);
+                const bool clean = !__any(has_fill(m)) || !alive;
+                if (polls == 0) dd.update(clean, s, adapt);
+                if (clean) break;
+                if (++polls >= A.max_polls || ((polls & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    if (polls >= A.max_polls && lane == 0) {
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (A.err_sink) atomicAdd(A.err_sink, 1u);
+                    }
+                    alive = false;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            prefetch();
+            f32x4 acc[MTL][NT];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    const uint4 ah = a[(mt * CB + i) * 2], al = a[(mt * CB + i) * 2 + 1];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(al, bh[i][nt], acc[mt][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bl[i][nt], acc[mt][nt]);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bh[i][nt], acc[mt][nt]);
+                }
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[s & 1][wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            __syncthreads();
+            dd.mark();
+            if (tid < MR * JT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cidx = q * JT + u;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += red[s & 1][w][bl_][cidx];
+                    pre[q] += sum * inv;
+                }
+            }
+        }
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
+        if (act) {
+            ig = sigmoidf_(pre[0]);
+            fg = sigmoidf_(pre[1]);
+            gg = tanhf_(pre[2]);
+            og = sigmoidf_(pre[3]);
+            c_reg = fg * cprev + ig * gg;
+            h = og * tanhf_(c_reg);
+        }
+        {
+            int plane;
+            const unsigned word = pair_word<false>(h * kHScale, lane, &plane);
+            if (act) {
+                const int ce = (j0 + u) & ~1;
+                unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
+                __hip_atomic_store(tq + handoff_index(ce, plane, bl_ & 15) / 2, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (j0 < H && j0 + JT >= H) {                     // owner of the last unit: the padding columns H .. KP32-1 (every step: they carry the pattern too)
+            const int pw2 = (A.KP32 - H) >> 1;
+            for (int e = tid; e < MR * pw2 * 2 && tid < ACTW * 64; e += ACTW * 64) {
+                const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = H + 2 * (rem - plane * pw2);
+                if (m0 + rl < nb) {
+                    unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
+                    __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (act) {
+            gp[0] = ig;
+            gp[H] = fg;
+            gp[2 * H] = gg;
+            gp[3 * H] = og;
+            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
+            A.c[o] = c_reg;
+            A.hy[o] = h;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Backward-through-time.  8 wavefronts, CB = 32-wide k blocks of K = 4H per wavefront (even split), CAB blocks in
 // flight per wavefront (re-requested as soon as their MFMAs have consumed them, as in lstm_bwd_persistent_kernel).
-template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false>
+template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
@@ -363,7 +628,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[NW][MR][17];
+    __shared__ float red[DAF ? 2 : 1][NW][MR][17];       // DAF: double-buffered by step parity (one barrier per step)
     const bool uniform = UNI || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
     auto bs_at = [&](int t) { if (UNI) return A.max_batch; return uniform ? A.max_batch : A.bs[t]; };
     auto offs_at = [&](int t) { if (UNI) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
@@ -396,6 +661,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const int b = m0 + bl_, j = n0 + jl;
     const size_t tile_elems = (size_t)A.G32 * 16;          // floats per (time, 16-row tile, direction)
     bool alive = true;
+    DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : 100u, 0u, 0ull};
+    const bool adapt = !(A.dbg & (1 << 24));
+    dd.mark();
     float dc_state = 0.f;
     float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;
     float amax = 0.f;                                      // max |dgates| this thread has produced
@@ -460,7 +728,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         const bool has_prev_c = b < npv;
         float c0v = 0.f;
         if (A.c0 && act && !has_prev_c) c0v = A.c0[((long long)dir * A.max_batch + b) * H + j];
-        if (has_rec) {
+        if (!DAF && has_rec) {
             if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             __syncthreads();
             const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * tile_elems;
@@ -512,12 +780,97 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][r] = (acc3[mt][0][q] + acc3[mt][1][q]) + acc3[mt][2][q];
+                for (int q = 0; q < 4; ++q) red[0][wave][mt * 16 + g4 * 4 + q][r] = (acc3[mt][0][q] + acc3[mt][1][q]) + acc3[mt][2][q];
             __syncthreads();
             if (tid < 16 * MR && b < nnext) {
                 float sum = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) sum += red[w][bl_][jl];
+                for (int w = 0; w < NW; ++w) sum += red[0][w][bl_][jl];
+                dh += sum;
+            }
+        }
+        if (DAF && has_rec) {
+            // data-as-flag: no poll, no barrier in front of the operand loads.  The k blocks of this wavefront go through two
+            // register sets in passes of CAB blocks: pass p is checked (and requested again until it is free of the fill
+            // pattern), pass p + 1 is requested, pass p is multiplied.
+            const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * tile_elems;
+            const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
+            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, A.G32 * 64, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(tbase + (MTL > 1 ? (size_t)A.ndir * tile_elems : 0)), 0, A.G32 * 64, 0x00020000);
+            const unsigned vb0 = m0 + r < nnext ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nnext) ? vin : 0x80000000u;
+            constexpr int NB = MTL * CB;
+            constexpr int CAB = CABW < NB ? CABW : NB;
+            constexpr int NP = (NB + CAB - 1) / CAB;
+            auto fragment = [&](int blk, int p) {           // compile-time constants after unrolling
+                const int mt = blk / CB, i = blk - mt * CB;
+                return __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, vb0, (min(i, ilast) * 2 + p) * 1024, 16)
+                                                         : __builtin_amdgcn_raw_buffer_load_b128(rs1, vb1, (min(i, ilast) * 2 + p) * 1024, 16));
+            };
+            uint4 fh[2][CAB], fl[2][CAB];
+            auto request = [&](int pass, int set) {
+#pragma unroll
+                for (int i = 0; i < CAB; ++i)
+                    if (pass * CAB + i < NB) {
+                        fh[set][i] = fragment(pass * CAB + i, 0);
+                        fl[set][i] = fragment(pass * CAB + i, 1);
+                    }
+            };
+            f32x4 acc3[MTL][3];
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc3[mt][k] = zero;
+            dd.wait();
+            request(0, 0);
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
+                const int set = pass & 1;
+                unsigned polls = 0;
+                for (;;) {
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int i = 0; i < CAB; ++i)
+                        if (pass * CAB + i < NB) {
+                            m = fold_max16(fh[set][i], m);
+                            m = fold_max16(fl[set][i], m);
+                        }
+                    const bool clean = !__any(has_fill(m)) || !alive;
+                    if (pass == 0 && polls == 0) dd.update(clean, s, adapt);
+                    if (clean) break;
+                    if (++polls >= A.max_polls || ((polls & 255u) == 255u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        if (polls >= A.max_polls && lane == 0) {
+                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (A.err_sink) atomicAdd(A.err_sink, 1u);
+                        }
+                        alive = false;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    request(pass, set);
+                }
+                if (pass + 1 < NP) request(pass + 1, set ^ 1);
+#pragma unroll
+                for (int i = 0; i < CAB; ++i) {
+                    const int blk = pass * CAB + i;
+                    if (blk < NB) {
+                        acc3[blk / CB][0] = mma16<true>(fl[set][i], bh[blk % CB], acc3[blk / CB][0]);
+                        acc3[blk / CB][1] = mma16<true>(fh[set][i], bl[blk % CB], acc3[blk / CB][1]);
+                        acc3[blk / CB][2] = mma16<true>(fh[set][i], bh[blk % CB], acc3[blk / CB][2]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTL; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) red[s & 1][wave][mt * 16 + g4 * 4 + q][r] = (acc3[mt][0][q] + acc3[mt][1][q]) + acc3[mt][2][q];
+            __syncthreads();
+            dd.mark();
+            if (tid < 16 * MR && b < nnext) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += red[s & 1][w][bl_][jl];
                 dh += sum;
             }
         }
@@ -568,10 +921,12 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                 }
             }
         }
-        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!DAF) {
+            if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (act) {                                    // row-major dgates (what the GEMMs read): nobody in this launch waits for them
             float* dgp = A.dg + og_;
             dgp[0] = gi;
@@ -582,7 +937,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     }
     if (s1 < A.T && carries) A.dc_carry[((size_t)dir * A.max_batch + b) * H + j] = dc_state;
     // bias gradient = sum of dgates over all rows; max |dgates| for the GEMMs that follow (operand scale)
-    float* const fold = &red[0][0][0];
+    float* const fold = &red[0][0][0][0];
     __syncthreads();
     if (tid < 16 * MR) {
         fold[(0 * MR + bl_) * 16 + jl] = sb0;
@@ -605,10 +960,30 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+static bool daf_enabled() {
+    static const bool on = !(getenv("PTMI_LSTM_DAF") != nullptr && atoi(getenv("PTMI_LSTM_DAF")) == 0);
+    return on;
+}
+
+bool fwd_daf_applies(int jt, bool small, bool one_per_cu) {
+    return daf_enabled() && one_per_cu && ((small && (jt == 12 || jt == 16)) || (!small && jt == 12));
+}
+
+bool bwd_daf_applies() { return daf_enabled(); }
+
 int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st) {
     constexpr int NW = 8, CB = 3;
     const dim3 block(NW * 64);
     const bool wide = jt >= 12;
+    if (fwd_daf_applies(jt, small, one_per_cu)) {
+        if (jt == 16 && small)
+            hipLaunchKernelGGL((lstm_fwd_daf_kernel<16, NW, CB, 1>), grid, block, 0, st, A);
+        else if (jt == 12 && small)
+            hipLaunchKernelGGL((lstm_fwd_daf_kernel<12, NW, CB, 1>), grid, block, 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_fwd_daf_kernel<12, NW, CB, 2>), grid, block, 0, st, A);
+        return launch_status();
+    }
     if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
         hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 1, 1, true>), grid, block, 0, st, A);
     else if (jt == 16 && small && getenv("PTMI_LSTM_PHASES"))
@@ -643,6 +1018,17 @@ int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStre
     const int cab = v ? atoi(v) : 3;
     // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
     const bool uni = A.uniform != 0 && !getenv("PTMI_LSTM_NO_UNI_T");
+    if (bwd_daf_applies()) {
+        if (mtl == 2 && uni)
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        else if (mtl == 2)
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, false, true>), dim3(nwg), dim3(512), 0, st, A);
+        else if (uni)
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, false, true>), dim3(nwg), dim3(512), 0, st, A);
+        return launch_status();
+    }
     if (mtl == 2 && uni)
         hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true>), dim3(nwg), dim3(512), 0, st, A);
     else if (mtl == 2)
