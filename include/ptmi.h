@@ -233,7 +233,7 @@ int32_t ptmi_lstm_handoff_cols(int32_t H, int32_t backward);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
-                                 int32_t ndir, ptmi_stream_t stream);
+                                 int32_t ndir, int32_t prefilled, ptmi_stream_t stream);
 
 /* Persistent backward-through-time (mirror of ptmi_lstm_forward_persistent; same results as
  * ptmi_lstm_backward; no dc_state scratch: the cell-state gradient stays in registers).  `flags` is a device
@@ -245,7 +245,7 @@ int64_t ptmi_lstm_scratch_elems(int32_t T, int32_t ndir, int32_t max_batch, int3
 int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t,
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                   uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
-                                  int32_t ndir, ptmi_stream_t stream);
+                                  int32_t ndir, int32_t prefilled, ptmi_stream_t stream);
 /* The same recurrence cut in time: processes the steps [s_begin, s_end) of the T processing steps (step s handles
  * time index T-1-s in direction 0, s in direction 1).  Ranges must be launched in order on one stream with the same
  * scratch; the first (s_begin == 0) zeroes it, dc_carry (device fp32 [ndir, max_batch, H]) takes the cell-state
@@ -256,7 +256,16 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
                                         const float* w_hh_t, float* dgates, const int32_t* batch_sizes_dev,
                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
-                                        int32_t s_end, ptmi_stream_t stream);
+                                        int32_t s_end, int32_t prefilled, ptmi_stream_t stream);
+/* Data-as-flag hand-off (the default of the split kernels; PTMI_LSTM_DAF=0 selects the flag protocol): the planes at the
+ * start of the scratch start out as 0xFFFF in every 16-bit value - a pattern no conversion to fp16 / bf16 produces -, producers
+ * only store, consumers re-request an operand tile until none of the values they are going to use is the pattern.  The
+ * persistent calls fill the planes themselves (prefilled = 0) unless the caller has done it with ptmi_lstm_scratch_prefill
+ * on any stream it orders before the launch (prefilled = 1: the fill then runs next to earlier work instead of in front of
+ * the recurrence).  ptmi_lstm_scratch_prefill returns 1 when it has filled, 0 when the launch for this configuration does
+ * not use the pattern (nothing done; pass prefilled = 0), < 0 on error. */
+int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward,
+                              ptmi_stream_t stream);
 
 /* Plans: the two time loops over FIXED buffers captured once as hipGraphs and replayed with one
  * host call each (same buffers / bookkeeping arguments as ptmi_lstm_forward / ptmi_lstm_backward;

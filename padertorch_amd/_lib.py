@@ -75,11 +75,12 @@ SIGNATURES = {
     'ptmi_lstm_split_enabled': (c_int, []),
     'ptmi_lstm_handoff_cols': (c_int32, [c_int32, c_int32]),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
-                                             c_int32, _P]),
+                                             c_int32, c_int32, _P]),
     'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
-                                              c_int32, _P]),
+                                              c_int32, c_int32, _P]),
     'ptmi_lstm_backward_persistent_range': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
-                                                    c_int32, c_int32, c_int32, _P]),
+                                                    c_int32, c_int32, c_int32, c_int32, _P]),
+    'ptmi_lstm_scratch_prefill': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_plan_create': (c_int, [POINTER(c_void_p), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
                                       c_int32, c_int32, c_int32]),
     'ptmi_lstm_plan_forward': (c_int, [c_void_p, _P]),

@@ -898,6 +898,25 @@ int ptmi_lstm_set_error_sink(uint32_t* word) {
 
 int ptmi_lstm_split_enabled(void) { return getenv("PTMI_LSTM_F32") ? 0 : 1; }
 
+static bool fwd_uses_daf(int max_batch, int H, int ndir);
+
+int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward,
+                              ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!scratch || T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2), PTMI_E_INVALID);
+    if (H % 4 != 0 || !ptmi_lstm_split_enabled()) return 0;
+    int cols;
+    if (backward) {
+        const int G32 = (4 * H + 31) / 32 * 32;
+        if ((G32 / 32 + 7) / 8 > 10 || !bwd_daf_applies()) return 0;
+        cols = G32;
+    } else {
+        if (!fwd_uses_daf(max_batch, H, ndir)) return 0;
+        cols = (H + 31) / 32 * 32;
+    }
+    const int rc = daf_prefill(scratch, (size_t)lstm_tile_elems(T, ndir, max_batch, cols), static_cast<hipStream_t>(stream));
+    return rc ? rc : 1;
+}
+
 int32_t ptmi_lstm_handoff_cols(int32_t H, int32_t backward) {
     if (H < 1 || H % 4 != 0 || !ptmi_lstm_split_enabled()) return 0;
     if (backward) {
@@ -908,10 +927,45 @@ int32_t ptmi_lstm_handoff_cols(int32_t H, int32_t backward) {
     return (KP32 / 32 + 7) / 8 <= 3 ? KP32 : 0;              // the rule of ptmi_lstm_forward_persistent
 }
 
+// Workgroup tile of the persistent forward launch (jt hidden units x 16 mtl rows) for a batch / layer size.
+static void fwd_tile_shape(int max_batch, int H, int ndir, bool split, int* jt_out, int* mtl_out) {
+    int jt = max_batch <= 16 ? 8 : 12, mtl = max_batch <= 32 ? 1 : 2;
+    // split kernels, one 16-row tile per workgroup: 16 units (38 instead of 50 workgroups per chain at H = 600) measured
+    // 3.19 against 3.27 us per step with the fragment-order hand-off copy, and leaves 48 more CUs to other queues
+    if (split && jt == 12 && mtl == 1) jt = 16;
+    if (jt == 12 && (long long)((H + 11) / 12) * ndir > cu_count()) jt = 16;      // wide tiles: one workgroup per CU
+    if (jt == 16 && (long long)((H + 15) / 16) * ndir > cu_count()) jt = 8;
+    if (const char* v = getenv("PTMI_LSTM_JT")) {
+        const int q = atoi(v);
+        jt = (q == 16 || q == 12 || (split && (q == 20 || q == 24))) ? q : 8;
+    }
+    if (const char* v = getenv("PTMI_LSTM_MTL")) mtl = atoi(v) == 1 ? 1 : 2;
+    *jt_out = jt;
+    *mtl_out = mtl;
+}
+
+// Does the persistent forward launch of this configuration hand its rows on by the data-as-flag protocol (planes pre-filled
+// with the pattern)?  One answer for all launches of a call (later launches have at most as many row tiles as the first).
+static bool fwd_uses_daf(int max_batch, int H, int ndir) {
+    const int KP32 = (H + 31) / 32 * 32;
+    const bool split = ptmi_lstm_split_enabled() && (KP32 / 32 + 7) / 8 <= 3;
+    if (!split) return false;
+    int jt, mtl;
+    fwd_tile_shape(max_batch, H, ndir, split, &jt, &mtl);
+    const bool wide = jt >= 12;
+    const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
+    const int jx = wide ? (H + jt - 1) / jt : (H + 7) / 8;
+    const int cus = cu_count();
+    const int cap = wide ? cus : cus * 7 / 4;
+    if ((long long)jx * ndir > cap) return false;
+    const int per_launch = std::min(ntiles, cap / (jx * ndir));
+    return fwd_daf_applies(jt, mtl == 1, (long long)jx * ndir * per_launch <= cus);
+}
+
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
-                                 int32_t ndir, ptmi_stream_t stream) {
+                                 int32_t ndir, int32_t prefilled, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !hy || !c || !w_hh_pad || !batch_sizes_dev || !offsets_dev || !flags, PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
@@ -930,17 +984,8 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     //   B <= 16: 16 x 8 (4.9);  B <= 32: two independent chains of 16 x 12 on separate CUs (200 workgroups:
     //   5.4; 16 x 16 on 152: 5.8; 32 x 8: 6.6; 16 x 8 with 300 workgroups sharing CUs: 8.3);
     //   B > 32: 32 x 12 (B = 64: 32 x 16 8.8, 32 x 8 11.6).
-    int jt = max_batch <= 16 ? 8 : 12, mtl = max_batch <= 32 ? 1 : 2;
-    // split kernels, one 16-row tile per workgroup: 16 units (38 instead of 50 workgroups per chain at H = 600) measured
-    // 3.19 against 3.27 us per step with the fragment-order hand-off copy, and leaves 48 more CUs to other queues
-    if (split && jt == 12 && mtl == 1) jt = 16;
-    if (jt == 12 && (long long)((H + 11) / 12) * ndir > cu_count()) jt = 16;      // wide tiles: one workgroup per CU
-    if (jt == 16 && (long long)((H + 15) / 16) * ndir > cu_count()) jt = 8;
-    if (const char* v = getenv("PTMI_LSTM_JT")) {
-        const int q = atoi(v);
-        jt = (q == 16 || q == 12 || (split && (q == 20 || q == 24))) ? q : 8;
-    }
-    if (const char* v = getenv("PTMI_LSTM_MTL")) mtl = atoi(v) == 1 ? 1 : 2;
+    int jt, mtl;
+    fwd_tile_shape(max_batch, H, ndir, split, &jt, &mtl);
     const bool small = mtl == 1, wide = jt >= 12;
     const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
     const int jx = wide ? (H + jt - 1) / jt : jx8;
@@ -963,6 +1008,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                       w_hh_amax, KP32};
     A.err_sink = error_sink();
     A.uniform = (rows == (int64_t)T * max_batch && !getenv("PTMI_LSTM_NO_UNIFORM")) ? 1 : 0;      // batch sizes never grow: equal lengths
+    const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
@@ -981,11 +1027,11 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
             A.nx = jx;
             A.nt = nt;
             const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
-            if (fwd_daf_applies(jt, small, one_per_cu) && t0 == 0) {       // every 16-bit value of the planes = 0xFFFF (no value can be)
+            if (daf && t0 == 0 && !prefilled) {       // every 16-bit value of the planes = 0xFFFF (no value can be)
                 int fe = daf_prefill(hyt, (size_t)lstm_tile_elems(T, ndir, max_batch, KP32), st);
                 if (fe) return fe;
             }
-            int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st);
+            int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st, daf);
             if (rc) return rc;
             continue;
         }
@@ -1016,16 +1062,16 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
 int ptmi_lstm_backward_persistent(const float* gates, const float* c, const float* c0, const float* dhy, const float* w_hh_t,
                                   float* dgates, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                   uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H,
-                                  int32_t ndir, ptmi_stream_t stream) {
+                                  int32_t ndir, int32_t prefilled, ptmi_stream_t stream) {
     return ptmi_lstm_backward_persistent_range(gates, c, c0, dhy, w_hh_t, dgates, batch_sizes_dev, offsets_dev, flags, nullptr, T,
-                                               max_batch, rows, H, ndir, 0, T, stream);
+                                               max_batch, rows, H, ndir, 0, T, prefilled, stream);
 }
 
 int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, const float* c0, const float* dhy,
                                         const float* w_hh_t, float* dgates, const int32_t* batch_sizes_dev,
                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin, int32_t s_end,
-                                        ptmi_stream_t stream) {
+                                        int32_t prefilled, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || !dgates || !batch_sizes_dev || !offsets_dev || !flags,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
@@ -1062,7 +1108,7 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
         hipError_t e = zero_words_async(flags, (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
         if (e != hipSuccess) return (int)e;
     }
-    if (s_begin == 0 && split && bwd_daf_applies()) {       // data-as-flag hand-off: the planes start as the fill pattern
+    if (s_begin == 0 && split && bwd_daf_applies() && !prefilled) {       // data-as-flag hand-off: the planes start as the fill pattern
         int fe = daf_prefill(dgt, (size_t)lstm_tile_elems(T, ndir, max_batch, G32), st);
         if (fe) return fe;
     }

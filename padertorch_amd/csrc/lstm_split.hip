@@ -971,11 +971,11 @@ bool fwd_daf_applies(int jt, bool small, bool one_per_cu) {
 
 bool bwd_daf_applies() { return daf_enabled(); }
 
-int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st) {
+int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st, bool daf) {
     constexpr int NW = 8, CB = 3;
     const dim3 block(NW * 64);
     const bool wide = jt >= 12;
-    if (fwd_daf_applies(jt, small, one_per_cu)) {
+    if (daf) {
         if (jt == 16 && small)
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<16, NW, CB, 1>), grid, block, 0, st, A);
         else if (jt == 12 && small)

@@ -183,14 +183,14 @@ def gemm_split_(out, x, a_kmajor, lda, amax_x, y, b_kmajor, ldb, amax_y, bias, M
 
 @_register('lstm_recurrence_backward_range(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!) dg, '
            'Tensor(b!) scratch, Tensor(c!) dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, int H, '
-           'int ndir, int s_begin, int s_end) -> bool')
+           'int ndir, int s_begin, int s_end, bool prefilled=False) -> bool')
 def lstm_recurrence_backward_range(gates, c, c0, dhy, w_hh_t, dg, scratch, dc_carry, bs_dev, offs_dev, T, max_batch, rows, H, ndir,
-                                   s_begin, s_end):
+                                   s_begin, s_end, prefilled=False):
     """The persistent backward recurrence over the processing steps [s_begin, s_end) (``ptmi_lstm_backward_persistent_range``;
     ranges in order, same ``dg`` / ``scratch`` / ``dc_carry``).  False: the launch cannot be resident (nothing was run)."""
     rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_range, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                     dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), scratch.data_ptr(),
-                    dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, _lib.stream(gates.device))
+                    dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)), _lib.stream(gates.device))
     if rc == -2:
         return False
     _lib.check(rc, 'ptmi_lstm_backward_persistent_range')
@@ -325,11 +325,23 @@ def unit_norm_backward(gy, y, inv, eps):
 
 
 # ------------------------------------------------------------------------------------------------ (B)LSTM recurrence
+@_register('lstm_scratch_prefill(Tensor(a!) scratch, int T, int ndir, int max_batch, int H, bool backward) -> bool')
+def lstm_scratch_prefill(scratch, T, ndir, max_batch, H, backward):
+    """The hand-off planes of a persistent recurrence's scratch filled with the data-as-flag pattern on the CURRENT stream
+    (``ptmi_lstm_scratch_prefill``).  True: pass ``prefilled=True`` to the launch (ordered behind this call); False: this
+    configuration does not use the pattern."""
+    rc = _lib.timed('lstm_prefill', _lib.load().ptmi_lstm_scratch_prefill, scratch.data_ptr(), T, ndir, max_batch, H, int(backward),
+                    _lib.stream(scratch.device))
+    if rc < 0:
+        _lib.check(rc, 'ptmi_lstm_scratch_prefill')
+    return rc == 1
+
+
 @_register('lstm_recurrence_forward(Tensor(a!) gates, Tensor(b!) hy, Tensor? c0, Tensor w_hh_pad, Tensor? w_amax, Tensor bs_dev, '
-           'Tensor offs_dev, int bs_host, int offs_host, int T, int max_batch, int rows, int H, int KP, int ndir, bool persistent) '
-           '-> (Tensor, Tensor?)')
+           'Tensor offs_dev, int bs_host, int offs_host, int T, int max_batch, int rows, int H, int KP, int ndir, bool persistent, '
+           'Tensor(c!)? scratch=None, bool prefilled=False) -> (Tensor, Tensor?)')
 def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, KP, ndir,
-                            persistent):
+                            persistent, scratch=None, prefilled=False):
     """gates: pre-activations in, activations out (in place); hy: output rows (a view into the caller's padded buffer).
     Returns (c, scratch): scratch = the persistent kernel's flag / hand-off buffer (its last 8 words are the watchdog
     words), None when the one-launch-per-timestep kernels ran.  bs_host / offs_host: addresses of the HOST copies of the
@@ -341,10 +353,12 @@ def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, b
     rc = -2
     flags = None
     if persistent:
-        flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 0)), dtype=torch.int32, device=dev)
+        n = int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 0))
+        flags = scratch if scratch is not None else torch.empty(n, dtype=torch.int32, device=dev)
+        assert flags.numel() >= n and flags.dtype == torch.int32
         rc = _lib.timed('lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
                         _lib.ptr(c0), w_hh_pad.data_ptr(), _lib.ptr(w_amax), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        flags.data_ptr(), T, max_batch, rows, H, KP, ndir, st)
+                        flags.data_ptr(), T, max_batch, rows, H, KP, ndir, int(bool(prefilled and scratch is not None)), st)
         if rc not in (0, -2):
             _lib.check(rc, 'ptmi_lstm_forward_persistent')
     if rc == -2:        # configuration not resident-able: one launch per timestep
@@ -356,8 +370,10 @@ def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, b
 
 
 @_register('lstm_recurrence_backward(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor bs_dev, Tensor offs_dev, '
-           'int bs_host, int offs_host, int T, int max_batch, int rows, int H, int ndir, bool persistent) -> (Tensor, Tensor?)')
-def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, ndir, persistent):
+           'int bs_host, int offs_host, int T, int max_batch, int rows, int H, int ndir, bool persistent, Tensor(a!)? scratch=None, '
+           'bool prefilled=False) -> (Tensor, Tensor?)')
+def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, ndir, persistent,
+                             scratch=None, prefilled=False):
     """Returns (dgates, scratch): scratch as above; behind its tile-major copy it carries the bias gradient [ndir * 4H]
     and, for the split kernels, the word with max |dgates| (see ``ops.lstm``)."""
     lib = _lib.load()
@@ -367,10 +383,12 @@ def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_hos
     rc = -2
     flags = None
     if persistent:
-        flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 1)), dtype=torch.int32, device=dev)
+        n = int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 1))
+        flags = scratch if scratch is not None else torch.empty(n, dtype=torch.int32, device=dev)
+        assert flags.numel() >= n and flags.dtype == torch.int32
         rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                         dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        flags.data_ptr(), T, max_batch, rows, H, ndir, st)
+                        flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
         if rc not in (0, -2):
             _lib.check(rc, 'ptmi_lstm_backward_persistent')
     if rc == -2:

@@ -171,6 +171,8 @@ _WGRAD_STREAMS = {}
 CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
 #: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
 TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
+#: the data-as-flag pattern of the recurrences' hand-off planes filled ahead of time on the side stream (see _LstmLayerFn.forward)
+PREFILL_AHEAD = os.environ.get('PTMI_PREFILL_AHEAD', '0') != '0'      # measured neutral (7.87 vs 7.85 ms: the fill competes with the recurrence it runs next to): off
 #: side queue: a layer's weight-gradient GEMMs start behind its recurrence, not behind its input-gradient GEMM
 WGRAD_BEFORE_DX = os.environ.get('PTMI_WGRAD_EARLY', '0') != '0'      # measured neutral (8.75 = 8.75 ms): off
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
@@ -432,9 +434,33 @@ class _LstmLayerFn(torch.autograd.Function):
             ctx.lease = lease
             ctx.ext = None
             ctx.gemm = None
+            ctx.scratch_b = (None, False)
             if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
                 lease.release()
         else:
+            # hand-off scratch of the persistent recurrence - and of this layer's backward pass when one will come -, their
+            # data-as-flag pattern filled on the side stream NOW: next to the projection GEMM (the forward one) resp. next to
+            # the forward recurrences (the backward one's 155 MB at B = 32), instead of in front of the recurrence launches
+            scratch_f = scratch_b = None
+            pre_f = pre_b = False
+            if PERSISTENT and PREFILL_AHEAD and x.is_cuda:
+                main_s = torch.cuda.current_stream(x.device)
+                pre = _prep_stream(x.device)
+                scratch_f = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 0)), dtype=torch.int32,
+                                        device=x.device)
+                if any(ctx.needs_input_grad):
+                    scratch_b = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
+                                            device=x.device)
+                pre.wait_stream(main_s)           # the blocks' previous users are ordered on the main stream
+                with torch.cuda.stream(pre):
+                    pre_f = torch.ops.ptmi.lstm_scratch_prefill(scratch_f, meta.T, ndir, meta.max_batch, H, False)
+                    if scratch_b is not None:
+                        pre_b = torch.ops.ptmi.lstm_scratch_prefill(scratch_b, meta.T, ndir, meta.max_batch, H, True)
+                filled = torch.cuda.Event()
+                filled.record(pre)
+                for t_ in (scratch_f, scratch_b):
+                    if t_ is not None:
+                        t_.record_stream(pre)
             use_gemm = _gemm.usable(x, w_ih)
             # operand ranges of the split GEMM: the layer input is taken as it is when it is a hidden state (|h| < 1,
             # a dropout scale aside), measured otherwise; the stacked weights' maximum is cached per optimizer step
@@ -487,9 +513,12 @@ class _LstmLayerFn(torch.autograd.Function):
                             else _gemm.absmax(w_pad.view(-1, KP)))
             if PERSISTENT:
                 _error_sink(x.device)           # the word a timed-out launch reports to (set before the first launch)
+            if scratch_f is not None:
+                torch.cuda.current_stream(x.device).wait_event(filled)
             c, flags = torch.ops.ptmi.lstm_recurrence_forward(
                 gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT)
+                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f)
+            ctx.scratch_b = (scratch_b, pre_b)
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
@@ -585,8 +614,8 @@ class _LstmLayerFn(torch.autograd.Function):
                 # the recurrence in `chunks` launches over consecutive step ranges: the weight-gradient GEMMs of the time
                 # range a launch has finished run on the side stream under the next launch (ptmi_lstm_backward_persistent_range)
                 dg = torch.empty_like(gates)
-                flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
-                                    device=dhy.device)
+                flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
+                    int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
                 carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device)
                 cuts = [T * i // chunks for i in range(chunks + 1)]
                 nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
@@ -596,7 +625,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 def launch(i):
                     return torch.ops.ptmi.lstm_recurrence_backward_range(
                         gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
-                        ndir, cuts[i], cuts[i + 1])
+                        ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]))
                 if launch(0):
                     for i in range(1, chunks):
                         snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
@@ -616,7 +645,7 @@ class _LstmLayerFn(torch.autograd.Function):
             if dg is None:
                 dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                     gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                    T, meta.max_batch, meta.rows, H, ndir, PERSISTENT)
+                    T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1])
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
