@@ -233,7 +233,7 @@ int32_t ptmi_lstm_handoff_cols(int32_t H, int32_t backward);
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
-                                 int32_t ndir, int32_t prefilled, ptmi_stream_t stream);
+                                 int32_t ndir, int32_t prefilled, uint32_t* backward_scratch, ptmi_stream_t stream);
 
 /* Persistent backward-through-time (mirror of ptmi_lstm_forward_persistent; same results as
  * ptmi_lstm_backward; no dc_state scratch: the cell-state gradient stays in registers).  `flags` is a device
@@ -266,6 +266,11 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
  * not use the pattern (nothing done; pass prefilled = 0), < 0 on error. */
 int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward,
                               ptmi_stream_t stream);
+/* backward_scratch of ptmi_lstm_forward_persistent (NULL: none): the scratch the caller will hand to this layer's
+ * ptmi_lstm_backward_persistent.  When ptmi_lstm_forward_fills(T, ndir, max_batch, H) != 0 the forward launch writes the
+ * pattern into its planes itself - an otherwise idle wavefront of every workgroup, a slice per time step, i.e. for free -
+ * and the caller passes prefilled = 1 to the backward launch.  Otherwise the pointer is ignored. */
+int ptmi_lstm_forward_fills(int32_t T, int32_t ndir, int32_t max_batch, int32_t H);
 
 /* Plans: the two time loops over FIXED buffers captured once as hipGraphs and replayed with one
  * host call each (same buffers / bookkeeping arguments as ptmi_lstm_forward / ptmi_lstm_backward;

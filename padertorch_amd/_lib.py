@@ -75,7 +75,8 @@ SIGNATURES = {
     'ptmi_lstm_split_enabled': (c_int, []),
     'ptmi_lstm_handoff_cols': (c_int32, [c_int32, c_int32]),
     'ptmi_lstm_forward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
-                                             c_int32, c_int32, _P]),
+                                             c_int32, c_int32, _P, _P]),
+    'ptmi_lstm_forward_fills': (c_int, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_lstm_backward_persistent': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
                                               c_int32, c_int32, _P]),
     'ptmi_lstm_backward_persistent_range': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,

@@ -899,6 +899,20 @@ int ptmi_lstm_set_error_sink(uint32_t* word) {
 int ptmi_lstm_split_enabled(void) { return getenv("PTMI_LSTM_F32") ? 0 : 1; }
 
 static bool fwd_uses_daf(int max_batch, int H, int ndir);
+static void fwd_tile_shape(int max_batch, int H, int ndir, bool split, int* jt_out, int* mtl_out);
+
+int ptmi_lstm_forward_fills(int32_t T, int32_t ndir, int32_t max_batch, int32_t H) {
+    if (T < 1 || max_batch < 1 || H < 1 || H % 4 != 0 || (ndir != 1 && ndir != 2) || !ptmi_lstm_split_enabled()) return 0;
+    if (getenv("PTMI_LSTM_NO_FWD_FILL")) return 0;
+    const int G32 = (4 * H + 31) / 32 * 32;
+    if ((G32 / 32 + 7) / 8 > 10 || !bwd_daf_applies() || !fwd_uses_daf(max_batch, H, ndir)) return 0;
+    // one forward launch (all row tiles resident at once), a wavefront without elements in its workgroups
+    int jt, mtl;
+    fwd_tile_shape(max_batch, H, ndir, true, &jt, &mtl);
+    const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
+    const int jx = (H + jt - 1) / jt;
+    return ((long long)jx * ndir * ntiles <= cu_count() && 16 * mtl * jt <= 7 * 64) ? 1 : 0;
+}
 
 int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward,
                               ptmi_stream_t stream) {
@@ -965,7 +979,7 @@ static bool fwd_uses_daf(int max_batch, int H, int ndir) {
 int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
-                                 int32_t ndir, int32_t prefilled, ptmi_stream_t stream) {
+                                 int32_t ndir, int32_t prefilled, uint32_t* backward_scratch, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !hy || !c || !w_hh_pad || !batch_sizes_dev || !offsets_dev || !flags, PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
@@ -1009,6 +1023,11 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     A.err_sink = error_sink();
     A.uniform = (rows == (int64_t)T * max_batch && !getenv("PTMI_LSTM_NO_UNIFORM")) ? 1 : 0;      // batch sizes never grow: equal lengths
     const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
+    if (backward_scratch && ptmi_lstm_forward_fills(T, ndir, max_batch, H)) {     // this layer's backward planes get their pattern here
+        const int G32 = (4 * H + 31) / 32 * 32;
+        A.fill_ptr = reinterpret_cast<uint4*>(backward_scratch);
+        A.fill_n16 = (unsigned long long)lstm_tile_elems(T, ndir, max_batch, G32) / 4;
+    }
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);

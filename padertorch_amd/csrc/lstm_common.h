@@ -44,6 +44,10 @@ struct LstmPersistArgs {
     // 3-D grid (unit tile, direction, row tile) in dispatch order
     int nx = 0, nt = 0, span = 0;
     int uniform = 0;         // split kernels: all sequences have the same length (bs[t] = max_batch, offs[t] = t max_batch)
+    // data-as-flag forward kernel: `fill_n16` 16-byte units from `fill_ptr` on (the hand-off planes of this layer's BACKWARD
+    // scratch) get the fill pattern from an otherwise idle wavefront, a slice per workgroup and step
+    uint4* fill_ptr = nullptr;
+    unsigned long long fill_n16 = 0;
 };
 
 // Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has

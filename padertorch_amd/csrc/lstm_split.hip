@@ -420,6 +420,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     constexpr int ACTW = (MR * JT + 63) / 64;
     int bx = blockIdx.x, bz = blockIdx.z, dir = blockIdx.y;
     if (A.span > 0 && !chain_tile(A.nx, A.nt, A.span, &bx, &bz, &dir, A.ndir * A.nt)) return;
+    // dense index of this workgroup among those that run (for its share of the backward scratch's fill)
+    const unsigned wg_lin = A.span > 0 ? (unsigned)((dir * A.nt + bz) * A.nx + bx)
+                                       : (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned wg_cnt = A.span > 0 ? (unsigned)(A.ndir * A.nt * A.nx) : gridDim.x * gridDim.y * gridDim.z;
     const int j0 = bx * JT;
     const int m0 = (A.tile0 + bz) * MR;
     const int H = A.H, G = 4 * H;
@@ -472,6 +476,19 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
         }
     }
+    // this workgroup's slice of the pattern fill, dealt out over the steps (the last wavefront owns no element here)
+    const unsigned long long fill_share = A.fill_ptr ? (A.fill_n16 + wg_cnt - 1) / wg_cnt : 0ull;
+    unsigned long long fill_pos = fill_share * wg_lin;
+    const unsigned long long fill_end = A.fill_ptr ? (fill_pos + fill_share < A.fill_n16 ? fill_pos + fill_share : A.fill_n16) : 0ull;
+    const unsigned long long fill_step = (fill_share + (unsigned)A.T - 1) / (unsigned)A.T;
+    auto fill_some = [&](bool all) {
+        if (ACTW < NW && wave >= ACTW && fill_pos < fill_end) {        // the wavefronts without elements share the step's portion
+            const unsigned long long stop = all ? fill_end : (fill_pos + fill_step < fill_end ? fill_pos + fill_step : fill_end);
+            const uint4 v = make_uint4(kFill, kFill, kFill, kFill);
+            for (unsigned long long i = fill_pos + (unsigned)(wave - ACTW) * 64u + lane; i < stop; i += 64u * (NW - ACTW)) A.fill_ptr[i] = v;
+            fill_pos = stop;
+        }
+    };
     DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : 100u, 0u, 0ull};      // (PTMI_LSTM_DBG bits 16-23: initial hold / 4)
     const bool adapt = !(A.dbg & (1 << 24));
     dd.mark();
@@ -498,7 +515,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                 for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
             }
         };
-        if (!has_rec) prefetch();
+        if (!has_rec) {
+            prefetch();
+            fill_some(s + 1 == A.T);
+        }
         if (has_rec) {
             if (act && b < nprev) cprev = c_reg;
             constexpr int NF = MTL * CB * 2;                 // fragments: (row tile mt, k block i, plane p)
@@ -559,6 +579,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[s & 1][wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
+            fill_some(s + 1 == A.T);
             __syncthreads();
             dd.mark();
             if (tid < MR * JT) {

@@ -339,9 +339,9 @@ def lstm_scratch_prefill(scratch, T, ndir, max_batch, H, backward):
 
 @_register('lstm_recurrence_forward(Tensor(a!) gates, Tensor(b!) hy, Tensor? c0, Tensor w_hh_pad, Tensor? w_amax, Tensor bs_dev, '
            'Tensor offs_dev, int bs_host, int offs_host, int T, int max_batch, int rows, int H, int KP, int ndir, bool persistent, '
-           'Tensor(c!)? scratch=None, bool prefilled=False) -> (Tensor, Tensor?)')
+           'Tensor(c!)? scratch=None, bool prefilled=False, Tensor(d!)? backward_scratch=None) -> (Tensor, Tensor?)')
 def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, KP, ndir,
-                            persistent, scratch=None, prefilled=False):
+                            persistent, scratch=None, prefilled=False, backward_scratch=None):
     """gates: pre-activations in, activations out (in place); hy: output rows (a view into the caller's padded buffer).
     Returns (c, scratch): scratch = the persistent kernel's flag / hand-off buffer (its last 8 words are the watchdog
     words), None when the one-launch-per-timestep kernels ran.  bs_host / offs_host: addresses of the HOST copies of the
@@ -358,7 +358,8 @@ def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, b
         assert flags.numel() >= n and flags.dtype == torch.int32
         rc = _lib.timed('lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
                         _lib.ptr(c0), w_hh_pad.data_ptr(), _lib.ptr(w_amax), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        flags.data_ptr(), T, max_batch, rows, H, KP, ndir, int(bool(prefilled and scratch is not None)), st)
+                        flags.data_ptr(), T, max_batch, rows, H, KP, ndir, int(bool(prefilled and scratch is not None)),
+                        _lib.ptr(backward_scratch), st)
         if rc not in (0, -2):
             _lib.check(rc, 'ptmi_lstm_forward_persistent')
     if rc == -2:        # configuration not resident-able: one launch per timestep

@@ -173,6 +173,8 @@ CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
 TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
 #: the data-as-flag pattern of the recurrences' hand-off planes filled ahead of time on the side stream (see _LstmLayerFn.forward)
 PREFILL_AHEAD = os.environ.get('PTMI_PREFILL_AHEAD', '0') != '0'      # measured neutral (7.87 vs 7.85 ms: the fill competes with the recurrence it runs next to): off
+#: the backward scratch's data-as-flag pattern written by the forward recurrence kernel (ptmi_lstm_forward_fills)
+FILL_IN_FORWARD = os.environ.get('PTMI_FILL_IN_FORWARD', '1') != '0'
 #: side queue: a layer's weight-gradient GEMMs start behind its recurrence, not behind its input-gradient GEMM
 WGRAD_BEFORE_DX = os.environ.get('PTMI_WGRAD_EARLY', '0') != '0'      # measured neutral (8.75 = 8.75 ms): off
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
@@ -461,6 +463,16 @@ class _LstmLayerFn(torch.autograd.Function):
                 for t_ in (scratch_f, scratch_b):
                     if t_ is not None:
                         t_.record_stream(pre)
+            if (PERSISTENT and scratch_b is None and x.is_cuda and any(ctx.needs_input_grad) and FILL_IN_FORWARD
+                    and lib.ptmi_lstm_forward_fills(meta.T, ndir, meta.max_batch, H)):
+                # the forward recurrence itself writes the pattern into the planes of this layer's backward scratch (an idle
+                # wavefront per workgroup, a slice per time step)
+                scratch_b = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
+                                        device=x.device)
+                pre_b = True
+                fill_b = scratch_b
+            else:
+                fill_b = None
             use_gemm = _gemm.usable(x, w_ih)
             # operand ranges of the split GEMM: the layer input is taken as it is when it is a hidden state (|h| < 1,
             # a dropout scale aside), measured otherwise; the stacked weights' maximum is cached per optimizer step
@@ -517,7 +529,9 @@ class _LstmLayerFn(torch.autograd.Function):
                 torch.cuda.current_stream(x.device).wait_event(filled)
             c, flags = torch.ops.ptmi.lstm_recurrence_forward(
                 gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f)
+                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b)
+            if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
+                pre_b = False
             ctx.scratch_b = (scratch_b, pre_b)
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:

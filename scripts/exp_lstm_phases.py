@@ -25,7 +25,7 @@ for it in range(3):
     hy = torch.empty(rows, ndir * H, device=dev); c = torch.empty_like(hy)
     scratch = torch.empty(n, dtype=torch.int32, device=dev)
     rc = lib.ptmi_lstm_forward_persistent(gates.data_ptr(), hy.data_ptr(), c.data_ptr(), None, w.data_ptr(), None, bs.data_ptr(),
-                                          offs.data_ptr(), scratch.data_ptr(), T, B, rows, H, KP, ndir, 0, _lib.stream(dev))
+                                          offs.data_ptr(), scratch.data_ptr(), T, B, rows, H, KP, ndir, 0, None, _lib.stream(dev))
     torch.cuda.synchronize()
     assert rc == 0, rc
 ph = scratch[:24].view(torch.int64).cpu().numpy().astype(np.float64) * 10.0 / (T - 1)      # ns per step (100 MHz clock)
