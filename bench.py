@@ -194,10 +194,11 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
         'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end)', 'hbm', feature_bytes),
         'pit_pairwise_sse': ('pit_pairwise_kernel (PIT mse+ips pairwise SSE)', 'hbm', pit_bytes),
         'pit_backward': ('pit_backward_kernel (d loss / d mask)', 'hbm', pit_bytes + K * F * 4 * fpl),
-        'lstm_forward': ('lstm_fwd_split_kernel (BLSTM recurrence, one persistent launch per layer, fp16 hi/lo MFMA products)',
+        'lstm_forward': ('lstm_fwd_daf_kernel (BLSTM recurrence, one persistent launch per layer, fp16 hi/lo MFMA products, data-as-flag '
+                         'hand-off)',
                          'mfma16x3', rec_flop),
-        'lstm_backward': ('lstm_bwd_split_kernel (BLSTM backward-through-time, one persistent launch per layer, bf16 hi/lo MFMA '
-                          'products)', 'mfma16x3', rec_flop),
+        'lstm_backward': ('lstm_bwd_split_kernel<DAF> (BLSTM backward-through-time, one persistent launch per layer, bf16 hi/lo MFMA '
+                          'products, data-as-flag hand-off)', 'mfma16x3', rec_flop),
     }
     kernels = []
     gemm, packs = {}, {}
@@ -238,7 +239,7 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
             e['us_per_timestep'] = ms * 1e3 / T
             e['frac_of_fp32_mfma_peak'] = achieved / FP32_MFMA_PEAK_TFLOPS       # the measure of round 1 (exact-fp32 MFMA kernels)
             e['peak_note'] = ('fp16/bf16 MFMA dense peak 2500 TFLOP/s / 3 products; the kernel is bound by the serial per-timestep '
-                              'hand-off (poll + operand gather + drain), not by the matrix cores')
+                              'hand-off (stores becoming visible + operand gather), not by the matrix cores')
         kernels.append(e)
     for (kind, products), e in gemm.items():
         if not e['launches']:
