@@ -987,7 +987,7 @@ static bool daf_enabled() {
 }
 
 bool fwd_daf_applies(int jt, bool small, bool one_per_cu) {
-    return daf_enabled() && one_per_cu && ((small && (jt == 12 || jt == 16)) || (!small && jt == 12));
+    return daf_enabled() && one_per_cu && ((small && (jt == 8 || jt == 12 || jt == 16)) || (!small && jt == 12));
 }
 
 bool bwd_daf_applies() { return daf_enabled(); }
@@ -1001,6 +1001,8 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<16, NW, CB, 1>), grid, block, 0, st, A);
         else if (jt == 12 && small)
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<12, NW, CB, 1>), grid, block, 0, st, A);
+        else if (jt == 8 && small)
+            hipLaunchKernelGGL((lstm_fwd_daf_kernel<8, NW, CB, 1>), grid, block, 0, st, A);
         else
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<12, NW, CB, 2>), grid, block, 0, st, A);
         return launch_status();

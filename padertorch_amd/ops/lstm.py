@@ -175,6 +175,8 @@ TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
 PREFILL_AHEAD = os.environ.get('PTMI_PREFILL_AHEAD', '0') != '0'      # measured neutral (7.87 vs 7.85 ms: the fill competes with the recurrence it runs next to): off
 #: the backward scratch's data-as-flag pattern written by the forward recurrence kernel (ptmi_lstm_forward_fills)
 FILL_IN_FORWARD = os.environ.get('PTMI_FILL_IN_FORWARD', '1') != '0'
+#: operand planes of the weight gradients that depend on forward data only (layer input, shifted output) packed during the forward pass
+PACK_IN_FORWARD = os.environ.get('PTMI_PACK_IN_FORWARD', '1') != '0'
 #: side queue: a layer's weight-gradient GEMMs start behind its recurrence, not behind its input-gradient GEMM
 WGRAD_BEFORE_DX = os.environ.get('PTMI_WGRAD_EARLY', '0') != '0'      # measured neutral (8.75 = 8.75 ms): off
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
@@ -437,6 +439,7 @@ class _LstmLayerFn(torch.autograd.Function):
             ctx.ext = None
             ctx.gemm = None
             ctx.scratch_b = (None, False)
+            ctx.fwd_planes = None
             if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
                 lease.release()
         else:
@@ -533,6 +536,28 @@ class _LstmLayerFn(torch.autograd.Function):
             if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
                 pre_b = False
             ctx.scratch_b = (scratch_b, pre_b)
+            # The transposed fp16 planes of this layer's input and of its shifted output - operand B of dW_ih = dg^T x and
+            # dW_hh = dg^T h_prev - depend on forward data only: packed NOW on the weight-gradient queue, which is idle during the
+            # forward pass (next to the recurrence just launched / the next layer's projection), instead of inside the backward
+            # phase, where that queue is the longer one.
+            ctx.fwd_planes = None
+            if (PACK_IN_FORWARD and use_gemm and _gemm.planes_enabled() and forms is not None and DEFER_WGRAD and WGRAD_SIDE_STREAM
+                    and not stateful and params is not None and torch.is_grad_enabled() and meta.equal_lengths
+                    and all(p.requires_grad and p.grad is not None for ps in params for p in ps)):
+                main_s = torch.cuda.current_stream(x.device)
+                side_s = _wgrad_stream(x.device)
+                ready = torch.cuda.Event()
+                ready.record(main_s)                     # behind the recurrence: x and hy (the shifted views of ext) are final
+                side_s.wait_event(ready)
+                with torch.cuda.stream(side_s):
+                    xp = _gemm.pack_t(x, amax_x)
+                    hp = [_gemm.pack_t(h_prev, _gemm.UNIT_RANGE)
+                          for _, h_prev in _recurrent_operands(meta, None, hy, ext if pad else None, None, ndir, H)]
+                    done = torch.cuda.Event()
+                    done.record(side_s)
+                for t_ in (x, ext):
+                    t_.record_stream(side_s)
+                ctx.fwd_planes = (xp, hp, done)
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
@@ -583,6 +608,9 @@ class _LstmLayerFn(torch.autograd.Function):
         main = torch.cuda.current_stream(x.device) if in_place else None
         side = _wgrad_stream(x.device) if use_side else main
         operands, xplanes = [None], {}
+        fwd_planes = getattr(ctx, 'fwd_planes', None) if (in_place and use_side) else None
+        if fwd_planes is not None and ctx.ext is None:
+            fwd_planes = None
 
         def wgrad_rows(dg, ranges, amax_dg, both_queues=False):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
@@ -601,11 +629,12 @@ class _LstmLayerFn(torch.autograd.Function):
                         k = r1 - r0
                         dgp = _gemm.pack_t(dgd[r0:r1], amax_dg)
                         key = (r0, r1)
+                        whole = fwd_planes is not None and key == (0, meta.rows)
                         if key not in xplanes:
-                            xplanes[key] = _gemm.pack_t(x[r0:r1], gm[0])
+                            xplanes[key] = fwd_planes[0] if whole else _gemm.pack_t(x[r0:r1], gm[0])
                         _gemm.mm_planes_(p_wih.grad, dgp, xplanes[key], G, x.shape[1], k, accumulate=True)
-                        _gemm.mm_planes_(p_whh.grad, dgp, _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None),
-                                         G, H, k, accumulate=True)
+                        hpl = fwd_planes[1][d] if whole else _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None)
+                        _gemm.mm_planes_(p_whh.grad, dgp, hpl, G, H, k, accumulate=True)
                     elif gm is not None:
                         _gemm.mm(dgt, x[r0:r1], out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=gm[0])
                         _gemm.mm(dgt, h_prev[r0:r1], out=p_whh.grad, accumulate=True, amax_x=amax_dg,
@@ -705,7 +734,13 @@ class _LstmLayerFn(torch.autograd.Function):
                     if ev is not None:
                         main.wait_event(ev)
                 operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
-                xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
+                if fwd_planes is not None:
+                    main.wait_event(fwd_planes[2])            # packed on the weight-gradient queue during the forward pass
+                    xplanes[todo[0]] = fwd_planes[0]
+                    for t in (fwd_planes[0][0],) + tuple(h[0] for h in fwd_planes[1]):
+                        t.record_stream(main)
+                else:
+                    xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
             if use_side and rec_done is not None and amax_kernel is not None and not both:
                 side.wait_event(rec_done)
             elif use_side:
@@ -752,11 +787,11 @@ def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
     """Per direction d the operands (a, b) of dW_hh[d] = a^T @ b: the gate gradients of every row and the
     hidden state that row's step consumed (zero / h0 for a sequence's first processed step)."""
     rows, G = meta.rows, 4 * H
-    dgv = dg.view(rows, ndir, G)
+    dgv = dg.view(rows, ndir, G) if dg is not None else None
     if ext is not None:             # equal lengths: the padded buffer of the forward pass, shifted by one step
         n0 = meta.bs0
         extv = ext.view(rows + 2 * n0, ndir, H)
-        return [(dgv[:, d], extv[:rows, 0] if d == 0 else extv[2 * n0:, 1]) for d in range(ndir)]
+        return [(dgv[:, d] if dgv is not None else None, extv[:rows, 0] if d == 0 else extv[2 * n0:, 1]) for d in range(ndir)]
     parts = [hy.view(rows, ndir, H), hy.new_zeros(1, ndir, H)]      # row `rows` = zero state
     prev = meta.prev_dev
     if h0 is not None:                                              # rows rows+1+b = h0[:, b]
