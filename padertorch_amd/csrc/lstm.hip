@@ -946,7 +946,8 @@ static void fwd_tile_shape(int max_batch, int H, int ndir, bool split, int* jt_o
     int jt = max_batch <= 16 ? 8 : 12, mtl = max_batch <= 32 ? 1 : 2;
     // split kernels, one 16-row tile per workgroup: 16 units (38 instead of 50 workgroups per chain at H = 600) measured
     // 3.19 against 3.27 us per step with the fragment-order hand-off copy, and leaves 48 more CUs to other queues
-    if (split && jt == 12 && mtl == 1) jt = 16;
+    // (flag-protocol kernels only; with the data-as-flag hand-off 12 units measure 2.48 against 2.55)
+    if (split && jt == 12 && mtl == 1 && !bwd_daf_applies()) jt = 16;
     if (jt == 12 && (long long)((H + 11) / 12) * ndir > cu_count()) jt = 16;      // wide tiles: one workgroup per CU
     if (jt == 16 && (long long)((H + 15) / 16) * ndir > cu_count()) jt = 8;
     if (const char* v = getenv("PTMI_LSTM_JT")) {
