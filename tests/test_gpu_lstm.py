@@ -339,3 +339,28 @@ def test_input_gradient_from_handoff_planes(B, T, H, monkeypatch):
     yc, _ = ref(torch.nn.utils.rnn.PackedSequence(xc, torch.full((T,), B, dtype=torch.int64)))
     (yc.data * w.cpu()).sum().backward()
     assert float((dx_planes.cpu() - xc.grad).abs().max()) < 1e-4 * scale
+
+
+@pytest.mark.gpu
+def test_nan_travels_through_the_data_as_flag_hand_off():
+    """The persistent kernels synchronise on the DATA (planes pre-filled with 0xFFFF in every 16-bit value; a consumer waits
+    while a value it needs still is that pattern).  A NaN hidden state must pass as data - the conversions produce the
+    canonical quiet NaN, not the fill pattern - and not stall the recurrence into its time-out."""
+    from padertorch_amd.ops import lstm as L
+    torch.manual_seed(3)
+    B, T, I, H = 32, 40, 64, 600
+    lstm = torch.nn.LSTM(I, H, 1, bidirectional=True).cuda()
+    xs = [torch.randn(T, I, device='cuda') for _ in range(B)]
+    xs[5][7, 3] = float('nan')                    # poisons sequence 5 from step 7 on (forward) / up to step 7 (reverse)
+    packed = torch.nn.utils.rnn.pack_sequence(xs)
+    before = int(L.error_count(torch.device('cuda', 0)).item())
+    with torch.no_grad():
+        y = L.packed_lstm(lstm, packed)
+    torch.cuda.synchronize()
+    out = y.data.view(T, B, 2 * H)
+    assert int(L.error_count(torch.device('cuda', 0)).item()) == before          # no wait ran out
+    assert torch.isnan(out[7:, 5, :H]).all() and torch.isnan(out[:8, 5, H:]).all()
+    ok = torch.ones(T, B, dtype=torch.bool, device='cuda')
+    ok[:, 5] = False
+    assert torch.isfinite(out[ok]).all()                                       # the other sequences are untouched
+    assert torch.isfinite(out[:7, 5, :H]).all() and torch.isfinite(out[8:, 5, H:]).all()
