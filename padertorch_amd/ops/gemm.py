@@ -149,6 +149,41 @@ def weight_planes_t(p):
     return v
 
 
+_SCALE_WORDS = {}
+
+
+def scale_word(device, value=8.0):
+    """Device word whose float value makes ``ptmi_gemm_planes`` take an operand scale of ``2^13 / value``: 8.0 for the forward
+    recurrence's hand-off planes, which hold fp16 halves of ``2^10 h``."""
+    key = (device.type, device.index, float(value))
+    if key not in _SCALE_WORDS:
+        _SCALE_WORDS[key] = torch.tensor([value], dtype=torch.float32, device=device).view(torch.int32)
+    return _SCALE_WORDS[key]
+
+
+def pad_direction_blocks(w, ndir, H, cols):
+    """``w [n, ndir * H]`` -> ``[n, ndir * cols]``: every direction's ``H`` input columns followed by ``cols - H`` zero columns
+    (the k layout of the forward recurrence's hand-off planes, ``ptmi_lstm_handoff_cols``)."""
+    out = w.new_zeros((w.shape[0], ndir, cols))
+    out[:, :, :H] = w.reshape(w.shape[0], ndir, H)
+    return out.view(w.shape[0], ndir * cols)
+
+
+def weight_planes_h(p, ndir, H, cols):
+    """``pack_n`` of a 2-D parameter ``W [out, ndir * H]`` with its input columns laid out like the hand-off planes
+    (:func:`pad_direction_blocks`), cached until the parameter is modified."""
+    key = ('h', id(p), cols)
+    hit = _WEIGHT_PLANES.get(key)
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+        return hit[2]
+    if len(_WEIGHT_PLANES) > 64:
+        _WEIGHT_PLANES.clear()
+    with torch.no_grad():
+        v = pack_n(pad_direction_blocks(p.detach(), ndir, H, cols), weight_absmax(p))
+    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v)
+    return v
+
+
 def stacked_planes_t_bf16(w, ndir, cols, key_params=None):
     """bf16 planes of the right operand of ``dgates @ w`` for ``w [ndir * G, I]`` (the two directions' ``weight_ih`` stacked)
     when ``dgates`` is taken from the backward recurrence's hand-off planes, whose k axis has ``cols >= G`` columns per

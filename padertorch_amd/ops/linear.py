@@ -28,6 +28,16 @@ class _LinearFn(torch.autograd.Function):
         if _gemm.planes_enabled() and x.stride(1) == 1:
             # both operands as fp16 planes (the weight's cached per optimizer step): csrc/gemm_planes.hip
             y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+            lh = _lstm.LAST_HANDOFF
+            if (lh is not None and _lstm.INPUT_FROM_HANDOFF and lh[0].data_ptr() == x.data_ptr() and lh[0].shape == x.shape
+                    and lh[0].stride() == x.stride() and lh[1] == x._version == lh[0]._version):
+                # x is the BLSTM output whose recurrence has left it as fp16 planes of 2^10 h: operand A as it lies
+                (scratch, cols), ndir, H = lh[2], lh[3], lh[4]
+                wpl = _gemm.weight_planes_h(module.weight, ndir, H, cols)
+                kh = ndir * cols
+                torch.ops.ptmi.gemm_planes_(y, scratch, _gemm.scale_word(x.device), wpl[0], wpl[1], bias, x.shape[0], weight.shape[0], kh,
+                                            False, _gemm.auto_split_k(x.shape[0], weight.shape[0], kh))
+                return y
             return _gemm.mm_planes_(y, _gemm.pack_n(x, amax_x), _gemm.weight_planes(module.weight), x.shape[0], weight.shape[0],
                                     x.shape[1], bias=bias)
         return _gemm.mm(x, weight.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)

@@ -177,6 +177,10 @@ PREFILL_AHEAD = os.environ.get('PTMI_PREFILL_AHEAD', '0') != '0'      # measured
 FILL_IN_FORWARD = os.environ.get('PTMI_FILL_IN_FORWARD', '1') != '0'
 #: operand planes of the weight gradients that depend on forward data only (layer input, shifted output) packed during the forward pass
 PACK_IN_FORWARD = os.environ.get('PTMI_PACK_IN_FORWARD', '1') != '0'
+#: the forward recurrence's hand-off planes as operand A of the next projection / of the dense layer behind the BLSTM (no pack pass)
+INPUT_FROM_HANDOFF = os.environ.get('PTMI_INPUT_HANDOFF', '1') != '0'
+#: (output tensor, its version, (scratch, cols), ndir, H) of the last packed_lstm call when its planes are valid, or None
+LAST_HANDOFF = None
 #: side queue: a layer's weight-gradient GEMMs start behind its recurrence, not behind its input-gradient GEMM
 WGRAD_BEFORE_DX = os.environ.get('PTMI_WGRAD_EARLY', '0') != '0'      # measured neutral (8.75 = 8.75 ms): off
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
@@ -384,12 +388,22 @@ def _stacked_weights(params, KP, stream=None):
                 I, H = p0.shape[1], params[0][1].shape[1]
                 # fp16 planes of the stacked input weights (the W of x W^T on csrc/gemm_planes.hip)
                 planes = _gemm.pack_n(w_ih_k[:, :I], amax[0:1]) if _gemm.planes_enabled() else None
+                # the same weights with their input columns laid out like the previous layer's hand-off planes (H columns per
+                # direction padded to the planes' width): that layer's scratch then is operand A of this layer's projection
+                planes_h = None
+                ndir_ = len(params)
+                cols_ = int(_lib.load().ptmi_lstm_handoff_cols(H, 0)) if (planes is not None and INPUT_FROM_HANDOFF) else 0
+                if cols_ and I == ndir_ * H:
+                    planes_h = (planes if cols_ == H else
+                                _gemm.pack_n(_gemm.pad_direction_blocks(w_ih_k[:, :I], ndir_, H, cols_), amax[0:1]), cols_)
             forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t,
-                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None, 'w_ih_planes': planes}
+                     'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None, 'w_ih_planes': planes,
+                     'w_ih_planes_h': planes_h}
             if stream is not None:
                 forms['ready'] = torch.cuda.Event()
                 forms['ready'].record(stream)
-                for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if planes is not None else ()):
+                for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if planes is not None else ()) + (
+                        (planes_h[0][0],) if planes_h is not None else ()):
                     t.record_stream(main)          # allocated on the side stream's pool, used (and later freed) on the main one
             _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
             _gemm.seed_weights_absmax([ps[1] for ps in params], amax[1:2])
@@ -413,7 +427,10 @@ class _LstmLayerFn(torch.autograd.Function):
     """x [rows, I] -> hy [rows, ndir*H] for one layer (both directions)."""
 
     @staticmethod
-    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False, anchor=None, forms=None):
+    def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False, anchor=None, forms=None, prev=None,
+                handoff=None):
+        # prev: {'planes': (scratch, cols)} of the layer whose output `x` is (its hand-off planes as this projection's operand);
+        # handoff: dict this call leaves its own planes in
         # anchor: a Parameter of the layer when (w_ih, bias, w_hh) are the cached detached forms (`forms`), so that the
         # node stays in the graph although none of its tensor inputs may require a gradient (first layer)
         lib = _lib.load()
@@ -482,7 +499,17 @@ class _LstmLayerFn(torch.autograd.Function):
             amax_x = (_gemm.UNIT_RANGE if x_unit else _gemm.absmax(x)) if use_gemm else None
             amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
                       if use_gemm else None)
-            if use_gemm and _gemm.planes_enabled() and forms is not None and forms.get('w_ih_planes') is not None:
+            hplanes = prev.get('planes') if prev else None
+            if (hplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
+                    and forms.get('w_ih_planes_h') is not None and forms['w_ih_planes_h'][1] == hplanes[1]):
+                # the previous layer's recurrence has left its output as fp16 (hi, lo) planes of 2^10 h in fragment order (its
+                # hand-off copy): operand A of this projection as it lies, no pack pass
+                gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
+                kh = (x.shape[1] // H) * hplanes[1]
+                wpl = forms['w_ih_planes_h'][0]
+                torch.ops.ptmi.gemm_planes_(gates, hplanes[0], _gemm.scale_word(x.device), wpl[0], wpl[1], bias, meta.rows, ndir * G, kh,
+                                            False, _gemm.auto_split_k(meta.rows, ndir * G, kh))
+            elif use_gemm and _gemm.planes_enabled() and forms is not None and forms.get('w_ih_planes') is not None:
                 # both operands as fp16 planes: the input split once here, the stacked weights' planes come with the forms
                 gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
                 _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), forms['w_ih_planes'], meta.rows, ndir * G, x.shape[1], bias=bias)
@@ -535,6 +562,10 @@ class _LstmLayerFn(torch.autograd.Function):
                 meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b)
             if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
                 pre_b = False
+            if handoff is not None and flags is not None and not stateful and meta.equal_lengths and meta.bs0 % 16 == 0:
+                cols_out = int(lib.ptmi_lstm_handoff_cols(H, 0))
+                if cols_out:
+                    handoff['planes'] = (flags, cols_out)
             ctx.scratch_b = (scratch_b, pre_b)
             # The transposed fp16 planes of this layer's input and of its shifted output - operand B of dW_ih = dg^T x and
             # dW_hh = dg^T h_prev - depend on forward data only: packed NOW on the weight-gradient queue, which is idle during the
@@ -769,7 +800,7 @@ class _LstmLayerFn(torch.autograd.Function):
                     t.record_stream(side)           # keep the operands alive until the side stream is done
             if GRAD_READY_HOOK is not None:
                 GRAD_READY_HOOK([p for ps in params for p in ps])
-            return (dx,) + (None,) * 10
+            return (dx,) + (None,) * 12
         db = dg.sum(0) if db_kernel is None else db_kernel
         if gm is not None:
             dw_ih = _gemm.mm(dg.t(), x, amax_x=amax_dg, amax_y=amax_x)
@@ -780,7 +811,7 @@ class _LstmLayerFn(torch.autograd.Function):
             dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
         if lease is not None:
             lease.release()
-        return (dx, dw_ih, db, dw_hh) + (None,) * 7
+        return (dx, dw_ih, db, dw_hh) + (None,) * 9
 
 
 def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
@@ -849,6 +880,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # the first layer's forms are needed at once: on the main queue itself (a cross-queue wait in front of the first
         # projection was measured to cost the main queue 110-260 us; the later layers' forms are long done when their
         # projection is reached, and a wait for a finished event costs nothing)
+    prev_handoff = None
     for layer in range(lstm.num_layers):
         params = all_params[layer]
         # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
@@ -871,17 +903,27 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0, anchor, forms)
+            prev_handoff = None
             hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
             h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:
-            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms)
+            out_handoff = {}
+            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms, prev_handoff, out_handoff)
+            prev_handoff = out_handoff
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
+            prev_handoff = None               # the next layer's input is no longer this layer's output
     if not (torch.is_grad_enabled() and h.requires_grad):
         # inference: nobody will run Trainer.clip_grad (which reads the watchdog words of the persistent kernels during
         # training) - check them here, so that results of a timed-out launch are never returned silently
         check_errors()
+    global LAST_HANDOFF
+    LAST_HANDOFF = None
+    if prev_handoff and prev_handoff.get('planes') is not None:
+        # (ops.linear takes these planes as operand A when its input is this very tensor)
+        # (the tensor itself is held: its memory cannot be handed to another tensor while the entry could still match)
+        LAST_HANDOFF = (h, h._version, prev_handoff['planes'], ndir, H)
     out = PackedSequence(h, packed.batch_sizes)
     if want_state:
         return out, (torch.stack(h_n), torch.stack(c_n))
