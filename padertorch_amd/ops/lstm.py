@@ -176,7 +176,7 @@ PREFILL_AHEAD = os.environ.get('PTMI_PREFILL_AHEAD', '0') != '0'      # measured
 #: the backward scratch's data-as-flag pattern written by the forward recurrence kernel (ptmi_lstm_forward_fills)
 FILL_IN_FORWARD = os.environ.get('PTMI_FILL_IN_FORWARD', '1') != '0'
 #: operand planes of the weight gradients that depend on forward data only (layer input, shifted output) packed during the forward pass
-PACK_IN_FORWARD = os.environ.get('PTMI_PACK_IN_FORWARD', '1') != '0'
+PACK_IN_FORWARD = os.environ.get('PTMI_PACK_IN_FORWARD', '0') != '0'      # measured: 7.95-8.07 vs 7.90 ms - pack passes next to a forward recurrence slow it by more than the backward phase gains
 #: the forward recurrence's hand-off planes as operand A of the next projection / of the dense layer behind the BLSTM (no pack pass)
 INPUT_FROM_HANDOFF = os.environ.get('PTMI_INPUT_HANDOFF', '1') != '0'
 #: (output tensor, its version, (scratch, cols), ndir, H) of the last packed_lstm call when its planes are valid, or None
@@ -573,7 +573,7 @@ class _LstmLayerFn(torch.autograd.Function):
             # phase, where that queue is the longer one.
             ctx.fwd_planes = None
             if (PACK_IN_FORWARD and use_gemm and _gemm.planes_enabled() and forms is not None and DEFER_WGRAD and WGRAD_SIDE_STREAM
-                    and not stateful and params is not None and torch.is_grad_enabled() and meta.equal_lengths
+                    and not stateful and params is not None and any(ctx.needs_input_grad) and meta.equal_lengths
                     and all(p.requires_grad and p.grad is not None for ps in params for p in ps)):
                 main_s = torch.cuda.current_stream(x.device)
                 side_s = _wgrad_stream(x.device)
