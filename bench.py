@@ -206,7 +206,7 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
         if n.startswith(('gemm_split:', 'gemm_planes:', 'gemm_planes_bf16:')):          # gemm_split:MxNxK:products, gemm_planes[_bf16]:MxNxK
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
-            key = ('planes', 3) if n.startswith('gemm_planes') else ('split', int(parts[2]))
+            key = ('planes_bf16', 3) if n.startswith('gemm_planes_bf16') else ('planes', 3) if n.startswith('gemm_planes') else ('split', int(parts[2]))
             e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
@@ -246,13 +246,15 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
             continue
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
-        label = ('gemm_planes_kernel (LSTM input projections, linears, their input gradients and all weight gradients: operands '
-                 'pre-split into fp16 (hi, lo) planes - bf16 planes straight from the backward recurrence for the LSTM input gradients -, 3 16-bit MFMA products per fp32 product)' if kind == 'planes' else
-                 f'gemm_split_ws_kernel (LSTM input gradients: fp32 operands split in registers, {products} fp16 MFMA products per '
-                 f'fp32 product)' if products == 3 else 'gemm_split_ws_kernel (dense layers, plain bf16 operands)')
+        label = ('gemm_planes_kernel<fp16> (LSTM input projections, linears, their input gradients and all weight gradients: operands '
+                 'pre-split into fp16 (hi, lo) planes, 3 fp16 MFMA products per fp32 product)' if kind == 'planes' else
+                 'gemm_planes_kernel<bf16> (LSTM input gradients dgates W_ih on the bf16 (hi, lo) planes the backward recurrence hands on, '
+                 '3 bf16 MFMA products per fp32 product)' if kind == 'planes_bf16' else
+                 f'gemm_split_ws_kernel (fp32 operands split in registers, {products} fp16 MFMA products per fp32 product)'
+                 if products == 3 else 'gemm_split_ws_kernel (dense layers, plain bf16 operands)')
         kernels.append(dict(
             kernel=label, bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak,
-            traffic=measured_traffic('gemm_' + kind),
+            traffic=measured_traffic('gemm_planes' if kind.startswith('planes') else 'gemm_' + kind),
             peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = '
                       f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream, i.e. '
                       f'mostly next to a running recurrence)',

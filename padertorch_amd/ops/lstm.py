@@ -396,14 +396,20 @@ def _stacked_weights(params, KP, stream=None):
                 if cols_ and I == ndir_ * H:
                     planes_h = (planes if cols_ == H else
                                 _gemm.pack_n(_gemm.pad_direction_blocks(w_ih_k[:, :I], ndir_, H, cols_), amax[0:1]), cols_)
-            forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t,
+                # bf16 planes of W_ih as the right operand of dx = dgates W_ih on the backward recurrence's planes (layers whose
+                # input needs a gradient: not the first); built here, off the backward pass' critical path
+                planes_dx = None
+                cols_b = int(_lib.load().ptmi_lstm_handoff_cols(H, 1)) if (planes is not None and DX_FROM_HANDOFF) else 0
+                if cols_b and I == ndir_ * H:
+                    planes_dx = (_gemm.stacked_planes_t_bf16(w_ih_k[:, :I], ndir_, cols_b), cols_b)
+            forms = {'w_ih': w_ih_k[:, :I], 'bias': bias, 'w_hh': w_pad[:, :, :H], 'w_pad': w_pad, 'w_t': w_t, 'w_ih_planes_dx': planes_dx,
                      'w_ih_kpad': w_ih_k if w_ih_k.shape[1] != I else None, 'ready': None, 'w_ih_planes': planes,
                      'w_ih_planes_h': planes_h}
             if stream is not None:
                 forms['ready'] = torch.cuda.Event()
                 forms['ready'].record(stream)
                 for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if planes is not None else ()) + (
-                        (planes_h[0][0],) if planes_h is not None else ()):
+                        (planes_h[0][0],) if planes_h is not None else ()) + ((planes_dx[0],) if planes_dx is not None else ()):
                     t.record_stream(main)          # allocated on the side stream's pool, used (and later freed) on the main one
             _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
             _gemm.seed_weights_absmax([ps[1] for ps in params], amax[1:2])
@@ -745,7 +751,9 @@ class _LstmLayerFn(torch.autograd.Function):
             elif cols and _gemm.planes_enabled() and meta.equal_lengths and meta.bs0 % 16 == 0:
                 # the recurrence has left its gate gradients as bf16 (hi, lo) planes in fragment order at the start of its
                 # scratch (the hand-off copy): for a batch of equal lengths they ARE operand A of dx = dgates W_ih
-                wplanes = _gemm.stacked_planes_t_bf16(w_ih, ndir, cols, None if params is None else [ps[0] for ps in params])
+                pdx = ctx.forms.get('w_ih_planes_dx') if ctx.forms is not None else None
+                wplanes = pdx[0] if (pdx is not None and pdx[1] == cols) else _gemm.stacked_planes_t_bf16(
+                    w_ih, ndir, cols, None if params is None else [ps[0] for ps in params])
                 dx = torch.empty((meta.rows, w_ih.shape[1]), dtype=torch.float32, device=dg.device)
                 torch.ops.ptmi.gemm_planes_bf16_(dx, flags, 0, wplanes, None, meta.rows, w_ih.shape[1], ndir * cols, False,
                                                  _gemm.auto_split_k(meta.rows, w_ih.shape[1], ndir * cols))
