@@ -36,3 +36,18 @@ def test_unpack_ragged_matches_torch():
         np.testing.assert_array_equal(a.numpy(), b.numpy())
     again = pm.pack_sequence(out)
     np.testing.assert_array_equal(again.data.numpy(), packed.data.numpy())
+
+
+def test_pad_direction_blocks_matches_the_hand_off_plane_layout():
+    """``ops.gemm.pad_direction_blocks``: every direction's H input columns followed by zero columns up to the width of the
+    forward recurrence's hand-off planes (the k layout the next projection's weights are packed with)."""
+    import torch
+    from padertorch_amd.ops.gemm import pad_direction_blocks
+    w = torch.arange(3 * 2 * 5, dtype=torch.float32).view(3, 10)          # 3 outputs, 2 directions x H = 5
+    p = pad_direction_blocks(w, 2, 5, 8)
+    assert p.shape == (3, 16)
+    assert torch.equal(p[:, 0:5], w[:, 0:5]) and torch.equal(p[:, 8:13], w[:, 5:10])
+    assert float(p[:, 5:8].abs().sum()) == 0 and float(p[:, 13:16].abs().sum()) == 0
+    x = torch.randn(4, 10)
+    xp = pad_direction_blocks(x, 2, 5, 8)
+    assert torch.allclose(xp @ p.t(), x @ w.t())                          # padded operands: same product
