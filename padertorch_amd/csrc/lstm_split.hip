@@ -412,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
 // operand tiles at once and again until none of their 16-bit values is the pattern: one store and one load round trip.
 // Every 4-byte word is written exactly once per launch and checked by the lane that uses it, so no ordering between
 // stores is assumed.  The partial sums are double-buffered in LDS (one barrier per step is left).
-template <int JT, int NW, int CB, int MTL>
+template <int JT, int NW, int CB, int MTL, int RED_PAD = 4>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
     constexpr int NT = NC / 16;
@@ -430,7 +430,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[2][NW][MR][NC + 1];
+    // row pitch NC + 4 (a multiple of 16, plus 4): the accumulator rows a wavefront writes at once - 4 g4 + q, 16 lanes each -
+    // fall into 64 different banks (pitch NC + 1: SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles)
+    __shared__ float red[2][NW][MR][NC + RED_PAD];
     const bool uniform = A.uniform != 0;
     auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
     auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[DAF ? 2 : 1][NW][MR][17];       // DAF: double-buffered by step parity (one barrier per step)
+    __shared__ float red[DAF ? 2 : 1][NW][MR][DAF ? 20 : 17];       // DAF: double-buffered by step parity (one barrier per step); pitch 20: conflict-free accumulator writes
     const bool uniform = UNI || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
     auto bs_at = [&](int t) { if (UNI) return A.max_batch; return uniform ? A.max_batch : A.bs[t]; };
     auto offs_at = [&](int t) { if (UNI) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
