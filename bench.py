@@ -440,6 +440,24 @@ def main():
             step(False, host)
         extras['ms_per_step_h2d'] = timed_loop(nx, source=host) / nx * 1e3
         extras['h2d_bytes_per_step'] = int((host['y'].numel() + host['s'].numel()) * 4 * micro)
+        # the same with the NEXT batch's transfer issued under the current step (padertorch_amd.data.DevicePrefetcher: what a
+        # data pipeline in front of Trainer.train does)
+        if micro == 1:
+            from padertorch_amd.data import DevicePrefetcher
+
+            def prefetched_loop(n):
+                sync()
+                t0 = time.perf_counter()
+                for src in DevicePrefetcher((host for _ in range(n)), device):
+                    feats = features(src)
+                    loss, _, _, _ = trainer.train_step(model, feats, device)
+                    loss.backward()
+                    trainer.optimizer_step()
+                trainer._check_pending(flush=True)
+                sync()
+                return time.perf_counter() - t0
+            prefetched_loop(3)
+            extras['ms_per_step_h2d_prefetched'] = prefetched_loop(nx) / nx * 1e3
     rccl = None
     if world > 1:
         flat = trainer._flat.flat

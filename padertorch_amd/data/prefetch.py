@@ -1,0 +1,71 @@
+"""Host -> device transfer of the NEXT batch under the current step.
+
+The reference moves a batch inside the step (``Trainer.step``: ``model.example_to_device(example, device)``,
+``padertorch/train/trainer.py:549``), i.e. the waveforms cross PCIe in front of the feature kernels (12.3 MB per
+optimizer step at BASELINE configs[1]: ~0.2 ms of the step).  :class:`DevicePrefetcher` wraps any iterable of nested
+examples (numpy arrays / pinned or pageable tensors) and hands out device copies that were issued one iteration early on a
+copy stream of their own; the consumer's stream only waits for the copy's event.  The examples it yields are what
+``example_to_device`` would have produced, so ``Trainer.step`` finds nothing left to move.
+"""
+import torch
+
+from .batch import example_to_device
+
+__all__ = ['DevicePrefetcher']
+
+
+def _tensors(example):
+    if torch.is_tensor(example):
+        yield example
+    elif isinstance(example, dict):
+        for v in example.values():
+            yield from _tensors(v)
+    elif isinstance(example, (list, tuple)):
+        for v in example:
+            yield from _tensors(v)
+
+
+class DevicePrefetcher:
+    """``for example in DevicePrefetcher(iterable, device): ...`` - ``example`` is already on ``device``.
+
+    ``to_device``: the function that moves one example (default: :func:`example_to_device`; a model's own
+    ``example_to_device`` can be passed when it does more than moving, as long as that work may run on the copy stream).
+    Host tensors should be pinned (``tensor.pin_memory()``) for the copy to be asynchronous.
+    """
+
+    def __init__(self, iterable, device, to_device=None):
+        self.iterable = iterable
+        self.device = torch.device(device)
+        self.to_device = to_device or example_to_device
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
+
+    def _issue(self, example):
+        if self._stream is None:
+            return self.to_device(example, self.device), None
+        with torch.cuda.stream(self._stream):
+            moved = self.to_device(example, self.device)
+            done = torch.cuda.Event()
+            done.record(self._stream)
+        return moved, done
+
+    def __iter__(self):
+        it = iter(self.iterable)
+        try:
+            nxt = self._issue(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            moved, done = nxt
+            try:
+                nxt = self._issue(next(it))       # the copy of the following batch runs under this batch's step
+            except StopIteration:
+                nxt = None
+            if done is not None:
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(done)
+                for t in _tensors(moved):
+                    t.record_stream(cur)          # allocated on the copy stream's pool, used (and freed) on the consumer's
+            yield moved
+
+    def __len__(self):
+        return len(self.iterable)

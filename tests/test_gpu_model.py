@@ -312,3 +312,18 @@ def test_trainer_rccl_path_world_size_1(g6, tmp_path, overlap):
         dist.destroy_process_group()
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), g6['pit_sd3_' + k], atol=2e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_device_prefetcher_overlaps_and_preserves_batches():
+    """``data.DevicePrefetcher`` on the GPU: pinned host batches arrive as device tensors with the right contents while the
+    consumer runs kernels in between (the copy of batch i + 1 is issued before batch i is consumed)."""
+    import torch
+    from padertorch_amd.data import DevicePrefetcher
+    host = [dict(y=torch.full((4, 1000), float(i)).pin_memory(), tag=i) for i in range(6)]
+    seen = []
+    for ex in DevicePrefetcher(host, 'cuda:0'):
+        assert ex['y'].is_cuda
+        z = ex['y'] * 2 + 1                       # consumer work on the current stream
+        seen.append((ex['tag'], float(z.min()), float(z.max())))
+    assert seen == [(i, 2.0 * i + 1, 2.0 * i + 1) for i in range(6)]

@@ -98,3 +98,17 @@ def test_sample_index_to_frame_index():
     # consistent with the frame count: the last sample of a signal maps to an existing frame
     for n in (600, 4000, 32000):
         assert st.sample_index_to_frame_index(n - 1) < st.samples_to_frames(n)
+
+
+def test_device_prefetcher_yields_what_example_to_device_would():
+    """``data.DevicePrefetcher`` (CPU: no copy stream, same values, same order, nested structure kept, nothing dropped)."""
+    import numpy as np
+    import torch
+    from padertorch_amd.data import DevicePrefetcher, example_to_device
+    batches = [dict(y=np.full((2, 3), i, dtype=np.float32), meta=dict(n=[3, 3], t=torch.tensor([i]))) for i in range(4)]
+    got = list(DevicePrefetcher(batches, 'cpu'))
+    assert len(got) == 4 and len(DevicePrefetcher(batches, 'cpu')) == 4
+    for i, g in enumerate(got):
+        want = example_to_device(batches[i], torch.device('cpu'))
+        assert torch.equal(g['y'], want['y']) and g['meta']['n'] == [3, 3] and int(g['meta']['t']) == i
+    assert list(DevicePrefetcher([], 'cpu')) == []
