@@ -212,3 +212,36 @@ def test_resume_restores_best_and_does_not_refire_triggers(g6, tmp_path):
     b.train(exs, resume=True, device='cpu')            # already at the stop iteration: nothing to do
     assert b._best == best
     assert (tmp_path / 'checkpoints' / 'ckpt_2.pth').stat().st_mtime_ns == mtime      # not validated / saved again
+
+
+def test_from_storage_dir_loads_a_reference_style_storage_dir(tmp_path):
+    """``Module.from_storage_dir`` (reference ``base.py:183-225``): the config file the reference Trainer writes names the
+    REFERENCE class; it resolves to this package's class, nested factories / partials are built, the weights come from
+    ``checkpoints/ckpt_best_loss.pth['model']``."""
+    import json
+    import torch
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    torch.manual_seed(0)
+    src = PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=3)
+    config = {'trainer': {'factory': 'padertorch.train.trainer.Trainer',
+                          'model': {'factory': 'padertorch.contrib.examples.source_separation.pit.model.'
+                                               'PermutationInvariantTrainingModel',
+                                    'F': 9, 'recurrent_layers': 2, 'units': 4, 'K': 3, 'dropout_input': 0.0,
+                                    'dropout_hidden': 0.0, 'dropout_linear': 0.0, 'output_activation': 'relu'},
+                          'optimizer': {'factory': 'padertorch.train.optimizer.Adam', 'lr': 0.001}}}
+    (tmp_path / 'checkpoints').mkdir()
+    (tmp_path / 'config.json').write_text(json.dumps(config))
+    torch.save({'model': src.state_dict(), 'iteration': 7}, tmp_path / 'checkpoints' / 'ckpt_best_loss.pth')
+    got = pt.Module.from_storage_dir(tmp_path)
+    assert type(got) is PermutationInvariantTrainingModel and got.K == 3
+    for (k, a), b in zip(src.state_dict().items(), got.state_dict().values()):
+        assert torch.equal(a, b), k
+    # an inner module, a partial and a plain torch factory
+    inner = {'net': {'factory': 'torch.nn.Linear', 'in_features': 3, 'out_features': 2},
+             'act': {'partial': 'torch.nn.functional.leaky_relu', 'negative_slope': 0.5}}
+    from padertorch_amd.base import _instantiate
+    built = _instantiate(inner)
+    assert isinstance(built['net'], torch.nn.Linear) and float(built['act'](torch.tensor(-2.0))) == -1.0
+    opt = _instantiate(config['trainer']['optimizer'])
+    assert isinstance(opt, pt.optimizer.Adam)
