@@ -167,12 +167,29 @@ def _rows_si_sdr(q, offset_invariant=False, grad_stop=False, soft_sdr_max=None):
     return -10 * torch.log10(s_norm / den)
 
 
+def _complex_as_real(x):
+    """complex64 ``[..., T]`` -> float32 ``[..., 2 T]`` (re, im interleaved): ``sum |e|^2``, ``sum |t|^2`` and ``Re sum e conj(t)``
+    of the complex signals are the plain sums of squares / the dot product of these real ones."""
+    if x.dtype != torch.complex64:
+        raise NotImplementedError(f'complex64 signals only, got {x.dtype}')
+    return torch.view_as_real(x.contiguous()).flatten(-2)
+
+
 def _plain(rows_fn, estimate, target, reduction, **kw):
+    halve_n = False
+    if isinstance(estimate, torch.Tensor) and isinstance(target, torch.Tensor) and (estimate.is_complex() or target.is_complex()):
+        # the error-energy losses are defined through |.| (reference ``regression.py:4-18``: torch.abs) and take complex
+        # signals; the scale-invariant ones use an unconjugated product there and stay real-only here
+        if rows_fn not in (_rows_mse, _rows_log_mse, _rows_log1p_mse, _rows_sdr):
+            raise NotImplementedError('complex signals: mse / log_mse / log1p_mse / sdr losses only')
+        assert estimate.is_complex() and target.is_complex(), (estimate.dtype, target.dtype)
+        estimate, target = _complex_as_real(estimate), _complex_as_real(target)
+        halve_n = True                                  # the time mean runs over T complex samples, not 2 T real ones
     estimate, target = _as_rows(estimate, 'estimate'), _as_rows(target, 'target')
     assert estimate.shape == target.shape, (estimate.shape, target.shape)
     lead, T = estimate.shape[:-1], estimate.shape[-1]
     q = pair_stats(estimate.reshape(-1, 1, T), target.reshape(-1, 1, T))
-    q = {k: (v.reshape(-1, 1) if k != 'n' else v) for k, v in q.items()}
+    q = {k: (v.reshape(-1, 1) if k != 'n' else (v / 2 if halve_n else v)) for k, v in q.items()}
     loss = rows_fn(q, **kw).reshape(lead)
     return _reduce(loss, reduction).to(estimate.dtype)
 

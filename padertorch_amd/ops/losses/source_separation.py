@@ -295,15 +295,29 @@ def pit_loss_from_loss_matrix(
 
     The assignment runs on the host with ``scipy.optimize.linear_sum_assignment`` exactly like the
     reference (one small D2H copy); returns scipy's ``col_ind`` (target index per estimate - the
-    inverse convention of :func:`pit_loss`).  ``algorithm='greedy'`` needs the third-party ``pb_bss``
-    package in the reference and is not provided here.
+    inverse convention of :func:`pit_loss`).  ``'greedy'`` / ``'brute_force'`` go through third-party
+    ``pb_bss.permutation_alignment._mapping_from_score_matrix`` in the reference (absent here, exercised by no
+    reference test beyond the doctest at ``:266-271``): restated from its published behaviour - greedy takes the
+    largest remaining score (smallest loss), removes its row and column and repeats; brute force is the optimal
+    assignment - and pinned by that doctest only (**parity otherwise unpinned**).
     """
     import scipy.optimize
     assert len(pair_wise_loss_matrix.shape) == 2, pair_wise_loss_matrix.shape
     assert pair_wise_loss_matrix.shape[-2] == pair_wise_loss_matrix.shape[-1], pair_wise_loss_matrix.shape
     pair_wise_loss_np = pair_wise_loss_matrix.detach().cpu().numpy()
-    if algorithm in ('optimal', 'hungarian'):
+    sources = pair_wise_loss_np.shape[-1]
+    if algorithm in ('optimal', 'hungarian', 'brute_force'):
         row_ind, col_ind = scipy.optimize.linear_sum_assignment(pair_wise_loss_np)
+    elif algorithm == 'greedy':
+        import numpy as np
+        left = np.array(pair_wise_loss_np, dtype=np.float64)
+        col_ind = np.zeros(sources, dtype=np.int64)
+        for _ in range(sources):
+            i, j = np.unravel_index(np.argmin(left), left.shape)       # first minimum in row-major order on ties
+            col_ind[i] = j
+            left[i, :] = np.inf
+            left[:, j] = np.inf
+        row_ind = np.arange(sources)
     else:
         raise ValueError(algorithm)
     if reduction is None:

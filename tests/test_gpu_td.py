@@ -182,3 +182,43 @@ def test_edge_shapes():
     want = norm_np.normalize(x, None, None, [1], 0, 1, None, True, True, 1e-5)
     np.testing.assert_allclose(y.cpu().numpy(), want[0], rtol=1e-4, atol=1e-5)
     assert n.cpu().numpy().tolist() == [[37.]] * 5
+
+
+@pytest.mark.gpu
+def test_complex_signals_error_energy_losses():
+    """mse / log_mse / log1p_mse / sdr on complex64 signals: the reference's formulas (``regression.py:4-18,47-160``: ``torch.abs``
+    of the error, time MEAN over the complex samples) evaluated directly in fp64 on the CPU, values and gradients; the
+    scale-invariant losses refuse complex input."""
+    import torch
+    from padertorch_amd.ops.losses import regression as R
+    torch.manual_seed(5)
+    e = torch.randn(3, 2, 777, dtype=torch.complex64)
+    t = torch.randn(3, 2, 777, dtype=torch.complex64)
+
+    def ref(name, e, t, soft=None):
+        err = (e - t).abs() ** 2
+        mse = err.mean(-1)
+        if name == 'mse':
+            return mse.sum()
+        if name == 'log_mse':
+            x = mse + (10 ** (-soft / 10) * (t.abs() ** 2).mean(-1) if soft else 0)
+            return torch.log10(x).sum()
+        if name == 'log1p_mse':
+            return torch.log10(1 + mse).sum()
+        num = (t.abs() ** 2).sum(-1)
+        den = err.sum(-1) + (10 ** (-soft / 10) * num if soft else 0)
+        return (-10 * torch.log10(num / den)).mean()
+
+    cases = [('mse', R.mse_loss, {}), ('log_mse', R.log_mse_loss, {}), ('log_mse', R.log_mse_loss, dict(soft_sdr_max=20)),
+             ('log1p_mse', R.log1p_mse_loss, {}), ('sdr', R.sdr_loss, {}), ('sdr', R.sdr_loss, dict(soft_sdr_max=30))]
+    for name, fn, kw in cases:
+        ed = e.to(torch.complex128).requires_grad_(True)
+        want = ref(name, ed, t.to(torch.complex128), kw.get('soft_sdr_max'))
+        want.backward()
+        eg = e.cuda().requires_grad_(True)
+        got = fn(eg, t.cuda(), **kw)
+        got.backward()
+        assert abs(float(got) - float(want)) < 2e-5 * max(1., abs(float(want))), (name, kw, float(got), float(want))
+        assert torch.allclose(eg.grad.cpu().to(torch.complex128), ed.grad, atol=2e-6, rtol=2e-4), (name, kw)
+    with pytest.raises(NotImplementedError):
+        R.si_sdr_loss(e.cuda(), t.cuda())

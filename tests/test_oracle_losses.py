@@ -62,3 +62,18 @@ def test_features_vs_reference(g3):
         assert f[k].dtype == np.float32 and f[k].shape == g3[k].shape
         np.testing.assert_array_equal(f[k], g3[k])
     np.testing.assert_array_equal(f['Y'], g3['Y'])
+
+
+def test_pit_loss_from_loss_matrix_greedy_doctest():
+    """The reference doctest of ``pit_loss_from_loss_matrix`` (``source_separation.py:258-271``): optimal -26, greedy -21 with
+    per-source losses [-11, -10, -0]."""
+    import numpy as np
+    import torch
+    from padertorch_amd.ops.losses.source_separation import pit_loss_from_loss_matrix
+    score = np.array([[11., 10, 0], [4, 5, 10], [6, 0, 5]])
+    m = torch.tensor(-score)
+    assert float(pit_loss_from_loss_matrix(m, reduction='sum', algorithm='optimal')) == -26.
+    assert float(pit_loss_from_loss_matrix(m, reduction='sum', algorithm='brute_force')) == -26.
+    assert float(pit_loss_from_loss_matrix(m, reduction='sum', algorithm='greedy')) == -21.
+    per, perm = pit_loss_from_loss_matrix(m, reduction=None, algorithm='greedy', return_permutation=True)
+    assert per.tolist() == [-11., -10., -0.] and list(perm) == [0, 2, 1]
