@@ -958,7 +958,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             dgp[3 * H] = go;
         }
     }
-    if (s1 < A.T && carries) A.dc_carry[((size_t)dir * A.max_batch + b) * H + j] = dc_state;
+    // cell-state gradient behind this launch's last step: what the next range continues from, and after the last range the
+    // gradient w.r.t. the initial cell state c0 (a sequence's thread keeps it from that sequence's first time step on)
+    if (carries) A.dc_carry[((size_t)dir * A.max_batch + b) * H + j] = dc_state;
     // bias gradient = sum of dgates over all rows; max |dgates| for the GEMMs that follow (operand scale)
     float* const fold = &red[0][0][0][0];
     __syncthreads();

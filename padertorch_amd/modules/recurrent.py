@@ -4,7 +4,8 @@ Same constructor; the parameters live in a ``torch.nn.LSTM`` (same ``state_dict`
 ``lstm.weight_ih_l0`` ...).  The time loop runs in ``csrc/lstm.hip`` (``ops.lstm.packed_lstm``); ``(h_n, c_n)`` of a call is
 carried into the next one like the reference does.  Documented difference: the carried states are
 constants of the next call (detached) - backpropagation does not reach across calls (the reference
-would need ``retain_graph`` for that; streaming use detaches anyway).
+would need ``retain_graph`` for that; streaming use detaches anyway).  ``ops.lstm.packed_lstm`` itself
+does differentiate w.r.t. an initial state handed to it.
 """
 import torch
 from torch.nn.utils.rnn import PackedSequence

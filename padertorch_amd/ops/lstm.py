@@ -444,7 +444,7 @@ class _LstmLayerFn(torch.autograd.Function):
         assert G == 4 * H
         KP = (H + 15) // 16 * 16
         stateful = h0 is not None or c0 is not None
-        if stateful:            # [ndir, B, H] constants (no gradient flows into the initial state)
+        if stateful:            # [ndir, B, H]; their gradients: see backward (persistent split kernels)
             h0 = torch.zeros_like(c0) if h0 is None else h0.detach().to(torch.float32).contiguous()
             c0 = torch.zeros_like(h0) if c0 is None else c0.detach().to(torch.float32).contiguous()
             assert h0.shape == c0.shape == (ndir, meta.max_batch, H), (h0.shape, c0.shape, meta.max_batch)
@@ -631,6 +631,8 @@ class _LstmLayerFn(torch.autograd.Function):
         else:
             x, w_ih, w_hh, gates, c, hy, h0, c0 = ctx.saved_tensors
             ndir, G, H = w_hh.shape
+        state_grad = False
+        carry = None
         gm, params = ctx.gemm, ctx.params
         has_grads = params is not None and all(p.grad is not None for ps in params for p in ps)
         if ctx.forms is not None and not has_grads:
@@ -690,7 +692,12 @@ class _LstmLayerFn(torch.autograd.Function):
             T = meta.T
             chunks = BWD_CHUNKS if (PERSISTENT and use_side and gm is not None and lib.ptmi_lstm_split_enabled()
                                     and T >= 64 * BWD_CHUNKS) else 1
-            if chunks > 1:
+            # gradients w.r.t. the initial state: the range entry point leaves the cell-state gradient behind the last step
+            state_grad = h0 is not None and any(ctx.needs_input_grad[5:7])
+            if state_grad and not (PERSISTENT and lib.ptmi_lstm_split_enabled()):
+                raise NotImplementedError('gradients w.r.t. the initial LSTM state need the persistent split kernels')
+            carry = None
+            if chunks > 1 or state_grad:
                 # the recurrence in `chunks` launches over consecutive step ranges: the weight-gradient GEMMs of the time
                 # range a launch has finished run on the side stream under the next launch (ptmi_lstm_backward_persistent_range)
                 dg = torch.empty_like(gates)
@@ -722,6 +729,9 @@ class _LstmLayerFn(torch.autograd.Function):
                     todo = [(offs[0], offs[T - s0]), (offs[s0], offs[T])][:ndir]
                 else:
                     dg = flags = None                                # not resident: the one-call path decides
+                    if state_grad:
+                        raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
+                                                  'persistent kernels')
             if dg is None:
                 dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                     gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
@@ -808,7 +818,10 @@ class _LstmLayerFn(torch.autograd.Function):
                     t.record_stream(side)           # keep the operands alive until the side stream is done
             if GRAD_READY_HOOK is not None:
                 GRAD_READY_HOOK([p for ps in params for p in ps])
-            return (dx,) + (None,) * 12
+            gh0 = gc0 = None
+            if state_grad:
+                gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
+            return (dx, None, None, None, None, gh0, gc0) + (None,) * 6
         db = dg.sum(0) if db_kernel is None else db_kernel
         if gm is not None:
             dw_ih = _gemm.mm(dg.t(), x, amax_x=amax_dg, amax_y=amax_x)
@@ -819,7 +832,20 @@ class _LstmLayerFn(torch.autograd.Function):
             dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
         if lease is not None:
             lease.release()
-        return (dx, dw_ih, db, dw_hh) + (None,) * 9
+        gh0 = gc0 = None
+        if lease is None and state_grad:
+            gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
+        return (dx, dw_ih, db, dw_hh, None, gh0, gc0) + (None,) * 6
+
+
+def _state_grads(meta, dg, w_hh, carry, ndir, G, needs):
+    """Gradients w.r.t. (h0, c0) ``[ndir, B, H]``: ``h0`` entered the pre-activations of each sequence's first processed step
+    through ``W_hh`` (``dh0 = dgates_first W_hh``), ``c0`` through that step's forget gate (the kernel's cell-state gradient
+    behind its last step)."""
+    dgv = dg.view(meta.rows, ndir, G)
+    gh0 = torch.stack([dgv[meta.first_rows[d], d] @ w_hh[d] for d in range(ndir)]) if needs[5] else None
+    gc0 = carry.clone() if needs[6] else None
+    return gh0, gc0
 
 
 def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
@@ -865,8 +891,6 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     want_state = return_state or hx is not None
     if hx is not None:
         h_all, c_all = hx
-        if h_all.requires_grad or c_all.requires_grad:
-            raise NotImplementedError('gradients w.r.t. the initial LSTM state are not implemented: detach it')
         assert h_all.shape == c_all.shape == (lstm.num_layers * ndir, meta.max_batch, H), (h_all.shape, meta.max_batch)
     h_n, c_n = [], []
     h = data.contiguous()

@@ -134,8 +134,12 @@ def test_initial_and_final_states_vs_torch_cpu(persistent, lens, monkeypatch):
     yr0, (hr0, cr0) = ref(pack_sequence(xs))
     np.testing.assert_allclose(hn0.cpu().numpy(), hr0.detach().numpy(), atol=3e-6)
     np.testing.assert_allclose(cn0.cpu().numpy(), cr0.detach().numpy(), atol=3e-6)
-    with pytest.raises(NotImplementedError):
-        packed_lstm(dut, pack_sequence(xd), hx=(h0.to(DEV).requires_grad_(True), c0.to(DEV)))
+    # a state that requires a gradient: served by the persistent split kernels (test_gradients_wrt_the_initial_state), refused -
+    # in the backward pass - by the one-launch-per-timestep kernels
+    out = packed_lstm(dut, pack_sequence([x.detach() for x in xd]), hx=(h0.to(DEV).requires_grad_(True), c0.to(DEV)))
+    if not persistent:
+        with pytest.raises(NotImplementedError):
+            out[0].data.sum().backward()
 
 
 def test_stateful_lstm_streams_like_the_reference_module():
@@ -364,3 +368,36 @@ def test_nan_travels_through_the_data_as_flag_hand_off():
     ok[:, 5] = False
     assert torch.isfinite(out[ok]).all()                                       # the other sequences are untouched
     assert torch.isfinite(out[:7, 5, :H]).all() and torch.isfinite(out[8:, 5, H:]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lens', [[9, 9, 9, 9], [12, 10, 7, 7, 3]])
+def test_gradients_wrt_the_initial_state(lens):
+    """``packed_lstm(lstm, packed, hx=(h0, c0))`` with states that require a gradient: ``dL/dh0`` (through ``W_hh`` into each
+    sequence's first processed step) and ``dL/dc0`` (the recurrence kernel's cell-state gradient behind its last step) against
+    torch's CPU LSTM, two layers, both directions, ragged batch."""
+    from padertorch_amd.ops import lstm as L
+    torch.manual_seed(11)
+    I, H, layers = 10, 12, 2
+    B = len(lens)
+    lstm = torch.nn.LSTM(I, H, layers, bidirectional=True).cuda()
+    ref = torch.nn.LSTM(I, H, layers, bidirectional=True)
+    ref.load_state_dict(lstm.state_dict())
+    xs = [torch.randn(n, I) for n in lens]
+    h0 = torch.randn(2 * layers, B, H) * 0.5
+    c0 = torch.randn(2 * layers, B, H) * 0.5
+    w = torch.randn(sum(lens), 2 * H)
+
+    def run(mod, dev, fn):
+        hh = h0.to(dev).requires_grad_(True)
+        cc = c0.to(dev).requires_grad_(True)
+        packed = pack_sequence([x.to(dev) for x in xs])
+        out = fn(mod, packed, (hh, cc))
+        (out.data * w.to(dev)).sum().backward()
+        return out.data.detach().cpu(), hh.grad.cpu(), cc.grad.cpu()
+
+    y, gh, gc = run(lstm, 'cuda', lambda m, p, hx: L.packed_lstm(m, p, hx=hx)[0])
+    yr, ghr, gcr = run(ref, 'cpu', lambda m, p, hx: m(p, hx)[0])
+    assert float((y - yr).abs().max()) < 2e-5
+    assert float((gh - ghr).abs().max()) < 1e-4 * max(1., float(ghr.abs().max())), float((gh - ghr).abs().max())
+    assert float((gc - gcr).abs().max()) < 1e-4 * max(1., float(gcr.abs().max())), float((gc - gcr).abs().max())
