@@ -186,6 +186,91 @@ __global__ __launch_bounds__(WM * WN * 64, 1) void gemm_planes_big_kernel(const 
 #endif
 }
 
+template <int MT, int NT, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 1) void gemm_planes_big3_kernel(const uint4* __restrict__ A, const uint4* __restrict__ B,
+                                                                          float* __restrict__ C, int M, int N, int KB, int ldc,
+                                                                          float inv_scale, int tiles_n) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int NWAVE = WM * WN, RA = WM * MT, RB = WN * NT, PIECES = 2 * (RA + RB), PW = PIECES / NWAVE;
+    static_assert(PIECES % NWAVE == 0, "pieces per wave");
+    __shared__ uint4 lds[3 * PIECES * FR];      // three stages: the pieces of stage kb + 2 are issued during step kb
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const uint4* gsrc[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        const int f = wave * PW + i;                       // piece: A pieces first (row tile, plane), then B
+        const bool isa = f < 2 * RA;
+        const int rt = (isa ? f : f - 2 * RA) >> 1, p = f & 1;
+        const long long row_tile = (long long)(isa ? tm * RA : tn * RB) + rt;
+        const long long max_tile = ((isa ? M : N) + 15) / 16 - 1;
+        gsrc[i] = (isa ? A : B) + ((min(row_tile, max_tile) * KB) * 2 + p) * FR + lane;
+    }
+    f4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PW; ++i) __builtin_amdgcn_global_load_lds(gsrc[i], &lds[(wave * PW + i) * FR], 16, 0, 0);
+    if (KB > 1) {
+#pragma unroll
+        for (int i = 0; i < PW; ++i) __builtin_amdgcn_global_load_lds(gsrc[i] + 2 * FR, &lds[(PIECES + wave * PW + i) * FR], 16, 0, 0);
+    }
+    int st = 0;
+    for (int kb = 0; kb < KB; ++kb) {
+        // stage kb has landed when at most the PW pieces of stage kb + 1 (issued during step kb - 1) are still in flight
+        if (kb + 1 < KB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int st2 = st >= 1 ? st - 1 : 2;           // (st + 2) % 3: the stage read in step kb - 1, free again behind the barrier
+        const uint4* sa = &lds[(st * PIECES + wm * MT * 2) * FR + lane];
+        const uint4* sb = &lds[(st * PIECES + 2 * RA + wn * NT * 2) * FR + lane];
+        const bool more = kb + 2 < KB;
+        h8 bh[NT], bl[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            bh[j] = __builtin_bit_cast(h8, sb[(j * 2 + 0) * FR]);
+            bl[j] = __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
+        }
+        h8 ah = __builtin_bit_cast(h8, sa[0]), al = __builtin_bit_cast(h8, sa[FR]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            h8 nh = ah, nl = al;
+            if (i + 1 < MT) {
+                nh = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 0) * FR]);
+                nl = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
+            }
+#pragma unroll
+            for (int q = 0; q < (PW + MT - 1) / MT; ++q) {
+                const int pc = i * ((PW + MT - 1) / MT) + q;
+                if (pc < PW && more)
+                    __builtin_amdgcn_global_load_lds(gsrc[pc] + (long long)(kb + 2) * 2 * FR, &lds[(st2 * PIECES + wave * PW + pc) * FR], 16, 0, 0);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? bl[j] : bh[j], p == 1 ? al : ah, acc[i][j], 0, 0, 0);
+            ah = nh;
+            al = nl;
+        }
+        st = st == 2 ? 0 : st + 1;
+    }
+    const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = (tm * WM + wm) * MT * 16 + i * 16 + r;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = (tn * WN + wn) * NT * 16 + j * 16 + g * 4;
+            if (m < M && n + 3 < N) *reinterpret_cast<f4*>(C + (long long)m * ldc + n) = acc[i][j] * inv_scale;
+        }
+    }
+#endif
+}
+
 // host-side packing of a row-major fp32 matrix [R][K] (scale s) into the plane-tile layout
 void pack(const std::vector<float>& x, int R, int K, float s, std::vector<_Float16>& out, bool linear) {
     const int RT = (R + 15) / 16, KB = (K + 31) / 32;
@@ -215,6 +300,18 @@ template <int MT, int NT, int WM, int WN>
 void launch_big(dim3, const uint4* a, const uint4* b, float* c, int M, int N, int KB, int ldc, float inv, int) {
     const int tn = (N + WN * NT * 16 - 1) / (WN * NT * 16), tmm = (M + WM * MT * 16 - 1) / (WM * MT * 16);
     hipLaunchKernelGGL((gemm_planes_big_kernel<MT, NT, WM, WN>), dim3(tmm * tn), dim3(WM * WN * 64), 0, 0, a, b, c, M, N, KB, ldc, inv, tn);
+}
+
+template <int MT, int NT, int WM, int WN>
+void launch_big3(dim3, const uint4* a, const uint4* b, float* c, int M, int N, int KB, int ldc, float inv, int) {
+    const int tn = (N + WN * NT * 16 - 1) / (WN * NT * 16), tmm = (M + WM * MT * 16 - 1) / (WM * MT * 16);
+    static bool once = false;
+    if (!once) {
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_planes_big3_kernel<MT, NT, WM, WN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+        once = true;
+    }
+    hipLaunchKernelGGL((gemm_planes_big3_kernel<MT, NT, WM, WN>), dim3(tmm * tn), dim3(WM * WN * 64), 0, 0, a, b, c, M, N, KB, ldc, inv, tn);
 }
 
 float run(launch_fn fn, const uint4* dA, const uint4* dB, float* dC, int M, int N, int K, float inv, int iters) {
@@ -260,6 +357,9 @@ int main(int argc, char** argv) {
             const float b2 = run(launch_big<4, 4, 4, 2>, dA, dB, dC, M, N, K, inv, 20);
             const float b3 = run(launch_big<4, 4, 2, 4>, dA, dB, dC, M, N, K, inv, 20);
             const float b4 = run(launch_big<4, 4, 2, 2>, dA, dB, dC, M, N, K, inv, 20);
+            const float c2 = run(launch_big3<4, 4, 4, 2>, dA, dB, dC, M, N, K, inv, 20);
+            const float c3 = run(launch_big3<4, 4, 2, 4>, dA, dB, dC, M, N, K, inv, 20);
+            printf("   3 stages, counted vmcnt, 8 waves: 256x128: %.1f us (%.0f)   128x256: %.1f us (%.0f)\n", c2, flop / c2 * 1e-6, c3, flop / c3 * 1e-6);
             printf("   8 waves 256x256: %.1f us (%.0f)   256x128: %.1f us (%.0f)   128x256: %.1f us (%.0f)   4 waves 128x128: %.1f us (%.0f)\n", b1, flop / b1 * 1e-6,
                    b2, flop / b2 * 1e-6, b3, flop / b3 * 1e-6, b4, flop / b4 * 1e-6);
         }
