@@ -426,6 +426,10 @@ int ptmi_pack_planes_t_bf16(const float* x, int64_t k_rows, int64_t cols, int64_
 int ptmi_pack_planes_n_bf16(const float* x, int64_t rows, int64_t k, int64_t ld, uint16_t* out, ptmi_stream_t stream);
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
                           int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream);
+/* Calls without split K run on a persistent big-tile kernel (8 wavefronts, workgroup tile picked per problem by a cost model:
+ * 0 = 256 x 320, 1 = 256 x 256, 2 = 256 x 192, 3 = 128 x 320, 4 = 128 x 256) or on the 128 x 128 kernel (5) that also carries
+ * every split-K call.  ptmi_gemm_planes_select_tile pins that choice for the process (tests, A/B timing); -1 = the cost model. */
+int ptmi_gemm_planes_select_tile(int32_t tile);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer step on the Trainer's flat gradient bucket (csrc/optim.hip): replaces, on the step path of

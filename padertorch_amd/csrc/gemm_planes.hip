@@ -15,6 +15,14 @@
 // (two workgroups per CU), ONE barrier per k step, the 8 LDS-DMA pieces of the next stage dealt out between the MFMA
 // groups of the current one; split K through slabs summed in slab order (reproducible, no atomics, nobody waits for a
 // sibling workgroup: safe next to the persistent recurrence kernels).  Prototype + measurements: scripts/mb/gemm_planes.hip.
+//
+// Round 3: gemm_planes_big_kernel - the same arithmetic as a PERSISTENT big-tile kernel for the shapes without split K (input
+// projections, LSTM input gradients, linears): 8 wavefronts (2 x 4), wave tile (16 MT) x (16 NT), workgroup tile 256 x 320 /
+// 256 x 256 / 128 x 320 / 256 x 192 / 128 x 256 picked per problem so that the tile count fills whole rounds of the CUs
+// (N = 4800 = 15 x 320); grid = min(tiles, CUs), every workgroup walks its tiles (XCD-aware, band-major) in ONE flat (tile, k step)
+// loop, so the LDS-DMA of the next tile's first stage is in flight while the finished tile is stored and the pipeline never
+// drains; LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds: one VGPR of lane offset, piece offsets in SGPRs).
+// No workgroup waits for another.  Prototype, ablations and the zero-data (DVFS) comparison: scripts/mb/gemm_big.hip, DESIGN 3.9.
 #include <algorithm>
 
 #include "common.h"
@@ -170,6 +178,188 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
             }
         }
     }
+#endif
+}
+
+struct BigArgs {
+    const uint4* A;             // planes of the M-side operand
+    const uint4* B;             // planes of the N-side operand
+    float* C;
+    const unsigned* amax_a;
+    const unsigned* amax_b;
+    const float* bias;          // [N] or null
+    int M, N, KB;               // KB = k blocks of 32 in the planes
+    long long ldc;
+    int accumulate;
+    int tiles_m, tiles_n, band;
+    unsigned a_bytes, b_bytes;  // extent of the planes (buffer descriptors: < 4 GB)
+};
+
+template <bool BF16, int MT, int NT>
+__global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int WM = 2, WN = 4, RA = WM * MT, RB = WN * NT, PIECES = 2 * (RA + RB);
+    constexpr int PA = 2 * RA / 8, PB = 2 * RB / 8, PW = PA + PB;          // 1 KB plane tiles every wavefront copies per k step
+    static_assert((2 * RA) % 8 == 0 && (2 * RB) % 8 == 0, "pieces per wave");
+    __shared__ uint4 lds[2 * PIECES * FR];      // two stages of [A pieces (row tile, plane) | B pieces]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(G.A), 0, G.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(G.B), 0, G.b_bytes, 0x00020000);
+    const int voff = lane * 16;
+    const int KB = G.KB;
+    const int rta = (G.M + 15) / 16, rtb = (G.N + 15) / 16;
+    const float inv = 1.f / (plane_scale(G.amax_a) * plane_scale(G.amax_b));
+
+    // this workgroup's tiles: workgroup id b runs on XCD b % 8; every XCD owns one contiguous range of the band-major tile list
+    // (bands of G.band tile rows, column by column), of which its j-th workgroup takes every (grid / 8)-th
+    const int T = G.tiles_m * G.tiles_n;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int q = T / 8, r8 = T % 8;
+    const int cnt = xcd < r8 ? q + 1 : q;
+    const int first = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    if (j0 >= cnt) return;
+    const int band_tiles = G.band * G.tiles_n;
+    auto tile_rc = [&](int idx, int& tm, int& tn) {
+        const int b = idx / band_tiles, rem = idx - b * band_tiles;
+        const int h = min(G.band, G.tiles_m - b * G.band);
+        tn = rem / h;
+        tm = b * G.band + (rem - tn * h);
+    };
+    auto issue = [&](int i, int tm, int tn, int kb, int st) {            // piece i of this wavefront for (tile, k step) into stage st
+        if (i < PA) {
+            const int f = wave * PA + i;
+            const int rt = min(tm * RA + (f >> 1), rta - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, &lds[(st * PIECES + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
+        } else {
+            const int f = wave * PB + (i - PA);
+            const int rt = min(tn * RB + (f >> 1), rtb - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, &lds[(st * PIECES + 2 * RA + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
+        }
+    };
+
+    f4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    int idx = j0, tm, tn;
+    tile_rc(first + idx, tm, tn);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) issue(i, tm, tn, 0, 0);
+    int st = 0;
+    constexpr int PPI = (PW + MT - 1) / MT;             // pieces issued per row-tile iteration
+    while (true) {
+        const int nidx = idx + per;
+        const bool has_next_tile = nidx < cnt;
+        int ntm = tm, ntn = tn;
+        if (has_next_tile) tile_rc(first + nidx, ntm, ntn);
+        for (int kb = 0; kb < KB; ++kb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of stage `st` have landed
+            __builtin_amdgcn_s_barrier();                             // everybody's have; everybody is done reading stage st ^ 1
+            // the stage requested during this step: the next k step of this tile, or the first one of the next tile (behind the
+            // very last step: this tile's first stage once more - never read, keeps the loop free of branches)
+            const bool last = kb + 1 == KB;
+            const int ptm = last ? ntm : tm, ptn = last ? ntn : tn, pkb = last ? 0 : kb + 1;
+            const uint4* sa = &lds[(st * PIECES + wm * MT * 2) * FR + lane];
+            const uint4* sb = &lds[(st * PIECES + 2 * RA + wn * NT * 2) * FR + lane];
+            h8 bh[NT], bl[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = __builtin_bit_cast(h8, sb[(j * 2 + 0) * FR]);
+                bl[j] = __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
+            }
+            h8 ah = __builtin_bit_cast(h8, sa[0]), al = __builtin_bit_cast(h8, sa[FR]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                h8 nh = ah, nl = al;
+                if (i + 1 < MT) {
+                    nh = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 0) * FR]);
+                    nl = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
+                }
+#pragma unroll
+                for (int pc = i * PPI; pc < (i + 1) * PPI; ++pc)
+                    if (pc < PW) issue(pc, ptm, ptn, pkb, st ^ 1);
+                // D[n = 4 (lane >> 4) + e][m = lane & 15]: the MFMA's "a" operand is the B fragment, so a lane holds four consecutive
+                // columns of C; product kind outermost: NT independent MFMAs between two on one accumulator
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = BF16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, p == 0 ? bl[j] : bh[j]),
+                                                                                   __builtin_bit_cast(b8, p == 1 ? al : ah), acc[i][j], 0, 0, 0)
+                                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? bl[j] : bh[j], p == 1 ? al : ah, acc[i][j], 0, 0, 0);
+                ah = nh;
+                al = nl;
+            }
+            st ^= 1;
+        }
+        // epilogue of tile (tm, tn); the next tile's first stage is in flight meanwhile
+        {
+            const int r = lane & 15, g = lane >> 4;
+            const int n0 = (tn * WN + wn) * NT * 16 + g * 4;
+            const bool vec = (G.ldc & 3) == 0 && (reinterpret_cast<unsigned long long>(G.C) & 15) == 0;
+            const bool full = vec && (tn * WN + wn + 1) * NT * 16 <= G.N;           // wave-uniform: every column of this wave's tile exists
+            f4 bv[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bv[j] = f4{0.f, 0.f, 0.f, 0.f};
+                if (G.bias) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bv[j][e] = G.bias[min(n0 + j * 16 + e, G.N - 1)];
+                }
+            }
+            const int mrow = (tm * WM + wm) * MT * 16 + r;
+            float* const crow = G.C + (long long)mrow * G.ldc + n0;
+            if (full && !G.accumulate) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const f4 v = acc[i][j] * inv + bv[j];
+                        acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                        if (mrow + i * 16 < G.M) *reinterpret_cast<f4*>(crow + (long long)i * 16 * G.ldc + j * 16) = v;
+                    }
+                }
+            } else if (full) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const bool ok = mrow + i * 16 < G.M;
+                    f4 old[NT];                         // all of a row tile's loads in flight before the first add
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        old[j] = ok ? *reinterpret_cast<const f4*>(crow + (long long)i * 16 * G.ldc + j * 16) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const f4 v = acc[i][j] * inv + bv[j] + old[j];
+                        acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                        if (ok) *reinterpret_cast<f4*>(crow + (long long)i * 16 * G.ldc + j * 16) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const bool ok = mrow + i * 16 < G.M;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const f4 v = acc[i][j] * inv + bv[j];
+                        acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                        float* o = crow + (long long)i * 16 * G.ldc + j * 16;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ok && n0 + j * 16 + e < G.N) o[e] = G.accumulate ? o[e] + v[e] : v[e];
+                    }
+                }
+            }
+        }
+        if (!has_next_tile) break;          // (the stage requested during the last step is never read; the wait below retires it)
+        idx = nidx;
+        tm = ntm;
+        tn = ntn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 
@@ -338,6 +528,74 @@ int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_
 
 }  // extern "C"
 
+// ---------------------------------------------------------------------------------------------------------------- big-tile dispatch
+static int g_tile_override = -1;        // ptmi_gemm_planes_select_tile
+
+static int cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            cus = v;
+        else
+            cus = 256;
+    }
+    return cus;
+}
+
+template <bool BF16, int MT, int NT>
+static void launch_big_inst(const BigArgs& G0, hipStream_t st) {
+    BigArgs G = G0;
+    G.tiles_m = (G.M + 32 * MT - 1) / (32 * MT);
+    G.tiles_n = (G.N + 64 * NT - 1) / (64 * NT);
+    const int T = G.tiles_m * G.tiles_n;
+    const int grid = std::min((T + 7) / 8 * 8, cu_count() / 8 * 8);
+    hipLaunchKernelGGL((gemm_planes_big_kernel<BF16, MT, NT>), dim3((unsigned)grid), dim3(512), 0, st, G);
+}
+
+// Picks the tile by a cost model fitted to scripts/mb/gemm_big.hip's measurements (profiles/r3_mb_gemm_big.txt): time ~ rounds of
+// the CUs x tile area / efficiency of the tile shape; the 128 x 128 kernel (two workgroups per CU at half speed each) is one of the
+// candidates.  Returns false when that one wins or the planes do not fit a buffer descriptor.  PTMI_GEMM_BIG=0: never.
+static bool launch_big(bool bf16, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias,
+                       float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st) {
+    static const bool enabled = !(getenv("PTMI_GEMM_BIG") && getenv("PTMI_GEMM_BIG")[0] == '0');
+    if (!enabled || g_tile_override == 5) return false;
+    const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
+    if (a_bytes >= (1ll << 32) || b_bytes >= (1ll << 32)) return false;
+    struct Cand { int mt, nt; double eff; };
+    static const Cand cands[] = {{8, 5, 1.0}, {8, 4, 1.0}, {8, 3, 0.92}, {4, 5, 0.86}, {4, 4, 0.85}};
+    const int cus = cu_count();
+    const long long t128 = (long long)((m + 127) / 128) * ((n + 127) / 128);
+    double best = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 2.0 * 128 * 128 / 0.79;
+    int pick = -1;
+    for (int i = 0; i < 5; ++i) {
+        const long long tiles = (long long)((m + 32 * cands[i].mt - 1) / (32 * cands[i].mt)) * ((n + 64 * cands[i].nt - 1) / (64 * cands[i].nt));
+        const double cost = (double)((tiles + cus - 1) / cus) * (32.0 * cands[i].mt) * (64.0 * cands[i].nt) / cands[i].eff;
+        if (cost < best) {
+            best = cost;
+            pick = i;
+        }
+    }
+    if (g_tile_override >= 0 && g_tile_override < 5) pick = g_tile_override;
+    if (pick < 0) return false;
+    BigArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, amax_a, amax_b, bias, m, n, KB, (long long)ldc,
+              accumulate ? 1 : 0, 0, 0, 4, (unsigned)a_bytes, (unsigned)b_bytes};
+#define PTMI_BIG_CASE(I, MT_, NT_)                                    \
+    case I:                                                           \
+        if (bf16) launch_big_inst<true, MT_, NT_>(G, st);             \
+        else launch_big_inst<false, MT_, NT_>(G, st);                 \
+        break;
+    switch (pick) {
+        PTMI_BIG_CASE(0, 8, 5)
+        PTMI_BIG_CASE(1, 8, 4)
+        PTMI_BIG_CASE(2, 8, 3)
+        PTMI_BIG_CASE(3, 4, 5)
+        PTMI_BIG_CASE(4, 4, 4)
+    }
+#undef PTMI_BIG_CASE
+    return true;
+}
+
 static int gemm_planes_impl(bool bf16, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
                             const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate,
                             int32_t split_k, float* workspace, ptmi_stream_t stream) {
@@ -348,10 +606,11 @@ static int gemm_planes_impl(bool bf16, const uint16_t* a, const uint32_t* amax_a
     const int per = (KB + splits - 1) / splits;
     splits = (KB + per - 1) / per;
     PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (splits == 1 && launch_big(bf16, a, amax_a, b, amax_b, bias, c, ldc, m, n, KB, accumulate, st)) return launch_status();
     PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, bias, m, n, KB,
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
     const int tiles = G.tiles_m * G.tiles_n;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
     if (bf16)
         hipLaunchKernelGGL(gemm_planes_kernel<true>, grid, dim3(256), 0, st, G);
@@ -372,6 +631,12 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
                      int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
                      ptmi_stream_t stream) {
     return gemm_planes_impl(false, a, amax_a, b, amax_b, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
+}
+
+int ptmi_gemm_planes_select_tile(int32_t tile) {
+    PTMI_RETURN_IF(tile < -1 || tile > 5, PTMI_E_INVALID);
+    g_tile_override = tile;
+    return PTMI_OK;
 }
 
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,

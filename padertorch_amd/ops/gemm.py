@@ -11,6 +11,7 @@ speed (fp32 MFMA runs at 1/16 of the fp16 rate on this part).
 reduced precision, reported as a delta, never the default).
 """
 import os
+import weakref
 
 import torch
 
@@ -29,7 +30,28 @@ PRODUCTS = 3
 #: [-1, 1], log-magnitude features): no scale, no reduction pass
 UNIT_RANGE = 'unit'
 
+#: Caches of values derived from parameters (operand scales, packed planes).  Keys are ``id(parameter)``; every entry also holds a
+#: WEAK reference to the parameter it was made from and is valid only while that very object is alive, its ``_version`` and its
+#: storage pointer are unchanged: a freed model's ids and device pointers can be reused by the next one (checkpoints evaluated in
+#: sequence), and then version and pointer alone would match.  Writing through ``p.data`` does not bump ``_version``: call
+#: :func:`invalidate` after such an edit.
 _WEIGHT_AMAX = {}
+
+
+def _refs(params):
+    return tuple(weakref.ref(p) for p in params)
+
+
+def _same(refs, params):
+    return refs is not None and len(refs) == len(params) and all(r() is p for r, p in zip(refs, params))
+
+
+def invalidate():
+    """Drop every cached parameter-derived value (after in-place edits that bypass autograd's version counter)."""
+    _WEIGHT_AMAX.clear()
+    _WEIGHT_PLANES.clear()
+    from . import lstm as _lstm
+    _lstm._STACKED.clear()
 
 
 def absmax(x):
@@ -48,12 +70,12 @@ def weight_absmax(p):
     """``absmax`` of a parameter, cached until the parameter is modified in place (optimizer step)."""
     key = id(p)
     hit = _WEIGHT_AMAX.get(key)
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
         return hit[2]
     if len(_WEIGHT_AMAX) > 256:
         _WEIGHT_AMAX.clear()
     v = absmax(p.detach() if p.dim() == 2 else p.detach().reshape(-1, p.shape[-1]))
-    _WEIGHT_AMAX[key] = (p._version, p.data_ptr(), v)
+    _WEIGHT_AMAX[key] = (p._version, p.data_ptr(), v, _refs((p,)))
     return v
 
 
@@ -65,12 +87,12 @@ def weights_absmax(params):
     key = tuple(id(p) for p in params)
     sig = tuple((p._version, p.data_ptr()) for p in params)
     hit = _WEIGHT_AMAX.get(key)
-    if hit is not None and hit[0] == sig:
+    if hit is not None and hit[0] == sig and _same(hit[3], params):
         return hit[2]
     v = weight_absmax(params[0])
     for p in params[1:]:
         v = torch.maximum(v, weight_absmax(p))       # non-negative floats order like their bit patterns
-    _WEIGHT_AMAX[key] = (sig, None, v)
+    _WEIGHT_AMAX[key] = (sig, None, v, _refs(params))
     return v
 
 
@@ -81,9 +103,9 @@ def seed_weights_absmax(params, word):
         _WEIGHT_AMAX.clear()
     if len(params) == 1:
         p = params[0]
-        _WEIGHT_AMAX[id(p)] = (p._version, p.data_ptr(), word)
+        _WEIGHT_AMAX[id(p)] = (p._version, p.data_ptr(), word, _refs((p,)))
     else:
-        _WEIGHT_AMAX[tuple(id(p) for p in params)] = (tuple((p._version, p.data_ptr()) for p in params), None, word)
+        _WEIGHT_AMAX[tuple(id(p) for p in params)] = (tuple((p._version, p.data_ptr()) for p in params), None, word, _refs(params))
 
 
 #: weight-gradient GEMMs (both operands reduce over their OUTER axis) on pre-split fp16 planes (csrc/gemm_planes.hip)
@@ -126,12 +148,12 @@ _WEIGHT_PLANES = {}
 def weight_planes(p):
     """``pack_n`` of a 2-D parameter used as the ``W`` of ``x W^T``, cached until the parameter is modified."""
     hit = _WEIGHT_PLANES.get(id(p))
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
         return hit[2]
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     v = pack_n(p.detach(), weight_absmax(p))
-    _WEIGHT_PLANES[id(p)] = (p._version, p.data_ptr(), v)
+    _WEIGHT_PLANES[id(p)] = (p._version, p.data_ptr(), v, _refs((p,)))
     return v
 
 
@@ -140,12 +162,12 @@ def weight_planes_t(p):
     over the outputs), cached until the parameter is modified."""
     key = ('t', id(p))
     hit = _WEIGHT_PLANES.get(key)
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
         return hit[2]
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     v = pack_t(p.detach(), weight_absmax(p))
-    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v)
+    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
     return v
 
 
@@ -174,13 +196,13 @@ def weight_planes_h(p, ndir, H, cols):
     (:func:`pad_direction_blocks`), cached until the parameter is modified."""
     key = ('h', id(p), cols)
     hit = _WEIGHT_PLANES.get(key)
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
         return hit[2]
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     with torch.no_grad():
         v = pack_n(pad_direction_blocks(p.detach(), ndir, H, cols), weight_absmax(p))
-    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v)
+    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
     return v
 
 
@@ -194,7 +216,7 @@ def stacked_planes_t_bf16(w, ndir, cols, key_params=None):
         key = ('tb', cols) + tuple(id(q) for q in key_params)
         sig = tuple((q._version, q.data_ptr()) for q in key_params)
         hit = _WEIGHT_PLANES.get(key)
-        if hit is not None and hit[0] == sig:
+        if hit is not None and hit[0] == sig and _same(hit[3], tuple(key_params)):
             return hit[2]
         if len(_WEIGHT_PLANES) > 64:
             _WEIGHT_PLANES.clear()
@@ -206,7 +228,7 @@ def stacked_planes_t_bf16(w, ndir, cols, key_params=None):
             w = wp.view(ndir * cols, -1)
         planes = torch.ops.ptmi.pack_planes_bf16(w.detach().contiguous(), True)
     if key is not None:
-        _WEIGHT_PLANES[key] = (sig, None, planes)
+        _WEIGHT_PLANES[key] = (sig, None, planes, _refs(key_params))
     return planes
 
 

@@ -89,5 +89,8 @@ def linear(module: torch.nn.Linear, x, x_range=None):
     """``module(x)`` for a 2-D ``x``.  ``x_range=ops.gemm.UNIT_RANGE`` when ``x`` is known to lie in a range fp16
     covers without scaling (e.g. LSTM outputs); by default its maximum is measured."""
     if x.dim() == 2 and _gemm.usable(x, module.weight):
+        if (_lstm.GRAD_USE_HOOK is not None and torch.is_grad_enabled() and _lstm.DEFER_WGRAD and module.weight.requires_grad
+                and module.weight.grad is not None and (module.bias is None or module.bias.grad is not None)):
+            _lstm.GRAD_USE_HOOK([module.weight] + ([module.bias] if module.bias is not None else []))
         return _LinearFn.apply(x, module.weight, module.bias, module, x_range)
     return module(x)

@@ -161,6 +161,9 @@ DEFER_WGRAD = False
 #: called with the list of parameters whose gradients have just been accumulated in place (the data-parallel
 #: Trainer issues the layer's all-reduce from it; autograd's post-accumulate hooks do not fire for in-place writes)
 GRAD_READY_HOOK = None
+#: called in the FORWARD pass with the parameters of a module whose weight gradients the backward pass will accumulate in place:
+#: one call per use, so that a module applied twice is reported ready only after its last backward use (GradBuckets.expect)
+GRAD_USE_HOOK = None
 #: False: the deferred accumulation runs on the current stream (same GEMM shapes, no overlap; used by the
 #: one-off GEMM tuning, which must not time kernels next to a running recurrence)
 WGRAD_SIDE_STREAM = True
@@ -357,8 +360,9 @@ def _prep_stream(device):
 
 
 def _stacked_stale(params):
-    hit = _STACKED.get(tuple(id(p) for ps in params for p in ps))
-    return hit is None or hit[0] != tuple((p._version, p.data_ptr()) for ps in params for p in ps)
+    flat = tuple(p for ps in params for p in ps)
+    hit = _STACKED.get(tuple(id(p) for p in flat))
+    return hit is None or hit[0] != tuple((p._version, p.data_ptr()) for p in flat) or not _gemm._same(hit[2], flat)
 
 
 def _stacked_weights(params, KP, stream=None):
@@ -370,8 +374,9 @@ def _stacked_weights(params, KP, stream=None):
     whose weight gradients do not travel through autograd (``DEFER_WGRAD`` path, or no graph at all)."""
     key = tuple(id(p) for ps in params for p in ps)
     sig = tuple((p._version, p.data_ptr()) for ps in params for p in ps)
+    flat_ps = tuple(p for ps in params for p in ps)
     hit = _STACKED.get(key)
-    if hit is not None and hit[0] == sig:
+    if hit is not None and hit[0] == sig and _gemm._same(hit[2], flat_ps):      # (weak references: see ops.gemm._WEIGHT_AMAX)
         return hit[1]
     if len(_STACKED) > 64:
         _STACKED.clear()
@@ -425,7 +430,7 @@ def _stacked_weights(params, KP, stream=None):
                 'w_pad': torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous(),
                 'w_t': w_hh.transpose(1, 2).contiguous(),
             }
-    _STACKED[key] = (sig, forms)
+    _STACKED[key] = (sig, forms, _gemm._refs(flat_ps))
     return forms
 
 
@@ -934,6 +939,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             sl = slice(layer * ndir, (layer + 1) * ndir)
             h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
+            if GRAD_USE_HOOK is not None and graph and in_place:
+                GRAD_USE_HOOK([p for ps in params for p in ps])
             h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0, anchor, forms)
             prev_handoff = None
             hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
@@ -941,6 +948,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:
             out_handoff = {}
+            if GRAD_USE_HOOK is not None and graph and in_place:
+                GRAD_USE_HOOK([p for ps in params for p in ps])
             h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms, prev_handoff, out_handoff)
             prev_handoff = out_handoff
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:

@@ -148,6 +148,10 @@ class Adam(Optimizer):
         groups = self.optimizer.param_groups
         if len(groups) != 1:
             return False
+        # limits of ptmi_adam_flat (csrc/optim.hip): a segment table of at most kMaxSegs = 1024 contiguous parameter tensors;
+        # anything else stays on torch's fused Adam (checked BEFORE _bind rewires the optimizer state)
+        if len(fg.params) > 1024 or not all(p.is_contiguous() for p in fg.params):
+            return False
         g = groups[0]
         return not (g.get('amsgrad') or g.get('maximize') or g.get('differentiable') or g.get('capturable'))
 

@@ -70,6 +70,12 @@ class GradBuckets:
     in-place accumulation of ``ops.lstm`` / ``ops.linear``); a bucket is reduced once all its parameters are
     ready AND every later bucket has been issued: all ranks - also one that ran no backward pass because the
     last group of examples was short - issue the collectives in the same order (last bucket first).
+
+    Readiness is tracked per DISTINCT parameter.  The in-place accumulation announces every use of a module in the forward
+    pass (``expect``, through ``ops.lstm.GRAD_USE_HOOK``) and reports every finished use in the backward pass, so a module
+    that is applied twice in one forward pass (shared weights) is ready only after its LAST backward use: its bucket is
+    never reduced while a later contribution is still to be added (autograd's post-accumulate hooks fire once per leaf and
+    need no announcement).
     """
 
     def __init__(self, model, flat_grads):
@@ -95,22 +101,37 @@ class GradBuckets:
         self.reset()
 
     def reset(self):
-        self.count = [0] * len(self.buckets)
+        self.done = [set() for _ in self.buckets]    # ids of the parameters whose gradients are final
+        self.uses = {}                           # id(parameter) -> announced in-place uses whose backward has not run yet
         self.next = len(self.buckets) - 1        # buckets are issued last to first
         self.works = []
         self.active = False                      # True during the last micro-step of an optimizer step
+
+    def expect(self, params):
+        """Forward pass of a module whose weight gradients will be accumulated in place: one more backward use to wait for."""
+        if not self.active:
+            return
+        for p in params:
+            if id(p) in self.bucket_of:
+                self.uses[id(p)] = self.uses.get(id(p), 0) + 1
 
     def ready(self, params, stream=None):
         if not self.active:
             return
         for p in params:
             i = self.bucket_of.get(id(p))
-            if i is not None:
-                self.count[i] += 1
+            if i is None:
+                continue
+            left = self.uses.get(id(p), 0)
+            if left > 1:                         # an earlier use of the same module is still to come in this backward pass
+                self.uses[id(p)] = left - 1
+                continue
+            self.uses.pop(id(p), None)
+            self.done[i].add(id(p))
         self._issue(stream, everything=False)
 
     def _issue(self, stream, everything):
-        while self.next >= 0 and (everything or self.count[self.next] >= self.buckets[self.next][2]):
+        while self.next >= 0 and (everything or len(self.done[self.next]) >= self.buckets[self.next][2]):
             start, end, _ = self.buckets[self.next]
             seg = self.flat[start:end]
             if seg.is_cuda and stream is not None:
@@ -299,6 +320,7 @@ class Trainer:
             for h in hooks:
                 h.remove()
             _lstm.GRAD_READY_HOOK = None
+            _lstm.GRAD_USE_HOOK = None
             self._buckets = None
             _lstm.sync_deferred()
             _lstm.DEFER_WGRAD = defer_before
@@ -612,6 +634,7 @@ class Trainer:
             buckets.ready((p,), side)
 
         _lstm.GRAD_READY_HOOK = lambda params: buckets.ready(params, side)
+        _lstm.GRAD_USE_HOOK = buckets.expect
         return [p.register_post_accumulate_grad_hook(on_grad) for p in self._flat.params]
 
     def _all_ranks_finite(self, mine):
@@ -651,10 +674,20 @@ class Trainer:
             self.optimizer.load_state_dict(state_dict['optimizer'])
         self.iteration, self.epoch = state_dict['iteration'], state_dict['epoch']
         hooks = state_dict.get('ptmi_hooks')
-        if hooks is not None:                           # best-checkpoint tracking continues across a resume
-            self._best = hooks.get('best')
-            self.validation_metric = hooks.get('validation_metric', self.validation_metric)
-            self.validation_maximize = hooks.get('validation_maximize', getattr(self, 'validation_maximize', False))
+        if hooks is not None:
+            # best-checkpoint tracking continues across a resume - for the metric and direction THIS run registered
+            # (register_validation_hook runs before load_checkpoint): a checkpoint written with another metric, another
+            # direction or without a validation hook leaves them alone and its `best` value does not carry over
+            same = (hooks.get('validation_metric', self.validation_metric) == self.validation_metric
+                    and bool(hooks.get('validation_maximize', False)) == bool(getattr(self, 'validation_maximize', False)))
+            if same:
+                self._best = hooks.get('best')
+            elif hooks.get('best') is not None:
+                import warnings
+                warnings.warn(f"checkpoint tracked its best by {hooks.get('validation_metric')!r} "
+                              f"(maximize={hooks.get('validation_maximize')}), this run validates {self.validation_metric!r} "
+                              f"(maximize={getattr(self, 'validation_maximize', False)}): starting a new best")
+                self._best = None
         # like the reference after a resume (trainer.py:845-851): the triggers have already fired for this iteration
         for trigger in (self.summary_trigger, self.checkpoint_trigger, self.stop_trigger):
             trigger.set_last(self.iteration, self.epoch)

@@ -187,3 +187,61 @@ def test_bf16_planes_gemm_vs_fp64(M, N, K, split):
     y2 = torch.empty(M, N, device='cuda')
     torch.ops.ptmi.gemm_planes_bf16_(y2, pa, 0, pw, None, M, N, K, False, sk)
     assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('M,N,K,acc,bias', [(1000, 700, 257, False, True), (530, 1282, 96, True, False), (257, 321, 1200, True, True),
+                                            (16, 4, 64, False, False)])
+def test_planes_big_tiles_vs_fp64(tile, M, N, K, acc, bias):
+    """Every workgroup tile of the persistent big-tile kernel (ptmi_gemm_planes_select_tile; 5 = the 128 x 128 kernel): rows /
+    columns that end inside a tile, inside an MFMA tile and inside a 4-column store group, several tiles per workgroup
+    (more tiles than CUs at 128-wide tiles is not reachable at test sizes - the flat tile loop is exercised through tiles > grid / 8
+    per XCD range), bias, accumulation into a strided C; bit-identical between two calls."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import gemm as G
+    lib = _lib.load()
+    torch.manual_seed(M + N + K + tile)
+    x = torch.randn(M, K, device='cuda') * 2.0
+    w = torch.randn(N, K, device='cuda') * 0.05
+    b = torch.randn(N, device='cuda') if bias else None
+    cbuf = torch.randn(M, N + 4, device='cuda')
+    c0 = cbuf.clone()
+    c = cbuf[:, :N]
+    want = x.double() @ w.double().t() + (b.double() if bias else 0) + (c.double() if acc else 0)
+    mag = x.double().abs() @ w.double().abs().t() + (b.double().abs() if bias else 0) + (c.double().abs() if acc else 0)
+    pa, pb = G.pack_n(x), G.pack_n(w)
+    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    try:
+        G.mm_planes_(c, pa, pb, M, N, K, accumulate=acc, split_k=1, bias=b)
+        torch.cuda.synchronize()
+        assert float(((c.double() - want).abs() / mag).max()) < 4e-7
+        assert torch.equal(cbuf[:, N:], c0[:, N:])          # nothing written past the matrix
+        again = c0.clone()
+        G.mm_planes_(again[:, :N], pa, pb, M, N, K, accumulate=acc, split_k=1, bias=b)
+        assert torch.equal(again, cbuf)
+    finally:
+        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+
+
+def test_planes_big_tile_many_tiles_per_workgroup():
+    """More tiles than CUs: every workgroup of the persistent kernel walks several tiles (the next tile's first stage is requested
+    during the last k step of the current one); 128 x 256 tiles at 4100 x 4100 = 33 x 17 = 561 tiles."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import gemm as G
+    lib = _lib.load()
+    torch.manual_seed(5)
+    M = N = 4100
+    K = 160
+    x = torch.randn(M, K, device='cuda')
+    w = torch.randn(N, K, device='cuda') * 0.1
+    want = x.double() @ w.double().t()
+    mag = x.double().abs() @ w.double().abs().t()
+    pa, pb = G.pack_n(x), G.pack_n(w)
+    for tile in (4, 0):
+        _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+        try:
+            y = torch.full((M, N), float('nan'), device='cuda')
+            G.mm_planes_(y, pa, pb, M, N, K, split_k=1)
+            assert float(((y.double() - want).abs() / mag).max()) < 4e-7
+        finally:
+            _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')

@@ -182,6 +182,80 @@ def test_data_parallel_non_finite_loss_raises_on_every_rank(g6, tmp_path):
     assert 'not finite' in out[1] and 'not finite' in out[0], out
 
 
+def _shared_module_worker(rank, world, port, out_dir):
+    """A module applied twice in one forward pass whose weight gradient is accumulated IN PLACE (the ops.lstm / ops.linear route,
+    imitated here on CPU): the forward pass announces every use (GradBuckets.expect through ops.lstm.GRAD_USE_HOOK), the backward
+    pass reports every finished use; the bucket's all-reduce must start only after the LAST one."""
+    from padertorch_amd.ops import lstm as _lstm
+    from padertorch_amd.train.trainer import GradBuckets
+    torch.set_num_threads(1)
+    torch.distributed.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.Linear(6, 3))
+    shared = model[0]
+    opt = pt.optimizer.Adam(1.)
+    opt.set_parameters(model.parameters())
+    flat = opt.use_flat_grads()
+    buckets = GradBuckets(model, flat)
+    assert [n for _, _, n in buckets.buckets] == [2, 2]
+    _lstm.GRAD_USE_HOOK = buckets.expect
+    _lstm.GRAD_READY_HOOK = lambda params: buckets.ready(params, None)
+    issued_at = []
+
+    class InPlaceLinear(torch.autograd.Function):          # dW accumulated into .grad by the op itself, like ops.linear under DEFER_WGRAD
+        @staticmethod
+        def forward(ctx, x, mod):
+            ctx.mod = mod
+            ctx.save_for_backward(x)
+            return x @ mod.weight.detach().t() + mod.bias.detach()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            mod = ctx.mod
+            before = len(buckets.works)
+            mod.weight.grad.add_(g.t() @ x)
+            mod.bias.grad.add_(g.sum(0))
+            _lstm.GRAD_READY_HOOK([mod.weight, mod.bias])
+            issued_at.append(len(buckets.works) - before)
+            return g @ mod.weight.detach(), None
+
+    def apply(mod, x):
+        _lstm.GRAD_USE_HOOK([mod.weight, mod.bias])
+        return InPlaceLinear.apply(x, mod)
+
+    try:
+        buckets.active = True
+        x = torch.full((4, 6), float(rank + 1), requires_grad=True)
+        y = apply(model[1], apply(shared, torch.tanh(apply(shared, x))))          # shared module: two uses
+        y.sum().backward()
+        # backward order: model[1] (bucket 1 issued), shared 2nd use (nothing: one use still to come), shared 1st use (bucket 0 issued)
+        assert issued_at == [1, 0, 1], issued_at
+        buckets.finish()
+        torch.save(flat.flat.clone(), os.path.join(out_dir, f'flat{rank}.pth'))
+        # reference: the same two ranks' gradients through plain autograd, summed
+        want = torch.zeros_like(flat.flat)
+        for r in range(world):
+            ref = torch.nn.Sequential(torch.nn.Linear(6, 6), torch.nn.Linear(6, 3))
+            ref.load_state_dict(model.state_dict())
+            xr = torch.full((4, 6), float(r + 1))
+            ref[1](ref[0](torch.tanh(ref[0](xr)))).sum().backward()
+            want += torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        torch.testing.assert_close(flat.flat, want, atol=1e-5, rtol=1e-5)
+    finally:
+        _lstm.GRAD_USE_HOOK = None
+        _lstm.GRAD_READY_HOOK = None
+        torch.distributed.destroy_process_group()
+
+
+def test_shared_module_bucket_waits_for_its_last_backward_use(tmp_path):
+    """a module applied twice must not have its bucket reduced after the first backward use (W = 2, gloo)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_shared_module_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / 'flat0.pth'), torch.load(tmp_path / 'flat1.pth')
+    assert torch.equal(a, b)
+
+
 def test_grad_buckets_follow_layers_and_issue_last_first(g6):
     from padertorch_amd.train.trainer import GradBuckets
     model = _model(g6)
@@ -245,3 +319,41 @@ def test_from_storage_dir_loads_a_reference_style_storage_dir(tmp_path):
     assert isinstance(built['net'], torch.nn.Linear) and float(built['act'](torch.tensor(-2.0))) == -1.0
     opt = _instantiate(config['trainer']['optimizer'])
     assert isinstance(opt, pt.optimizer.Adam)
+
+
+def test_resume_keeps_the_validation_metric_of_the_current_run(g6, tmp_path):
+    """load_state_dict must not overwrite the metric / direction registered by the resuming run; the old metric's best
+    value does not carry over to a different metric."""
+    exs = _examples(g6)
+    kw = dict(loss_weights=LW, summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1, 'iteration'), virtual_minibatch_size=1)
+    a = pt.Trainer(_model(g6), tmp_path, pt.optimizer.Adam(1.), stop_trigger=(1, 'iteration'), **kw)
+    a.register_validation_hook(exs[:1])
+    a.train(exs, device='cpu')
+    assert a._best is not None
+    b = pt.Trainer(_model(g6), tmp_path, pt.optimizer.Adam(1.), stop_trigger=(1, 'iteration'), **kw)
+    b.register_validation_hook(exs[:1], metric='pit_mse_loss', maximize=True)
+    with pytest.warns(UserWarning, match='starting a new best'):
+        b.load_checkpoint()
+    assert b.validation_metric == 'pit_mse_loss' and b.validation_maximize is True and b._best is None
+
+
+def test_weight_caches_do_not_survive_their_parameter(monkeypatch):
+    """the operand-scale / plane caches are keyed by id(parameter); an entry must not match another parameter object
+    that happens to reuse the id, the version and the storage pointer (a freed model followed by a freshly loaded one)."""
+    from padertorch_amd.ops import gemm as G
+    calls = []
+    monkeypatch.setattr(G, 'absmax', lambda x: calls.append(1) or x.abs().max().reshape(1))
+    G.invalidate()
+    p1 = torch.nn.Parameter(torch.ones(3, 4))
+    v1 = G.weight_absmax(p1)
+    assert G.weight_absmax(p1) is v1 and len(calls) == 1              # a hit for the very same object
+    p2 = torch.nn.Parameter(torch.full((3, 4), 2.))
+    entry = G._WEIGHT_AMAX[id(p1)]
+    G._WEIGHT_AMAX[id(p2)] = (p2._version, p2.data_ptr(), entry[2], entry[3])      # the coincidence: p1's entry under p2's identity
+    assert float(G.weight_absmax(p2)) == 2. and len(calls) == 2         # not served from p1's entry
+    del p1
+    import gc
+    gc.collect()
+    assert entry[3][0]() is None                                         # the entry held no strong reference
+    G.invalidate()
+    assert not G._WEIGHT_AMAX and not G._WEIGHT_PLANES
