@@ -24,6 +24,10 @@ extern "C" {
 typedef void* ptmi_stream_t; /* hipStream_t */
 
 const char* ptmi_version(void);
+/* Test utility: `workgroups` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for `ticks_100mhz`
+ * ticks of the 100 MHz clock - a stand-in for a communication kernel holding CUs next to the persistent recurrence kernels
+ * (the RCCL all-reduce of padertorch/train/trainer.py:396-442's data-parallel branch runs beside them). */
+int ptmi_debug_occupy(int32_t workgroups, int32_t threads, int32_t lds_bytes, int64_t ticks_100mhz, ptmi_stream_t stream);
 const char* ptmi_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------------
@@ -94,6 +98,19 @@ int ptmi_pit_features(const float* y, const float* s, int64_t batch, int32_t K, 
                       int64_t num_samples, const int32_t* row_samples, const float* window,
                       const float* twiddle, const ptmi_stft_geom* g, int64_t out_frames, float* Y_abs,
                       float* X_abs, float* cos_pd, ptmi_stream_t stream);
+/* The same launch, also writing the model's first-layer input (pit/model.py:91-94: pack_sequence(Y_abs) -> log1p):
+ *   log1p_packed    device [rows, F] fp32, rows = sum of the examples' frame counts: log1p(Y_abs) as PackedSequence data, the row
+ *                   of frame t of example b = packed_offsets[t] + b (examples sorted by descending length), or t * batch + b
+ *                   when packed_offsets is NULL (all examples have out_frames frames)
+ *   log1p_planes    NULL, or the same matrix as fp16 (hi, lo) planes of 2^9 log1p(Y_abs) in the layout of ptmi_pack_planes_n
+ *                   (ptmi_planes_elems(rows, F) values, 16-byte aligned, ZEROED by the caller: padding is not written): operand A
+ *                   of the first input projection on ptmi_gemm_planes with an operand-scale word of 16.0f (scale 2^13 / 16).
+ *                   The fixed scale holds for every finite input: log1p(FLT_MAX) 2^9 < 65504. */
+int ptmi_pit_features_packed(const float* y, const float* s, int64_t batch, int32_t K, int64_t row_stride,
+                             int64_t num_samples, const int32_t* row_samples, const float* window,
+                             const float* twiddle, const ptmi_stft_geom* g, int64_t out_frames, float* Y_abs,
+                             float* X_abs, float* cos_pd, float* log1p_packed, uint16_t* log1p_planes,
+                             const int64_t* packed_offsets, ptmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Permutation-invariant training loss.

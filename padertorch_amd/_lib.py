@@ -44,6 +44,8 @@ SIGNATURES = {
                                    c_int64, c_int64, _P, _P]),
     'ptmi_pit_features': (c_int, [_P, _P, c_int64, c_int32, c_int64, c_int64, _P, _P, _P, _G, c_int64,
                                   _P, _P, _P, _P]),
+    'ptmi_pit_features_packed': (c_int, [_P, _P, c_int64, c_int32, c_int64, c_int64, _P, _P, _P, _G, c_int64,
+                                         _P, _P, _P, _P, _P, _P, _P]),
     'ptmi_pit_workspace_elems': (c_int64, [c_int64, c_int64, c_int32, c_int32]),
     'ptmi_pit_pairwise_sse': (c_int, [_P, _P, _P, _P, c_int64, c_int64, _I64P, c_int32, c_int32, _P,
                                       _P, _P, _P]),
@@ -100,6 +102,7 @@ SIGNATURES = {
     'ptmi_pack_planes_n_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_gemm_planes_bf16': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'ptmi_gemm_planes_select_tile': (c_int, [c_int32]),
+    'ptmi_debug_occupy': (c_int, [c_int32, c_int32, c_int32, c_int64, _P]),
     'ptmi_grad_norm_workspace_elems': (c_int64, []),
     'ptmi_grad_norm': (c_int32, [_P, c_int64, _P, _P, _P]),
     'ptmi_adam_flat': (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, c_double, c_double, c_double,

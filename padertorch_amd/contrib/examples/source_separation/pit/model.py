@@ -92,18 +92,29 @@ class PermutationInvariantTrainingModel(base.Model):
         Returns: List of mask tensors, each list element has shape (T, K, F)
         """
         batch = self.prepare_batch(batch)
-        h = ops.pack_sequence(batch['Y_abs'])
+        packed = getattr(batch['Y_abs'], 'packed_log1p', None)
+        input_planes = None
+        if packed is not None and not (self.training and self.dropout_input.p > 0):
+            # the feature kernel has written log1p(Y_abs) in PackedSequence order itself (and as fp16 planes for the first
+            # projection): no pack_sequence / log1p / scale / split pass (ops.pit_features, csrc/stft.hip)
+            h = PackedSequence(packed.data, packed.batch_sizes)
+            if packed.planes() is not None:
+                input_planes = (packed.planes(), ops.features.LOG1P_SCALE_WORD_VALUE)
+            F = h.data.shape[1]
+            assert F == self.F, f'self.F = {self.F} != F = {F}'
+        else:
+            h = ops.pack_sequence(batch['Y_abs'])
 
-        _, F = h.data.size()
-        assert F == self.F, f'self.F = {self.F} != F = {F}'
+            _, F = h.data.size()
+            assert F == self.F, f'self.F = {self.F} != F = {F}'
 
-        h_data = self.dropout_input(h.data)
-        h_data = ops.sequence.log1p(h_data)
-        h = PackedSequence(h_data, h.batch_sizes)
+            h_data = self.dropout_input(h.data)
+            h_data = ops.sequence.log1p(h_data)
+            h = PackedSequence(h_data, h.batch_sizes)
 
         # Returns tensor with shape (t, b, num_directions * hidden_size)
         if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
-            h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
+            h = ops.packed_lstm(self.blstm, h, input_planes=input_planes)        # HIP time recurrence (csrc/lstm.hip)
         else:
             h, _ = self.blstm(h)                      # library LSTM (MIOpen)
 

@@ -54,11 +54,19 @@ class DeepClusteringModel(base.Model):
             transform = self._TRANSFORMS[self.input_feature_transform]
         except KeyError:
             raise NotImplementedError(self.input_feature_transform) from None
-        h = transform(ops.pack_sequence(batch['Y_abs']))
+        packed = getattr(batch['Y_abs'], 'packed_log1p', None)
+        input_planes = None
+        if packed is not None and self.input_feature_transform == 'log1p':
+            # written by the feature kernel itself (ops.pit_features): PackedSequence rows of log1p(Y_abs) + their fp16 planes
+            h = PackedSequence(packed.data, packed.batch_sizes)
+            if packed.planes() is not None:
+                input_planes = (packed.planes(), ops.features.LOG1P_SCALE_WORD_VALUE)
+        else:
+            h = transform(ops.pack_sequence(batch['Y_abs']))
         F = h.data.shape[1]
         assert F == self.F, f'self.F = {self.F} != F = {F}'
         if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
-            h = ops.packed_lstm(self.blstm, h)        # HIP time recurrence (csrc/lstm.hip)
+            h = ops.packed_lstm(self.blstm, h, input_planes=input_planes)        # HIP time recurrence (csrc/lstm.hip)
         else:
             h = self.blstm(h)[0]
         return ops.unpack_sequence(PackedSequence(self._embed_rows(h.data), h.batch_sizes))

@@ -72,6 +72,13 @@ struct FwdArgs {
     const float* mel_w;       // [nnz] weights, zero-padded to whole groups
     int mel_M, mel_nnz, mel_power, mel_log;
     float mel_eps;
+    // features kernel: the model's first-layer input written on the way out (ptmi_pit_features_packed): log1p(|Y|) as
+    // PackedSequence rows (time-major: row = lp_offs[t] + b, or t * batch + b when lp_offs is null) in fp32 and as fp16 (hi, lo)
+    // planes of 2^9 log1p(|Y|) in MFMA-fragment order (csrc/gemm_planes.hip: operand A of the first input projection)
+    float* lp_out;
+    _Float16* lp_planes;
+    const long long* lp_offs;
+    int lp_kb;
 };
 
 // W_size^j for 0 <= j < size from the half-circle table (j = 0..M): W^(j) = -W^(j-M) for j > M.
@@ -707,6 +714,27 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
                         if (q == 0) {
                             yph[f * YS + k] = pk;
                             if (km != k) yph[f * YS + km] = pm;
+                            if (A.lp_out && valid) {
+                                // pit/model.py:91-94: pack_sequence -> log1p, and the fp16 planes the first projection multiplies
+                                const int t = tw0 + f;
+                                const long long prow = (A.lp_offs ? A.lp_offs[t] : (long long)t * A.batch) + b;
+                                const float lk = log1pf(mk), lm = log1pf(mm);
+                                float* lrow = A.lp_out + prow * F;
+                                lrow[k] = lk;
+                                if (km != k) lrow[km] = lm;
+                                if (A.lp_planes) {
+                                    _Float16* tile = A.lp_planes + ((prow >> 4) * A.lp_kb * 2) * 512 + (prow & 15) * 8;
+                                    auto put = [&](int kk, float v) {
+                                        const float sv = v * 512.f;
+                                        const _Float16 hi = (_Float16)sv;
+                                        _Float16* o = tile + (long long)(kk >> 5) * 1024 + ((kk & 31) >> 3) * 128 + (kk & 7);
+                                        o[0] = hi;
+                                        o[512] = (_Float16)(sv - (float)hi);
+                                    };
+                                    put(k, lk);
+                                    if (km != k) put(km, lm);
+                                }
+                            }
                         } else {
                             // cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)
                             const cpx ck = yk[u] * pk, cm = ym[u] * pm;
@@ -1360,7 +1388,18 @@ int ptmi_pit_features(const float* y, const float* s, int64_t batch, int32_t K, 
                       int64_t num_samples, const int32_t* row_samples, const float* window,
                       const float* twiddle, const ptmi_stft_geom* g, int64_t out_frames, float* Y_abs,
                       float* X_abs, float* cos_pd, ptmi_stream_t stream) {
+    return ptmi_pit_features_packed(y, s, batch, K, row_stride, num_samples, row_samples, window, twiddle, g, out_frames, Y_abs, X_abs,
+                                    cos_pd, nullptr, nullptr, nullptr, stream);
+}
+
+int ptmi_pit_features_packed(const float* y, const float* s, int64_t batch, int32_t K, int64_t row_stride,
+                             int64_t num_samples, const int32_t* row_samples, const float* window,
+                             const float* twiddle, const ptmi_stft_geom* g, int64_t out_frames, float* Y_abs,
+                             float* X_abs, float* cos_pd, float* log1p_packed, uint16_t* log1p_planes,
+                             const int64_t* packed_offsets, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!geom_ok(g) || !y || !window || !twiddle || !Y_abs, PTMI_E_INVALID);
+    PTMI_RETURN_IF(log1p_planes && !log1p_packed, PTMI_E_INVALID);
+    PTMI_RETURN_IF(log1p_planes && (reinterpret_cast<uintptr_t>(log1p_planes) & 15) != 0, PTMI_E_INVALID);
     PTMI_RETURN_IF(s && (!X_abs || !cos_pd || K < 1), PTMI_E_INVALID);
     PTMI_RETURN_IF(batch < 0 || out_frames < 0, PTMI_E_INVALID);
     PTMI_RETURN_IF(num_samples > 0x7ff00000LL || out_frames > 0x7ff00000LL / (g->size + 2), PTMI_E_UNSUPPORTED);
@@ -1380,6 +1419,10 @@ int ptmi_pit_features(const float* y, const float* s, int64_t batch, int32_t K, 
     A.out_frames = out_frames;
     A.edge_scale = 1.f;
     A.g = to_geo(g);
+    A.lp_out = log1p_packed;
+    A.lp_planes = reinterpret_cast<_Float16*>(log1p_planes);
+    A.lp_offs = reinterpret_cast<const long long*>(packed_offsets);
+    A.lp_kb = (g->size / 2 + 1 + 31) / 32;
     return dispatch_fwd(A, batch, true, static_cast<hipStream_t>(stream));
 }
 

@@ -14,9 +14,33 @@ from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 from ._stft import STFT
 from .sequence.pack_module import PaddedList
 
-__all__ = ['pit_features']
+__all__ = ['pit_features', 'PackedLog1p']
 
 _default_stft = None
+
+#: fp16 operand scale of the log-magnitude planes: 2^9 (log1p(FLT_MAX) 2^9 < 65504: no input can overflow); as the float whose
+#: exponent makes ptmi_gemm_planes take that scale (2^13 / 16)
+LOG1P_SCALE_WORD_VALUE = 16.0
+
+_PLANES = {}        # (device, rows, F) -> [zero-initialised planes buffer, generation]
+
+
+class PackedLog1p:
+    """``log1p(Y_abs)`` as the ``PackedSequence`` the model builds in ``pit/model.py:91-94`` (``data [rows, F]`` fp32,
+    ``batch_sizes``), written by the feature kernel itself, plus the same matrix as fp16 planes for the first input projection.
+    The planes live in a buffer that the next ``pit_features`` call of the same shape overwrites: :meth:`planes` returns them
+    only while they are still this call's (otherwise the consumer packs ``data`` itself)."""
+
+    def __init__(self, data, batch_sizes, planes_entry, generation):
+        self.data = data
+        self.batch_sizes = batch_sizes
+        self._entry = planes_entry
+        self._generation = generation
+
+    def planes(self):
+        if self._entry is not None and self._entry[1] == self._generation:
+            return self._entry[0]
+        return None
 
 
 def _pad_rows(rows, dim_last_pad_to):
@@ -26,7 +50,7 @@ def _pad_rows(rows, dim_last_pad_to):
     return out
 
 
-def pit_features(y, s=None, num_samples=None, stft: STFT = None):
+def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=True):
     """Waveforms -> ``dict(Y_abs, X_abs, cos_phase_difference, num_frames)`` (model batch contract).
 
     Args:
@@ -34,6 +58,8 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None):
         s: sources: list of ``(K, N_b)`` tensors or a padded ``[B, K, N]`` (None: only ``Y_abs``)
         num_samples: list of ints when ``y`` / ``s`` are padded and ragged
         stft: an :class:`STFT` (default ``STFT(512, 128)`` = paderbox defaults used by the example)
+        packed_log1p: also write ``log1p(Y_abs)`` in PackedSequence order (``Y_abs.packed_log1p``: :class:`PackedLog1p`), the
+            first BLSTM layer's input of both example models, so that no pack / log1p / scale / split pass follows the kernel
     Every entry of the result is a :class:`PaddedList` (list of per-example views, e.g.
     ``Y_abs[b]: (T_b, F)``, ``X_abs[b]: (T_b, K, F)``).
     """
@@ -68,10 +94,34 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None):
     ns_dev = torch.tensor(num_samples, dtype=torch.int32, device=dev) if ragged else None
     tb = stft._tables.get(dev)
     g = stft._geom
-    Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features(
-        y, s, ns_dev, tb['window'], tb['twiddle'], [g.size, g.shift, g.window_length, g.pad_left, g.pad_right, g.pad], T)
+    geom = [g.size, g.shift, g.window_length, g.pad_left, g.pad_right, g.pad]
+    packed = None
+    if packed_log1p and T > 0 and all(a >= b for a, b in zip(frames, frames[1:])):
+        # the model's first-layer input on the way out: log1p(Y_abs) in PackedSequence order, fp32 and as fp16 planes
+        from . import gemm as _gemm, lstm as _lstm
+        bs = torch.tensor([sum(1 for f in frames if f > t) for t in range(T)], dtype=torch.int64) if ragged else \
+            torch.full((T,), B, dtype=torch.int64)
+        meta = _lstm.pack_meta(bs, dev)
+        lp = torch.empty((meta.rows, F), dtype=torch.float32, device=dev)
+        entry = None
+        if _gemm.planes_enabled():
+            key = (dev.type, dev.index, meta.rows, F)
+            entry = _PLANES.get(key)
+            if entry is None:
+                if len(_PLANES) > 8:
+                    _PLANES.clear()
+                entry = _PLANES[key] = [torch.zeros(int(lib.ptmi_planes_elems(meta.rows, F)), dtype=torch.float16, device=dev), 0]
+            entry[1] += 1
+        Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features_packed(
+            y, s, ns_dev, tb['window'], tb['twiddle'], geom, T, lp, None if entry is None else entry[0],
+            meta.offs_dev if ragged else None)
+        packed = PackedLog1p(lp, bs, entry, None if entry is None else entry[1])
+    else:
+        Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features(y, s, ns_dev, tb['window'], tb['twiddle'], geom, T)
     fl = torch.tensor(frames, dtype=torch.int32, device=dev) if ragged else None
     out = dict(Y_abs=PaddedList(Y_abs, frames, True, fl), num_frames=frames)
+    #: consumed by PermutationInvariantTrainingModel.forward / DeepClusteringModel.forward when the list is handed on untouched
+    out['Y_abs'].packed_log1p = packed
     if K:
         out['X_abs'] = PaddedList(X_abs, frames, True, fl)
         out['cos_phase_difference'] = PaddedList(cos_pd, frames, True, fl)

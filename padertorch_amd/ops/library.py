@@ -81,6 +81,18 @@ def istft_forward(spec, window, twiddle, geom, layout, edge_scale, cut_left, out
 @_register('pit_features(Tensor y, Tensor? s, Tensor? num_samples, Tensor window, Tensor twiddle, int[] geom, int frames) '
            '-> (Tensor, Tensor?, Tensor?)')
 def pit_features(y, s, num_samples, window, twiddle, geom, frames):
+    return _pit_features(y, s, num_samples, window, twiddle, geom, frames, None, None, None)
+
+
+@_register('pit_features_packed(Tensor y, Tensor? s, Tensor? num_samples, Tensor window, Tensor twiddle, int[] geom, int frames, '
+           'Tensor(a!) log1p_packed, Tensor(b!)? log1p_planes, Tensor? packed_offsets) -> (Tensor, Tensor?, Tensor?)')
+def pit_features_packed(y, s, num_samples, window, twiddle, geom, frames, log1p_packed, log1p_planes, packed_offsets):
+    """``pit_features`` that also writes the first BLSTM layer's input: ``log1p(Y_abs)`` as PackedSequence rows (fp32, and as fp16
+    planes in ``log1p_planes`` - zeroed once by the caller, the kernel never writes the padding)."""
+    return _pit_features(y, s, num_samples, window, twiddle, geom, frames, log1p_packed, log1p_planes, packed_offsets)
+
+
+def _pit_features(y, s, num_samples, window, twiddle, geom, frames, log1p_packed, log1p_planes, packed_offsets):
     lib = _lib.load()
     B, N = y.shape
     K = s.shape[1] if s is not None else 0
@@ -91,9 +103,9 @@ def pit_features(y, s, num_samples, window, twiddle, geom, frames):
     if K:
         X_abs = torch.empty((B, frames, K, F), dtype=torch.float32, device=dev)
         cos_pd = torch.empty((B, frames, K, F), dtype=torch.float32, device=dev)
-    rc = _lib.timed('pit_features', lib.ptmi_pit_features, y.data_ptr(), _lib.ptr(s), B, K, N, N, _lib.ptr(num_samples),
+    rc = _lib.timed('pit_features', lib.ptmi_pit_features_packed, y.data_ptr(), _lib.ptr(s), B, K, N, N, _lib.ptr(num_samples),
                     window.data_ptr(), twiddle.data_ptr(), _geom(geom), frames, Y_abs.data_ptr(), _lib.ptr(X_abs),
-                    _lib.ptr(cos_pd), _lib.stream(dev))
+                    _lib.ptr(cos_pd), _lib.ptr(log1p_packed), _lib.ptr(log1p_planes), _lib.ptr(packed_offsets), _lib.stream(dev))
     if rc == -2:
         raise NotImplementedError(f'pit_features needs a power-of-two STFT size in 64..2048 (got {geom[0]})')
     _lib.check(rc, 'ptmi_pit_features')

@@ -365,6 +365,37 @@ def _stacked_stale(params):
     return hit is None or hit[0] != tuple((p._version, p.data_ptr()) for p in flat) or not _gemm._same(hit[2], flat)
 
 
+def refresh_parameter_forms(device):
+    """Right behind an optimizer update: re-make, on the preparation stream, the operand forms of every LSTM layer and Linear
+    weight the last steps ran on (``_stacked_weights`` / ``ops.gemm.refresh_cached``) - they depend on the parameters only, so
+    the next step's first projection finds them ready instead of waiting for ~40 us of preparation kernels per layer at its head
+    (``Trainer.optimizer_step``; layer order = order of first use, so the first layer's forms are made first)."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return
+    pre = None
+    for key, (sig, forms, refs) in list(_STACKED.items()):
+        ps = [r() for r in refs]
+        if any(p is None for p in ps):
+            _STACKED.pop(key, None)
+            continue
+        if not ps[0].is_cuda or ps[0].device != device or 'w_t' not in forms or len(ps) % 4:
+            continue
+        params = [tuple(ps[i:i + 4]) for i in range(0, len(ps), 4)]
+        if not _stacked_stale(params):
+            continue
+        if pre is None:
+            pre = _prep_stream(device)
+            pre.wait_stream(torch.cuda.current_stream(device))
+        H = ps[1].shape[1]
+        _stacked_weights(params, (H + 15) // 16 * 16, stream=pre)
+    if _gemm._RECIPES:
+        if pre is None:
+            pre = _prep_stream(device)
+            pre.wait_stream(torch.cuda.current_stream(device))
+        _gemm.refresh_cached(pre)
+
+
 def _stacked_weights(params, KP, stream=None):
     """The per-layer operand forms of a BLSTM layer's parameters - both directions' ``weight_ih`` stacked (and, for an
     input width that is not a multiple of 4, zero-padded along the reduction axis), the summed biases, ``weight_hh``
@@ -507,11 +538,23 @@ class _LstmLayerFn(torch.autograd.Function):
             use_gemm = _gemm.usable(x, w_ih)
             # operand ranges of the split GEMM: the layer input is taken as it is when it is a hidden state (|h| < 1,
             # a dropout scale aside), measured otherwise; the stacked weights' maximum is cached per optimizer step
-            amax_x = (_gemm.UNIT_RANGE if x_unit else _gemm.absmax(x)) if use_gemm else None
+            hplanes = prev.get('planes') if prev else None
+            xplanes = prev.get('xplanes') if prev else None
+            if not (xplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
+                    and forms.get('w_ih_planes') is not None):
+                xplanes = None
+            amax_x = ((_gemm.UNIT_RANGE if x_unit else _gemm.scale_word(x.device, xplanes[1]) if xplanes is not None
+                       else _gemm.absmax(x)) if use_gemm else None)
             amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
                       if use_gemm else None)
-            hplanes = prev.get('planes') if prev else None
-            if (hplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
+            if xplanes is not None:
+                # the producer of x has left it as fp16 planes with a fixed operand scale (the feature kernel: 2^9 log1p|Y|);
+                # the same scale word serves the weight gradient's pack of the fp32 x in the backward pass
+                word = amax_x
+                gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
+                wpl = forms['w_ih_planes']
+                torch.ops.ptmi.gemm_planes_(gates, xplanes[0], word, wpl[0], wpl[1], bias, meta.rows, ndir * G, x.shape[1], False, 1)
+            elif (hplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
                     and forms.get('w_ih_planes_h') is not None and forms['w_ih_planes_h'][1] == hplanes[1]):
                 # the previous layer's recurrence has left its output as fp16 (hi, lo) planes of 2^10 h in fragment order (its
                 # hand-off copy): operand A of this projection as it lies, no pack pass
@@ -876,8 +919,12 @@ def supported(lstm, data):
             and lstm.bias and data.is_cuda and data.dtype == torch.float32)
 
 
-def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False):
+def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False, input_planes=None):
     """``lstm(packed, hx)`` through the HIP recurrence.
+
+    ``input_planes = (planes, scale value)``: ``packed.data`` once more as fp16 (hi, lo) planes in the layout of
+    ``ptmi_pack_planes_n`` (written by the producer of the data, e.g. ``ops.pit_features``), with the float whose exponent gives
+    their operand scale (``ops.gemm.scale_word``): the first layer's projection takes them as they lie.
 
     ``hx = (h_0, c_0)``, each ``[num_layers * num_directions, B, H]`` like ``torch.nn.LSTM``, are taken
     as constants (no gradient flows into the initial state).  Returns the output PackedSequence, or
@@ -950,6 +997,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             out_handoff = {}
             if GRAD_USE_HOOK is not None and graph and in_place:
                 GRAD_USE_HOOK([p for ps in params for p in ps])
+            if layer == 0 and input_planes is not None and prev_handoff is None:
+                prev_handoff = {'xplanes': input_planes}
             h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms, prev_handoff, out_handoff)
             prev_handoff = out_handoff
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:

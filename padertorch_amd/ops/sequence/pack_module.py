@@ -50,6 +50,12 @@ class PaddedList(list):
         self.lengths_dev = lengths_dev
 
     def to(self, device):
+        if device is None:
+            return self
+        dev = torch.device(device)
+        mine = self.padded.device
+        if dev.type == mine.type and (dev.index is None or dev.index == mine.index):
+            return self                 # already there: the same object (keeps what the producer attached, e.g. packed_log1p)
         ld = None if self.lengths_dev is None else self.lengths_dev.to(device)
         return PaddedList(self.padded.to(device), self.lengths, self.batch_first, ld)
 

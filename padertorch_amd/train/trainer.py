@@ -421,6 +421,10 @@ class Trainer:
         else:
             self.optimizer.step()
             self.optimizer.zero_grad()
+        if self._flat is not None and self._flat.flat.is_cuda and self.model.training:
+            # the parameters' operand forms of the NEXT step (stacked / padded / transposed LSTM weights, fp16 planes, operand
+            # scales) on the preparation stream, right behind the update: off that step's critical path
+            _lstm.refresh_parameter_forms(self._flat.flat.device)
         self._opt_step += 1
         return summary
 
@@ -444,16 +448,32 @@ class Trainer:
                 if loss_acc is not None:
                     bad = bad | ~torch.isfinite(loss_acc)
                 found = bad.to(torch.float32)
-                if self.world_size > 1:                    # a rank-local non-finite loss skips the update everywhere
-                    dist.all_reduce(found, op=dist.ReduceOp.MAX)
+                timeouts = _lstm.error_count(grad_norm.device).reshape(1)
+                if self._dp_active():
+                    # a rank-local non-finite loss skips the update everywhere, and a timed-out recurrence launch on ONE rank is
+                    # seen by ALL of them one step later (same branch everywhere: nobody is left waiting in a collective)
+                    both = torch.cat([found.reshape(1), timeouts.to(torch.float32)])
+                    dist.all_reduce(both, op=dist.ReduceOp.MAX)
+                    found, timeouts = both[0], both[1:2].to(torch.int32)
                 opt.found_inf, opt.grad_scale = found, None    # gates optimizer.step on the device
+                host = self._stage('grad_norm', [grad_norm.detach().reshape(1), timeouts], summary)
+                summary['scalars']['grad_norm'] = host[0][0]
+                summary['histograms']['grad_norm_'] = host[0]
+                return summary
             host = self._stage('grad_norm', [grad_norm.detach().reshape(1), _lstm.error_count(grad_norm.device).reshape(1)],
                                summary)
             summary['scalars']['grad_norm'] = host[0][0]
             summary['histograms']['grad_norm_'] = host[0]
             return summary
         grad_norm = float(grad_norm)                       # host sync
-        _lstm.check_errors()                               # persistent-kernel watchdog words
+        if self._dp_active() and self._flat is not None and self._flat.flat.is_cuda:
+            # persistent-kernel watchdog: every rank learns about a timeout on ANY rank before the next collective
+            cnt = _lstm.error_count(self._flat.flat.device).reshape(1).clone()
+            dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
+            if _lstm.errors_since_last_report(self._flat.flat.device, int(cnt)):
+                _lstm.raise_timeout(self._flat.flat.device)
+        else:
+            _lstm.check_errors()                           # persistent-kernel watchdog words
         if not np.isfinite(grad_norm):
             path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': summary})
             raise RuntimeError(f'The grad_norm ({grad_norm}) is not finite.\n'

@@ -10,8 +10,8 @@ from pathlib import Path
 REPO = Path(__file__).resolve().parent.parent
 
 
-def _run(*extra):
-    env = dict(os.environ, OMP_NUM_THREADS='4')
+def _run(*extra, **env_extra):
+    env = dict(os.environ, OMP_NUM_THREADS='4', **env_extra)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--dry', '--steps', '2', '--warmup', '1', *extra],
@@ -28,9 +28,21 @@ def test_self_launch_two_ranks_bucketed_allreduce():
     assert out['config']['parallelism'] == 'dp2' and out['config']['global_batch'] == 64
     r = out['rccl']
     assert r['world_size'] == 2 and r['overlap_allreduce'] is True
+    assert r['schedule']['used'] == 'overlap' and set(r['schedule']['probe_ms_per_step']) == {'overlap', 'no_overlap'}
     # PIT model: three BLSTM layers and two linears -> five layer buckets covering all 23 480 914 parameters
     assert len(r['buckets']) == 5 and sum(r['buckets']) == 23480914 and r['flat_gradient_bytes'] == 4 * 23480914
     assert out['value'] > 0 and out['unit'] == 'frames/s'
+
+
+def test_recurrence_timeout_falls_back_to_the_unoverlapped_schedule():
+    """a watchdog timeout of a persistent recurrence kernel while the bucketed all-reduce runs beside it must not
+    end the multi-GPU run: every rank raises in the same step (simulated here in the stub step), bench.py reruns with one
+    all-reduce in optimizer_step and says so."""
+    out = _run('--gpus', '2', PTMI_BENCH_FAKE_TIMEOUT='1')
+    sched = out['rccl']['schedule']
+    assert sched['used'] == 'no_overlap' and sched['probe_ms_per_step']['overlap'] is None
+    assert sched['probe_ms_per_step']['no_overlap'] > 0 and any('timeout' in n for n in sched['notes'])
+    assert out['rccl']['overlap_allreduce'] is False and out['value'] > 0
 
 
 def test_c4_micro_steps_single_allreduce_per_optimizer_step():

@@ -120,3 +120,121 @@ def test_dc_step_config5_shape_vs_oracle():
     assert worst < 1e-5, worst
     assert abs(float(loss) - float(rloss)) < 1e-4 * max(1., abs(float(rloss))), (float(loss), float(rloss))
     _grad_check(model, ref)
+
+
+def test_pit_step_config1_batch4_vs_oracle():
+    """BASELINE configs[0]: batch 4 x 4 s at 8 kHz (the reference's own CPU-runnable case): the 8-unit forward tiles of B <= 16."""
+    _pit_case(4, 8000, seed=7)
+
+
+def test_pit_step_config3_full_batch_vs_oracle():
+    """BASELINE configs[2] at its FULL batch: 64 x 4 s at 16 kHz, equal lengths - exactly what `bench.py --config c3` times: 32-row
+    chains, T = 503, the hand-off planes as GEMM operands (equal-length batch), the 256 x 320 tiles at M = 32192."""
+    _pit_case(64, 16000, seed=9)
+
+
+def test_dc_step_config5_full_batch_vs_oracle():
+    """BASELINE configs[4] at its full batch (64 x 4 s at 16 kHz, K = 3, equal lengths): `bench.py --config c5`."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
+    from padertorch_amd.ops import lstm as _lstm
+    from oracle import torch_ref
+    B, K, n = 64, 3, 64000
+    torch.manual_seed(15)
+    model = DeepClusteringModel()
+    ref = torch_ref.DCModelRef()
+    ref.load_state_dict(model.state_dict())
+    model.to(DEV).train()
+    s = _waveforms(B, K, n, [n] * B, 16).to(DEV)
+    feats = pt.ops.pit_features(s.sum(1), s, [n] * B)
+    target = [torch.nn.functional.one_hot(x.argmax(1), K).permute(0, 2, 1).to(torch.float32) for x in feats['X_abs']]
+    batch = dict(Y_abs=feats['Y_abs'], target_mask=target, num_frames=feats['num_frames'])
+    _lstm.CHECK_PERSISTENT_ERRORS = True
+    try:
+        emb = model(batch)
+        loss = model.review(batch, emb)['losses']['dc_loss']
+        loss.backward()
+    finally:
+        _lstm.CHECK_PERSISTENT_ERRORS = False
+    torch.cuda.synchronize()
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    rb = dict(Y_abs=[t.detach().cpu() for t in feats['Y_abs']], target_mask=[t.cpu() for t in target])
+    remb = ref(rb)
+    rloss = ref.review(rb, remb)['losses']['dc_loss']
+    rloss.backward()
+    worst = max(float((m.detach().cpu() - r.detach()).abs().max()) for m, r in zip(emb, remb))
+    assert worst < 1e-5, worst
+    assert abs(float(loss) - float(rloss)) < 1e-4 * max(1., abs(float(rloss))), (float(loss), float(rloss))
+    _grad_check(model, ref)
+
+
+def test_config4_four_micro_steps_one_optimizer_step_vs_oracle(tmp_path):
+    """BASELINE configs[3], the work of ONE GPU (W = 1): batch 64 at 16 kHz, virtual_minibatch_size = 4 - four micro-steps whose
+    gradients ACCUMULATE in the flat bucket (in place, side stream; 32-row chains), then one clip + Adam - through the Trainer,
+    against the oracle's train_step arithmetic over the same four batches (trainer.py:357-393,512-532): the four losses (1e-4),
+    the ACCUMULATED gradient of every parameter (2e-4 of its largest entry), the clipped norm, and the Adam update wherever it is
+    well conditioned (first step: lr g / (|g| + eps) - entries with |g| >> eps move by lr sign(g)).  Signals of 0.5 s keep the
+    oracle's four CPU passes at batch 64 affordable; the full 4 s step at batch 64 is test_pit_step_config3_full_batch_vs_oracle,
+    and the data-parallel run adds only the all-reduce(SUM) of the bucket (tests/test_trainer.py, gloo)."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    from padertorch_amd.ops import lstm as _lstm
+    from oracle import torch_ref
+    B, n, micro = 64, 8000, 4
+    lw = dict(pit_ips_loss=1., pit_mse_loss=0.)
+    torch.manual_seed(21)
+    model = PermutationInvariantTrainingModel()
+    ref = torch_ref.PITModelRef()
+    ref.load_state_dict(model.state_dict())
+    before = {k: v.clone() for k, v in ref.state_dict().items()}
+    trainer = pt.Trainer(model, tmp_path, pt.optimizer.Adam(gradient_clipping=1.), loss_weights=lw, virtual_minibatch_size=micro)
+    trainer.to(torch.device(DEV))
+    trainer._flat = trainer.optimizer.use_flat_grads()
+    model.train()
+    defer = _lstm.DEFER_WGRAD
+    _lstm.DEFER_WGRAD = True
+    _lstm.warm_side_stream(torch.device(DEV))
+    losses, rbatches = [], []
+    try:
+        for m in range(micro):
+            s = _waveforms(B, 2, n, [n] * B, 30 + m).to(DEV)
+            feats = pt.ops.pit_features(s.sum(1), s, [n] * B)
+            rbatches.append({k: [t.detach().cpu() for t in feats[k]] for k in ('Y_abs', 'X_abs', 'cos_phase_difference')})
+            loss, _, _, _ = trainer.train_step(model, feats, torch.device(DEV))
+            loss.backward()
+            losses.append(float(loss))
+            del feats, loss
+        _lstm.sync_deferred()
+        torch.cuda.synchronize()
+        grads = {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}
+        summary = trainer.optimizer_step()
+        torch.cuda.synchronize()
+        _lstm.check_errors()
+    finally:
+        _lstm.DEFER_WGRAD = defer
+    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
+    opt = torch.optim.Adam(ref.parameters())
+    rlosses = []
+    for rb in rbatches:                                     # oracle.torch_ref.train_step, with a look at the gradients before the clip
+        out = ref(rb)
+        rl = torch_ref.review_to_loss(ref.review(rb, out), lw)
+        rl.backward()
+        rlosses.append(float(rl))
+    for a, b in zip(losses, rlosses):
+        assert abs(a - b) < 1e-4, (losses, rlosses)
+    rgrads = {k: p.grad.detach().clone() for k, p in ref.named_parameters()}
+    for k, r in rgrads.items():
+        scale = float(r.abs().max())
+        assert float((grads[k].double() - r.double()).abs().max()) <= 2e-4 * scale + 1e-9, (k, scale)
+    rnorm = float(torch.nn.utils.clip_grad_norm_(list(ref.parameters()), 1.))
+    opt.step()
+    gn = float(summary['scalars']['grad_norm'])
+    assert abs(gn - rnorm) < 2e-4 * rnorm, (gn, rnorm)
+    clip = min(1., 1. / (rnorm + 1e-6))
+    for (k, v), vr in zip(model.state_dict().items(), ref.state_dict().values()):
+        du, dr = v.cpu() - before[k], vr - before[k]
+        g = rgrads[k].abs() * clip                         # |g| >> eps = 1e-8 and >> the gradient's own error: update = lr sign(g)
+        firm = g > max(1e-6, 2e-3 * float(g.max()))
+        if firm.any():
+            assert float((du - dr)[firm].abs().max()) < 1e-5, (k, float((du - dr)[firm].abs().max()))
+        assert float(du.abs().max()) <= 1.001e-3 + 1e-7            # no entry moves by more than lr

@@ -401,3 +401,42 @@ def test_gradients_wrt_the_initial_state(lens):
     assert float((y - yr).abs().max()) < 2e-5
     assert float((gh - ghr).abs().max()) < 1e-4 * max(1., float(ghr.abs().max())), float((gh - ghr).abs().max())
     assert float((gc - gcr).abs().max()) < 1e-4 * max(1., float(gcr.abs().max())), float((gc - gcr).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('wgs,threads,lds', [(256, 256, 0), (64, 512, 65536), (512, 256, 0)])
+def test_recurrences_next_to_a_cu_occupying_kernel(wgs, threads, lds, monkeypatch):
+    """the persistent recurrence kernels need all their workgroups co-resident; a communication kernel on
+    another queue (RCCL's channels during the bucketed all-reduce of the data-parallel Trainer, trainer.py:396-442) holds CUs
+    meanwhile.  Stand-in: ptmi_debug_occupy keeps `wgs` workgroups resident for ~1.5 ms, launched back to back on a third
+    stream while a BLSTM layer of the BASELINE size runs forward and backward on the main stream: no timed-out wait, and
+    bit-identical results to the undisturbed run (the hand-off protocol does not depend on timing)."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import packed_lstm, lstm as L
+    lib = _lib.load()
+    torch.manual_seed(11)
+    B, T, I, H = 32, 120, 64, 600
+    lstm = torch.nn.LSTM(I, H, 1, bidirectional=True).to(DEV)
+    xs = [torch.randn(T, I, device=DEV) for _ in range(B)]
+    g = torch.randn(T * B, 2 * H, device=DEV)
+
+    def run(disturb):
+        lstm.zero_grad()
+        xd = [x.clone().requires_grad_(True) for x in xs]
+        side = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        if disturb:
+            with torch.cuda.stream(side):
+                for _ in range(12):          # ~18 ms of occupancy: covers the forward and the backward recurrence
+                    _lib.check(lib.ptmi_debug_occupy(wgs, threads, lds, 150000, _lib.stream(torch.device(DEV))), 'occupy')
+        y = packed_lstm(lstm, pack_sequence(xd))
+        (y.data * g).sum().backward()
+        torch.cuda.synchronize()
+        L.check_errors()                     # raises on a timed-out bounded spin
+        return y.data.detach().clone(), [x.grad.clone() for x in xd], [p.grad.clone() for p in lstm.parameters()]
+
+    base = run(False)
+    got = run(True)
+    assert torch.equal(base[0], got[0])
+    for a, b in zip(base[1] + base[2], got[1] + got[2]):
+        assert torch.equal(a, b)

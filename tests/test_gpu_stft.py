@@ -204,3 +204,62 @@ def test_pit_features_ragged_batch_vs_oracle():
         assert err.max() < 2e-5
     # padded frames are exactly zero
     assert f['Y_abs'].padded[3, f['num_frames'][3]:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('lens', [[4000, 3500, 3499, 900], [2048] * 32, [3000] * 5])
+def test_pit_features_write_the_packed_log_magnitude_input(lens):
+    """SURVEY row a9 (``pit/model.py:91-94``, ``ops/sequence/pointwise.py:37``): the feature kernel itself writes the first BLSTM
+    layer's input - log1p(Y_abs) in PackedSequence order, fp32 and as fp16 (hi, lo) planes with the fixed scale 2^9 - equal to what
+    pack_sequence + log1p (+ the pack pass) make of its Y_abs: rows bit-exact positions, values to an ulp of log1p, planes =
+    hi + lo of 2^9 x within fp16's 22 bits, padding zero; a second call of the same shape retires the first call's planes."""
+    from torch.nn.utils.rnn import pack_sequence
+    from padertorch_amd.ops import pit_features
+    from padertorch_amd.ops import gemm as G
+    rng = np.random.RandomState(len(lens))
+    exs = [features_np.synthetic_mixture(rng, n) for n in lens]
+    ys = [torch.from_numpy(y).to(DEV) for _, y in exs]
+    ss = [torch.from_numpy(s).to(DEV) for s, _ in exs]
+    f = pit_features(ys, ss)
+    pk = f['Y_abs'].packed_log1p
+    assert pk is not None
+    want = pack_sequence([torch.log1p(a) for a in f['Y_abs']])
+    assert torch.equal(pk.batch_sizes, want.batch_sizes) and pk.data.shape == want.data.shape
+    torch.testing.assert_close(pk.data, want.data, atol=1e-6, rtol=2e-7)
+    planes = pk.planes()
+    assert planes is not None
+    rows, F = want.data.shape
+    KB = (F + 31) // 32
+    p = planes.view((rows + 15) // 16, KB, 2, 4, 16, 8).float()          # [row tile][k block][plane][k group][row][8]
+    val = (p[:, :, 0] + p[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(-1, KB * 32) / 512.        # [rows padded][k padded]
+    torch.testing.assert_close(val[:rows, :F], pk.data, atol=2e-7, rtol=3e-7)
+    assert float(val[rows:].abs().max() if val.shape[0] > rows else 0.) == 0. and float(val[:, F:].abs().max()) == 0.
+    hi = p[:, :, 0].permute(0, 3, 1, 2, 4).reshape(-1, KB * 32)[:rows, :F]
+    assert torch.equal(hi, (pk.data * 512.).half().float())              # the hi plane is THE fp16 rounding of 2^9 x
+    # the first projection on these planes == on planes packed from the fp32 rows with the same scale word
+    w = torch.randn(48, F, device=DEV) * 0.1
+    word = G.scale_word(torch.device(DEV), 16.0)
+    ya, yb = torch.empty(rows, 48, device=DEV), torch.empty(rows, 48, device=DEV)
+    wp = G.pack_n(w)
+    torch.ops.ptmi.gemm_planes_(ya, planes, word, wp[0], wp[1], None, rows, 48, F, False, 1)
+    G.mm_planes_(yb, G.pack_n(pk.data, word), wp, rows, 48, F, split_k=1)
+    assert torch.equal(ya, yb)
+    f2 = pit_features(ys, ss)
+    assert pk.planes() is None and f2['Y_abs'].packed_log1p.planes() is not None
+
+
+def test_models_take_the_packed_log_magnitude_when_the_list_is_untouched():
+    """The model consumes ``Y_abs.packed_log1p`` (no pack / log1p kernels) and gives the masks of the generic path bit for bit
+    apart from the first projection's operand scale (2^9 instead of the measured one): compared at 1e-6."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    rng = np.random.RandomState(3)
+    lens = [4000, 3300, 2100]
+    exs = [features_np.synthetic_mixture(rng, n) for n in lens]
+    torch.manual_seed(0)
+    model = PermutationInvariantTrainingModel(F=257, recurrent_layers=2, units=24, K=2).to(DEV).eval()
+    f = pt.ops.pit_features([torch.from_numpy(y).to(DEV) for _, y in exs], [torch.from_numpy(s).to(DEV) for s, _ in exs])
+    with torch.no_grad():
+        fused = model(f)
+        plain = model(dict(Y_abs=list(f['Y_abs'])))          # a plain list: pack_sequence + log1p + measured scale
+    for a, b in zip(fused, plain):
+        torch.testing.assert_close(a, b, atol=1e-6, rtol=0)
