@@ -76,7 +76,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='skip the sync-checks / host-to-device / all-reduce side measurements')
     ap.add_argument('--library-gemms', action='store_true',
                     help='dense layers on the BLAS library (TunableOp selections of padertorch_amd/tuned) instead of csrc/gemm.hip')
-    ap.add_argument('--bf16', action='store_true', help='plain bf16 operands in the dense layers (reduced precision; reports the delta)')
+    ap.add_argument('--bf16', action='store_true',
+                    help="BASELINE configs[1]'s reduced-precision run: plain 16-bit operands in the dense layers (the hi halves only: fp16 "
+                         'for activations and weights, bf16 for the gate gradients), fp32 accumulation; not the default')
     ap.add_argument('--sync-checks', action='store_true',
                     help='loss / grad-norm finiteness checks in the step they belong to (two host syncs per step, '
                          'the reference behaviour) instead of Trainer(deferred_checks=True)')
@@ -181,7 +183,7 @@ def measured_traffic(kernel):
     return json.loads(f.read_text()).get(kernel, {}).get('hbm_bytes_per_launch')
 
 
-def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
+def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_mode=3):
     """One entry per hand-written kernel family seen in the timed steps: HIP-event time of every launch (events
     recorded on the launch stream around the C-ABI call), algorithmic bytes or flops per launch."""
     import numpy as np
@@ -208,10 +210,10 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
     kernels = []
     gemm, packs = {}, {}
     for n, v in by_name.items():
-        if n.startswith(('gemm_split:', 'gemm_planes:', 'gemm_planes_bf16:')):          # gemm_split:MxNxK:products, gemm_planes[_bf16]:MxNxK
+        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:')):          # gemm_planes[_bf16]:MxNxK
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
-            key = ('planes_bf16', 3) if n.startswith('gemm_planes_bf16') else ('planes', 3) if n.startswith('gemm_planes') else ('split', int(parts[2]))
+            key = ('planes_bf16', products_mode) if n.startswith('gemm_planes_bf16') else ('planes', products_mode)
             e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
@@ -251,15 +253,14 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro):
             continue
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
-        label = ('gemm_planes_kernel<fp16> (LSTM input projections, linears, their input gradients and all weight gradients: operands '
-                 'pre-split into fp16 (hi, lo) planes, 3 fp16 MFMA products per fp32 product)' if kind == 'planes' else
-                 'gemm_planes_kernel<bf16> (LSTM input gradients dgates W_ih on the bf16 (hi, lo) planes the backward recurrence hands on, '
-                 '3 bf16 MFMA products per fp32 product)' if kind == 'planes_bf16' else
-                 f'gemm_split_ws_kernel (fp32 operands split in registers, {products} fp16 MFMA products per fp32 product)'
-                 if products == 3 else 'gemm_split_ws_kernel (dense layers, plain bf16 operands)')
+        label = ('gemm_planes_big_kernel / gemm_planes_kernel <fp16> (LSTM input projections, linears, their input gradients and all weight '
+                 f'gradients: operands pre-split into fp16 (hi, lo) planes, {products} fp16 MFMA product(s) per product; persistent '
+                 'big-tile kernel without split K, 128 x 128 kernel with slabs for the weight gradients)' if kind == 'planes' else
+                 'gemm_planes_big_kernel<bf16> (LSTM input gradients dgates W_ih on the bf16 (hi, lo) planes the backward recurrence hands '
+                 f'on, {products} bf16 MFMA product(s) per product)')
         kernels.append(dict(
             kernel=label, bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak,
-            traffic=measured_traffic('gemm_planes' if kind.startswith('planes') else 'gemm_' + kind),
+            traffic=measured_traffic('gemm_planes'),
             peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = '
                       f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream, i.e. '
                       f'mostly next to a running recurrence)',
@@ -571,7 +572,7 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'bf16' if args.bf16 else 'f32',
+            'dtype': 'fp16/bf16 operands, f32 accumulate (reduced precision)' if args.bf16 else 'f32',
             'data': 'synthetic',
             'config': {
                 'workload': f'{cfg["label"]}, {cfg["batch"]} x {SECONDS} s {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
@@ -582,7 +583,7 @@ def main():
                 'parallelism': f'dp{world}',
                 'blstm': 'HIP recurrence (csrc/lstm_split.hip)',
                 'gemms': ('hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)' if args.library_gemms else
-                          'csrc/gemm.hip, plain bf16 operands (reduced precision)' if args.bf16 else
+                          'csrc/gemm_planes.hip, the hi planes only: plain 16-bit operands (reduced precision)' if args.bf16 else
                           'csrc/gemm_planes.hip: fp32 in / out, 3 16-bit MFMA products per product (fp32-equivalent accuracy); projections, '
                           'linears and weight gradients on operands pre-split into fp16 planes, LSTM input gradients on the bf16 planes the '
                           'backward recurrence hands on'),
@@ -595,7 +596,8 @@ def main():
             out['dry'] = True
             out['roofline'] = None
         else:
-            kernels = kernel_report(timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro)
+            kernels = kernel_report(timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro,
+                                    1 if args.bf16 else 3)
             out['kernel_event_steps'] = counted[1]
             out['roofline'] = kernels[0] if kernels else None
             out['other_kernels'] = kernels[1:]

@@ -385,36 +385,21 @@ int ptmi_td_lincomb(const float* x, const float* y, const int32_t* lengths, cons
                     const float* coef_b, const float* coef_c, int64_t batch, int32_t K, int64_t T,
                     const int64_t* strides, float* out, ptmi_stream_t stream);
 
-/* ---- Dense layers: fp32 GEMM on the fp16 matrix cores (split operands) ----------------------------
+/* ---- Dense layers: fp32 GEMM on the 16-bit matrix cores (split operands) --------------------------
  * Replaces the library GEMMs behind torch.nn.LSTM's input projections and torch.nn.Linear in
  * padertorch/contrib/examples/source_separation/pit/model.py:60-66,97-104 and contrib/tcl/dc.py:32-40,61-66
- * (forward, input gradients, weight gradients).
+ * (forward, input gradients, weight gradients): every fp32 operand value v is used as v s = hi + lo (16-bit halves, s a power
+ * of two per operand tensor) and every product as hi hi + hi lo + lo hi with fp32 accumulation - as close to the exact result as
+ * an fp32 MFMA chain at several times its rate (fp32 MFMA runs at 1/16 of the 16-bit rate on gfx950).
  *
  * ptmi_absmax: out_bits[0] = float bits of max |x[r, c]| over a [rows, cols] fp32 matrix with row stride ld
- * (device; zeroed and written on `stream`).  The GEMM derives the power-of-two operand scale from it.
- *
- * ptmi_gemm_split:  C[m, n] (+)= A B + bias  with fp32 operands and result,
- *   a  device fp32: [m][k] with row stride lda when a_kmajor, else [k][m] (lda between consecutive k)
- *   b  device fp32: [n][k] with row stride ldb when b_kmajor, else [k][n]
- *   amax_a / amax_b  device words from ptmi_absmax over the WHOLE operand tensor, or NULL (operand within
- *                    fp16's range as it is, e.g. |v| <= 1: scale 1)
- *   bias   device fp32 [n] or NULL;  accumulate != 0: C += ...;  ldc row stride of C
- *   products  3: every product as hi*hi + hi*lo + lo*hi of fp16 halves, fp32 accumulation (fp32-equivalent
- *                result, see csrc/gemm.hip);  1: operands rounded to bf16, one product ("bf16 mode")
- *   split_k   > 1: that many K ranges per output tile, each into its own slab of `workspace`
- *             (ptmi_gemm_workspace_elems floats), summed in slab order by a second kernel (reproducible) */
+ * (device; zeroed and written on `stream`).  The pack passes derive the operand scale 2^(13 - exponent) from it. */
 int ptmi_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* out_bits, ptmi_stream_t stream);
-int ptmi_gemm_split(const float* a, int32_t a_kmajor, int64_t lda, const uint32_t* amax_a, const float* b,
-                    int32_t b_kmajor, int64_t ldb, const uint32_t* amax_b, const float* bias, float* c, int64_t ldc,
-                    int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t products, int32_t split_k,
-                    float* workspace, ptmi_stream_t stream);
-int64_t ptmi_gemm_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k);
 
 /* ------------------------------------------------------------------------------------------------------------
- * The same GEMM on operands already split into fp16 (hi, lo) planes in MFMA-fragment order (csrc/gemm_planes.hip):
- * the weight-gradient form dW = dg^T x of padertorch/contrib/examples/source_separation/pit/model.py:60-66,97-104
- * (torch.nn.LSTM / nn.Linear backward), where both fp32 operands have the reduction axis (the batch's rows) as their
- * OUTER axis.
+ * The GEMM itself runs on operands already split into fp16 (hi, lo) planes in MFMA-fragment order (csrc/gemm_planes.hip); a
+ * streaming pass per operand makes them from either storage order (weights: once per optimizer step; activations that a
+ * recurrence or the feature kernel has already left as planes: not at all).
  *
  * ptmi_pack_planes_t: source x[k][c] fp32, k_rows x cols, row stride ld  ->  planes of the operand whose rows are the
  *   columns c and whose reduction axis is k: [ceil(cols / 16)][ceil(k_rows / 32)][hi | lo][64 chunks of 8 fp16]
@@ -423,7 +408,8 @@ int64_t ptmi_gemm_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split
  * ptmi_pack_planes_n: the same planes from a source x[r][k] whose reduction axis is contiguous (rows x k, row stride ld):
  *   activations and weights of the forward form x W^T.
  * ptmi_gemm_planes:  C[m, n] (+)= sum_k A[m, k] B[n, k] / (scale_a scale_b) + bias[n]  with A, B as planes of m x k and n x k
- *   operands (same amax words as at packing), three fp16 MFMA products per product, fp32 accumulation;
+ *   operands (same amax words as at packing), fp32 accumulation; products = 3: hi hi + hi lo + lo hi (fp32-equivalent), 1: the
+ *   hi planes only (plain 16-bit operands: the reduced-precision mode of BASELINE configs[1]);
  *   split_k > 1: that many k ranges, summed in order by a second kernel (workspace:
  *   ptmi_gemm_planes_workspace_elems floats). */
 int64_t ptmi_planes_elems(int64_t rows, int64_t k);
@@ -433,8 +419,8 @@ int ptmi_pack_planes_n(const float* x, int64_t rows, int64_t k, int64_t ld, cons
                        ptmi_stream_t stream);
 int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k);
 int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
-                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
-                     ptmi_stream_t stream);
+                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products,
+                     float* workspace, ptmi_stream_t stream);
 /* The bf16 flavour of the three calls above: the planes hold bf16 (hi, lo) halves, no operand scale (fp32's exponent range).
  * It exists for the LSTM input gradient dx = dgates W_ih (torch.nn.LSTM backward inside pit/model.py:60-66): the persistent
  * backward recurrence hands its gate gradients on as exactly such planes (its scratch, ptmi_lstm_handoff_cols), so the
@@ -442,7 +428,7 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
 int ptmi_pack_planes_t_bf16(const float* x, int64_t k_rows, int64_t cols, int64_t ld, uint16_t* out, ptmi_stream_t stream);
 int ptmi_pack_planes_n_bf16(const float* x, int64_t rows, int64_t k, int64_t ld, uint16_t* out, ptmi_stream_t stream);
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
-                          int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream);
+                          int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace, ptmi_stream_t stream);
 /* Calls without split K run on a persistent big-tile kernel (8 wavefronts, workgroup tile picked per problem by a cost model:
  * 0 = 256 x 320, 1 = 256 x 256, 2 = 256 x 192, 3 = 128 x 320, 4 = 128 x 256) or on the 128 x 128 kernel (5) that also carries
  * every split-K call.  ptmi_gemm_planes_select_tile pins that choice for the process (tests, A/B timing); -1 = the cost model. */

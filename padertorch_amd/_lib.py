@@ -90,17 +90,14 @@ SIGNATURES = {
     'ptmi_lstm_plan_backward': (c_int, [c_void_p, _P]),
     'ptmi_lstm_plan_destroy': (None, [c_void_p]),
     'ptmi_absmax': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
-    'ptmi_gemm_split': (c_int, [_P, c_int32, c_int64, _P, _P, c_int32, c_int64, _P, _P, _P, c_int64, c_int32, c_int32,
-                                c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    'ptmi_gemm_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_planes_elems': (c_int64, [c_int64, c_int64]),
     'ptmi_pack_planes_t': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
     'ptmi_gemm_planes_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_pack_planes_n': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
-    'ptmi_gemm_planes': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'ptmi_gemm_planes': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'ptmi_pack_planes_t_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_pack_planes_n_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
-    'ptmi_gemm_planes_bf16': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'ptmi_gemm_planes_bf16': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'ptmi_gemm_planes_select_tile': (c_int, [c_int32]),
     'ptmi_debug_occupy': (c_int, [c_int32, c_int32, c_int32, c_int64, _P]),
     'ptmi_grad_norm_workspace_elems': (c_int64, []),

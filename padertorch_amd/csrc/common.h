@@ -21,16 +21,14 @@ inline int launch_status() {
 
 // Zeroing of a few device words in front of a kernel that accumulates into them.  A kernel of this library, not
 // hipMemsetAsync: the runtime's fill goes through its blit path, and on a queue whose memory pool another queue is
-// working in it has been measured to start 60-260 us late (scripts/step_timeline.py: the gaps in front of every
-// __amd_rocclr_fillBufferAligned of the step; PTMI_USE_MEMSET=1 brings the runtime call back for that comparison).
+// working in it has been measured to start 60-260 us late (round 2, scripts/step_timeline.py: the gaps in front of every
+// __amd_rocclr_fillBufferAligned of the step).
 static __global__ void zero_words_kernel(uint32_t* p, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
 
 inline hipError_t zero_words_async(void* p, size_t n_words, hipStream_t st) {
-    static const bool use_memset = getenv("PTMI_USE_MEMSET") != nullptr;
-    if (use_memset) return hipMemsetAsync(p, 0, n_words * sizeof(uint32_t), st);
     if (n_words == 0) return hipSuccess;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t*>(p), n_words);
     return hipGetLastError();

@@ -457,7 +457,7 @@ static int dc_fill(DcArgs& A, const float* x, const float* t, int64_t T, const i
     A.F = F;
     A.nchunks = (int)(((T * F + kDcTile - 1) / kDcTile + kDcTilesPerWg - 1) / kDcTilesPerWg);
     if (A.nchunks < 1) A.nchunks = 1;
-    A.dbg = getenv("PTMI_DC_DBG") ? atoi(getenv("PTMI_DC_DBG")) : 0;
+    A.dbg = 0;
     // fast kernels: inner-contiguous, non-negative strides, one example within 1 GiB, E <= 24, K <= 8
     A.x_span = A.t_span = 0;
     bool fast = T > 0 && A.xs[3] == 1 && A.ts[3] == 1 && E <= 24 && K <= kDcKX && !(A.dbg & 8);

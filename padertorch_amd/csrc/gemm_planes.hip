@@ -61,7 +61,8 @@ struct PlanesArgs {
 
 // BF16: the planes hold bf16 halves (fp32's exponent range: no operand scale) - the backward recurrence's hand-off copy of the
 // gate gradients, whose range is not known before they are computed, and weights packed to match (csrc/lstm_split.hip)
-template <bool BF16>
+// ONE: only the hi planes are multiplied (one product per element: plain 16-bit operands - the reduced-precision "bf16 mode")
+template <bool BF16, bool ONE>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G) {
 #if __HIP_DEVICE_COMPILE__          // (the host pass cannot parse the LDS-DMA builtin; it only needs the stub)
     constexpr int PIECES = 32;      // plane tiles per stage: (8 row tiles + 8 column tiles) x 2 planes
@@ -94,7 +95,8 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
         for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
     if (kb0 < kb1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(gsrc[i], &lds[(wave * 8 + i) * FR], 16, 0, 0);
+        for (int i = 0; i < 8; ++i)
+            if (!ONE || !(i & 1)) __builtin_amdgcn_global_load_lds(gsrc[i], &lds[(wave * 8 + i) * FR], 16, 0, 0);
     }
     for (int kb = kb0; kb < kb1; ++kb) {
         const int st = (kb - kb0) & 1;
@@ -107,26 +109,28 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             bh[j] = __builtin_bit_cast(h8, sb[(j * 2 + 0) * FR]);
-            bl[j] = __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
+            bl[j] = ONE ? bh[j] : __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
         }
-        h8 ah = __builtin_bit_cast(h8, sa[0]), al = __builtin_bit_cast(h8, sa[FR]);
+        h8 ah = __builtin_bit_cast(h8, sa[0]), al = ONE ? ah : __builtin_bit_cast(h8, sa[FR]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             h8 nh = ah, nl = al;
             if (i + 1 < 4) {
                 nh = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 0) * FR]);
-                nl = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
+                nl = ONE ? nh : __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
             }
             if (more) {         // two pieces of the next stage per MFMA group
 #pragma unroll
                 for (int pc = 2 * i; pc < 2 * i + 2; ++pc)
-                    __builtin_amdgcn_global_load_lds(gsrc[pc] + (long long)(kb + 1 - kb0) * 2 * FR,
-                                                     &lds[((st ^ 1) * PIECES + wave * 8 + pc) * FR], 16, 0, 0);
+                    if (!ONE || !(pc & 1))
+                        __builtin_amdgcn_global_load_lds(gsrc[pc] + (long long)(kb + 1 - kb0) * 2 * FR,
+                                                         &lds[((st ^ 1) * PIECES + wave * 8 + pc) * FR], 16, 0, 0);
             }
             // D[n = 4 (lane >> 4) + e][m = lane & 15]: the MFMA's "a" operand is the B fragment, so a lane holds four
             // consecutive columns of C; product kind outermost: 4 independent MFMAs between two on one accumulator
+            // (p = 2: hi hi, 1: hi lo, 0: lo hi; ONE: p = 2 only)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = ONE ? 2 : 0; p < 3; ++p)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = BF16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, p == 0 ? bl[j] : bh[j]),
@@ -195,7 +199,7 @@ struct BigArgs {
     unsigned a_bytes, b_bytes;  // extent of the planes (buffer descriptors: < 4 GB)
 };
 
-template <bool BF16, int MT, int NT>
+template <bool BF16, int MT, int NT, bool ONE>
 __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int WM = 2, WN = 4, RA = WM * MT, RB = WN * NT, PIECES = 2 * (RA + RB);
@@ -231,11 +235,13 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
         if (i < PA) {
             const int f = wave * PA + i;
             const int rt = min(tm * RA + (f >> 1), rta - 1);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, &lds[(st * PIECES + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
+            if (!ONE || !(f & 1))           // (ONE: the lo planes stay where they are)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, &lds[(st * PIECES + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
         } else {
             const int f = wave * PB + (i - PA);
             const int rt = min(tn * RB + (f >> 1), rtb - 1);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, &lds[(st * PIECES + 2 * RA + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
+            if (!ONE || !(f & 1))
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, &lds[(st * PIECES + 2 * RA + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
         }
     };
 
@@ -269,15 +275,15 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 bh[j] = __builtin_bit_cast(h8, sb[(j * 2 + 0) * FR]);
-                bl[j] = __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
+                bl[j] = ONE ? bh[j] : __builtin_bit_cast(h8, sb[(j * 2 + 1) * FR]);
             }
-            h8 ah = __builtin_bit_cast(h8, sa[0]), al = __builtin_bit_cast(h8, sa[FR]);
+            h8 ah = __builtin_bit_cast(h8, sa[0]), al = ONE ? ah : __builtin_bit_cast(h8, sa[FR]);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 h8 nh = ah, nl = al;
                 if (i + 1 < MT) {
                     nh = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 0) * FR]);
-                    nl = __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
+                    nl = ONE ? nh : __builtin_bit_cast(h8, sa[((i + 1) * 2 + 1) * FR]);
                 }
 #pragma unroll
                 for (int pc = i * PPI; pc < (i + 1) * PPI; ++pc)
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                 // D[n = 4 (lane >> 4) + e][m = lane & 15]: the MFMA's "a" operand is the B fragment, so a lane holds four consecutive
                 // columns of C; product kind outermost: NT independent MFMAs between two on one accumulator
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = ONE ? 2 : 0; p < 3; ++p)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = BF16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, p == 0 ? bl[j] : bh[j]),
@@ -361,6 +367,47 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+}
+
+// max |x| as float bits (non-negative floats order like unsigned integers): one atomicMax per workgroup
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long rows, long long cols, long long ld,
+                                                     unsigned* __restrict__ out) {
+    __shared__ unsigned red[4];
+    const long long n = rows * cols;
+    unsigned m = 0u;
+    if (ld == cols && (cols & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        // four independent 16-byte loads per lane and iteration (few workgroups - see ptmi_absmax - so each has to keep
+        // enough bytes in flight itself)
+        const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
+        const f4* x4 = reinterpret_cast<const f4*>(x);
+        long long i = blockIdx.x * 256ll + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const f4 v0 = x4[i], v1 = x4[i + stride], v2 = x4[i + 2 * stride], v3 = x4[i + 3 * stride];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                m = max(max(m, __float_as_uint(v0[q]) & 0x7fffffffu),
+                        max(max(__float_as_uint(v1[q]) & 0x7fffffffu, __float_as_uint(v2[q]) & 0x7fffffffu), __float_as_uint(v3[q]) & 0x7fffffffu));
+        }
+        for (; i < n4; i += stride) {
+            const f4 v = x4[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m = max(m, __float_as_uint(v[q]) & 0x7fffffffu);
+        }
+    } else {
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const long long r = i / cols, c = i - r * cols;
+            m = max(m, __float_as_uint(x[r * ld + c]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m >= 0x7f800000u) m = 0x7f7fffffu;          // inf / nan: the GEMM result will be non-finite anyway
+        atomicMax(out, m);
+    }
 }
 
 // 8 values -> their 16-bit (hi, lo) halves as one 16-byte chunk per plane (round to nearest; v - hi is exact in fp32)
@@ -464,6 +511,20 @@ using namespace ptmi;
 
 extern "C" {
 
+int ptmi_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* out_bits, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!x || !out_bits || rows < 0 || cols < 0 || ld < cols, PTMI_E_INVALID);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = zero_words_async(out_bits, 1, st);
+    if (e != hipSuccess) return (int)e;
+    if (rows * cols == 0) return PTMI_OK;
+    // every workgroup ends with one atomicMax on the same word: ~12 ns each at the L2 (2048 workgroups spent 25 us there,
+    // whatever the size of the matrix), so at most 512 of them
+    const long long work = (rows * cols + 4095) / 4096;
+    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>(work, 1), 512);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, st, x, (long long)rows, (long long)cols, (long long)ld, out_bits);
+    return launch_status();
+}
+
 int64_t ptmi_planes_elems(int64_t rows, int64_t k) {
     return ((rows + 15) / 16) * ((k + 31) / 32) * 2 * 512;          // fp16 values
 }
@@ -543,23 +604,22 @@ static int cu_count() {
     return cus;
 }
 
-template <bool BF16, int MT, int NT>
+template <bool BF16, int MT, int NT, bool ONE>
 static void launch_big_inst(const BigArgs& G0, hipStream_t st) {
     BigArgs G = G0;
     G.tiles_m = (G.M + 32 * MT - 1) / (32 * MT);
     G.tiles_n = (G.N + 64 * NT - 1) / (64 * NT);
     const int T = G.tiles_m * G.tiles_n;
     const int grid = std::min((T + 7) / 8 * 8, cu_count() / 8 * 8);
-    hipLaunchKernelGGL((gemm_planes_big_kernel<BF16, MT, NT>), dim3((unsigned)grid), dim3(512), 0, st, G);
+    hipLaunchKernelGGL((gemm_planes_big_kernel<BF16, MT, NT, ONE>), dim3((unsigned)grid), dim3(512), 0, st, G);
 }
 
 // Picks the tile by a cost model fitted to scripts/mb/gemm_big.hip's measurements (profiles/r3_mb_gemm_big.txt): time ~ rounds of
 // the CUs x tile area / efficiency of the tile shape; the 128 x 128 kernel (two workgroups per CU at half speed each) is one of the
-// candidates.  Returns false when that one wins or the planes do not fit a buffer descriptor.  PTMI_GEMM_BIG=0: never.
-static bool launch_big(bool bf16, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias,
+// candidates.  Returns false when that one wins or the planes do not fit a buffer descriptor.
+static bool launch_big(bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias,
                        float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st) {
-    static const bool enabled = !(getenv("PTMI_GEMM_BIG") && getenv("PTMI_GEMM_BIG")[0] == '0');
-    if (!enabled || g_tile_override == 5) return false;
+    if (g_tile_override == 5) return false;
     const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
     if (a_bytes >= (1ll << 32) || b_bytes >= (1ll << 32)) return false;
     struct Cand { int mt, nt; double eff; };
@@ -582,8 +642,10 @@ static bool launch_big(bool bf16, const uint16_t* a, const uint32_t* amax_a, con
               accumulate ? 1 : 0, 0, 0, 4, (unsigned)a_bytes, (unsigned)b_bytes};
 #define PTMI_BIG_CASE(I, MT_, NT_)                                    \
     case I:                                                           \
-        if (bf16) launch_big_inst<true, MT_, NT_>(G, st);             \
-        else launch_big_inst<false, MT_, NT_>(G, st);                 \
+        if (bf16 && one) launch_big_inst<true, MT_, NT_, true>(G, st);        \
+        else if (bf16) launch_big_inst<true, MT_, NT_, false>(G, st);         \
+        else if (one) launch_big_inst<false, MT_, NT_, true>(G, st);          \
+        else launch_big_inst<false, MT_, NT_, false>(G, st);                  \
         break;
     switch (pick) {
         PTMI_BIG_CASE(0, 8, 5)
@@ -596,7 +658,7 @@ static bool launch_big(bool bf16, const uint16_t* a, const uint32_t* amax_a, con
     return true;
 }
 
-static int gemm_planes_impl(bool bf16, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
+static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
                             const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate,
                             int32_t split_k, float* workspace, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
@@ -607,15 +669,19 @@ static int gemm_planes_impl(bool bf16, const uint16_t* a, const uint32_t* amax_a
     splits = (KB + per - 1) / per;
     PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (splits == 1 && launch_big(bf16, a, amax_a, b, amax_b, bias, c, ldc, m, n, KB, accumulate, st)) return launch_status();
+    if (splits == 1 && launch_big(bf16, one, a, amax_a, b, amax_b, bias, c, ldc, m, n, KB, accumulate, st)) return launch_status();
     PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, bias, m, n, KB,
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
     const int tiles = G.tiles_m * G.tiles_n;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
-    if (bf16)
-        hipLaunchKernelGGL(gemm_planes_kernel<true>, grid, dim3(256), 0, st, G);
+    if (bf16 && one)
+        hipLaunchKernelGGL((gemm_planes_kernel<true, true>), grid, dim3(256), 0, st, G);
+    else if (bf16)
+        hipLaunchKernelGGL((gemm_planes_kernel<true, false>), grid, dim3(256), 0, st, G);
+    else if (one)
+        hipLaunchKernelGGL((gemm_planes_kernel<false, true>), grid, dim3(256), 0, st, G);
     else
-        hipLaunchKernelGGL(gemm_planes_kernel<false>, grid, dim3(256), 0, st, G);
+        hipLaunchKernelGGL((gemm_planes_kernel<false, false>), grid, dim3(256), 0, st, G);
     int rc = launch_status();
     if (rc != PTMI_OK || splits == 1) return rc;
     const long long total = (long long)m * n;
@@ -628,9 +694,10 @@ static int gemm_planes_impl(bool bf16, const uint16_t* a, const uint32_t* amax_a
 extern "C" {
 
 int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
-                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, float* workspace,
-                     ptmi_stream_t stream) {
-    return gemm_planes_impl(false, a, amax_a, b, amax_b, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
+                     int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products,
+                     float* workspace, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(products != 3 && products != 1, PTMI_E_INVALID);
+    return gemm_planes_impl(false, products == 1, a, amax_a, b, amax_b, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
 }
 
 int ptmi_gemm_planes_select_tile(int32_t tile) {
@@ -640,8 +707,9 @@ int ptmi_gemm_planes_select_tile(int32_t tile) {
 }
 
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
-                          int32_t k, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream) {
-    return gemm_planes_impl(true, a, nullptr, b, nullptr, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
+                          int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(products != 3 && products != 1, PTMI_E_INVALID);
+    return gemm_planes_impl(true, products == 1, a, nullptr, b, nullptr, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
 }
 
 }  // extern "C"

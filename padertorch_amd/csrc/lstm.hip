@@ -903,7 +903,6 @@ static void fwd_tile_shape(int max_batch, int H, int ndir, bool split, int* jt_o
 
 int ptmi_lstm_forward_fills(int32_t T, int32_t ndir, int32_t max_batch, int32_t H) {
     if (T < 1 || max_batch < 1 || H < 1 || H % 4 != 0 || (ndir != 1 && ndir != 2) || !ptmi_lstm_split_enabled()) return 0;
-    if (getenv("PTMI_LSTM_NO_FWD_FILL")) return 0;
     const int G32 = (4 * H + 31) / 32 * 32;
     if ((G32 / 32 + 7) / 8 > 10 || !bwd_daf_applies() || !fwd_uses_daf(max_batch, H, ndir)) return 0;
     // one forward launch (all row tiles resident at once), a wavefront without elements in its workgroups
@@ -947,14 +946,8 @@ static void fwd_tile_shape(int max_batch, int H, int ndir, bool split, int* jt_o
     // split kernels, one 16-row tile per workgroup: 16 units (38 instead of 50 workgroups per chain at H = 600) measured
     // 3.19 against 3.27 us per step with the fragment-order hand-off copy, and leaves 48 more CUs to other queues
     // (flag-protocol kernels only; with the data-as-flag hand-off 12 units measure 2.48 against 2.55)
-    if (split && jt == 12 && mtl == 1 && !bwd_daf_applies()) jt = 16;
     if (jt == 12 && (long long)((H + 11) / 12) * ndir > cu_count()) jt = 16;      // wide tiles: one workgroup per CU
     if (jt == 16 && (long long)((H + 15) / 16) * ndir > cu_count()) jt = 8;
-    if (const char* v = getenv("PTMI_LSTM_JT")) {
-        const int q = atoi(v);
-        jt = (q == 16 || q == 12 || (split && (q == 20 || q == 24))) ? q : 8;
-    }
-    if (const char* v = getenv("PTMI_LSTM_MTL")) mtl = atoi(v) == 1 ? 1 : 2;
     *jt_out = jt;
     *mtl_out = mtl;
 }
@@ -1022,7 +1015,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                       getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, 0, ntiles, c0, max_batch, hyt, (max_batch + 15) / 16,
                       w_hh_amax, KP32};
     A.err_sink = error_sink();
-    A.uniform = (rows == (int64_t)T * max_batch && !getenv("PTMI_LSTM_NO_UNIFORM")) ? 1 : 0;      // batch sizes never grow: equal lengths
+    A.uniform = (rows == (int64_t)T * max_batch) ? 1 : 0;      // batch sizes never grow: equal lengths
     const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
     if (backward_scratch && ptmi_lstm_forward_fills(T, ndir, max_batch, H)) {     // this layer's backward planes get their pattern here
         const int G32 = (4 * H + 31) / 32 * 32;
@@ -1038,12 +1031,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
             // one workgroup per CU: the workgroups of a chain (direction x row tile) on 8 / chains neighbouring XCDs, as in the
             // backward kernel (a chain's hand-off rows and slots then live in the L2s of those XCDs only)
             const int chains = ndir * nt;
-            A.span = (one_per_cu && chains <= 8 && 8 % chains == 0 && (jx + 8 / chains - 1) / (8 / chains) * 8 <= cus &&
-                      !getenv("PTMI_LSTM_FWD_NO_XCD")) ? 8 / chains : 0;
-            if (const char* v = getenv("PTMI_LSTM_FWD_SPAN")) {        // experiment: fewer XCDs per chain (the others stay idle)
-                const int sp = atoi(v);
-                if (A.span && sp >= 1 && sp <= A.span && (jx + sp - 1) / sp <= cus / 8) A.span = sp;
-            }
+            A.span = (one_per_cu && chains <= 8 && 8 % chains == 0 && (jx + 8 / chains - 1) / (8 / chains) * 8 <= cus) ? 8 / chains : 0;
             A.nx = jx;
             A.nt = nt;
             const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
@@ -1055,9 +1043,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
             if (rc) return rc;
             continue;
         }
-        if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1, true>), grid, block, 0, st, A);
-        else if (jt == 12 && small)
+        if (jt == 12 && small)
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1>), grid, block, 0, st, A);
         else if (wide && small)
             hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 1, 1>), grid, block, 0, st, A);
@@ -1113,7 +1099,6 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
     PTMI_RETURN_IF((long long)nx * ndir > resident || nx > kSlots, PTMI_E_UNSUPPORTED);
     const bool fits8 = split || (4 * H / 16 + 7) / 8 <= 19;
     int mtl = (nt16 > resident / (nx * ndir) && fits8) ? 2 : 1;
-    if (const char* v = getenv("PTMI_LSTM_BWD_MTL")) mtl = (atoi(v) == 2 && fits8) ? 2 : 1;
     const int ntiles = (nt16 + mtl - 1) / mtl;
     const int per_launch = std::min(ntiles, resident / (nx * ndir));
     const long long dg_bytes = rows * ndir * 4 * H * 4;
@@ -1141,7 +1126,7 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
                          getenv("PTMI_LSTM_DBG") ? atoi(getenv("PTMI_LSTM_DBG")) : 0, c0, max_batch, 0, 0, 0, dgt, nt16, dbias,
                          split ? dg_amax : nullptr, G32};
     A.err_sink = error_sink();
-    A.uniform = (rows == (int64_t)T * max_batch && !getenv("PTMI_LSTM_NO_UNIFORM")) ? 1 : 0;
+    A.uniform = (rows == (int64_t)T * max_batch) ? 1 : 0;
     A.s_begin = s_begin;
     A.s_end = s_end;
     A.dc_carry = dc_carry;
@@ -1151,7 +1136,7 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
         const int chains = nt * ndir;
         A.nx = nx;
         A.nt = nt;
-        A.span = (chains <= 8 && 8 % chains == 0 && !getenv("PTMI_LSTM_NO_XCD")) ? 8 / chains : 0;
+        A.span = (chains <= 8 && 8 % chains == 0) ? 8 / chains : 0;
         const unsigned nwg = A.span ? (unsigned)((nx + A.span - 1) / A.span * 8) : (unsigned)(nx * chains);
         if (split) {
             int rc = launch_bwd_split(A, mtl, nwg, st);
@@ -1160,7 +1145,7 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
         }
         if (mtl == 2)
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19, 2>), dim3(nwg), dim3(512), 0, st, A);
-        else if (!getenv("PTMI_LSTM_BWD16") && fits8)    // 8 wavefronts x 19 K blocks; 16 x 10 (128 VGPRs per lane, spills) only for wider layers
+        else if (fits8)    // 8 wavefronts x 19 K blocks; 16 x 10 (128 VGPRs per lane, spills) only for wider layers
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3(nwg), dim3(512), 0, st, A);
         else
             hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3(nwg), dim3(NW * 64), 0, st, A);
@@ -1197,23 +1182,6 @@ int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float*
 
 int ptmi_lstm_plan_forward(ptmi_lstm_plan* plan, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!plan || !plan->fwd, PTMI_E_INVALID);
-    if (getenv("PTMI_LSTM_TIME")) {      // diagnostic: GPU time of one replay
-        hipStream_t user = static_cast<hipStream_t>(stream);
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        (void)hipStreamSynchronize(user);
-        (void)hipEventRecord(e0, user);
-        (void)hipGraphLaunch(plan->fwd, user);
-        (void)hipEventRecord(e1, user);
-        (void)hipEventSynchronize(e1);
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        fprintf(stderr, "[ptmi] lstm fwd graph replay: %.1f us\n", ms * 1e3f);
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        return PTMI_OK;
-    }
     hipError_t e = hipGraphLaunch(plan->fwd, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? PTMI_OK : (int)e;
 }

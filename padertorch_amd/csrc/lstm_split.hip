@@ -985,16 +985,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static bool daf_enabled() {
-    static const bool on = !(getenv("PTMI_LSTM_DAF") != nullptr && atoi(getenv("PTMI_LSTM_DAF")) == 0);
-    return on;
-}
-
 bool fwd_daf_applies(int jt, bool small, bool one_per_cu) {
-    return daf_enabled() && one_per_cu && ((small && (jt == 8 || jt == 12 || jt == 16)) || (!small && jt == 12));
+    return one_per_cu && ((small && (jt == 8 || jt == 12 || jt == 16)) || (!small && jt == 12));
 }
 
-bool bwd_daf_applies() { return daf_enabled(); }
+bool bwd_daf_applies() { return true; }
 
 int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st, bool daf) {
     constexpr int NW = 8, CB = 3;
@@ -1011,23 +1006,8 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<12, NW, CB, 2>), grid, block, 0, st, A);
         return launch_status();
     }
-    if (jt == 12 && small && getenv("PTMI_LSTM_PHASES"))
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 1, 1, true>), grid, block, 0, st, A);
-    else if (jt == 16 && small && getenv("PTMI_LSTM_PHASES"))
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 1, 1, true>), grid, block, 0, st, A);
-    else if (jt == 20 && small)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 1, 1>), grid, block, 0, st, A);
-    else if (jt == 20)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<20, NW, CB, 2, 1>), grid, block, 0, st, A);
-    else if (jt == 24 && small)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<24, NW, CB, 1, 1>), grid, block, 0, st, A);
-    else if (jt == 12 && small)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 1, 1>), grid, block, 0, st, A);
-    else if (wide && small)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 1, 1>), grid, block, 0, st, A);
-    else if (jt == 12)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<12, NW, CB, 2, 1>), grid, block, 0, st, A);
-    else if (wide)
+    // flag-protocol kernels: the tile shapes the data-as-flag kernels do not cover (fwd_daf_applies)
+    if (wide)
         hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 2, 1>), grid, block, 0, st, A);
     else if (small && one_per_cu)
         hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 1, 1>), grid, block, 0, st, A);
@@ -1041,33 +1021,16 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 }
 
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
-    const char* v = getenv("PTMI_LSTM_BWD_CAB");
-    const int cab = v ? atoi(v) : 3;
     // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
-    const bool uni = A.uniform != 0 && !getenv("PTMI_LSTM_NO_UNI_T");
-    if (bwd_daf_applies()) {
-        if (mtl == 2 && uni)
-            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
-        else if (mtl == 2)
-            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, false, true>), dim3(nwg), dim3(512), 0, st, A);
-        else if (uni)
-            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
-        else
-            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, false, true>), dim3(nwg), dim3(512), 0, st, A);
-        return launch_status();
-    }
+    const bool uni = A.uniform != 0;
     if (mtl == 2 && uni)
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true>), dim3(nwg), dim3(512), 0, st, A);
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
     else if (mtl == 2)
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3>), dim3(nwg), dim3(512), 0, st, A);
-    else if (uni && cab < 5)
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, true>), dim3(nwg), dim3(512), 0, st, A);
-    else if (cab >= 10)
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 10>), dim3(nwg), dim3(512), 0, st, A);
-    else if (cab >= 5)
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 5>), dim3(nwg), dim3(512), 0, st, A);
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, false, true>), dim3(nwg), dim3(512), 0, st, A);
+    else if (uni)
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
     else
-        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3>), dim3(nwg), dim3(512), 0, st, A);
+        hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, false, true>), dim3(nwg), dim3(512), 0, st, A);
     return launch_status();
 }
 

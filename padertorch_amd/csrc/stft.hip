@@ -1158,14 +1158,9 @@ static int launch_inv(InvArgs& A, long long batch, hipStream_t st) {
     const long long total = A.cut_left + A.out_samples;                 // OLA samples needed
     const int min_hops = std::max(2 * PL::FPW, 2 * A.halo);
     int run_hops = std::max(64, min_hops);
-    const char* rh_env = getenv("PTMI_ISTFT_RUN");
-    if (rh_env) {
-        run_hops = std::max(atoi(rh_env), 1);
-    } else {
-        while (run_hops / 2 >= min_hops &&
-               batch * ((total + (long long)run_hops * shift - 1) / ((long long)run_hops * shift)) < resident_waves)
-            run_hops /= 2;
-    }
+    while (run_hops / 2 >= min_hops &&
+           batch * ((total + (long long)run_hops * shift - 1) / ((long long)run_hops * shift)) < resident_waves)
+        run_hops /= 2;
     A.run_hops = (run_hops + PL::FPW - 1) / PL::FPW * PL::FPW;
     A.groups = (A.halo + A.run_hops + PL::FPW - 1) / PL::FPW;
     const char* dbg_env = getenv("PTMI_STFT_DBG");

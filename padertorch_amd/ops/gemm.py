@@ -1,4 +1,4 @@
-"""fp32 matrix products on the fp16 matrix cores of the MI355X (``csrc/gemm.hip``).
+"""fp32 matrix products on the fp16 matrix cores of the MI355X (``csrc/gemm_planes.hip``).
 
 The dense layers of the hot path - the LSTM input projections and ``torch.nn.Linear`` layers of
 ``padertorch/contrib/examples/source_separation/pit/model.py:60-66,97-104`` / ``contrib/tcl/dc.py:32-40`` and
@@ -7,8 +7,9 @@ product evaluated as three fp16 products of the operands' (hi, lo) halves with f
 is as close to the fp64 result as an exact fp32 GEMM (``tests/test_gpu_gemm.py``) at several times its
 speed (fp32 MFMA runs at 1/16 of the fp16 rate on this part).
 
-``PRODUCTS = 1`` switches every product to plain bf16 operands (BASELINE's "bf16" run of the model:
-reduced precision, reported as a delta, never the default).
+``PRODUCTS = 1`` multiplies the hi planes only - plain 16-bit operands (fp16 for activations and weights, bf16 for the gate
+gradients the backward recurrence hands on), fp32 accumulation: BASELINE's "bf16" run of the model, reduced precision, reported
+as a delta, never the default.
 """
 import os
 import weakref
@@ -23,7 +24,7 @@ __all__ = ['mm', 'absmax', 'weight_absmax', 'UNIT_RANGE', 'PRODUCTS', 'ENABLED',
 #: False: the dense layers go back to the BLAS library (torch.addmm / F.linear): the round-1 path, kept for A/B runs
 ENABLED = True
 
-#: 3 = split fp16 (fp32-equivalent), 1 = plain bf16 operands
+#: 3 = split 16-bit halves (fp32-equivalent), 1 = the hi halves only (plain 16-bit operands)
 PRODUCTS = 3
 
 #: pass as ``amax_x`` / ``amax_y`` for operands known to lie in a range fp16 covers as it is (activations in
@@ -152,12 +153,11 @@ def seed_weights_absmax(params, word):
 
 
 #: weight-gradient GEMMs (both operands reduce over their OUTER axis) on pre-split fp16 planes (csrc/gemm_planes.hip)
-PLANES = os.environ.get('PTMI_GEMM_PLANES', '1') != '0'
+PLANES = True
 
 
 def planes_enabled():
-    """The planes GEMM exists in the fp32-equivalent (three-product) form only."""
-    return ENABLED and PLANES and PRODUCTS == 3
+    return ENABLED and PLANES
 
 
 def pack_t(x, amax=None):
@@ -286,18 +286,6 @@ def usable(*tensors):
     return ENABLED and all(t.is_cuda and t.dtype == torch.float32 for t in tensors)
 
 
-def _operand(t, reduce_first):
-    """(pointer, k-major flag, leading dimension) of a 2-D operand whose reduction axis is axis 1 (``x`` of
-    ``x @ y``, ``reduce_first`` False) or axis 0 (``y``)."""
-    red, other = (0, 1) if reduce_first else (1, 0)
-    if t.stride(red) == 1 and (t.stride(other) >= t.shape[red] or t.shape[other] == 1):
-        return t, 1, max(t.stride(other), t.shape[red])
-    if t.stride(other) == 1 and (t.stride(red) >= t.shape[other] or t.shape[red] == 1):
-        return t, 0, max(t.stride(red), t.shape[other])
-    t = t.contiguous()
-    return _operand(t, reduce_first)
-
-
 def auto_split_k(M, N, K):
     """K ranges per output tile: weight-gradient shapes (few 128 x 128 tiles, K = all rows of the batch) are cut until
     about two workgroups per CU exist (measured at the step's shapes: 2400 x 1200 x 8096 311 / 274 / 262 / 254 us with 1 / 2 / 4 / 8
@@ -305,12 +293,14 @@ def auto_split_k(M, N, K):
     tiles = -(-M // 128) * -(-N // 128)
     if tiles >= 384:
         return 1
-    return max(1, min(int(os.environ.get('PTMI_GEMM_SPLIT_TARGET', '512')) // tiles, K // 512, 8))
+    return max(1, min(512 // tiles, K // 512, 8))
 
 
-def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, split_k=None, products=None):
-    """``out (+)= x @ y + bias`` for fp32 CUDA tensors ``x [M, K]``, ``y [K, N]`` (any strides with one unit stride:
-    transposed views and column blocks of wider matrices are consumed in place).
+def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, split_k=None):
+    """``out (+)= x @ y + bias`` for fp32 CUDA tensors ``x [M, K]``, ``y [K, N]`` with one unit stride each (transposed views
+    and column blocks of wider matrices are consumed in place): either operand is split into planes by the pack pass of its
+    storage order (``pack_planes_n``: reduction axis contiguous, ``pack_planes_t``: reduction axis outermost), then
+    ``gemm_planes_``.
 
     ``amax_x`` / ``amax_y``: device words from :func:`absmax` / :func:`weight_absmax` over the operand (computed here
     when ``None``), or :data:`UNIT_RANGE`.  ``split_k``: K ranges per output tile (default: :func:`auto_split_k`).
@@ -318,11 +308,8 @@ def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, sp
     assert x.dim() == 2 and y.dim() == 2 and x.shape[1] == y.shape[0], (x.shape, y.shape)
     assert x.dtype == y.dtype == torch.float32, (x.dtype, y.dtype)
     _lib.require_gpu(x, y, bias, out)
-    products = PRODUCTS if products is None else products
     M, K = x.shape
     N = y.shape[1]
-    x, a_kmajor, lda = _operand(x, False)
-    y, b_kmajor, ldb = _operand(y, True)
     if out is None:
         assert not accumulate
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
@@ -335,13 +322,24 @@ def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, sp
             if bias is not None:
                 out += bias
         return out
-    if products == 3:
-        ax = None if amax_x is UNIT_RANGE else (absmax(x) if amax_x is None else amax_x)
-        ay = None if amax_y is UNIT_RANGE else (absmax(y) if amax_y is None else amax_y)
-    else:
-        ax = ay = None
     if bias is not None:
         assert bias.shape == (N,) and bias.is_contiguous() and bias.dtype == torch.float32
-    split_k = int(split_k) if split_k else auto_split_k(M, N, K)
-    torch.ops.ptmi.gemm_split_(out, x, a_kmajor, lda, ax, y, b_kmajor, ldb, ay, bias, M, N, K, bool(accumulate), products, split_k)
-    return out
+
+    def planes(t, reduce_first, amax):
+        # t's reduction axis is axis 0 (y) or axis 1 (x); the operand's rows are the other axis
+        red, other = (0, 1) if reduce_first else (1, 0)
+        if not ((t.stride(red) == 1 or t.shape[red] == 1) or (t.stride(other) == 1 or t.shape[other] == 1)):
+            t = t.contiguous()
+        if t.stride(red) == 1 or t.shape[red] == 1:         # reduction axis contiguous: rows of the operand = rows in memory
+            src = t.t() if reduce_first else t
+            if src.stride(1) != 1:
+                src = src.contiguous()
+            return pack_n(src, amax)
+        src = t if reduce_first else t.t()                  # [k, c] with unit inner stride
+        if src.stride(1) != 1:
+            src = src.contiguous()
+        return pack_t(src, amax)
+
+    a = planes(x, False, amax_x)
+    b = planes(y, True, amax_y)
+    return mm_planes_(out, a, b, M, N, K, accumulate=accumulate, split_k=split_k, bias=bias)

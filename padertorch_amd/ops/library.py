@@ -16,8 +16,8 @@ with CPU tensors fails in the dispatcher (``NotImplementedError: ... 'CPU' backe
     torch.ops.ptmi.unit_norm_forward / _backward   ptmi_unit_norm_*           (contrib/tcl/dc.py:70)
     torch.ops.ptmi.lstm_recurrence_forward / _backward   ptmi_lstm_*_persistent, falling back to ptmi_lstm_forward / _backward
                                                                               (torch.nn.LSTM in pit/model.py:60-66,97)
-    torch.ops.ptmi.absmax, torch.ops.ptmi.gemm_split_    ptmi_absmax, ptmi_gemm_split   (nn.LSTM input projections, nn.Linear)
-    torch.ops.ptmi.pack_planes_t, torch.ops.ptmi.gemm_planes_   ptmi_pack_planes_t, ptmi_gemm_planes   (weight-gradient GEMMs)
+    torch.ops.ptmi.absmax                          ptmi_absmax                (operand scale of the dense layers' fp32 operands)
+    torch.ops.ptmi.pack_planes_t / _n, torch.ops.ptmi.gemm_planes_   ptmi_pack_planes_t / _n, ptmi_gemm_planes   (nn.LSTM input projections, nn.Linear, all their gradients)
     torch.ops.ptmi.lstm_weight_prep                ptmi_lstm_weight_prep      (the nn.LSTM parameters' operand forms, once per optimizer step)
     torch.ops.ptmi.grad_norm, torch.ops.ptmi.adam_flat_  ptmi_grad_norm, ptmi_adam_flat (train/optimizer.py:27-42, trainer.py:512-532)
 """
@@ -181,18 +181,6 @@ def absmax(x, rows, cols, ld):
     return out
 
 
-@_register('gemm_split_(Tensor(a!) out, Tensor x, int a_kmajor, int lda, Tensor? amax_x, Tensor y, int b_kmajor, int ldb, '
-           'Tensor? amax_y, Tensor? bias, int M, int N, int K, bool accumulate, int products, int split_k) -> ()')
-def gemm_split_(out, x, a_kmajor, lda, amax_x, y, b_kmajor, ldb, amax_y, bias, M, N, K, accumulate, products, split_k):
-    lib = _lib.load()
-    nws = int(lib.ptmi_gemm_workspace_elems(M, N, K, split_k))
-    ws = torch.empty(nws, dtype=torch.float32, device=x.device) if nws else None
-    _lib.check(_lib.timed(f'gemm_split:{M}x{N}x{K}:{products}', lib.ptmi_gemm_split, x.data_ptr(), a_kmajor, lda,
-                          _lib.ptr(amax_x), y.data_ptr(), b_kmajor, ldb, _lib.ptr(amax_y), _lib.ptr(bias), out.data_ptr(),
-                          max(out.stride(0), N), M, N, K, int(accumulate), products, split_k, _lib.ptr(ws),
-                          _lib.stream(x.device)), 'ptmi_gemm_split')
-
-
 @_register('lstm_recurrence_backward_range(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!) dg, '
            'Tensor(b!) scratch, Tensor(c!) dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, int H, '
            'int ndir, int s_begin, int s_end, bool prefilled=False) -> bool')
@@ -284,8 +272,13 @@ def gemm_planes_(out, a, amax_a, b, amax_b, bias, M, N, K, accumulate, split_k):
     ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
     _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}', lib.ptmi_gemm_planes, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
                           _lib.ptr(amax_b), _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k,
-                          _lib.ptr(ws),
-                          _lib.stream(out.device)), 'ptmi_gemm_planes')
+                          _products(), _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes')
+
+
+def _products():
+    """3 (fp32-equivalent) or 1 (the hi planes only: ``ops.gemm.PRODUCTS``, the reduced-precision reporting mode)."""
+    from . import gemm
+    return 1 if gemm.PRODUCTS == 1 else 3
 
 
 
@@ -312,8 +305,8 @@ def gemm_planes_bf16_(out, a, a_offset, b, bias, M, N, K, accumulate, split_k):
     nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
     ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
     _lib.check(_lib.timed(f'gemm_planes_bf16:{M}x{N}x{K}', lib.ptmi_gemm_planes_bf16, a.data_ptr() + a_offset, b.data_ptr(),
-                          _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k, _lib.ptr(ws),
-                          _lib.stream(out.device)), 'ptmi_gemm_planes_bf16')
+                          _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k, _products(),
+                          _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes_bf16')
 
 
 # ------------------------------------------------------------------------------------------------ unit norm
@@ -337,18 +330,6 @@ def unit_norm_backward(gy, y, inv, eps):
 
 
 # ------------------------------------------------------------------------------------------------ (B)LSTM recurrence
-@_register('lstm_scratch_prefill(Tensor(a!) scratch, int T, int ndir, int max_batch, int H, bool backward) -> bool')
-def lstm_scratch_prefill(scratch, T, ndir, max_batch, H, backward):
-    """The hand-off planes of a persistent recurrence's scratch filled with the data-as-flag pattern on the CURRENT stream
-    (``ptmi_lstm_scratch_prefill``).  True: pass ``prefilled=True`` to the launch (ordered behind this call); False: this
-    configuration does not use the pattern."""
-    rc = _lib.timed('lstm_prefill', _lib.load().ptmi_lstm_scratch_prefill, scratch.data_ptr(), T, ndir, max_batch, H, int(backward),
-                    _lib.stream(scratch.device))
-    if rc < 0:
-        _lib.check(rc, 'ptmi_lstm_scratch_prefill')
-    return rc == 1
-
-
 @_register('lstm_recurrence_forward(Tensor(a!) gates, Tensor(b!) hy, Tensor? c0, Tensor w_hh_pad, Tensor? w_amax, Tensor bs_dev, '
            'Tensor offs_dev, int bs_host, int offs_host, int T, int max_batch, int rows, int H, int KP, int ndir, bool persistent, '
            'Tensor(c!)? scratch=None, bool prefilled=False, Tensor(d!)? backward_scratch=None) -> (Tensor, Tensor?)')

@@ -171,32 +171,21 @@ _WGRAD_STREAMS = {}
 
 
 #: run BLSTM layers on per-parameter-version cached stacked weights where autograd does not need the concatenations
-CACHE_STACKED_WEIGHTS = os.environ.get('PTMI_CACHE_WEIGHTS', '1') != '0'
+CACHE_STACKED_WEIGHTS = True
 #: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
-TAIL_ON_BOTH_QUEUES = os.environ.get('PTMI_TAIL_BOTH', '1') != '0'
-#: the data-as-flag pattern of the recurrences' hand-off planes filled ahead of time on the side stream (see _LstmLayerFn.forward)
-PREFILL_AHEAD = os.environ.get('PTMI_PREFILL_AHEAD', '0') != '0'      # measured neutral (7.87 vs 7.85 ms: the fill competes with the recurrence it runs next to): off
+TAIL_ON_BOTH_QUEUES = True
 #: the backward scratch's data-as-flag pattern written by the forward recurrence kernel (ptmi_lstm_forward_fills)
-FILL_IN_FORWARD = os.environ.get('PTMI_FILL_IN_FORWARD', '1') != '0'
-#: operand planes of the weight gradients that depend on forward data only (layer input, shifted output) packed during the forward pass
-PACK_IN_FORWARD = os.environ.get('PTMI_PACK_IN_FORWARD', '0') != '0'      # measured: 7.95-8.07 vs 7.90 ms - pack passes next to a forward recurrence slow it by more than the backward phase gains
+FILL_IN_FORWARD = True
 #: the forward recurrence's hand-off planes as operand A of the next projection / of the dense layer behind the BLSTM (no pack pass)
-INPUT_FROM_HANDOFF = os.environ.get('PTMI_INPUT_HANDOFF', '1') != '0'
+INPUT_FROM_HANDOFF = True
 #: (output tensor, its version, (scratch, cols), ndir, H) of the last packed_lstm call when its planes are valid, or None
 LAST_HANDOFF = None
-#: side queue: a layer's weight-gradient GEMMs start behind its recurrence, not behind its input-gradient GEMM
-WGRAD_BEFORE_DX = os.environ.get('PTMI_WGRAD_EARLY', '0') != '0'      # measured neutral (8.75 = 8.75 ms): off
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
-DX_FROM_HANDOFF = os.environ.get('PTMI_DX_HANDOFF', '1') != '0'
-#: the first layer's parameter forms on the main stream, the later layers' on the side stream (see packed_lstm)
-PREP_FIRST_ON_MAIN = os.environ.get('PTMI_PREP_MAIN', '1') != '0'
+DX_FROM_HANDOFF = True
 _WGRAD_DONE = {}
-#: launches per backward recurrence: > 1 cuts it into step ranges (``ptmi_lstm_backward_persistent_range``) so that the
-#: finished range's weight-gradient GEMMs start on the side stream under the next launch instead of after the whole layer.
-#: Measured at the B = 32 step (ms per step, two boxes): 1: 10.56 / 10.56, 2: 10.52 / 10.60, 3: 10.75 / 10.75 - the side
-#: stream's idle time during the last layer's recurrence is not free throughput: what the GEMMs gain by starting earlier,
-#: the recurrence next to them loses (5.8 instead of 5.0 us per step), plus ~30 us per extra launch.  Default 1.
-BWD_CHUNKS = int(os.environ.get('PTMI_LSTM_BWD_CHUNKS', '1'))
+# (Measured in round 2 and not kept - DESIGN.md sections 3.9 / 4 have the numbers -: the pattern fill ahead of time on a side stream,
+# the weight gradients' forward-data operand planes packed during the forward pass, a layer's weight gradients started behind its
+# recurrence instead of behind its input-gradient GEMM, the backward recurrence cut into several launches.)
 
 
 def _wgrad_stream(device):
@@ -498,33 +487,13 @@ class _LstmLayerFn(torch.autograd.Function):
             ctx.ext = None
             ctx.gemm = None
             ctx.scratch_b = (None, False)
-            ctx.fwd_planes = None
             if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
                 lease.release()
         else:
-            # hand-off scratch of the persistent recurrence - and of this layer's backward pass when one will come -, their
-            # data-as-flag pattern filled on the side stream NOW: next to the projection GEMM (the forward one) resp. next to
-            # the forward recurrences (the backward one's 155 MB at B = 32), instead of in front of the recurrence launches
+            # hand-off scratch of this layer's backward pass when one will come: its data-as-flag pattern is written by the forward
+            # recurrence kernel itself (below); the forward scratch is allocated and filled by the op
             scratch_f = scratch_b = None
             pre_f = pre_b = False
-            if PERSISTENT and PREFILL_AHEAD and x.is_cuda:
-                main_s = torch.cuda.current_stream(x.device)
-                pre = _prep_stream(x.device)
-                scratch_f = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 0)), dtype=torch.int32,
-                                        device=x.device)
-                if any(ctx.needs_input_grad):
-                    scratch_b = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
-                                            device=x.device)
-                pre.wait_stream(main_s)           # the blocks' previous users are ordered on the main stream
-                with torch.cuda.stream(pre):
-                    pre_f = torch.ops.ptmi.lstm_scratch_prefill(scratch_f, meta.T, ndir, meta.max_batch, H, False)
-                    if scratch_b is not None:
-                        pre_b = torch.ops.ptmi.lstm_scratch_prefill(scratch_b, meta.T, ndir, meta.max_batch, H, True)
-                filled = torch.cuda.Event()
-                filled.record(pre)
-                for t_ in (scratch_f, scratch_b):
-                    if t_ is not None:
-                        t_.record_stream(pre)
             if (PERSISTENT and scratch_b is None and x.is_cuda and any(ctx.needs_input_grad) and FILL_IN_FORWARD
                     and lib.ptmi_lstm_forward_fills(meta.T, ndir, meta.max_batch, H)):
                 # the forward recurrence itself writes the pattern into the planes of this layer's backward scratch (an idle
@@ -609,8 +578,6 @@ class _LstmLayerFn(torch.autograd.Function):
                             else _gemm.absmax(w_pad.view(-1, KP)))
             if PERSISTENT:
                 _error_sink(x.device)           # the word a timed-out launch reports to (set before the first launch)
-            if scratch_f is not None:
-                torch.cuda.current_stream(x.device).wait_event(filled)
             c, flags = torch.ops.ptmi.lstm_recurrence_forward(
                 gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
                 meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b)
@@ -621,28 +588,6 @@ class _LstmLayerFn(torch.autograd.Function):
                 if cols_out:
                     handoff['planes'] = (flags, cols_out)
             ctx.scratch_b = (scratch_b, pre_b)
-            # The transposed fp16 planes of this layer's input and of its shifted output - operand B of dW_ih = dg^T x and
-            # dW_hh = dg^T h_prev - depend on forward data only: packed NOW on the weight-gradient queue, which is idle during the
-            # forward pass (next to the recurrence just launched / the next layer's projection), instead of inside the backward
-            # phase, where that queue is the longer one.
-            ctx.fwd_planes = None
-            if (PACK_IN_FORWARD and use_gemm and _gemm.planes_enabled() and forms is not None and DEFER_WGRAD and WGRAD_SIDE_STREAM
-                    and not stateful and params is not None and any(ctx.needs_input_grad) and meta.equal_lengths
-                    and all(p.requires_grad and p.grad is not None for ps in params for p in ps)):
-                main_s = torch.cuda.current_stream(x.device)
-                side_s = _wgrad_stream(x.device)
-                ready = torch.cuda.Event()
-                ready.record(main_s)                     # behind the recurrence: x and hy (the shifted views of ext) are final
-                side_s.wait_event(ready)
-                with torch.cuda.stream(side_s):
-                    xp = _gemm.pack_t(x, amax_x)
-                    hp = [_gemm.pack_t(h_prev, _gemm.UNIT_RANGE)
-                          for _, h_prev in _recurrent_operands(meta, None, hy, ext if pad else None, None, ndir, H)]
-                    done = torch.cuda.Event()
-                    done.record(side_s)
-                for t_ in (x, ext):
-                    t_.record_stream(side_s)
-                ctx.fwd_planes = (xp, hp, done)
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
@@ -695,9 +640,6 @@ class _LstmLayerFn(torch.autograd.Function):
         main = torch.cuda.current_stream(x.device) if in_place else None
         side = _wgrad_stream(x.device) if use_side else main
         operands, xplanes = [None], {}
-        fwd_planes = getattr(ctx, 'fwd_planes', None) if (in_place and use_side) else None
-        if fwd_planes is not None and ctx.ext is None:
-            fwd_planes = None
 
         def wgrad_rows(dg, ranges, amax_dg, both_queues=False):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
@@ -716,11 +658,10 @@ class _LstmLayerFn(torch.autograd.Function):
                         k = r1 - r0
                         dgp = _gemm.pack_t(dgd[r0:r1], amax_dg)
                         key = (r0, r1)
-                        whole = fwd_planes is not None and key == (0, meta.rows)
                         if key not in xplanes:
-                            xplanes[key] = fwd_planes[0] if whole else _gemm.pack_t(x[r0:r1], gm[0])
+                            xplanes[key] = _gemm.pack_t(x[r0:r1], gm[0])
                         _gemm.mm_planes_(p_wih.grad, dgp, xplanes[key], G, x.shape[1], k, accumulate=True)
-                        hpl = fwd_planes[1][d] if whole else _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None)
+                        hpl = _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None)
                         _gemm.mm_planes_(p_whh.grad, dgp, hpl, G, H, k, accumulate=True)
                     elif gm is not None:
                         _gemm.mm(dgt, x[r0:r1], out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=gm[0])
@@ -738,48 +679,21 @@ class _LstmLayerFn(torch.autograd.Function):
                 _error_sink(dhy.device)
             dg = flags = None
             T = meta.T
-            chunks = BWD_CHUNKS if (PERSISTENT and use_side and gm is not None and lib.ptmi_lstm_split_enabled()
-                                    and T >= 64 * BWD_CHUNKS) else 1
             # gradients w.r.t. the initial state: the range entry point leaves the cell-state gradient behind the last step
             state_grad = h0 is not None and any(ctx.needs_input_grad[5:7])
             if state_grad and not (PERSISTENT and lib.ptmi_lstm_split_enabled()):
                 raise NotImplementedError('gradients w.r.t. the initial LSTM state need the persistent split kernels')
             carry = None
-            if chunks > 1 or state_grad:
-                # the recurrence in `chunks` launches over consecutive step ranges: the weight-gradient GEMMs of the time
-                # range a launch has finished run on the side stream under the next launch (ptmi_lstm_backward_persistent_range)
+            if state_grad:
                 dg = torch.empty_like(gates)
                 flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
                     int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
                 carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device)
-                cuts = [T * i // chunks for i in range(chunks + 1)]
-                nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
-                amax_word = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
-                offs = [int(v) for v in meta.offs_host[:T]] + [meta.rows]
-
-                def launch(i):
-                    return torch.ops.ptmi.lstm_recurrence_backward_range(
+                if not torch.ops.ptmi.lstm_recurrence_backward_range(
                         gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
-                        ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]))
-                if launch(0):
-                    for i in range(1, chunks):
-                        snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
-                        done = torch.cuda.Event()
-                        done.record(main)
-                        side.wait_event(done)
-                        s0, s1 = cuts[i - 1], cuts[i]                # steps finished by the previous launch
-                        part = [(offs[T - s1], offs[T - s0]), (offs[s0], offs[s1])][:ndir]
-                        wgrad_rows(dg, part, snap)
-                        snap.record_stream(side)
-                        if not launch(i):
-                            raise RuntimeError('ptmi_lstm_backward_persistent_range: a later range was refused')
-                    s0 = cuts[chunks - 1]
-                    todo = [(offs[0], offs[T - s0]), (offs[s0], offs[T])][:ndir]
-                else:
-                    dg = flags = None                                # not resident: the one-call path decides
-                    if state_grad:
-                        raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
-                                                  'persistent kernels')
+                        ndir, 0, T, bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0])):
+                    raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
+                                              'persistent kernels')
             if dg is None:
                 dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                     gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
@@ -793,12 +707,6 @@ class _LstmLayerFn(torch.autograd.Function):
                 if lib.ptmi_lstm_split_enabled():
                     amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
         amax_dg = None
-        rec_done = None
-        if in_place and use_side and WGRAD_BEFORE_DX:
-            # the weight gradients need the gate gradients, not the input gradient that is computed next: the side queue may
-            # start them as soon as the recurrence is done, next to the input-gradient GEMM of the main queue
-            rec_done = torch.cuda.Event()
-            rec_done.record(main)
         if gm is not None:
             amax_x, amax_w = gm
             # one scale for the whole gate-gradient tensor (both directions): the backward kernel tracked its maximum
@@ -831,16 +739,8 @@ class _LstmLayerFn(torch.autograd.Function):
                     if ev is not None:
                         main.wait_event(ev)
                 operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
-                if fwd_planes is not None:
-                    main.wait_event(fwd_planes[2])            # packed on the weight-gradient queue during the forward pass
-                    xplanes[todo[0]] = fwd_planes[0]
-                    for t in (fwd_planes[0][0],) + tuple(h[0] for h in fwd_planes[1]):
-                        t.record_stream(main)
-                else:
-                    xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
-            if use_side and rec_done is not None and amax_kernel is not None and not both:
-                side.wait_event(rec_done)
-            elif use_side:
+                xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
+            if use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
@@ -959,7 +859,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         pre = _prep_stream(data.device)
         pre.wait_stream(torch.cuda.current_stream(data.device))
         for layer, ps_ in enumerate(all_params):
-            if _stacked_stale(ps_) and not (layer == 0 and PREP_FIRST_ON_MAIN):
+            if _stacked_stale(ps_) and layer > 0:
                 _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre)
         # the first layer's forms are needed at once: on the main queue itself (a cross-queue wait in front of the first
         # projection was measured to cost the main queue 110-260 us; the later layers' forms are long done when their

@@ -120,7 +120,7 @@ class Optimizer:
 class Adam(Optimizer):
     optimizer_cls = optim.Adam
     #: clip + update + zero_grad on the flat bucket by the kernels of ``csrc/optim.hip`` (GPU buckets only)
-    native = os.environ.get('PTMI_NATIVE_ADAM', '1') != '0'
+    native = True
 
     def __init__(self, gradient_clipping=1e10, lr=1e-3, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0, amsgrad=False):

@@ -70,12 +70,12 @@ def test_kernels_are_registered_torch_ops_without_a_cpu_kernel():
     import padertorch_amd  # noqa: F401  (registers the library)
     names = {'stft_forward', 'istft_forward', 'pit_features', 'pit_loss_forward', 'pit_loss_backward', 'dc_loss_forward',
              'dc_loss_backward', 'unit_norm_forward', 'unit_norm_backward', 'lstm_recurrence_forward',
-             'lstm_recurrence_backward', 'absmax', 'gemm_split_'}
+             'lstm_recurrence_backward', 'absmax', 'gemm_planes_', 'pack_planes_n', 'pack_planes_t', 'pit_features_packed'}
     for n in names:
         op = getattr(torch.ops.ptmi, n)
         assert op.default._schema.name == f'ptmi::{n}'
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f'ptmi::{n}', 'CUDA')
         assert not torch._C._dispatch_has_kernel_for_dispatch_key(f'ptmi::{n}', 'CPU')
-    assert torch.ops.ptmi.gemm_split_.default._schema.arguments[0].alias_info.is_write      # out is written in place
+    assert torch.ops.ptmi.gemm_planes_.default._schema.arguments[0].alias_info.is_write     # out is written in place
     with pytest.raises(NotImplementedError):
         torch.ops.ptmi.absmax(torch.ones(2, 2), 2, 2, 2)                                    # CPU tensor: no kernel, no fallback

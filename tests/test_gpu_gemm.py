@@ -1,4 +1,4 @@
-"""Split-fp16 GEMM (csrc/gemm.hip, through the C ABI) against fp64: the result must be as close to the exact
+"""Split-fp16 GEMM (csrc/gemm_planes.hip, through the C ABI) against fp64: the result must be as close to the exact
 product as an fp32 GEMM is.  Error measure: |C - C64| / (|A| @ |B|) (error relative to the magnitude of the terms
 of each dot product), the same measure as scripts/mb/split_mfma_accuracy.hip."""
 import pytest
@@ -71,16 +71,25 @@ def test_wide_dynamic_range_bias_accumulate_views():
     assert float(flat[:5].abs().max()) == 0.
 
 
-def test_bf16_mode_is_reduced_precision():
+def test_one_product_mode_is_reduced_precision(monkeypatch):
+    """``ops.gemm.PRODUCTS = 1`` (BASELINE configs[1]'s "bf16" run): only the hi planes are multiplied - plain 16-bit operands
+    (here fp16 halves of the scaled values: 11 significant bits), fp32 accumulation."""
     from padertorch_amd.ops import gemm
     dev = _dev()
     g = torch.Generator(device='cpu').manual_seed(5)
     a = (torch.rand(300, 640, generator=g) * 2 - 1).to(dev)
     b = (0.05 * torch.randn(640, 200, generator=g)).to(dev)
-    c = gemm.mm(a, b, products=1)
-    ref = (a.bfloat16().double() @ b.bfloat16().double())
-    assert float((c.double() - ref).abs().max()) < 1e-4            # bf16 operands, fp32 accumulation
-    assert 1e-6 < _err(c, a, b) < 5e-3
+    full = gemm.mm(a, b)
+    monkeypatch.setattr(gemm, 'PRODUCTS', 1)
+    c = gemm.mm(a, b)
+    assert 1e-6 < _err(c, a, b) < 2e-3 and _err(full, a, b) < 4e-7         # 11-bit operands vs 22-bit ones
+    # the bf16 planes (the gate gradients' route): hi halves = bf16-rounded values
+    pa = torch.ops.ptmi.pack_planes_bf16(a, False)
+    pw = torch.ops.ptmi.pack_planes_bf16(b, True)
+    y = torch.empty(300, 200, device=dev)
+    torch.ops.ptmi.gemm_planes_bf16_(y, pa, 0, pw, None, 300, 200, 640, False, 1)
+    ref16 = a.bfloat16().double() @ b.bfloat16().double()
+    assert float((y.double() - ref16).abs().max()) < 1e-4
 
 
 def test_padded_row_stride_views_take_the_aligned_path():

@@ -272,9 +272,9 @@ def test_weight_prep_forms(I, H, ndir):
 
 @pytest.mark.parametrize('lens', [[130] * 32, [200, 180, 180, 131, 77, 64, 3]])
 def test_in_place_weight_gradients_and_time_ranges(lens, monkeypatch):
-    """The Trainer's path - weight gradients accumulated in place on the side stream, the backward recurrence in 1, 2 or 3
-    launches over step ranges (ptmi_lstm_backward_persistent_range) with the finished range's weight-gradient GEMMs under
-    the next launch - against autograd through torch's CPU LSTM."""
+    """The Trainer's path - weight gradients accumulated in place on the side stream - against autograd through torch's CPU
+    LSTM; then the backward recurrence of the same layer in TWO launches over step ranges (the C ABI's
+    ptmi_lstm_backward_persistent_range, whose whole-range form the initial-state gradients use): bit-identical gate gradients."""
     import copy
     from padertorch_amd.ops import lstm as L
     from padertorch_amd.ops import packed_lstm
@@ -288,8 +288,7 @@ def test_in_place_weight_gradients_and_time_ranges(lens, monkeypatch):
     (out.data * pack_sequence(w).data).sum().backward()
     want = {k: p.grad.clone() for k, p in ref.named_parameters()}
     monkeypatch.setattr(L, 'DEFER_WGRAD', True)
-    for chunks in (1, 2, 3):
-        monkeypatch.setattr(L, 'BWD_CHUNKS', chunks)
+    for chunks in (1,):
         net = copy.deepcopy(ref).cuda()
         for p in net.parameters():
             p.grad = torch.zeros_like(p)
@@ -305,6 +304,30 @@ def test_in_place_weight_gradients_and_time_ranges(lens, monkeypatch):
         for k, p in net.named_parameters():
             scale = max(1.0, float(want[k].abs().max()))
             assert float((p.grad.cpu() - want[k]).abs().max()) < 3e-4 * scale, (chunks, k)
+    # one layer's backward recurrence through the range entry point: [0, T) in one launch == [0, T/2) + [T/2, T) in two
+    from padertorch_amd import _lib
+    lib = _lib.load()
+    if not lib.ptmi_lstm_split_enabled():
+        return
+    meta = L.pack_meta(pack_sequence(xs).batch_sizes, torch.device(DEV))
+    T, B, rows = meta.T, meta.max_batch, meta.rows
+    torch.manual_seed(1)
+    gates = torch.rand(rows, 2 * 4 * H, device=DEV)          # saved activations: any values in (0, 1)
+    c = torch.randn(rows, 2 * H, device=DEV)
+    dhy = torch.randn(rows, 2 * H, device=DEV)
+    w_t = (torch.randn(2, H, 4 * H, device=DEV) * 0.05).contiguous()
+    res = []
+    for cuts in ([0, T], [0, T // 2, T]):
+        dg = torch.empty_like(gates)
+        flags = torch.empty(int(lib.ptmi_lstm_scratch_elems(T, 2, B, H, 1)), dtype=torch.int32, device=DEV)
+        carry = torch.empty(2, B, H, device=DEV)
+        for a, b in zip(cuts, cuts[1:]):
+            assert torch.ops.ptmi.lstm_recurrence_backward_range(gates, c, None, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev,
+                                                                 T, B, rows, H, 2, a, b, False)
+        torch.cuda.synchronize()
+        L.check_errors()
+        res.append(dg)
+    assert torch.equal(res[0], res[1])
 
 
 @pytest.mark.gpu
