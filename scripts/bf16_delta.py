@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""BASELINE configs[1] "bf16" mode: the same PIT training step with the dense layers' operands rounded to bf16 (one MFMA
-product, ops.gemm.PRODUCTS = 1) against the default (three fp16 products per fp32 product), same weights, same inputs:
-delta of loss, masks and gradients, and the step time of both.  Reported, not asserted."""
+"""BASELINE configs[1] "bf16" mode: the same PIT training step with the dense layers multiplying plain 16-bit operands (the hi
+planes only, ops.gemm.PRODUCTS = 1: fp16 for activations and weights, bf16 for the gate gradients; fp32 accumulation) against
+the default (three 16-bit products per product, fp32-equivalent), same weights, same inputs: delta of loss, masks and
+gradients, and the time of both.  Reported, not asserted."""
 import json
 import sys
 import time
@@ -49,7 +50,7 @@ m1, l1, g1 = step(1)
 rel = {k: float((g1[k] - g3[k]).norm() / g3[k].norm().clamp_min(1e-30)) for k in g3}
 out = dict(workload='PIT 3xBLSTM-600, B=32, T=253 (BASELINE configs[1] shape), forward + review + backward, no optimizer',
            reference='dense layers with 3 fp16 products per fp32 product (default, fp32-equivalent)',
-           bf16='dense layers with operands rounded to bf16, one product; recurrence unchanged',
+           bf16='dense layers on the hi planes only (plain fp16 / bf16 operands, fp32 accumulation); recurrence unchanged',
            loss_default=l3, loss_bf16=l1, loss_delta={k: l1[k] - l3[k] for k in l3},
            mask_max_abs_delta=float((m1 - m3).abs().max()), mask_rms_delta=float((m1 - m3).pow(2).mean().sqrt()),
            grad_rel_l2_delta_max=max(rel.values()), grad_rel_l2_delta=rel,

@@ -11,12 +11,12 @@ import sys
 from pathlib import Path
 
 prof = Path(__file__).resolve().parent.parent / 'profiles'
-tag = sys.argv[1] if len(sys.argv) > 1 else 'r2'
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r3'
 # kernel name fragment -> key = the timer name bench.py files the kernel family under (_lib.timed)
 KEYS = {'pit_features_kernel': 'pit_features', 'pit_pairwise_kernel': 'pit_pairwise_sse',
         'pit_backward_kernel': 'pit_backward', 'lstm_fwd_split_kernel': 'lstm_forward', 'lstm_fwd_daf_kernel': 'lstm_forward',
         'lstm_bwd_split_kernel': 'lstm_backward', 'lstm_fwd_persistent_kernel': 'lstm_forward',
-        'lstm_bwd_persistent_kernel': 'lstm_backward', 'gemm_split_kernel': 'gemm_split', 'gemm_split_ws_kernel': 'gemm_split',
+        'lstm_bwd_persistent_kernel': 'lstm_backward', 'gemm_planes_big_kernel': 'gemm_planes',
         'gemm_planes_kernel': 'gemm_planes', 'stft_fwd_kernel': 'stft_fwd',
         'istft_kernel': 'istft'}
 

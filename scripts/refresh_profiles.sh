@@ -3,7 +3,7 @@
 #   bench line, rocprofv3 kernel trace of the same bench command, FETCH_SIZE / WRITE_SIZE PMC passes
 #   (separate runs, kernel-trace only), kernel micro-benchmarks.  Text summaries -> gpurun_out/p/.
 # usage: scripts/refresh_profiles.sh <round-tag>
-tag=${1:-r2}
+tag=${1:-r3}
 repo=$(pwd)
 out=$repo/gpurun_out/p
 mkdir -p $out
@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   if [ -n "$db" ]; then python $repo/scripts/profile_summary.py "$db" --pmc > $out/${tag}_pmc_$lc.txt 2>&1 </dev/null; else tail -5 /tmp/pmc_$c.log > $out/${tag}_pmc_$lc.txt; fi
 done
 timeout 600 python $repo/scripts/bench_kernels.py --big 2>/dev/null | grep '^{' > $out/${tag}_kernel_microbench.jsonl
-timeout 600 python $repo/scripts/bench_gemm.py 2>/dev/null | grep '^{' > $out/${tag}_gemm_microbench.jsonl
+( timeout 600 python $repo/scripts/bench_gemm.py 2>/dev/null | grep '^{'; timeout 600 python $repo/scripts/bench_gemm.py 32192 2>/dev/null | grep '^{' ) > $out/${tag}_gemm_microbench.jsonl
 # one step's kernels in start order (critical path) from the kernel trace
 db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python $repo/scripts/step_timeline.py "$db" --min-us 25 > $out/${tag}_step_timeline.txt 2>&1 </dev/null
@@ -28,10 +28,12 @@ db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --library-gemms 2>/dev/null | tail -1
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1
   PTMI_LSTM_F32=1 timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
-bash $repo/scripts/mb/run_mb.sh > /dev/null 2>&1
-for f in accuracy dispatch_probe handoff gemm_planes; do cp $repo/gpurun_out/mb/$f.txt $out/${tag}_mb_$f.txt 2>/dev/null; done
+# the big-tile GEMM prototype: tile shapes and ablations, on random and on zero-filled operands (DVFS)
+if [ -x $repo/scripts/mb/gemm_big ]; then
+  bash $repo/scripts/mb/run_gemm_big.sh "8096 4800 1216" "8096 1200 4864" "32192 4800 1216" "8192 8192 4096" > /dev/null 2>&1; cp $repo/gpurun_out/mb/gemm_big.txt $out/${tag}_mb_gemm_big.txt
+  ZERO=1 bash $repo/scripts/mb/run_gemm_big.sh "8096 4800 1216" "8192 8192 4096" > /dev/null 2>&1; cp $repo/gpurun_out/mb/gemm_big.txt $out/${tag}_mb_gemm_big_zero.txt
+fi
 timeout 600 python $repo/scripts/bf16_delta.py 2>/dev/null | tail -1 > $out/${tag}_bf16_delta.json
 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' > $out/${tag}_lstm_us_per_step.txt
 PTMI_LSTM_F32=1 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' | sed 's/^/exact-fp32 kernels: /' >> $out/${tag}_lstm_us_per_step.txt
-timeout 300 python $repo/scripts/exp_lstm_phases.py > $out/${tag}_lstm_fwd_phases.txt 2>/dev/null
 ls -la $out
