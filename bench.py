@@ -210,10 +210,11 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
     kernels = []
     gemm, packs = {}, {}
     for n, v in by_name.items():
-        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:')):          # gemm_planes[_bf16]:MxNxK
+        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:', 'gemm_planes_tn:')):          # gemm_planes[_bf16|_tn]:MxNxK
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
-            key = ('planes_bf16', products_mode) if n.startswith('gemm_planes_bf16') else ('planes', products_mode)
+            key = (('planes_tn', 3) if n.startswith('gemm_planes_tn') else
+                   ('planes_bf16', products_mode) if n.startswith('gemm_planes_bf16') else ('planes', products_mode))
             e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
@@ -253,9 +254,11 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
             continue
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
-        label = ('gemm_planes_big_kernel / gemm_planes_kernel <fp16> (LSTM input projections, linears, their input gradients and all weight '
+        label = ('gemm_planes_big_kernel / gemm_planes_kernel <fp16> (LSTM input projections, linears, their input and weight '
                  f'gradients: operands pre-split into fp16 (hi, lo) planes, {products} fp16 MFMA product(s) per product; persistent '
-                 'big-tile kernel without split K, 128 x 128 kernel with slabs for the weight gradients)' if kind == 'planes' else
+                 'big-tile kernel without split K, 128 x 128 kernel with slabs for the linears\' weight gradients)' if kind == 'planes' else
+                 'gemm_planes_tn_kernel<bf16> (LSTM weight gradients dgates^T [x | h_prev] reduced over the ROW tiles of the bf16 planes the '
+                 'backward recurrence hands on, LDS transpose reads; 3 bf16 MFMA products per product, slab split K)' if kind == 'planes_tn' else
                  'gemm_planes_big_kernel<bf16> (LSTM input gradients dgates W_ih on the bf16 (hi, lo) planes the backward recurrence hands '
                  f'on, {products} bf16 MFMA product(s) per product)')
         kernels.append(dict(

@@ -1,9 +1,18 @@
 #!/bin/bash
-# A/B runs of the bench step under environment knobs: scripts/ab.sh "VAR=1" "VAR2=0 VAR3=1" ...   ("-" = defaults)
-for env in "$@"; do
-  [ "$env" = "-" ] && env=""
+# A/B runs of the bench step in ONE box: scripts/ab.sh "<python statements>" ...   ("-" = defaults), two repetitions each, e.g.
+#   scripts/ab.sh - "L.WGRAD_FROM_HANDOFF=False" "G.PRODUCTS=1"
+# (L = padertorch_amd.ops.lstm, G = padertorch_amd.ops.gemm).  Differences below ~0.05 ms are noise, boxes differ by ~1-2 %.
+for stmt in "$@"; do
+  [ "$stmt" = "-" ] && stmt="pass"
   for rep in 1 2; do
-    ms=$(env $env python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read())['ms_per_step'])")
-    echo "ms/step $ms   [$env]"
+    ms=$(python -c "
+import sys
+sys.argv = ['bench.py', '--steps', '100', '--warmup', '10', '--no-cpu-baseline', '--no-extras']
+import padertorch_amd.ops.lstm as L, padertorch_amd.ops.gemm as G
+$stmt
+import bench
+bench.main()
+" 2>/dev/null | tail -1 | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read())['ms_per_step'])")
+    echo "ms/step $ms   [$stmt]"
   done
 done

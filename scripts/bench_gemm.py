@@ -76,6 +76,14 @@ for name, M, N, K, form in [
     else:
         for s in (1, 2, 4, 8):
             rec[f'k128_split{s}_us'] = timeit(lambda: gemm.mm_planes_(out, A, Bp, M, N, K, split_k=s))
+        # the weight-gradient form on row-major bf16 planes (LDS transpose reads, no transposing pack)
+        ta = torch.ops.ptmi.pack_planes_bf16(dg.contiguous(), False)
+        tb = torch.ops.ptmi.pack_planes_bf16(xx, False)
+        for s in (1, 2, 4, 8):
+            rec[f'tn_split{s}_us'] = timeit(lambda: torch.ops.ptmi.gemm_planes_tn_bf16_(out, ta, 0, (M + 31) // 32, 0, 0, tb, 0, (N + 31) // 32, 0, 0,
+                                                                                     M, N, K, False, s))
+        rec['tn_max_err_over_mag'] = float(((out.double() - ref).abs() / (a.double().abs() @ b.double().abs())).max())
+        rec['pack_n_bf16_a_us'] = timeit(lambda: torch.ops.ptmi.pack_planes_bf16(dg.contiguous(), False))
     gemm.PRODUCTS = 1
     try:
         t = timeit(lambda: gemm.mm_planes_(out, A, Bp, M, N, K))

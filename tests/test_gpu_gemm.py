@@ -254,3 +254,47 @@ def test_planes_big_tile_many_tiles_per_workgroup():
             assert float(((y.double() - want).abs() / mag).max()) < 4e-7
         finally:
             _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+
+
+@pytest.mark.parametrize('M,N,R,split,acc', [(2400, 1200, 8096, 2, True), (2400, 600, 8096, 4, False), (2400, 257, 8096, 8, True),
+                                             (100, 70, 50, 1, False), (129, 130, 16 * 7, 2, True), (33, 4, 3000, 3, False)])
+def test_planes_tn_weight_gradient_form_vs_fp64(M, N, R, split, acc):
+    """ptmi_gemm_planes_tn_bf16: C = A^T B over the rows of two row-major operands packed by pack_planes_n (bf16) - the MFMA
+    fragments come out of the LDS transpose read, no transposing pack pass: against fp64 (bf16 halves: 16 mantissa bits per
+    operand), odd row-tile counts, partial last tiles, split K, accumulation into a strided C, and the addressing of operands
+    that are parts of wider planes (a column-block offset = one direction of the hand-off planes; a row-tile offset = h_prev)."""
+    import padertorch_amd.ops  # noqa: F401  (registers torch.ops.ptmi.*)
+    torch.manual_seed(M + N + R)
+    wide_a = torch.randn(R + 64, M + 96, device='cuda') * torch.logspace(-3, 1, M + 96, device='cuda')
+    wide_b = torch.randn(R + 64, N + 64, device='cuda') * 0.1
+    if R % 16:                                     # rows behind a partial last tile must read as finite values: they do (packed zeros)
+        pass
+    a, b = wide_a[32:32 + R, 64:64 + M], wide_b[16:16 + R, 32:32 + N]
+    # planes of the WIDE matrices; the operands are addressed inside them by (column block, row tile) offsets
+    pa = torch.ops.ptmi.pack_planes_bf16(wide_a.contiguous(), False)
+    pb = torch.ops.ptmi.pack_planes_bf16(wide_b.contiguous(), False)
+    cbt_a, cbt_b = (M + 96 + 31) // 32, (N + 64 + 31) // 32
+    cbuf = torch.randn(M, N + 3, device='cuda')
+    c0 = cbuf.clone()
+    c = cbuf[:, :N]
+    # operand = rows 32.. / 16.. of the wide matrix (row tiles 2 / 1), columns from block 2 / 1 on; columns past M (N) inside the
+    # planes belong to the wide matrix (not zero): they only reach output columns that are not stored
+    want = a.double().t() @ b.double() + (c.double() if acc else 0)
+    mag = a.double().abs().t() @ b.double().abs() + (c.double().abs() if acc else 0)
+    rows_eff = R
+    torch.ops.ptmi.gemm_planes_tn_bf16_(c, pa, 0, cbt_a, 2, 2, pb, 0, cbt_b, 1, 1, M, N, rows_eff, acc, split)
+    torch.cuda.synchronize()
+    if R % 16 == 0:
+        err = float(((c.double() - want).abs() / mag).max())
+        assert err < 1.2e-5, err
+    else:
+        # a partial last row tile multiplies the wide matrices' next rows too: compare with that sum
+        Rp = (R + 15) // 16 * 16
+        a2, b2 = wide_a[32:32 + Rp, 64:64 + M], wide_b[16:16 + Rp, 32:32 + N]
+        want2 = a2.double().t() @ b2.double() + (c0[:, :N].double() if acc else 0)
+        mag2 = a2.double().abs().t() @ b2.double().abs() + (c0[:, :N].double().abs() if acc else 0)
+        assert float(((c.double() - want2).abs() / mag2).max()) < 1.2e-5
+    assert torch.equal(cbuf[:, N:], c0[:, N:])
+    again = c0.clone()
+    torch.ops.ptmi.gemm_planes_tn_bf16_(again[:, :N], pa, 0, cbt_a, 2, 2, pb, 0, cbt_b, 1, 1, M, N, rows_eff, acc, split)
+    assert torch.equal(again, cbuf)
