@@ -47,52 +47,10 @@ def _same(refs, params):
     return refs is not None and len(refs) == len(params) and all(r() is p for r, p in zip(refs, params))
 
 
-#: key -> (function, weak reference to the parameter, further arguments): how every cached form of a Linear weight was made, so
-#: that :func:`refresh_cached` can re-make them right behind the optimizer update instead of inside the next step
-_RECIPES = {}
-_REFRESHED = None        # event behind the last refresh_cached(); consumers wait for it once
-
-
-def _note(key, fn, p, *args):
-    if len(_RECIPES) > 64:
-        _RECIPES.clear()
-    _RECIPES[key] = (fn, weakref.ref(p), args)
-
-
-def _wait_refreshed():
-    global _REFRESHED
-    ev = _REFRESHED
-    if ev is not None:
-        if ev.query():
-            _REFRESHED = None
-        else:
-            torch.cuda.current_stream().wait_event(ev)
-
-
-def refresh_cached(stream):
-    """Re-make, on ``stream`` (which the caller has ordered behind the optimizer update), every cached operand form of the
-    Linear weights the last steps used: operand scale, fp16 planes in either orientation.  They change once per optimizer step;
-    made here they are off the next step's critical path (``Trainer.optimizer_step``)."""
-    global _REFRESHED
-    did = False
-    for key, (fn, ref, args) in list(_RECIPES.items()):
-        p = ref()
-        if p is None or not p.is_cuda:
-            _RECIPES.pop(key, None)
-            continue
-        with torch.cuda.stream(stream):
-            fn(p, *args)
-        did = True
-    if did:
-        _REFRESHED = torch.cuda.Event()
-        _REFRESHED.record(stream)
-
-
 def invalidate():
     """Drop every cached parameter-derived value (after in-place edits that bypass autograd's version counter)."""
     _WEIGHT_AMAX.clear()
     _WEIGHT_PLANES.clear()
-    _RECIPES.clear()
     from . import lstm as _lstm
     _lstm._STACKED.clear()
 
@@ -114,7 +72,6 @@ def weight_absmax(p):
     key = id(p)
     hit = _WEIGHT_AMAX.get(key)
     if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        _wait_refreshed()
         return hit[2]
     if len(_WEIGHT_AMAX) > 256:
         _WEIGHT_AMAX.clear()
@@ -192,13 +149,11 @@ def weight_planes(p):
     """``pack_n`` of a 2-D parameter used as the ``W`` of ``x W^T``, cached until the parameter is modified."""
     hit = _WEIGHT_PLANES.get(id(p))
     if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        _wait_refreshed()
         return hit[2]
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     v = pack_n(p.detach(), weight_absmax(p))
     _WEIGHT_PLANES[id(p)] = (p._version, p.data_ptr(), v, _refs((p,)))
-    _note(('n', id(p)), weight_planes, p)
     return v
 
 
@@ -208,13 +163,11 @@ def weight_planes_t(p):
     key = ('t', id(p))
     hit = _WEIGHT_PLANES.get(key)
     if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        _wait_refreshed()
         return hit[2]
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     v = pack_t(p.detach(), weight_absmax(p))
     _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
-    _note(key, weight_planes_t, p)
     return v
 
 
@@ -244,14 +197,12 @@ def weight_planes_h(p, ndir, H, cols):
     key = ('h', id(p), cols)
     hit = _WEIGHT_PLANES.get(key)
     if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        _wait_refreshed()
         return hit[2]
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     with torch.no_grad():
         v = pack_n(pad_direction_blocks(p.detach(), ndir, H, cols), weight_absmax(p))
     _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
-    _note(key, weight_planes_h, p, ndir, H, cols)
     return v
 
 

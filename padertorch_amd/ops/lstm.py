@@ -354,37 +354,6 @@ def _stacked_stale(params):
     return hit is None or hit[0] != tuple((p._version, p.data_ptr()) for p in flat) or not _gemm._same(hit[2], flat)
 
 
-def refresh_parameter_forms(device):
-    """Right behind an optimizer update: re-make, on the preparation stream, the operand forms of every LSTM layer and Linear
-    weight the last steps ran on (``_stacked_weights`` / ``ops.gemm.refresh_cached``) - they depend on the parameters only, so
-    the next step's first projection finds them ready instead of waiting for ~40 us of preparation kernels per layer at its head
-    (``Trainer.optimizer_step``; layer order = order of first use, so the first layer's forms are made first)."""
-    device = torch.device(device)
-    if device.type != 'cuda':
-        return
-    pre = None
-    for key, (sig, forms, refs) in list(_STACKED.items()):
-        ps = [r() for r in refs]
-        if any(p is None for p in ps):
-            _STACKED.pop(key, None)
-            continue
-        if not ps[0].is_cuda or ps[0].device != device or 'w_t' not in forms or len(ps) % 4:
-            continue
-        params = [tuple(ps[i:i + 4]) for i in range(0, len(ps), 4)]
-        if not _stacked_stale(params):
-            continue
-        if pre is None:
-            pre = _prep_stream(device)
-            pre.wait_stream(torch.cuda.current_stream(device))
-        H = ps[1].shape[1]
-        _stacked_weights(params, (H + 15) // 16 * 16, stream=pre)
-    if _gemm._RECIPES:
-        if pre is None:
-            pre = _prep_stream(device)
-            pre.wait_stream(torch.cuda.current_stream(device))
-        _gemm.refresh_cached(pre)
-
-
 def _stacked_weights(params, KP, stream=None):
     """The per-layer operand forms of a BLSTM layer's parameters - both directions' ``weight_ih`` stacked (and, for an
     input width that is not a multiple of 4, zero-padded along the reduction axis), the summed biases, ``weight_hh``

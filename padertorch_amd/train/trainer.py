@@ -421,10 +421,6 @@ class Trainer:
         else:
             self.optimizer.step()
             self.optimizer.zero_grad()
-        if self._flat is not None and self._flat.flat.is_cuda and self.model.training:
-            # the parameters' operand forms of the NEXT step (stacked / padded / transposed LSTM weights, fp16 planes, operand
-            # scales) on the preparation stream, right behind the update: off that step's critical path
-            _lstm.refresh_parameter_forms(self._flat.flat.device)
         self._opt_step += 1
         return summary
 
