@@ -195,10 +195,12 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
     T = frames_per_step // B
     fpl = frames_per_step            # frames one launch processes (one micro-step)
     rec_flop = 2.0 * 2 * B * hidden * 4 * hidden * T          # both directions, one layer, one pass
-    feature_bytes = (3 * SHIFT * 4 + (1 + 2 * K) * F * 4) * fpl if K == 2 else ((1 + K) * SHIFT * 4 + (1 + 2 * K) * F * 4) * fpl
+    # per frame: (1 + K) x shift samples in, (1 + 2 K) x F magnitudes / cosines out, and the first layer's input the kernel writes
+    # itself: F fp32 log-magnitudes in PackedSequence order + their fp16 (hi, lo) planes (F rounded up to 32-wide blocks)
+    feature_bytes = ((1 + K) * SHIFT * 4 + (1 + 2 * K) * F * 4 + F * 4 + (F + 31) // 32 * 32 * 2 * 2) * fpl
     pit_bytes = (1 + 3 * K) * F * 4 * fpl
     spec = {
-        'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end)', 'hbm', feature_bytes),
+        'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end incl. the packed log-magnitude input of the first layer)', 'hbm', feature_bytes),
         'pit_pairwise_sse': ('pit_pairwise_kernel (PIT mse+ips pairwise SSE)', 'hbm', pit_bytes),
         'pit_backward': ('pit_backward_kernel (d loss / d mask)', 'hbm', pit_bytes + K * F * 4 * fpl),
         'lstm_forward': ('lstm_fwd_daf_kernel (BLSTM recurrence, one persistent launch per layer, fp16 hi/lo MFMA products, data-as-flag '

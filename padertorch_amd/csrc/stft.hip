@@ -718,21 +718,18 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
                                 // pit/model.py:91-94: pack_sequence -> log1p, and the fp16 planes the first projection multiplies
                                 const int t = tw0 + f;
                                 const long long prow = (A.lp_offs ? A.lp_offs[t] : (long long)t * A.batch) + b;
-                                const float lk = log1pf(mk), lm = log1pf(mm);
+                                // log1p on the hardware log2 (v_log_f32): the kernel is VALU-bound and the library log1pf costs
+                                // ~35 instructions per value; 1 + |Y| rounds with an absolute error <= 6e-8, far inside the tolerance
+                                // the features are compared at (the oracle's log1p: atol 1e-6)
+                                const float lk = __log2f(1.f + mk) * 0.69314718f, lm = __log2f(1.f + mm) * 0.69314718f;
                                 float* lrow = A.lp_out + prow * F;
                                 lrow[k] = lk;
                                 if (km != k) lrow[km] = lm;
                                 if (A.lp_planes) {
-                                    _Float16* tile = A.lp_planes + ((prow >> 4) * A.lp_kb * 2) * 512 + (prow & 15) * 8;
-                                    auto put = [&](int kk, float v) {
-                                        const float sv = v * 512.f;
-                                        const _Float16 hi = (_Float16)sv;
-                                        _Float16* o = tile + (long long)(kk >> 5) * 1024 + ((kk & 31) >> 3) * 128 + (kk & 7);
-                                        o[0] = hi;
-                                        o[512] = (_Float16)(sv - (float)hi);
-                                    };
-                                    put(k, lk);
-                                    if (km != k) put(km, lm);
+                                    // parked in the spectrum slots this lane has just consumed (k and M - k; slot M is nobody's):
+                                    // the planes are written in 16-byte chunks of 8 bins by the pass behind this loop
+                                    wbuf[f * FS + k].x = lk;
+                                    if (km != k) wbuf[f * FS + km].x = lm;
                                 }
                             }
                         } else {
@@ -742,6 +739,29 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
                             if (km != k) cp[f * fstride + km] = valid ? cm.x + cm.y : 0.f;
                         }
                     }
+                }
+            }
+            if (q == 0 && A.lp_planes && !(A.dbg & 8)) {
+                // fp16 (hi, lo) planes of 2^9 log1p|Y| in MFMA-fragment order: chunk (bins 8 c .. 8 c + 7 of one packed row) = one
+                // 16-byte store per plane; bins past F are zero (csrc/gemm_planes.hip reads whole 32-wide blocks)
+                wave_sync();
+                const int chunks = A.lp_kb * 4;
+                for (int c = lane; c < nfr * chunks; c += 64) {
+                    const int f = c / chunks, ch = c - f * chunks, t = tw0 + f;
+                    if (t >= frames_b) continue;
+                    const long long prow = (A.lp_offs ? A.lp_offs[t] : (long long)t * A.batch) + b;
+                    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+                    h8v hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int kk = ch * 8 + e;
+                        const float sv = kk < F ? wbuf[f * FS + kk].x * 512.f : 0.f;
+                        hi[e] = (_Float16)sv;
+                        lo[e] = (_Float16)(sv - (float)hi[e]);
+                    }
+                    _Float16* o = A.lp_planes + (((prow >> 4) * A.lp_kb + (ch >> 2)) * 2) * 512 + ((ch & 3) * 16 + (prow & 15)) * 8;
+                    *reinterpret_cast<h8v*>(o) = hi;
+                    *reinterpret_cast<h8v*>(o + 512) = lo;
                 }
             }
             wave_sync();   // the next transposition reuses wbuf; yph is read by the following signals

@@ -57,7 +57,10 @@ def main():
         t = timeit(lambda: st.inverse(X))
         res.append(dict(kernel='istft', B=rows, N=N, frames=rows * T, us=t, GBs=rows * T * 2568 / t / 1e3))
         t = timeit(lambda: pt.ops.pit_features(y, s))
-        res.append(dict(kernel='pit_features', B=B, N=N, frames=B * T, us=t, GBs=B * T * 6676 / t / 1e3))
+        res.append(dict(kernel='pit_features (+ packed log1p fp32 and fp16 planes: 8856 B / frame)', B=B, N=N, frames=B * T, us=t,
+                        GBs=B * T * 8856 / t / 1e3))
+        t = timeit(lambda: pt.ops.pit_features(y, s, packed_log1p=False))
+        res.append(dict(kernel='pit_features (plain: 6676 B / frame)', B=B, N=N, frames=B * T, us=t, GBs=B * T * 6676 / t / 1e3))
         f = pt.ops.pit_features(y, s)
         mask = torch.rand(B, T, K, 257, device=dev, requires_grad=True)
         Y, Xa, C = f['Y_abs'].padded, f['X_abs'].padded, f['cos_phase_difference'].padded
