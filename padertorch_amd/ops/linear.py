@@ -1,4 +1,4 @@
-"""``torch.nn.Linear`` on the split-fp16 GEMM (``csrc/gemm.hip``), with the weight gradient joining the in-place
+"""``torch.nn.Linear`` on the split-fp16 GEMM (``csrc/gemm_planes.hip``), with the weight gradient joining the in-place
 side-stream accumulation of ``ops.lstm.DEFER_WGRAD``.
 
 The dense layers behind the BLSTM (``padertorch/contrib/examples/source_separation/pit/model.py:98-104``,
