@@ -149,10 +149,13 @@ class PermutationInvariantTrainingModel(base.Model):
             y = _pad_rows(list(y), max(num_samples))
         if num_samples is None:
             num_samples = [y.shape[-1]] * y.shape[0]
-        feats = ops.pit_features(y, None, num_samples, stft=stft)
-        masks = self.forward(dict(Y_abs=feats['Y_abs']))                  # PaddedList, [T, B, K, F]
+        # ONE transform of the mixture: the complex spectrum (frames past a row's own count are zero), its magnitude as the
+        # model input (round 2 ran the fused feature kernel for |Y| and the STFT again for Y)
         ns = torch.tensor(num_samples, dtype=torch.int32, device=y.device)
         Y = stft(y, num_samples=ns)                                       # [B, T, F] complex
+        frames = [int(stft.samples_to_frames(n)) for n in num_samples]
+        from padertorch_amd.ops.sequence.pack_module import PaddedList
+        masks = self.forward(dict(Y_abs=PaddedList(Y.abs(), frames, True)))   # PaddedList, [T, B, K, F]
         m = masks.padded if not masks.batch_first else masks.padded.transpose(0, 1)
         Z = m.permute(1, 2, 0, 3) * Y[:, None, :, :]                      # 't b k f -> b k t f' times Y
         z = stft.inverse(Z.contiguous())                                  # [B, K, samples]
