@@ -274,7 +274,7 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream);
-/* Data-as-flag hand-off (the default of the split kernels; PTMI_LSTM_DAF=0 selects the flag protocol): the planes at the
+/* Data-as-flag hand-off (the split kernels' protocol wherever their tile shapes allow it): the planes at the
  * start of the scratch start out as 0xFFFF in every 16-bit value - a pattern no conversion to fp16 / bf16 produces -, producers
  * only store, consumers re-request an operand tile until none of the values they are going to use is the pattern.  The
  * persistent calls fill the planes themselves (prefilled = 0) unless the caller has done it with ptmi_lstm_scratch_prefill

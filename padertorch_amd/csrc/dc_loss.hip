@@ -31,7 +31,7 @@ struct DcArgs {
     long long ts[4];             // t element (b, t, k, f) likewise
     int E, K, F;                 // F = inner extent per time step (rows n = t*F + f)
     int nchunks;                 // workgroups per example
-    int dbg;                     // PTMI_DC_DBG (1: no MFMA, 2: no loads, 4: no LDS staging: timing ablations; 8: generic kernels)
+    int dbg;                     // timing-ablation bits of round 1 (1: no MFMA, 2: no loads, 4: no LDS staging; 8: generic kernels); always 0 now
     unsigned x_span, t_span;     // bytes one example of x / t spans (0: not known to fit the fast kernels)
 };
 

@@ -18,9 +18,9 @@
 //     of W_hh lives in registers for all T steps; steps are chained by write-through stores into a
 //     tile-major hand-off copy (one contiguous KB per operand load), a drain, and per-chain arrival
 //     counters.  All workgroups must be co-resident (host-checked); every spin is bounded.
-// Environment knobs (experiments / ablations): PTMI_LSTM_DBG (16 no poll, 32 no drain,
-// 64 no MFMA, 128 no operand loads, 256 no look-ahead loads: results void), PTMI_LSTM_JT, PTMI_LSTM_MTL,
-// PTMI_LSTM_BWD16, PTMI_LSTM_BWD_MTL, PTMI_LSTM_NO_XCD, PTMI_LSTM_MAX_POLLS.
+// Environment: PTMI_LSTM_F32 (these exact-fp32 kernels instead of csrc/lstm_split.hip: the A/B reference),
+// PTMI_LSTM_DBG (timing ablations - 16 no poll, 32 no drain, 64 no MFMA, 128 no operand loads, 256 no look-ahead loads:
+// results void), PTMI_LSTM_MAX_POLLS (watchdog budget).  Round 2's tile / placement knobs are gone with round 3's prune.
 //
 // Layouts (rows = packed time-major rows of the PackedSequence, row(t, b) = offs[t] + b):
 //   gx / gates / dgates  [rows][ndir][4][H]   (pre-activations in, activations out: in place)
@@ -330,7 +330,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // workgroups share CUs, and one chain's hand-off latency hides behind the other chain's MFMAs.
 // OCC = workgroups per CU the register budget allows (2: up to 448 co-resident workgroups; 1: up to
 // 256, twice the registers, no spills).
-// PHASES: instrumented variant (PTMI_LSTM_PHASES): lane 0 of workgroup 0 sums the 100 MHz clock over the
+// PHASES: instrumented variant (a template parameter the library no longer instantiates; it produced the phase tables of
+// DESIGN.md 3.3): lane 0 of workgroup 0 sums the 100 MHz clock over the
 // phases of a step and leaves the sums in the first words of the scratch.
 template <int JT, int NW, int CH, int MTL, int OCC, bool PHASES = false>
 __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {

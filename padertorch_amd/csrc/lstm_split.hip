@@ -209,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
     unsigned* const err = A.flags + A.err_off;
     const int bl_ = tid / JT, u = tid - bl_ * JT;
     const int b = m0 + bl_;
-    // PHASES (PTMI_LSTM_PHASES): thread 0 of every workgroup (written out by workgroup (0, 0, 0)) sums the 100 MHz clock per phase of a step (scripts/exp_lstm_phases.py)
+    // PHASES (instrumentation, not instantiated in the library): thread 0 of every workgroup (written out by workgroup (0, 0, 0)) sums the 100 MHz clock per phase of a step (scripts/exp_lstm_phases.py)
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
     auto mark = [&](int kk) {
         if (PHASES && tid == 0) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Forward, data-as-flag hand-off (experiment, PTMI_LSTM_DAF=1; 16-row chains, one workgroup per CU).
+// Forward, data-as-flag hand-off (the default wherever fwd_daf_applies; one workgroup per CU).
 // The protocol above costs every step two store round trips in series (the write-through drain, then the flag) and two
 // load round trips (the poll, then the operands).  Here the scratch planes are pre-filled with a pattern no value can
 // have (0xFFFF: a NaN in fp16), producers only issue their write-through stores, and a consumer wavefront requests its

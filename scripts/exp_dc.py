@@ -10,7 +10,7 @@ x = torch.nn.functional.normalize(torch.randn(T, B, E, F, device=dev), dim=-2).r
 tm = torch.nn.functional.one_hot(torch.randint(0, K, (B, T, F), device=dev), K).permute(0, 1, 3, 2).float().contiguous()
 nbytes = T * B * F * (E + K) * 4
 t = timeit(lambda: dc_loss_batched(x.detach(), tm), iters=10)
-print(f"DBG={os.environ.get('PTMI_DC_DBG')} dc forward {t:.1f} us {nbytes / t / 1e3:.0f} GB/s")
+print(f"dc forward {t:.1f} us {nbytes / t / 1e3:.0f} GB/s")
 loss = dc_loss_batched(x, tm)[0]
 t = timeit(lambda: torch.autograd.grad(loss, x, retain_graph=True), iters=10)
-print(f"DBG={os.environ.get('PTMI_DC_DBG')} dc backward {t:.1f} us {(nbytes + T * B * F * E * 4) / t / 1e3:.0f} GB/s")
+print(f"dc backward {t:.1f} us {(nbytes + T * B * F * E * 4) / t / 1e3:.0f} GB/s")

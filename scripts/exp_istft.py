@@ -11,4 +11,4 @@ x = (0.1 * torch.randn(B, N)).to(dev)
 X = st(x)
 t = timeit(lambda: st.inverse(X), iters=10)
 nbytes = X.numel() * 8 + B * N * 4
-print(f"DBG={os.environ.get('PTMI_STFT_DBG')} RUN={os.environ.get('PTMI_ISTFT_RUN')} istft {t:.1f} us {nbytes / t / 1e3:.0f} GB/s")
+print(f"DBG={os.environ.get('PTMI_STFT_DBG')} istft {t:.1f} us {nbytes / t / 1e3:.0f} GB/s")
