@@ -182,6 +182,9 @@ INPUT_FROM_HANDOFF = True
 LAST_HANDOFF = None
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
 DX_FROM_HANDOFF = True
+#: the top layer's backward recurrence in two launches for batches of at least this many packed rows (see _LstmLayerFn.backward)
+SPLIT_TOP_BACKWARD = True
+SPLIT_TOP_BACKWARD_ROWS = 16384
 _WGRAD_DONE = {}
 # (Measured in round 2 and not kept - DESIGN.md sections 3.9 / 4 have the numbers -: the pattern fill ahead of time on a side stream,
 # the weight gradients' forward-data operand planes packed during the forward pass, a layer's weight gradients started behind its
@@ -428,7 +431,7 @@ class _LstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False, anchor=None, forms=None, prev=None,
-                handoff=None):
+                handoff=None, top=False):
         # prev: {'planes': (scratch, cols)} of the layer whose output `x` is (its hand-off planes as this projection's operand);
         # handoff: dict this call leaves its own planes in
         # anchor: a Parameter of the layer when (w_ih, bias, w_hh) are the cached detached forms (`forms`), so that the
@@ -566,6 +569,7 @@ class _LstmLayerFn(torch.autograd.Function):
         ctx.meta = meta
         ctx.params = params
         ctx.forms = forms
+        ctx.top = bool(top)          # the layer whose backward pass runs first (nothing else is on the weight-gradient queue then)
         if stateful:
             ctx.mark_non_differentiable(c)
             return hy, c
@@ -653,16 +657,49 @@ class _LstmLayerFn(torch.autograd.Function):
             if state_grad and not (PERSISTENT and lib.ptmi_lstm_split_enabled()):
                 raise NotImplementedError('gradients w.r.t. the initial LSTM state need the persistent split kernels')
             carry = None
-            if state_grad:
+            # The TOP layer's backward recurrence runs while the weight-gradient queue is still empty; for long batches, where
+            # that queue is the critical one of the backward phase (16 kHz configurations: 11.9 ms of GEMMs and pack passes
+            # beside 9.7 ms of recurrences), it runs as two launches over step ranges and the finished half's weight gradients
+            # start under the second launch (ptmi_lstm_backward_persistent_range).  For every layer, or at B = 32 / T = 253,
+            # the same cut measured neutral to slower (a recurrence next to GEMMs loses what the GEMMs gain): c3 23.97 -> 23.55 ms
+            # with the top layer in two launches, 23.35 / 23.33 in three / four, 23.70 with every layer in two.
+            chunks = 2 if (SPLIT_TOP_BACKWARD and getattr(ctx, 'top', False) and PERSISTENT and use_side and gm is not None
+                           and _gemm.planes_enabled() and lib.ptmi_lstm_split_enabled() and T >= 128
+                           and meta.rows >= SPLIT_TOP_BACKWARD_ROWS) else 1
+            if chunks > 1 or state_grad:
                 dg = torch.empty_like(gates)
                 flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
                     int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
                 carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device)
-                if not torch.ops.ptmi.lstm_recurrence_backward_range(
+                cuts = [T * i // chunks for i in range(chunks + 1)]
+                nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
+                amax_word = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
+                offs = [int(v) for v in meta.offs_host[:T]] + [meta.rows]
+
+                def launch(i):
+                    return torch.ops.ptmi.lstm_recurrence_backward_range(
                         gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
-                        ndir, 0, T, bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0])):
-                    raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
-                                              'persistent kernels')
+                        ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]))
+                if launch(0):
+                    for i in range(1, chunks):
+                        snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
+                        done = torch.cuda.Event()
+                        done.record(main)
+                        side.wait_event(done)
+                        s0, s1 = cuts[i - 1], cuts[i]                # steps finished by the previous launch
+                        part = [(offs[T - s1], offs[T - s0]), (offs[s0], offs[s1])][:ndir]
+                        wgrad_rows(dg, part, snap)
+                        snap.record_stream(side)
+                        if not launch(i):
+                            raise RuntimeError('ptmi_lstm_backward_persistent_range: a later range was refused')
+                    if chunks > 1:
+                        s0 = cuts[chunks - 1]
+                        todo = [(offs[0], offs[T - s0]), (offs[s0], offs[T])][:ndir]
+                else:
+                    dg = flags = None                                # not resident: the one-call path decides
+                    if state_grad:
+                        raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
+                                                  'persistent kernels')
             if dg is None:
                 dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                     gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
@@ -738,7 +775,7 @@ class _LstmLayerFn(torch.autograd.Function):
             gh0 = gc0 = None
             if state_grad:
                 gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
-            return (dx, None, None, None, None, gh0, gc0) + (None,) * 6
+            return (dx, None, None, None, None, gh0, gc0) + (None,) * 7
         db = dg.sum(0) if db_kernel is None else db_kernel
         if gm is not None:
             dw_ih = _gemm.mm(dg.t(), x, amax_x=amax_dg, amax_y=amax_x)
@@ -752,7 +789,7 @@ class _LstmLayerFn(torch.autograd.Function):
         gh0 = gc0 = None
         if lease is None and state_grad:
             gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
-        return (dx, dw_ih, db, dw_hh, None, gh0, gc0) + (None,) * 6
+        return (dx, dw_ih, db, dw_hh, None, gh0, gc0) + (None,) * 7
 
 
 def _state_grads(meta, dg, w_hh, carry, ndir, G, needs):
@@ -868,7 +905,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
                 GRAD_USE_HOOK([p for ps in params for p in ps])
             if layer == 0 and input_planes is not None and prev_handoff is None:
                 prev_handoff = {'xplanes': input_planes}
-            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms, prev_handoff, out_handoff)
+            h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms, prev_handoff, out_handoff,
+                                   layer + 1 == lstm.num_layers)
             prev_handoff = out_handoff
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
