@@ -208,6 +208,142 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const BigArgs G) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------- 32 x 32 x 16 MFMA variant
+// The same tile loop on v_mfma_f32_32x32x16_f16 (half the operand-register reads per MAC): does the power-limited rate change?
+// 256 x 256 tile, 8 wavefronts (2 x 4), wave tile 128 x 64 = 4 x 2 MFMA tiles of 32 x 32; fragments from the same 16 x 32 plane tiles:
+// lane l = (row l % 32 of two adjacent row tiles, k group l / 32) reads chunk (g = 2 h + l / 32, r = l % 16) of row tile (l % 32) / 16.
+typedef float f16v __attribute__((ext_vector_type(16)));
+template <int VAR>
+__global__ __launch_bounds__(512, 2) void gemm_big32_kernel(const BigArgs G) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int MT = 8, NT = 4, WN = 4, RA = 16, RB = 16, PIECES = 64, PA = 4, PB = 4, PW = 8;
+    __shared__ uint4 lds[2 * PIECES * FR];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(G.A), 0, G.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(G.B), 0, G.b_bytes, 0x00020000);
+    const int voff = lane * 16;
+    const int KB = G.KB;
+    const int rta = (G.M + 15) / 16, rtb = (G.N + 15) / 16;
+    const int T = G.tiles_m * G.tiles_n;
+    const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int q = T / 8, r8 = T % 8;
+    const int cnt = xcd < r8 ? q + 1 : q;
+    const int first = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    if (j0 >= cnt) return;
+    const int band_tiles = G.band * G.tiles_n;
+    auto tile_rc = [&](int idx, int& tm, int& tn) {
+        const int b = idx / band_tiles, rem = idx - b * band_tiles;
+        const int h = min(G.band, G.tiles_m - b * G.band);
+        tn = rem / h;
+        tm = b * G.band + (rem - tn * h);
+    };
+    auto issue = [&](int i, int tm, int tn, int kb, int st) {
+        if (i < PA) {
+            const int f = wave * PA + i;
+            const int rt = min(tm * RA + (f >> 1), rta - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, &lds[(st * PIECES + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
+        } else {
+            const int f = wave * PB + (i - PA);
+            const int rt = min(tn * RB + (f >> 1), rtb - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, &lds[(st * PIECES + 2 * RA + f) * FR], 16, voff, ((rt * KB + kb) * 2 + (f & 1)) * 1024, 0, 0);
+        }
+    };
+    f16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    int idx = j0, tm, tn;
+    tile_rc(first + idx, tm, tn);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) issue(i, tm, tn, 0, 0);
+    int st = 0;
+    // lane's chunk inside a 32-row pair of plane tiles: row tile (l % 32) / 16 (pieces are (row tile, plane): + 2 pieces), slot 16 g + r
+    const int lofs = ((lane & 31) >> 4) * 2 * FR + (lane >> 5) * 16 + (lane & 15);       // in uint4; + h * 32 for the k half, + FR for lo
+    while (true) {
+        const int nidx = idx + per;
+        const bool has_next_tile = nidx < cnt;
+        int ntm = tm, ntn = tn;
+        if (has_next_tile) tile_rc(first + nidx, ntm, ntn);
+        for (int kb = 0; kb < KB; ++kb) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const bool last = kb + 1 == KB;
+            const int ptm = last ? ntm : tm, ptn = last ? ntn : tn, pkb = last ? 0 : kb + 1;
+            const uint4* sa = &lds[(st * PIECES + wm * MT * 2) * FR + lofs];
+            const uint4* sb = &lds[(st * PIECES + 2 * RA + wn * NT * 2) * FR + lofs];
+            h8 bh[2][2], bl[2][2];          // [32-column tile][k half]
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bh[j][h] = __builtin_bit_cast(h8, sb[j * 4 * FR + h * 32]);
+                    bl[j][h] = __builtin_bit_cast(h8, sb[j * 4 * FR + FR + h * 32]);
+                }
+            h8 ah[2], al[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ah[h] = __builtin_bit_cast(h8, sa[h * 32]);
+                al[h] = __builtin_bit_cast(h8, sa[FR + h * 32]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h8 nh[2] = {ah[0], ah[1]}, nl[2] = {al[0], al[1]};
+                if (i + 1 < 4) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        nh[h] = __builtin_bit_cast(h8, sa[(i + 1) * 4 * FR + h * 32]);
+                        nl[h] = __builtin_bit_cast(h8, sa[(i + 1) * 4 * FR + FR + h * 32]);
+                    }
+                }
+#pragma unroll
+                for (int pc = i * 2; pc < i * 2 + 2; ++pc) issue(pc, ptm, ptn, pkb, st ^ 1);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 0 ? bl[j][h] : bh[j][h], p == 1 ? al[h] : ah[h], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    ah[h] = nh[h];
+                    al[h] = nl[h];
+                }
+            }
+            st ^= 1;
+        }
+        {
+            // D[n = 8 (e / 4) + 4 (lane / 32) + e % 4][m = lane % 32]: four consecutive columns of C per 4 accumulator registers
+            const int ml = lane & 31, nq = (lane >> 5) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = (tm * 2 + wm) * 128 + i * 32 + ml;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) {
+                        const int n = (tn * 4 + wn) * 64 + j * 32 + e4 * 8 + nq;
+                        const f4 v = f4{acc[i][j][e4 * 4], acc[i][j][e4 * 4 + 1], acc[i][j][e4 * 4 + 2], acc[i][j][e4 * 4 + 3]} * G.inv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][e4 * 4 + e] = 0.f;
+                        if (m < G.M && n + 3 < G.N) *reinterpret_cast<f4*>(G.C + (long long)m * G.ldc + n) = v;
+                    }
+            }
+        }
+        if (!has_next_tile) break;
+        idx = nidx;
+        tm = ntm;
+        tn = ntn;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------------------------- the product's 128 x 128 kernel (baseline)
 template <bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const uint4* __restrict__ A, const uint4* __restrict__ B, float* __restrict__ C,
@@ -322,6 +458,14 @@ void launch_big(const Problem& P, int band, int cus) {
     hipLaunchKernelGGL((gemm_big_kernel<false, MT, NT, VAR>), dim3(grid), dim3(512), 0, 0, G);
 }
 
+void launch_big32(const Problem& P, int band, int cus) {
+    BigArgs G{P.dA, P.dB, P.dC, nullptr, P.M, P.N, P.KB, (long long)P.N, 0, (P.M + 255) / 256, (P.N + 255) / 256,
+              band, (unsigned)P.a_bytes, (unsigned)P.b_bytes, P.inv};
+    const int T = G.tiles_m * G.tiles_n;
+    const int grid = std::min((T + 7) / 8 * 8, cus);
+    hipLaunchKernelGGL((gemm_big32_kernel<0>), dim3(grid), dim3(512), 0, 0, G);
+}
+
 void launch_old(const Problem& P, int, int) {
     const int tm = (P.M + 127) / 128, tn = (P.N + 127) / 128;
     hipLaunchKernelGGL((gemm_planes_kernel<false>), dim3((tm * tn + 7) / 8 * 8), dim3(256), 0, 0, P.dA, P.dB, P.dC, P.M, P.N, P.KB, (long long)P.N,
@@ -393,6 +537,7 @@ int main(int argc, char** argv) {
         {"old 128x128 (product r2)      ", launch_old, 0},
         {"big 256x256 band 4            ", launch_big<8, 4, 0>, 4},
         {"big 256x256 band 4 setprio    ", launch_big<8, 4, 1>, 4},
+        {"big 256x256 32x32x16 MFMA     ", launch_big32, 4},
         {"big 256x320 band 4            ", launch_big<8, 5, 0>, 4},
         {"big 256x320 band 4 setprio    ", launch_big<8, 5, 1>, 4},
         {"big 256x320 waves 4-7 prio 1  ", launch_big<8, 5, 16>, 4},
