@@ -196,7 +196,7 @@ struct BigArgs {
     long long ldc;
     int accumulate;
     int tiles_m, tiles_n, band;
-    unsigned a_bytes, b_bytes;  // extent of the planes (buffer descriptors: < 4 GB)
+    unsigned a_bytes, b_bytes;  // extent of the planes (buffer descriptors; < 2 GB: launch_big)
 };
 
 template <bool BF16, int MT, int NT, bool ONE>
@@ -763,7 +763,7 @@ static bool launch_big(bool bf16, bool one, const uint16_t* a, const uint32_t* a
                        float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st) {
     if (g_tile_override == 5) return false;
     const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
-    if (a_bytes >= (1ll << 32) || b_bytes >= (1ll << 32)) return false;
+    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return false;      // piece offsets are formed in 32-bit signed arithmetic
     struct Cand { int mt, nt; double eff; };
     static const Cand cands[] = {{8, 5, 1.0}, {8, 4, 1.0}, {8, 3, 0.92}, {4, 5, 0.86}, {4, 4, 0.85}};
     const int cus = cu_count();
