@@ -217,10 +217,19 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
             M, N, Kd = (int(x) for x in parts[1].split('x'))
             key = (('planes_tn', 3) if n.startswith('gemm_planes_tn') else
                    ('planes_bf16', products_mode) if n.startswith('gemm_planes_bf16') else ('planes', products_mode))
-            e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0))
+            e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0, members={}))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v))
             e['launches'] += len(v)
+            # the kernel behind the call (csrc/gemm_planes.hip): split K > 1 -> gemm_planes_kernel (128 x 128, slabs), else the
+            # persistent big-tile kernel; per kernel: what rocprofv3's summary of the same command lists
+            split = int(parts[2]) if len(parts) > 2 and parts[2].lstrip('-').isdigit() else 1
+            kname = ('gemm_planes_tn_kernel' if key[0] == 'planes_tn' else
+                     'gemm_planes_kernel (128 x 128, slab split K)' if split > 1 else 'gemm_planes_big_kernel (persistent, tile per problem)')
+            mem = e['members'].setdefault(kname, dict(flop=0., ms=0., launches=0))
+            mem['flop'] += 2.0 * M * N * Kd * len(v)
+            mem['ms'] += float(np.sum(v))
+            mem['launches'] += len(v)
             continue
         if n.startswith('pack_planes'):          # pack_planes_t:KxC / pack_planes_n:RxK: 4 B read + 4 B written per element
             a_, b_ = (int(x) for x in n.split(':')[1].split('x'))
@@ -270,7 +279,10 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
                       f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream, i.e. '
                       f'mostly next to a running recurrence)',
             avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
-            algorithmic_flop_per_step=e['flop'] / steps))
+            algorithmic_flop_per_step=e['flop'] / steps,
+            members=[dict(kernel=k, launches_per_step=m['launches'] / steps, avg_launch_ms=m['ms'] / m['launches'],
+                          ms_per_step=m['ms'] / steps, achieved=m['flop'] / (m['ms'] * 1e-3) / 1e12,
+                          frac=m['flop'] / (m['ms'] * 1e-3) / 1e12 / peak) for k, m in e['members'].items()]))
     for e in packs.values():
         achieved = e['bytes'] / (e['ms'] * 1e-3) / 1e9
         kernels.append(dict(

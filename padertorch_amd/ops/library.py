@@ -270,7 +270,7 @@ def gemm_planes_(out, a, amax_a, b, amax_b, bias, M, N, K, accumulate, split_k):
     lib = _lib.load()
     nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
     ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
-    _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}', lib.ptmi_gemm_planes, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
+    _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}:{split_k}', lib.ptmi_gemm_planes, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
                           _lib.ptr(amax_b), _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k,
                           _products(), _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes')
 
@@ -304,7 +304,7 @@ def gemm_planes_bf16_(out, a, a_offset, b, bias, M, N, K, accumulate, split_k):
     lib = _lib.load()
     nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
     ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
-    _lib.check(_lib.timed(f'gemm_planes_bf16:{M}x{N}x{K}', lib.ptmi_gemm_planes_bf16, a.data_ptr() + a_offset, b.data_ptr(),
+    _lib.check(_lib.timed(f'gemm_planes_bf16:{M}x{N}x{K}:{split_k}', lib.ptmi_gemm_planes_bf16, a.data_ptr() + a_offset, b.data_ptr(),
                           _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k, _products(),
                           _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes_bf16')
 
