@@ -427,6 +427,13 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
  * GEMM takes them as operand A as they lie and only W_ih is packed (once per optimizer step). */
 int ptmi_pack_planes_t_bf16(const float* x, int64_t k_rows, int64_t cols, int64_t ld, uint16_t* out, ptmi_stream_t stream);
 int ptmi_pack_planes_n_bf16(const float* x, int64_t rows, int64_t k, int64_t ld, uint16_t* out, ptmi_stream_t stream);
+/* Any of the four pack passes writing INTO a wider operand: `out` are planes with kb_total k blocks (of 32) per row tile; the
+ * source's k blocks land at k block kb_offset, kb_count of them (>= ceil(k / 32); the surplus is zero).  x is [rows_or_k][cols]:
+ * transposed = 0: rows x k (ptmi_pack_planes_n), 1: k x operand rows (ptmi_pack_planes_t); bf16 = 1: the bf16 flavour (amax NULL).
+ * The stacked input weights of a BLSTM layer as the operand of the previous layer's hand-off planes (k = H columns per direction,
+ * padded to ptmi_lstm_handoff_cols) are packed direction by direction this way - no padded fp32 copy. */
+int ptmi_pack_planes_into(const float* x, int64_t rows_or_k, int64_t cols, int64_t ld, int32_t transposed, int32_t bf16, const uint32_t* amax,
+                          uint16_t* out, int64_t kb_total, int64_t kb_offset, int64_t kb_count, ptmi_stream_t stream);
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
                           int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace, ptmi_stream_t stream);
 /* The weight-gradient form on the SAME planes: C[m, n] (+)= sum over rows r of A[r, m] B[r, n], both operands bf16 planes of

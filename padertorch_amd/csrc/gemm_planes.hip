@@ -594,7 +594,8 @@ __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restr
 // Workgroup: 32 k x 64 c; loads coalesced along c, a transpose through LDS, one 16 B chunk per thread and plane.
 template <bool BF16>
 __global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restrict__ x, long long krows, long long cols, long long ld,
-                                                            const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB) {
+                                                            const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KBS,
+                                                            long long KBO) {
     __shared__ float tile[32][65];
     const int tid = threadIdx.x;
     const long long kb = blockIdx.x, c0 = (long long)blockIdx.y * 64;
@@ -615,7 +616,50 @@ __global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restr
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = tile[g * 8 + e][rl * 16 + r];
-    uint4* o = out + ((rt * KB + kb) * 2) * FR + g * 16 + r;
+    uint4* o = out + ((rt * KBS + KBO + kb) * 2) * FR + g * 16 + r;
+    split_chunk<BF16>(v, o, o + FR);
+}
+
+// The same pass for sources whose rows are 16-byte aligned (x and ld: every operand of the training step but the 257-column
+// input): float4 loads (16 lanes per row, 16 rows per pass), column blocks fastest in the grid so that workgroups running together
+// read whole rows.  scripts/mb/pack_t.hip: 32192 x 2400 of 4800 columns 153 -> 117 us, 32192 x 1200 82 -> 52 us (a copy of the same
+// bytes: 121 / 52 us); wider tiles or strips with the next tile's loads in flight are no faster.
+template <bool BF16>
+__global__ __launch_bounds__(256) void pack_planes_t4_kernel(const float* __restrict__ x, long long krows, long long cols, long long ld,
+                                                             const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KBS,
+                                                             long long KBO) {
+    constexpr int P = 68;                                   // row pitch: float4 stores stay aligned
+    __shared__ float tile[32 * P];
+    const int tid = threadIdx.x;
+    const long long kb = blockIdx.y, c0 = (long long)blockIdx.x * 64;
+    const float s = plane_scale(amax);
+    const int lx = tid & 15, ly = tid >> 4;
+    f4 regs[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const long long k = kb * 32 + ly + p * 16, c = c0 + lx * 4;
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+        if (k < krows) {
+            if (c + 4 <= cols) {
+                z = *reinterpret_cast<const f4*>(x + k * ld + c);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c + e < cols) z[e] = x[k * ld + c + e];
+            }
+        }
+        regs[p] = z;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<f4*>(&tile[(ly + p * 16) * P + lx * 4]) = regs[p] * s;
+    __syncthreads();
+    const int rl = tid >> 6, g = (tid >> 4) & 3, r = tid & 15;
+    const long long rt = (long long)blockIdx.x * 4 + rl;
+    if (rt * 16 >= ((cols + 15) / 16) * 16) return;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[(g * 8 + e) * P + rl * 16 + r];
+    uint4* o = out + ((rt * KBS + KBO + kb) * 2) * FR + g * 16 + r;
     split_chunk<BF16>(v, o, o + FR);
 }
 
@@ -623,7 +667,8 @@ __global__ __launch_bounds__(256) void pack_planes_t_kernel(const float* __restr
 // 16-row tile x 4 k blocks; a thread makes one chunk (8 consecutive k of one row: 32 B read, 2 x 16 B written).
 template <bool BF16>
 __global__ __launch_bounds__(256) void pack_planes_n_kernel(const float* __restrict__ x, long long rows, long long K, long long ld,
-                                                            const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB) {
+                                                            const unsigned* __restrict__ amax, uint4* __restrict__ out, long long KB,
+                                                            long long KBS, long long KBO) {
     const int tid = threadIdx.x;
     const int r = tid >> 4, c = tid & 15;
     const long long rt = blockIdx.y, kb = (long long)blockIdx.x * 4 + (c >> 2);
@@ -643,7 +688,7 @@ __global__ __launch_bounds__(256) void pack_planes_n_kernel(const float* __restr
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] *= s;
-    uint4* o = out + ((rt * KB + kb) * 2) * FR + g * 16 + r;
+    uint4* o = out + ((rt * KBS + KBO + kb) * 2) * FR + g * 16 + r;
     split_chunk<BF16>(v, o, o + FR);
 }
 
@@ -671,37 +716,51 @@ int64_t ptmi_planes_elems(int64_t rows, int64_t k) {
     return ((rows + 15) / 16) * ((k + 31) / 32) * 2 * 512;          // fp16 values
 }
 
+// kbs / kbo / kbn: the operand's k blocks per row tile, the first k block this pass writes and how many (>= the source's own
+// ceil(k / 32); the surplus is zero): 0 / 0 / 0 = an operand of its own
 static int pack_t_impl(bool bf16, const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
-                       ptmi_stream_t stream) {
+                       ptmi_stream_t stream, int64_t kbs = 0, int64_t kbo = 0, int64_t kbn = 0) {
     PTMI_RETURN_IF(!x || !out || k_rows < 1 || cols < 1 || ld < cols, PTMI_E_INVALID);
     PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(out) & 15) != 0, PTMI_E_INVALID);
-    const long long KB = (k_rows + 31) / 32, cb = (cols + 63) / 64;
+    const long long own = (k_rows + 31) / 32, KB = kbn ? kbn : own, KBS = kbs ? kbs : KB, cb = (cols + 63) / 64;
+    PTMI_RETURN_IF(KB < own || kbo < 0 || kbo + KB > KBS, PTMI_E_INVALID);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (ld % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && KB <= 65535) {
+        const dim3 grid4((unsigned)cb, (unsigned)KB);
+        if (bf16)
+            hipLaunchKernelGGL(pack_planes_t4_kernel<true>, grid4, dim3(256), 0, st, x, (long long)k_rows, (long long)cols, (long long)ld, amax,
+                               reinterpret_cast<uint4*>(out), KBS, (long long)kbo);
+        else
+            hipLaunchKernelGGL(pack_planes_t4_kernel<false>, grid4, dim3(256), 0, st, x, (long long)k_rows, (long long)cols, (long long)ld, amax,
+                               reinterpret_cast<uint4*>(out), KBS, (long long)kbo);
+        return launch_status();
+    }
     PTMI_RETURN_IF(cb > 65535, PTMI_E_UNSUPPORTED);
     const dim3 grid((unsigned)KB, (unsigned)cb);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (bf16)
         hipLaunchKernelGGL(pack_planes_t_kernel<true>, grid, dim3(256), 0, st, x, (long long)k_rows, (long long)cols, (long long)ld, amax,
-                           reinterpret_cast<uint4*>(out), KB);
+                           reinterpret_cast<uint4*>(out), KBS, (long long)kbo);
     else
         hipLaunchKernelGGL(pack_planes_t_kernel<false>, grid, dim3(256), 0, st, x, (long long)k_rows, (long long)cols, (long long)ld, amax,
-                           reinterpret_cast<uint4*>(out), KB);
+                           reinterpret_cast<uint4*>(out), KBS, (long long)kbo);
     return launch_status();
 }
 
 static int pack_n_impl(bool bf16, const float* x, int64_t rows, int64_t k, int64_t ld, const uint32_t* amax, uint16_t* out,
-                       ptmi_stream_t stream) {
+                       ptmi_stream_t stream, int64_t kbs = 0, int64_t kbo = 0, int64_t kbn = 0) {
     PTMI_RETURN_IF(!x || !out || rows < 1 || k < 1 || ld < k, PTMI_E_INVALID);
     PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(out) & 15) != 0, PTMI_E_INVALID);
-    const long long KB = (k + 31) / 32, rt = (rows + 15) / 16;
+    const long long own = (k + 31) / 32, KB = kbn ? kbn : own, KBS = kbs ? kbs : KB, rt = (rows + 15) / 16;
+    PTMI_RETURN_IF(KB < own || kbo < 0 || kbo + KB > KBS, PTMI_E_INVALID);
     PTMI_RETURN_IF(rt > 65535, PTMI_E_UNSUPPORTED);
     const dim3 grid((unsigned)((KB + 3) / 4), (unsigned)rt);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bf16)
         hipLaunchKernelGGL(pack_planes_n_kernel<true>, grid, dim3(256), 0, st, x, (long long)rows, (long long)k, (long long)ld, amax,
-                           reinterpret_cast<uint4*>(out), KB);
+                           reinterpret_cast<uint4*>(out), KB, KBS, (long long)kbo);
     else
         hipLaunchKernelGGL(pack_planes_n_kernel<false>, grid, dim3(256), 0, st, x, (long long)rows, (long long)k, (long long)ld, amax,
-                           reinterpret_cast<uint4*>(out), KB);
+                           reinterpret_cast<uint4*>(out), KB, KBS, (long long)kbo);
     return launch_status();
 }
 
@@ -721,6 +780,13 @@ int ptmi_pack_planes_t_bf16(const float* x, int64_t k_rows, int64_t cols, int64_
 
 int ptmi_pack_planes_n_bf16(const float* x, int64_t rows, int64_t k, int64_t ld, uint16_t* out, ptmi_stream_t stream) {
     return pack_n_impl(true, x, rows, k, ld, nullptr, out, stream);
+}
+
+int ptmi_pack_planes_into(const float* x, int64_t rows_or_k, int64_t cols, int64_t ld, int32_t transposed, int32_t bf16, const uint32_t* amax,
+                          uint16_t* out, int64_t kb_total, int64_t kb_offset, int64_t kb_count, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(kb_total < 1 || kb_count < 1, PTMI_E_INVALID);
+    return transposed ? pack_t_impl(bf16 != 0, x, rows_or_k, cols, ld, amax, out, stream, kb_total, kb_offset, kb_count)
+                      : pack_n_impl(bf16 != 0, x, rows_or_k, cols, ld, amax, out, stream, kb_total, kb_offset, kb_count);
 }
 
 int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k) {

@@ -47,10 +47,41 @@ def _same(refs, params):
     return refs is not None and len(refs) == len(params) and all(r() is p for r, p in zip(refs, params))
 
 
+#: device -> (event, {id(parameter): (weak reference, version)}): the kernel that last rewrote these parameters in place
+#: (:func:`note_update`)
+_UPDATED = {}
+
+
+def note_update(params):
+    """An optimizer has just rewritten ``params`` in place on the current stream (and bumped their versions): remember an event
+    behind that kernel.  Work that only reads these parameters - their operand forms of the next step, made on a side stream -
+    then waits for THIS event instead of for everything the main stream has queued since (:func:`update_event`)."""
+    params = [p for p in params if p.is_cuda]
+    if not params:
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(params[0].device))
+    _UPDATED[params[0].device] = (ev, {id(p): (weakref.ref(p), p._version) for p in params})
+
+
+def update_event(params):
+    """The event of :func:`note_update` if every one of ``params`` was written by that kernel and by nothing since (same
+    objects, same versions); else ``None`` (wait for the stream)."""
+    hit = _UPDATED.get(params[0].device) if params else None
+    if hit is None:
+        return None
+    for p in params:
+        e = hit[1].get(id(p))
+        if e is None or e[0]() is not p or e[1] != p._version:
+            return None
+    return hit[0]
+
+
 def invalidate():
     """Drop every cached parameter-derived value (after in-place edits that bypass autograd's version counter)."""
     _WEIGHT_AMAX.clear()
     _WEIGHT_PLANES.clear()
+    _UPDATED.clear()
     from . import lstm as _lstm
     _lstm._STACKED.clear()
 
@@ -191,6 +222,19 @@ def pad_direction_blocks(w, ndir, H, cols):
     return out.view(w.shape[0], ndir * cols)
 
 
+def pack_n_direction_blocks(w, ndir, H, cols, amax):
+    """``pack_n(pad_direction_blocks(w, ndir, H, cols), amax)[0]`` without the padded fp32 copy: every direction's column block is
+    packed into its k blocks of the wider operand (``torch.ops.ptmi.pack_planes_into_``)."""
+    assert w.dim() == 2 and w.stride(1) == 1 and w.shape[1] == ndir * H and w.dtype == torch.float32, (w.shape, w.stride())
+    if cols % 32:
+        return pack_n(pad_direction_blocks(w, ndir, H, cols), amax)[0]
+    n = w.shape[0]
+    out = torch.empty((n + 15) // 16 * (ndir * cols // 32) * 1024, dtype=torch.float16, device=w.device)
+    for d in range(ndir):
+        torch.ops.ptmi.pack_planes_into_(out, w[:, d * H:(d + 1) * H], amax, False, ndir * cols // 32, d * cols // 32, cols // 32)
+    return out
+
+
 def weight_planes_h(p, ndir, H, cols):
     """``pack_n`` of a 2-D parameter ``W [out, ndir * H]`` with its input columns laid out like the hand-off planes
     (:func:`pad_direction_blocks`), cached until the parameter is modified."""
@@ -201,7 +245,8 @@ def weight_planes_h(p, ndir, H, cols):
     if len(_WEIGHT_PLANES) > 64:
         _WEIGHT_PLANES.clear()
     with torch.no_grad():
-        v = pack_n(pad_direction_blocks(p.detach(), ndir, H, cols), weight_absmax(p))
+        amax = weight_absmax(p)
+        v = (pack_n_direction_blocks(p.detach(), ndir, H, cols, amax), amax)
     _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
     return v
 
@@ -222,11 +267,18 @@ def stacked_planes_t_bf16(w, ndir, cols, key_params=None):
             _WEIGHT_PLANES.clear()
     G = w.shape[0] // ndir
     with torch.no_grad():
-        if cols != G:
-            wp = w.new_zeros((ndir, cols, w.shape[1]))
-            wp[:, :G] = w.view(ndir, G, -1)
-            w = wp.view(ndir * cols, -1)
-        planes = torch.ops.ptmi.pack_planes_bf16(w.detach().contiguous(), True)
+        if cols != G and cols % 32 == 0 and w.stride(1) == 1:
+            # every direction's rows into its k blocks of the wider operand (no padded fp32 copy)
+            planes = torch.empty((w.shape[1] + 15) // 16 * (ndir * cols // 32) * 1024, dtype=torch.bfloat16, device=w.device)
+            for d in range(ndir):
+                torch.ops.ptmi.pack_planes_into_(planes, w.detach()[d * G:(d + 1) * G], None, True, ndir * cols // 32, d * cols // 32,
+                                                 cols // 32)
+        else:
+            if cols != G:
+                wp = w.new_zeros((ndir, cols, w.shape[1]))
+                wp[:, :G] = w.view(ndir, G, -1)
+                w = wp.view(ndir * cols, -1)
+            planes = torch.ops.ptmi.pack_planes_bf16(w.detach().contiguous(), True)
     if key is not None:
         _WEIGHT_PLANES[key] = (sig, None, planes, _refs(key_params))
     return planes

@@ -296,6 +296,19 @@ def pack_planes_bf16(x, transposed):
     return out
 
 
+@_register('pack_planes_into_(Tensor(a!) out, Tensor x, Tensor? amax, bool transposed, int kb_total, int kb_offset, int kb_count) -> ()')
+def pack_planes_into_(out, x, amax, transposed, kb_total, kb_offset, kb_count):
+    """A pack pass writing ``kb_count`` k blocks at k block ``kb_offset`` of planes ``out`` that have ``kb_total`` k blocks per row
+    tile (``ptmi_pack_planes_into``); fp16 or bf16 by ``out.dtype``; ``x [r, k]``, or ``[k, c]`` when ``transposed``."""
+    lib = _lib.load()
+    a, b = x.shape
+    rows = b if transposed else a
+    assert out.dtype in (torch.float16, torch.bfloat16) and out.numel() >= (rows + 15) // 16 * kb_total * 1024, (out.dtype, out.numel())
+    _lib.check(_lib.timed(f'pack_planes_into:{a}x{b}', lib.ptmi_pack_planes_into, x.data_ptr(), a, b, x.stride(0), int(transposed),
+                          int(out.dtype == torch.bfloat16), _lib.ptr(amax), out.data_ptr(), kb_total, kb_offset, kb_count,
+                          _lib.stream(x.device)), 'ptmi_pack_planes_into')
+
+
 @_register('gemm_planes_bf16_(Tensor(a!) out, Tensor a, int a_offset, Tensor b, Tensor? bias, int M, int N, int K, bool accumulate, '
            'int split_k) -> ()')
 def gemm_planes_bf16_(out, a, a_offset, b, bias, M, N, K, accumulate, split_k):

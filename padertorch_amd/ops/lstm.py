@@ -357,6 +357,25 @@ def _stacked_stale(params):
     return hit is None or hit[0] != tuple((p._version, p.data_ptr()) for p in flat) or not _gemm._same(hit[2], flat)
 
 
+class _LazyPlanes:
+    """``ops.gemm.pack_n(w, amax)`` on first use (on the stream current then; ``w`` and ``amax`` were written on the stream the
+    forms were made on, whose ``ready`` event every consumer has waited for)."""
+
+    def __init__(self, w, amax):
+        self.w, self.amax, self.value = w, amax, None
+
+    def get(self):
+        if self.value is None:
+            with torch.no_grad():
+                self.value = _gemm.pack_n(self.w, self.amax)
+        return self.value
+
+
+def _w_ih_planes(forms):
+    v = forms['w_ih_planes']
+    return v.get() if isinstance(v, _LazyPlanes) else v
+
+
 def _stacked_weights(params, KP, stream=None):
     """The per-layer operand forms of a BLSTM layer's parameters - both directions' ``weight_ih`` stacked (and, for an
     input width that is not a multiple of 4, zero-padded along the reduction axis), the summed biases, ``weight_hh``
@@ -383,16 +402,20 @@ def _stacked_weights(params, KP, stream=None):
                     [ps[0].detach() for ps in params], [ps[1].detach() for ps in params], [ps[2].detach() for ps in params],
                     [ps[3].detach() for ps in params], KP)
                 I, H = p0.shape[1], params[0][1].shape[1]
-                # fp16 planes of the stacked input weights (the W of x W^T on csrc/gemm_planes.hip)
-                planes = _gemm.pack_n(w_ih_k[:, :I], amax[0:1]) if _gemm.planes_enabled() else None
-                # the same weights with their input columns laid out like the previous layer's hand-off planes (H columns per
-                # direction padded to the planes' width): that layer's scratch then is operand A of this layer's projection
-                planes_h = None
+                # the stacked input weights with their input columns laid out like the previous layer's hand-off planes (H columns
+                # per direction padded to the planes' width): that layer's scratch then is operand A of this layer's projection
+                planes = planes_h = None
                 ndir_ = len(params)
-                cols_ = int(_lib.load().ptmi_lstm_handoff_cols(H, 0)) if (planes is not None and INPUT_FROM_HANDOFF) else 0
+                cols_ = int(_lib.load().ptmi_lstm_handoff_cols(H, 0)) if (_gemm.planes_enabled() and INPUT_FROM_HANDOFF) else 0
                 if cols_ and I == ndir_ * H:
-                    planes_h = (planes if cols_ == H else
-                                _gemm.pack_n(_gemm.pad_direction_blocks(w_ih_k[:, :I], ndir_, H, cols_), amax[0:1]), cols_)
+                    planes_h = ((_gemm.pack_n_direction_blocks(w_ih_k[:, :I], ndir_, H, cols_, amax[0:1]), amax[0:1]), cols_)
+                    if cols_ == H:
+                        planes = planes_h[0]
+                # fp16 planes of the stacked input weights as they are (the W of x W^T on csrc/gemm_planes.hip): at once for a
+                # layer that has no other form (the first: its input is no hidden state), on first use (a dropout between the
+                # layers, an initial state) for the others
+                if _gemm.planes_enabled() and planes is None:
+                    planes = _gemm.pack_n(w_ih_k[:, :I], amax[0:1]) if planes_h is None else _LazyPlanes(w_ih_k[:, :I], amax[0:1])
                 # bf16 planes of W_ih as the right operand of dx = dgates W_ih on the backward recurrence's planes (layers whose
                 # input needs a gradient: not the first); built here, off the backward pass' critical path
                 planes_dx = None
@@ -405,7 +428,7 @@ def _stacked_weights(params, KP, stream=None):
             if stream is not None:
                 forms['ready'] = torch.cuda.Event()
                 forms['ready'].record(stream)
-                for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if planes is not None else ()) + (
+                for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if isinstance(planes, tuple) else ()) + (
                         (planes_h[0][0],) if planes_h is not None else ()) + ((planes_dx[0],) if planes_dx is not None else ()):
                     t.record_stream(main)          # allocated on the side stream's pool, used (and later freed) on the main one
             _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
@@ -493,7 +516,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 # the same scale word serves the weight gradient's pack of the fp32 x in the backward pass
                 word = amax_x
                 gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
-                wpl = forms['w_ih_planes']
+                wpl = _w_ih_planes(forms)
                 torch.ops.ptmi.gemm_planes_(gates, xplanes[0], word, wpl[0], wpl[1], bias, meta.rows, ndir * G, x.shape[1], False, 1)
             elif (hplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
                     and forms.get('w_ih_planes_h') is not None and forms['w_ih_planes_h'][1] == hplanes[1]):
@@ -507,7 +530,7 @@ class _LstmLayerFn(torch.autograd.Function):
             elif use_gemm and _gemm.planes_enabled() and forms is not None and forms.get('w_ih_planes') is not None:
                 # both operands as fp16 planes: the input split once here, the stacked weights' planes come with the forms
                 gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
-                _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), forms['w_ih_planes'], meta.rows, ndir * G, x.shape[1], bias=bias)
+                _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), _w_ih_planes(forms), meta.rows, ndir * G, x.shape[1], bias=bias)
             elif use_gemm:
                 # an input width that is not a multiple of 4 (F = 257) would send the projection and its weight gradient
                 # down the kernel's unaligned (scalar-load) path: zero-pad the reduction axis of both operands instead
@@ -614,11 +637,15 @@ class _LstmLayerFn(torch.autograd.Function):
         side = _wgrad_stream(x.device) if use_side else main
         operands, xplanes = [None], {}
 
+        dgplanes = {}
+
         def wgrad_rows(dg, ranges, amax_dg, both_queues=False):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
-            (both_queues: the reverse direction on the main stream - see TAIL_ON_BOTH_QUEUES)."""
+            (both_queues: all but the forward direction's dW_hh on the main stream - see TAIL_ON_BOTH_QUEUES)."""
             for d, ((p_wih, p_whh, _, _), (r0, r1)) in enumerate(zip(params, ranges)):
-                with torch.cuda.stream(main if both_queues and d == 1 else side):
+                q_ih = main if both_queues else side
+                q_hh = main if both_queues and d == 1 else side
+                with torch.cuda.stream(q_ih):
                     if operands[0] is None:
                         operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
                     dgd, h_prev = operands[0][d]
@@ -629,13 +656,16 @@ class _LstmLayerFn(torch.autograd.Function):
                         # both operands reduce over the batch's rows (their outer axis): split them into fp16 planes once
                         # (dg for two GEMMs, the layer input for both directions) and run the plain 16-bit GEMM
                         k = r1 - r0
-                        dgp = _gemm.pack_t(dgd[r0:r1], amax_dg)
                         key = (r0, r1)
+                        dgp = dgplanes.get((d, key))
+                        if dgp is None:
+                            dgp = _gemm.pack_t(dgd[r0:r1], amax_dg)
                         if key not in xplanes:
                             xplanes[key] = _gemm.pack_t(x[r0:r1], gm[0])
                         _gemm.mm_planes_(p_wih.grad, dgp, xplanes[key], G, x.shape[1], k, accumulate=True)
-                        hpl = _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None)
-                        _gemm.mm_planes_(p_whh.grad, dgp, hpl, G, H, k, accumulate=True)
+                        with torch.cuda.stream(q_hh):
+                            hpl = _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None)
+                            _gemm.mm_planes_(p_whh.grad, dgp, hpl, G, H, k, accumulate=True)
                     elif gm is not None:
                         _gemm.mm(dgt, x[r0:r1], out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=gm[0])
                         _gemm.mm(dgt, h_prev[r0:r1], out=p_whh.grad, accumulate=True, amax_x=amax_dg,
@@ -734,38 +764,44 @@ class _LstmLayerFn(torch.autograd.Function):
         else:
             dx = dg @ w_ih if ctx.needs_input_grad[0] else None           # [rows, I]
         if in_place:
-            # the first layer's weight gradients are the step's tail (nothing but the optimizer follows): the reverse
-            # direction's pack passes and GEMMs on the otherwise idle main queue, next to the forward direction's on the side
-            # queue (small launches with ~12 us of dispatch gap between dependent kernels of one queue)
+            # the first layer's weight gradients are the step's tail (nothing but the optimizer follows), and the side queue reaches
+            # them ~0.25 ms after the main queue has gone idle (it still has the layer above's GEMMs: scripts/phase_events.py): all
+            # but the forward direction's dW_hh go to the main queue, so that the side queue is done first and the optimizer does
+            # not start behind a cross-queue hand-over (small launches with ~12 us of dispatch gap between dependent kernels of
+            # one queue; a wait for an event that has not fired yet costs 30-60 us)
             both = (TAIL_ON_BOTH_QUEUES and use_side and ndir > 1 and gm is not None and _gemm.planes_enabled()
                     and not ctx.needs_input_grad[0] and todo[0] == (0, meta.rows))
             if both:
-                for p in params[1][:2]:                       # earlier side-stream accumulations into the same .grad views
+                for p in (params[0][0], params[1][0], params[1][1]):     # earlier side-stream accumulations into the same .grad views
                     ev = _WGRAD_DONE.get(id(p))
                     if ev is not None:
                         main.wait_event(ev)
                 operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
-                xplanes[todo[0]] = _gemm.pack_t(x, gm[0])     # shared by both directions: before the queues part
+                # shared between the queues: packed before they part
+                xplanes[todo[0]] = _gemm.pack_t(x, gm[0])
+                dgplanes[(0, todo[0])] = _gemm.pack_t(operands[0][0][0], amax_dg)
             if use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
             wgrad_rows(dg, todo, amax_dg, both_queues=both)
-            if both:
-                side.wait_stream(main)                         # whoever orders itself after `side` sees both directions
-                for t in xplanes[todo[0]][:1]:
-                    t.record_stream(side)
+            with torch.cuda.stream(side):
+                for d, (_, _, p_bih, p_bhh) in enumerate(params):
+                    db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
+                    p_bih.grad.add_(db_d)
+                    p_bhh.grad.add_(db_d)
             if use_side:
                 done = torch.cuda.Event()
                 done.record(side)
                 for ps in params:
                     for p in ps[:2]:
                         _WGRAD_DONE[id(p)] = done
-            with torch.cuda.stream(side):
-                for d, (_, _, p_bih, p_bhh) in enumerate(params):
-                    db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
-                    p_bih.grad.add_(db_d)
-                    p_bhh.grad.add_(db_d)
+            if both:
+                main.wait_event(done)                          # the main queue is now behind both
+                for t in dgplanes[(0, todo[0])][:1]:
+                    t.record_stream(side)
+                if GRAD_READY_HOOK is not None:
+                    side.wait_stream(main)                     # whoever orders itself after `side` sees every gradient
             if use_side:
                 for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
                         + tuple(h_prev for _, h_prev in operands[0]):
@@ -863,7 +899,11 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # after an optimizer step: the operand forms of ALL layers on a side stream, next to whatever the main stream is
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
         pre = _prep_stream(data.device)
-        pre.wait_stream(torch.cuda.current_stream(data.device))
+        updated = _gemm.update_event(flat_params)
+        if updated is not None:
+            pre.wait_event(updated)       # behind the optimizer kernel, i.e. next to the step's front-end, not behind it
+        else:
+            pre.wait_stream(torch.cuda.current_stream(data.device))
         for layer, ps_ in enumerate(all_params):
             if _stacked_stale(ps_) and layer > 0:
                 _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre)

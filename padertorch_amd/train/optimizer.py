@@ -211,6 +211,8 @@ class Adam(Optimizer):
         # the kernel wrote the parameters through raw pointers: tell autograd (and everything that caches per parameter
         # version, e.g. the operand scales and stacked weights of ops.gemm / ops.lstm) that they changed
         torch.autograd.graph.increment_version(fg.params)
+        from ..ops import gemm as _gemm
+        _gemm.note_update(fg.params)                      # (the next step's operand forms may start behind THIS kernel)
         steps.add_(applied)                               # a skipped step does not count (fused Adam's semantics)
         self._norm = None
 

@@ -159,6 +159,49 @@ def test_planes_pack_layout_and_unit_range():
     assert float(p[1, :, :, :, 4:, :].abs().sum()) == 0 and float(p[:, 2, :, 0, :, 6:].abs().sum()) == 0      # past the matrix
 
 
+@pytest.mark.parametrize('K,C,ld', [(8096, 2400, 4800), (1000, 514, 516), (70, 18, 20), (33, 257, 260), (5000, 1200, 1200)])
+def test_planes_pack_t_aligned_path_equals_scalar_path(K, C, ld):
+    """The float4 form of the transposing pack (16-byte aligned rows) writes the same planes as the scalar form (the same values
+    from a source shifted by one float), fp16 and bf16, ragged k and column tails."""
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(K + C)
+    wide = torch.randn(K, ld, device='cuda')
+    src = wide[:, :C]
+    shifted = torch.zeros(K * ld + 1, device='cuda')[1:].view(K, ld)
+    shifted.copy_(wide)
+    assert src.data_ptr() % 16 == 0 and shifted.data_ptr() % 16 != 0
+    amax = G.absmax(src)
+    a, b = G.pack_t(src, amax), G.pack_t(shifted[:, :C], amax)
+    assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16))
+    a16 = torch.ops.ptmi.pack_planes_bf16(src, True)
+    b16 = torch.ops.ptmi.pack_planes_bf16(shifted[:, :C], True)
+    assert torch.equal(a16.view(torch.int16), b16.view(torch.int16))
+
+
+@pytest.mark.parametrize('n,ndir,H,cols', [(4800, 2, 600, 608), (1200, 2, 600, 608), (70, 2, 20, 32), (33, 1, 40, 64)])
+def test_planes_pack_into_wider_operand_equals_padded_copy(n, ndir, H, cols):
+    """``pack_planes_into_`` (a direction's column / row block into its k blocks of a wider operand) against the pack of the
+    zero-padded fp32 copy: the forward form (``pack_n_direction_blocks``) and the bf16 transposed form of the LSTM input
+    gradient's weights (``stacked_planes_t_bf16``), bit for bit."""
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(n + H)
+    w = torch.randn(n, ndir * H, device='cuda') * 0.1
+    amax = G.absmax(w)
+    direct = G.pack_n_direction_blocks(w, ndir, H, cols, amax)
+    padded = G.pack_n(G.pad_direction_blocks(w, ndir, H, cols), amax)[0]
+    assert torch.equal(direct.view(torch.int16), padded.view(torch.int16))
+    # transposed bf16 form: w2 [ndir * g, I], every direction's g rows padded to `cols2` k columns
+    g, cols2 = 4 * H, (4 * H + 63) // 64 * 64 + 64
+    w2 = torch.randn(ndir * g, n, device='cuda') * 0.1
+    direct2 = G.stacked_planes_t_bf16(w2, ndir, cols2)
+    wp = w2.new_zeros((ndir, cols2, n))
+    wp[:, :g] = w2.view(ndir, g, n)
+    padded2 = torch.ops.ptmi.pack_planes_bf16(wp.view(ndir * cols2, n), True)
+    assert torch.equal(direct2.view(torch.int16), padded2.view(torch.int16))
+    with pytest.raises(RuntimeError):       # k blocks past the operand
+        torch.ops.ptmi.pack_planes_into_(direct, w[:, :H], amax, False, ndir * cols // 32, ndir * cols // 32, cols // 32)
+
+
 @pytest.mark.parametrize('M,N,K,split', [(8096, 4800, 1200, None), (8096, 514, 1200, None), (300, 70, 257, 1), (17, 5, 33, 2)])
 def test_planes_forward_form_with_bias(M, N, K, split):
     """x W^T + b with both operands packed from k-contiguous sources (pack_planes_n), odd K / N, strided x."""
