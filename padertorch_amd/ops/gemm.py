@@ -82,6 +82,7 @@ def invalidate():
     _WEIGHT_AMAX.clear()
     _WEIGHT_PLANES.clear()
     _UPDATED.clear()
+    _KNOWN.clear()
     from . import lstm as _lstm
     _lstm._STACKED.clear()
 
@@ -98,17 +99,74 @@ def absmax(x):
     return torch.ops.ptmi.absmax(x, rows, cols, max(ld, cols))
 
 
+#: id(parameter) -> (weak reference, forms this parameter has been asked for: 'n' / 't' / ('h', ndir, H, cols)): what
+#: :func:`prefetch_known` re-makes after an optimizer step
+_KNOWN = {}
+_WAITED = {}                # stream -> the prefetch event it has waited for last
+_PREFETCHING = [None]      # the event new cache entries carry while prefetch_known fills the caches on a side stream
+
+
+def _cached(cache, key, p, make, limit, form=None):
+    """``make()`` cached per ``key`` until the parameter ``p`` is modified (version, storage, identity).  Entries made by
+    :func:`prefetch_known` on a side stream carry an event: a hit makes the current stream wait for it (nothing, once it has
+    fired) and keeps the tensors alive for that stream."""
+    hit = cache.get(key)
+    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
+        if hit[4] is not None and hit[4] is not _PREFETCHING[0]:
+            cur = torch.cuda.current_stream(p.device)
+            if _WAITED.get(cur.cuda_stream) is not hit[4]:       # one wait per stream and prefetch (a barrier packet each otherwise)
+                cur.wait_event(hit[4])
+                _WAITED[cur.cuda_stream] = hit[4]
+            # (no record_stream: the tensors' memory belongs to the preparation stream's pool, whose every piece of work is
+            # enqueued behind the optimizer kernel and so behind every reader - see ops.lstm._stacked_weights)
+        return hit[2]
+    if len(cache) > limit:
+        cache.clear()
+    with torch.no_grad():
+        v = make()
+    cache[key] = (p._version, p.data_ptr(), v, _refs((p,)), _PREFETCHING[0])
+    if form is not None:
+        known = _KNOWN.get(id(p))
+        if known is None or known[0]() is not p:
+            if len(_KNOWN) > 256:
+                _KNOWN.clear()
+            known = _KNOWN[id(p)] = (weakref.ref(p), set())
+        known[1].add(form)
+    return v
+
+
+def prefetch_known(device):
+    """Re-make, on the CURRENT stream (a side stream ordered behind the optimizer kernel: ``ops.lstm.packed_lstm``), the operand
+    forms - maximum, fp16 planes in either orientation - that the dense layers asked for in earlier steps and that an optimizer step
+    has made stale: a handful of small launches (~5 us each, 45 us per step of the PIT model) that otherwise sit in front of the
+    first use on the main stream, between the last recurrence and the loss."""
+    todo = []
+    for pid, (ref, forms) in list(_KNOWN.items()):
+        q = ref()
+        if q is None:
+            del _KNOWN[pid]
+        elif q.device == device and q.dim() == 2:
+            todo.append((q, sorted(forms, key=str)))
+    if not todo or _PREFETCHING[0] is not None:
+        return
+    ev = _PREFETCHING[0] = torch.cuda.Event()
+    try:
+        for q, forms in todo:
+            for form in forms:
+                if form == 'n':
+                    weight_planes(q)
+                elif form == 't':
+                    weight_planes_t(q)
+                else:
+                    weight_planes_h(q, *form[1:])
+    finally:
+        _PREFETCHING[0] = None
+        ev.record(torch.cuda.current_stream(device))
+
+
 def weight_absmax(p):
     """``absmax`` of a parameter, cached until the parameter is modified in place (optimizer step)."""
-    key = id(p)
-    hit = _WEIGHT_AMAX.get(key)
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        return hit[2]
-    if len(_WEIGHT_AMAX) > 256:
-        _WEIGHT_AMAX.clear()
-    v = absmax(p.detach() if p.dim() == 2 else p.detach().reshape(-1, p.shape[-1]))
-    _WEIGHT_AMAX[key] = (p._version, p.data_ptr(), v, _refs((p,)))
-    return v
+    return _cached(_WEIGHT_AMAX, id(p), p, lambda: absmax(p.detach() if p.dim() == 2 else p.detach().reshape(-1, p.shape[-1])), 256)
 
 
 def weights_absmax(params):
@@ -135,7 +193,7 @@ def seed_weights_absmax(params, word):
         _WEIGHT_AMAX.clear()
     if len(params) == 1:
         p = params[0]
-        _WEIGHT_AMAX[id(p)] = (p._version, p.data_ptr(), word, _refs((p,)))
+        _WEIGHT_AMAX[id(p)] = (p._version, p.data_ptr(), word, _refs((p,)), None)
     else:
         _WEIGHT_AMAX[tuple(id(p) for p in params)] = (tuple((p._version, p.data_ptr()) for p in params), None, word, _refs(params))
 
@@ -178,28 +236,13 @@ _WEIGHT_PLANES = {}
 
 def weight_planes(p):
     """``pack_n`` of a 2-D parameter used as the ``W`` of ``x W^T``, cached until the parameter is modified."""
-    hit = _WEIGHT_PLANES.get(id(p))
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        return hit[2]
-    if len(_WEIGHT_PLANES) > 64:
-        _WEIGHT_PLANES.clear()
-    v = pack_n(p.detach(), weight_absmax(p))
-    _WEIGHT_PLANES[id(p)] = (p._version, p.data_ptr(), v, _refs((p,)))
-    return v
+    return _cached(_WEIGHT_PLANES, id(p), p, lambda: pack_n(p.detach(), weight_absmax(p)), 64, 'n')
 
 
 def weight_planes_t(p):
     """``pack_t`` of a 2-D parameter ``W [out, in]`` used as the right operand of ``g W`` (rows = input features, reduction
     over the outputs), cached until the parameter is modified."""
-    key = ('t', id(p))
-    hit = _WEIGHT_PLANES.get(key)
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        return hit[2]
-    if len(_WEIGHT_PLANES) > 64:
-        _WEIGHT_PLANES.clear()
-    v = pack_t(p.detach(), weight_absmax(p))
-    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
-    return v
+    return _cached(_WEIGHT_PLANES, ('t', id(p)), p, lambda: pack_t(p.detach(), weight_absmax(p)), 64, 't')
 
 
 _SCALE_WORDS = {}
@@ -238,17 +281,10 @@ def pack_n_direction_blocks(w, ndir, H, cols, amax):
 def weight_planes_h(p, ndir, H, cols):
     """``pack_n`` of a 2-D parameter ``W [out, ndir * H]`` with its input columns laid out like the hand-off planes
     (:func:`pad_direction_blocks`), cached until the parameter is modified."""
-    key = ('h', id(p), cols)
-    hit = _WEIGHT_PLANES.get(key)
-    if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr() and _same(hit[3], (p,)):
-        return hit[2]
-    if len(_WEIGHT_PLANES) > 64:
-        _WEIGHT_PLANES.clear()
-    with torch.no_grad():
+    def make():
         amax = weight_absmax(p)
-        v = (pack_n_direction_blocks(p.detach(), ndir, H, cols, amax), amax)
-    _WEIGHT_PLANES[key] = (p._version, p.data_ptr(), v, _refs((p,)))
-    return v
+        return pack_n_direction_blocks(p.detach(), ndir, H, cols, amax), amax
+    return _cached(_WEIGHT_PLANES, ('h', id(p), cols), p, make, 64, ('h', ndir, H, cols))
 
 
 def stacked_planes_t_bf16(w, ndir, cols, key_params=None):

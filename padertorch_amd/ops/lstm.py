@@ -428,9 +428,12 @@ def _stacked_weights(params, KP, stream=None):
             if stream is not None:
                 forms['ready'] = torch.cuda.Event()
                 forms['ready'].record(stream)
-                for t in (w_ih_k, bias, w_pad, w_t, amax) + ((planes[0],) if isinstance(planes, tuple) else ()) + (
-                        (planes_h[0][0],) if planes_h is not None else ()) + ((planes_dx[0],) if planes_dx is not None else ()):
-                    t.record_stream(main)          # allocated on the side stream's pool, used (and later freed) on the main one
+                # These tensors come from the preparation stream's pool and are read on the main stream.  They are NOT marked with
+                # record_stream(main): the allocator would then record one event per tensor on the MAIN queue when they are freed
+                # (20 marker packets = a 75 us bubble behind the top layer's recurrence, where the previous step's graph let go
+                # of them: scripts/phase_events.py, rocprofv3 --hip-runtime-trace).  Their memory can only be handed out again
+                # by an allocation on the preparation stream, and every piece of work on that stream is enqueued behind a wait
+                # for the optimizer kernel / the main stream (packed_lstm), i.e. behind every reader of the old forms.
             _gemm.seed_weights_absmax([ps[0] for ps in params], amax[0:1])
             _gemm.seed_weights_absmax([ps[1] for ps in params], amax[1:2])
         else:
@@ -907,6 +910,9 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         for layer, ps_ in enumerate(all_params):
             if _stacked_stale(ps_) and layer > 0:
                 _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre)
+        if updated is not None:
+            with torch.cuda.stream(pre):
+                _gemm.prefetch_known(data.device)         # the dense layers' operand forms of the last steps, behind them
         # the first layer's forms are needed at once: on the main queue itself (a cross-queue wait in front of the first
         # projection was measured to cost the main queue 110-260 us; the later layers' forms are long done when their
         # projection is reached, and a wait for a finished event costs nothing)
@@ -960,7 +966,9 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     if prev_handoff and prev_handoff.get('planes') is not None:
         # (ops.linear takes these planes as operand A when its input is this very tensor)
         # (the tensor itself is held: its memory cannot be handed to another tensor while the entry could still match)
-        LAST_HANDOFF = (h, h._version, prev_handoff['planes'], ndir, H)
+        # (detached: the entry must not keep this step's autograd graph - every layer's context with its operand forms and
+        # scratch - alive until the next forward pass lets go of it in the middle of its critical path)
+        LAST_HANDOFF = (h.detach(), h._version, prev_handoff['planes'], ndir, H)
     out = PackedSequence(h, packed.batch_sizes)
     if want_state:
         return out, (torch.stack(h_n), torch.stack(c_n))

@@ -85,6 +85,40 @@ def test_trainer_deferred_checks_match_golden(g6, tmp_path):
     assert np.isfinite(scalars['loss']) and np.isfinite(scalars['grad_norm']), scalars
 
 
+def test_trainer_prefetched_weight_forms_change_nothing(g6, tmp_path, monkeypatch):
+    """From the second optimizer step on, the dense layers' operand forms (maximum, planes) and the later LSTM layers' are made on the
+    preparation stream behind the optimizer kernel (ops.gemm.note_update / prefetch_known, ops.lstm._stacked_weights): the cache
+    entries carry that stream's event, and training ends at the very same parameters as with everything made at first use."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    from padertorch_amd.ops import gemm as G
+    batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
+    exs = [{k: [v[b] for b in idx] for k, v in batch.items()} for idx in g6['train_example_indices']]
+
+    def run(sub):
+        G.invalidate()
+        model = _load(PermutationInvariantTrainingModel(F=9, recurrent_layers=2, units=4, K=2), g6, 'pit_sd_')
+        t = pt.Trainer(model, tmp_path / sub, pt.optimizer.Adam(gradient_clipping=1.),
+                       loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), summary_trigger=(1000, 'iteration'),
+                       checkpoint_trigger=(1000, 'iteration'), stop_trigger=(3, 'iteration'), virtual_minibatch_size=2,
+                       deferred_checks=True)
+        t.train(exs, device=DEV)
+        return model
+
+    model = run('a')
+    w1 = model.linear1.weight
+    assert id(w1) in G._KNOWN and G._KNOWN[id(w1)][0]() is w1 and G._KNOWN[id(w1)][1]
+    # (the last forward pass ran on forms the preparation stream had made: an event is attached)
+    entries = [e for k, e in G._WEIGHT_PLANES.items() if (k == id(w1) or (isinstance(k, tuple) and id(w1) in k)) and len(e) == 5]
+    assert entries and any(e[4] is not None for e in entries), [len(e) for e in entries]
+    want = {k: v.clone() for k, v in model.state_dict().items()}
+    monkeypatch.setattr(G, 'prefetch_known', lambda device: None)
+    monkeypatch.setattr(G, 'update_event', lambda params: None)
+    got = run('b').state_dict()
+    for k, v in want.items():
+        assert torch.equal(v, got[k]), k
+
+
 @pytest.mark.parametrize('deferred', [False, True])
 def test_trainer_non_finite_loss_raises_and_keeps_parameters(g6, tmp_path, deferred):
     """A NaN in the third optimizer step's input: RuntimeError('The loss (nan) is not finite...') as in

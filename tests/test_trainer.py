@@ -349,7 +349,7 @@ def test_weight_caches_do_not_survive_their_parameter(monkeypatch):
     assert G.weight_absmax(p1) is v1 and len(calls) == 1              # a hit for the very same object
     p2 = torch.nn.Parameter(torch.full((3, 4), 2.))
     entry = G._WEIGHT_AMAX[id(p1)]
-    G._WEIGHT_AMAX[id(p2)] = (p2._version, p2.data_ptr(), entry[2], entry[3])      # the coincidence: p1's entry under p2's identity
+    G._WEIGHT_AMAX[id(p2)] = (p2._version, p2.data_ptr(), entry[2], entry[3], None)      # the coincidence: p1's entry under p2's identity
     assert float(G.weight_absmax(p2)) == 2. and len(calls) == 2         # not served from p1's entry
     del p1
     import gc
