@@ -33,6 +33,14 @@ if [ -x $repo/scripts/mb/gemm_big ]; then
   bash $repo/scripts/mb/run_gemm_big.sh "8096 4800 1216" "8096 1200 4864" "32192 4800 1216" "8192 8192 4096" > /dev/null 2>&1; cp $repo/gpurun_out/mb/gemm_big.txt $out/${tag}_mb_gemm_big.txt
   ZERO=1 bash $repo/scripts/mb/run_gemm_big.sh "8096 4800 1216" "8192 8192 4096" > /dev/null 2>&1; cp $repo/gpurun_out/mb/gemm_big.txt $out/${tag}_mb_gemm_big_zero.txt
 fi
+# where the step's critical path goes without a profiler attached (HIP events around the phase-marking launches), c2 and c3
+timeout 300 python $repo/scripts/phase_events.py 2>/dev/null | grep -E '^#|^[ms] ' > $out/${tag}_phase_events.txt
+timeout 300 python $repo/scripts/phase_events.py --config c3 --steps 24 2>/dev/null | grep -E '^#|^[ms] ' > $out/${tag}_phase_events_c3.txt
+# HIP runtime calls between kernel launches (event-record / stream-wait clusters = marker packets in front of a kernel)
+rm -rf /tmp/kt3; timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace -d /tmp/kt3 -o p -- python $repo/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras > /tmp/kt3.log 2>&1 </dev/null
+db3=$(find /tmp/kt3 -name "*.db" 2>/dev/null | head -1)
+[ -n "$db3" ] && python $repo/scripts/hip_api_between_launches.py "$db3" --min 2 > $out/${tag}_hip_api_between_launches.txt 2>&1 </dev/null
+[ -x $repo/scripts/mb/pack_t ] && { cd $repo/scripts/mb; { ./pack_t 8096 2400 4800; ./pack_t 32192 2400 4800; ./pack_t 32192 1200 1200; } > $out/${tag}_mb_pack_t.txt 2>&1; cd /tmp; }
 timeout 600 python $repo/scripts/bf16_delta.py 2>/dev/null | tail -1 > $out/${tag}_bf16_delta.json
 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' > $out/${tag}_lstm_us_per_step.txt
 PTMI_LSTM_F32=1 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' | sed 's/^/exact-fp32 kernels: /' >> $out/${tag}_lstm_us_per_step.txt
