@@ -395,6 +395,10 @@ int ptmi_td_lincomb(const float* x, const float* y, const int32_t* lengths, cons
  * ptmi_absmax: out_bits[0] = float bits of max |x[r, c]| over a [rows, cols] fp32 matrix with row stride ld
  * (device; zeroed and written on `stream`).  The pack passes derive the operand scale 2^(13 - exponent) from it. */
 int ptmi_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* out_bits, ptmi_stream_t stream);
+/* The same reduction INTO a word that already holds float bits of a non-negative value (0: a pre-zeroed word): the word ends as the
+ * maximum of both - a running maximum over several matrices, or ptmi_absmax without its zeroing launch when the caller hands out words
+ * of a buffer it has zeroed once. */
+int ptmi_absmax_accumulate(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* inout_bits, ptmi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * The GEMM itself runs on operands already split into fp16 (hi, lo) planes in MFMA-fragment order (csrc/gemm_planes.hip); a

@@ -90,6 +90,7 @@ SIGNATURES = {
     'ptmi_lstm_plan_backward': (c_int, [c_void_p, _P]),
     'ptmi_lstm_plan_destroy': (None, [c_void_p]),
     'ptmi_absmax': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
+    'ptmi_absmax_accumulate': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_planes_elems': (c_int64, [c_int64, c_int64]),
     'ptmi_pack_planes_t': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
     'ptmi_gemm_planes_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),

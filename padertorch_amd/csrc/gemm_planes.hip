@@ -712,6 +712,16 @@ int ptmi_absmax(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t
     return launch_status();
 }
 
+int ptmi_absmax_accumulate(const float* x, int64_t rows, int64_t cols, int64_t ld, uint32_t* inout_bits, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!x || !inout_bits || rows < 0 || cols < 0 || ld < cols, PTMI_E_INVALID);
+    if (rows * cols == 0) return PTMI_OK;
+    const long long work = (rows * cols + 4095) / 4096;
+    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>(work, 1), 512);
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), x, (long long)rows, (long long)cols, (long long)ld,
+                       inout_bits);
+    return launch_status();
+}
+
 int64_t ptmi_planes_elems(int64_t rows, int64_t k) {
     return ((rows + 15) / 16) * ((k + 31) / 32) * 2 * 512;          // fp16 values
 }

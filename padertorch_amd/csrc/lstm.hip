@@ -1008,8 +1008,14 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     PTMI_RETURN_IF(KP != (H + 15) / 16 * 16, PTMI_E_UNSUPPORTED);
     float* const hyt = reinterpret_cast<float*>(flags);
     flags += lstm_tile_elems(T, ndir, max_batch, KP32);
-    hipError_t e = zero_words_async(flags, (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
-    if (e != hipSuccess) return (int)e;
+    const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
+    if (daf && !prefilled) {        // every 16-bit value of the planes = 0xFFFF (no value can be), the counters behind them zero: one launch
+        int fe = daf_prefill_and_zero(hyt, (size_t)lstm_tile_elems(T, ndir, max_batch, KP32), flags, (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
+        if (fe) return fe;
+    } else {
+        hipError_t e = zero_words_async(flags, (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
+        if (e != hipSuccess) return (int)e;
+    }
     LstmPersistArgs A{gates, hy, c, w_hh_pad, batch_sizes_dev, offsets_dev, flags, T, H, KP, ndir,
                       (unsigned)jx, getenv("PTMI_LSTM_MAX_POLLS") ? (unsigned)atoi(getenv("PTMI_LSTM_MAX_POLLS")) : 1u << 22, (int)hy_bytes,
                       (unsigned)(ptmi_lstm_flags_elems(T, ndir, max_batch) - 8),
@@ -1017,7 +1023,6 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                       w_hh_amax, KP32};
     A.err_sink = error_sink();
     A.uniform = (rows == (int64_t)T * max_batch) ? 1 : 0;      // batch sizes never grow: equal lengths
-    const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
     if (backward_scratch && ptmi_lstm_forward_fills(T, ndir, max_batch, H)) {     // this layer's backward planes get their pattern here
         const int G32 = (4 * H + 31) / 32 * 32;
         A.fill_ptr = reinterpret_cast<uint4*>(backward_scratch);
@@ -1036,10 +1041,6 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
             A.nx = jx;
             A.nt = nt;
             const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
-            if (daf && t0 == 0 && !prefilled) {       // every 16-bit value of the planes = 0xFFFF (no value can be)
-                int fe = daf_prefill(hyt, (size_t)lstm_tile_elems(T, ndir, max_batch, KP32), st);
-                if (fe) return fe;
-            }
             int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st, daf);
             if (rc) return rc;
             continue;
@@ -1111,12 +1112,14 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
     flags += lstm_tile_elems(T, ndir, max_batch, G32);
     float* const dbias = reinterpret_cast<float*>(flags);
     if (s_begin == 0) {         // a later range continues on the first one's counters, bias sums and maximum
-        hipError_t e = zero_words_async(flags, (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)), st);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (s_begin == 0 && split && bwd_daf_applies() && !prefilled) {       // data-as-flag hand-off: the planes start as the fill pattern
-        int fe = daf_prefill(dgt, (size_t)lstm_tile_elems(T, ndir, max_batch, G32), st);
-        if (fe) return fe;
+        const size_t nz = (size_t)(ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch));
+        if (split && bwd_daf_applies() && !prefilled) {       // data-as-flag hand-off: the planes start as the fill pattern (same launch)
+            int fe = daf_prefill_and_zero(dgt, (size_t)lstm_tile_elems(T, ndir, max_batch, G32), flags, nz, st);
+            if (fe) return fe;
+        } else {
+            hipError_t e = zero_words_async(flags, nz, st);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     flags += ndir * 4 * H;
     uint32_t* const dg_amax = flags;

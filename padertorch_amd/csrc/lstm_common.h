@@ -144,6 +144,7 @@ __device__ __forceinline__ bool chain_tile(int nx, int nt, int span, int* x, int
 bool fwd_daf_applies(int jt, bool small, bool one_per_cu);
 bool bwd_daf_applies();
 int daf_prefill(void* p, size_t words, hipStream_t st);
+int daf_prefill_and_zero(void* p, size_t words, void* z, size_t zero_words, hipStream_t st);      // + `zero_words` zeroed words at z, one launch
 int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st, bool daf);
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st);
 

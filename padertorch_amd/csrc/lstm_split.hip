@@ -92,6 +92,22 @@ int daf_prefill(void* p, size_t words, hipStream_t st) {
     return launch_status();
 }
 
+// The set-up of a persistent launch in ONE kernel: the planes start as the pattern, the words behind them (bias sums, arrival
+// slots, error words) as zero.  (Two launches before: ~5 us of queue time each in front of every recurrence of the step.)
+__global__ void fill_and_zero_kernel(uint4* p, size_t n16, unsigned word, unsigned* z, size_t nz) {
+    const uint4 v = make_uint4(word, word, word, word);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < n16; i += step) p[i] = v;
+    for (size_t i = i0; i < nz; i += step) z[i] = 0u;
+}
+
+int daf_prefill_and_zero(void* p, size_t words, void* z, size_t zero_words, hipStream_t st) {
+    const size_t n16 = words / 4;
+    const unsigned grid = (unsigned)std::min<size_t>((std::max(n16, zero_words) + 255) / 256, 8192);
+    hipLaunchKernelGGL(fill_and_zero_kernel, dim3(grid), dim3(256), 0, st, static_cast<uint4*>(p), n16, kFill, static_cast<unsigned*>(z), zero_words);
+    return launch_status();
+}
+
 constexpr float kHScale = 1024.f;       // forward: h is handed on as halves of 2^10 h (lo stays normal down to |h| = 2^-13)
 
 __device__ __forceinline__ float pow2_scale(const unsigned* amax_bits) {

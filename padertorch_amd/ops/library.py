@@ -174,10 +174,26 @@ def dc_loss_backward(x, t, gram, g_loss, row_frames, B, T, E, K, F, strides, zer
 
 
 # ------------------------------------------------------------------------------------------------ dense layers
+_ZERO_WORDS = {}
+
+
+def _zero_word(device):
+    """One int32 word that is zero on the current stream: words of a buffer zeroed ONCE (a fill launch per 256 words instead of a
+    zeroing launch in front of every reduction: five per training step); a buffer per stream, each word handed out once."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    pool = _ZERO_WORDS.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        if len(_ZERO_WORDS) > 16:
+            _ZERO_WORDS.clear()
+        pool = _ZERO_WORDS[key] = [torch.zeros(256, dtype=torch.int32, device=device), 0]
+    pool[1] += 1
+    return pool[0][pool[1] - 1:pool[1]]
+
+
 @_register('absmax(Tensor x, int rows, int cols, int ld) -> Tensor')
 def absmax(x, rows, cols, ld):
-    out = torch.empty(1, dtype=torch.int32, device=x.device)
-    _lib.check(_lib.load().ptmi_absmax(x.data_ptr(), rows, cols, ld, out.data_ptr(), _lib.stream(x.device)), 'ptmi_absmax')
+    out = _zero_word(x.device)
+    _lib.check(_lib.load().ptmi_absmax_accumulate(x.data_ptr(), rows, cols, ld, out.data_ptr(), _lib.stream(x.device)), 'ptmi_absmax')
     return out
 
 

@@ -562,8 +562,9 @@ class _LstmLayerFn(torch.autograd.Function):
             ext = torch.empty((meta.rows + 2 * pad, ndir * H), dtype=torch.float32, device=x.device)
             hy = ext[pad:pad + meta.rows]
             if pad:
-                ext[:pad].zero_()
-                ext[pad + meta.rows:].zero_()
+                # (both ends in ONE fill launch: a [2, pad, C] view over the first and the last `pad` rows)
+                C_ = ndir * H
+                torch.as_strided(ext, (2, pad, C_), ((pad + meta.rows) * C_, C_, 1)).zero_()
                 if stateful:
                     ext[:pad].view(pad, ndir, H)[:, 0] = h0[0]
                     if ndir > 1:

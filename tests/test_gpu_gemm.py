@@ -159,6 +159,32 @@ def test_planes_pack_layout_and_unit_range():
     assert float(p[1, :, :, :, 4:, :].abs().sum()) == 0 and float(p[:, 2, :, 0, :, 6:].abs().sum()) == 0      # past the matrix
 
 
+def test_absmax_words_and_running_maximum():
+    """``ops.gemm.absmax``: the float bits of max |x| in a word of a buffer zeroed once (no zeroing launch per call; every call its
+    own word, per stream), for either unit stride; ``ptmi_absmax_accumulate`` keeps a running maximum; ``ptmi_absmax`` zeroes."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(3)
+    xs = [torch.randn(300, 70, device='cuda') * s for s in (1., 5., 0.2)]
+    words = [G.absmax(x) for x in xs] + [G.absmax(xs[1][:, 3:50]), G.absmax(xs[1].t())]
+    assert len({w.data_ptr() for w in words}) == len(words)
+    for w, x in zip(words, xs + [xs[1][:, 3:50], xs[1].t()]):
+        assert float(w.view(torch.float32)) == float(x.abs().max())
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        side.wait_stream(torch.cuda.default_stream())
+        w2 = G.absmax(xs[2])
+    side.synchronize()
+    assert float(w2.view(torch.float32)) == float(xs[2].abs().max())
+    lib = _lib.load()
+    run = torch.zeros(1, dtype=torch.int32, device='cuda')
+    for x in xs:
+        _lib.check(lib.ptmi_absmax_accumulate(x.data_ptr(), x.shape[0], x.shape[1], x.stride(0), run.data_ptr(), _lib.stream(x.device)))
+    assert float(run.view(torch.float32)) == max(float(x.abs().max()) for x in xs)
+    _lib.check(lib.ptmi_absmax(xs[2].data_ptr(), 300, 70, 70, run.data_ptr(), _lib.stream(run.device)))       # zeroes first
+    assert float(run.view(torch.float32)) == float(xs[2].abs().max())
+
+
 @pytest.mark.parametrize('K,C,ld', [(8096, 2400, 4800), (1000, 514, 516), (70, 18, 20), (33, 257, 260), (5000, 1200, 1200)])
 def test_planes_pack_t_aligned_path_equals_scalar_path(K, C, ld):
     """The float4 form of the transposing pack (16-byte aligned rows) writes the same planes as the scalar form (the same values
