@@ -194,6 +194,7 @@ class Trainer:
         self.overlap_allreduce = overlap_allreduce
         self._buckets = None
         self._pending = []           # [(what, event, host tensor, context, optimizer step)]
+        self._stage_queue = []       # staged scalars whose copies are not enqueued yet (_flush_stage)
         self._opt_step = 0
         self._loss_acc = None        # device scalar: sum of the losses of the current optimizer step (non-finite -> skip)
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
@@ -421,6 +422,7 @@ class Trainer:
         else:
             self.optimizer.step()
             self.optimizer.zero_grad()
+        self._flush_stage()            # this step's staged scalars (deferred_checks): copied behind the update
         self._opt_step += 1
         return summary
 
@@ -583,26 +585,37 @@ class Trainer:
 
     def _stage(self, what, vals, context):
         """Asynchronous device -> pinned host copy of a few scalars (a tensor, or a list of tensors that each keep their
-        dtype); ``_check_pending`` inspects them later."""
+        dtype); ``_check_pending`` inspects them later.  The copies themselves are enqueued by ``_flush_stage`` behind the
+        optimizer kernel: in front of it (loss values between the loss and the backward pass, the gradient norm between the norm
+        and the update) every copy is a blit launch of ~5 us on the step's critical path."""
         if isinstance(vals, (list, tuple)):
-            host = []
-            for v in vals:
-                h = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
-                h.copy_(v.detach(), non_blocking=True)
-                host.append(h)
+            vals = [v.detach() for v in vals]
+            host = [torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for v in vals]
         else:
             vals = vals.detach().to(torch.float32)
             if what == 'loss':      # a non-finite loss makes the sum non-finite: what the optimizer update is gated on
                 self._loss_acc = vals[-1] if self._loss_acc is None else self._loss_acc + vals[-1]
             host = torch.empty(vals.shape, dtype=torch.float32, pin_memory=True)
-            host.copy_(vals, non_blocking=True)
+        self._stage_queue.append((what, vals, host, context, self._opt_step))
+        return host
+
+    def _flush_stage(self):
+        """Enqueue the staged copies (one event behind all of them)."""
+        jobs, self._stage_queue = self._stage_queue, []
+        if not jobs:
+            return
+        for _, vals, host, _, _ in jobs:
+            for h, v in (zip(host, vals) if isinstance(host, list) else ((host, vals),)):
+                h.copy_(v, non_blocking=True)
         event = torch.cuda.Event()
         event.record()
-        self._pending.append((what, event, host, context, self._opt_step))
-        return host
+        for what, _, host, context, opt_step in jobs:
+            self._pending.append((what, event, host, context, opt_step))
 
     def _check_pending(self, flush=False):
         """Raise the reference's errors for the staged values of EARLIER optimizer steps (all with flush)."""
+        if flush:
+            self._flush_stage()
         todo = [p for p in self._pending if flush or p[4] < self._opt_step]
         self._pending = [p for p in self._pending if not (flush or p[4] < self._opt_step)]
         for what, event, host, context, _ in todo:
