@@ -84,6 +84,9 @@ def parse_args(argv=None):
                          'the reference behaviour) instead of Trainer(deferred_checks=True)')
     ap.add_argument('--no-overlap', action='store_true',
                     help='LSTM weight gradients through autograd on the main stream (ops.lstm.DEFER_WGRAD off)')
+    ap.add_argument('--ragged', action='store_true',
+                    help="SURVEY 8d's training distribution: example lengths ~ U[3 s, 6 s] (sorted, zero-padded waveforms) instead of "
+                         'the fixed 4 s of the headline; a reported mode (no roofline entry)')
     ap.add_argument('--no-overlap-allreduce', action='store_true', help='one all-reduce of the flat buffer in optimizer_step')
     return ap.parse_args(argv)
 
@@ -101,12 +104,16 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
-def synthetic_batch(seed, batch, K, n, device):
-    """K sources 0.1*N(0,1) fp32, mixture = sum (seeded)."""
+def synthetic_batch(seed, batch, K, n, device, lengths=None):
+    """K sources 0.1*N(0,1) fp32, mixture = sum (seeded); ``lengths``: samples per example (descending; rows
+    zero past their length), default all ``n``."""
     import torch
     g = torch.Generator(device='cpu').manual_seed(seed)
     s = 0.1 * torch.randn(batch, K, n, generator=g)
-    return dict(y=s.sum(1).to(device), s=s.to(device), num_samples=[n] * batch)
+    if lengths is not None:
+        for b, nb in enumerate(lengths):
+            s[b, :, nb:] = 0.
+    return dict(y=s.sum(1).to(device), s=s.to(device), num_samples=list(lengths) if lengths is not None else [n] * batch)
 
 
 def cpu_baseline_variant(threads, max_seconds=12., b=4):
@@ -359,7 +366,16 @@ def main():
 
     n = cfg['fs'] * SECONDS
     K = cfg['K']
-    frames_per_micro = cfg['batch'] * ((n + 2 * (SIZE - SHIFT) - SIZE + SHIFT - 1) // SHIFT + 1)      # fading='full', pad
+    def frames_of(samples):
+        return (samples + 2 * (SIZE - SHIFT) - SIZE + SHIFT - 1) // SHIFT + 1      # fading='full', pad
+
+    lengths = None
+    if args.ragged:
+        import random
+        rnd = random.Random(1234)                         # the same lengths on every rank: equal work per rank (weak scaling)
+        lengths = sorted((rnd.randint(3 * cfg['fs'], 6 * cfg['fs']) for _ in range(cfg['batch'])), reverse=True)
+        n = lengths[0]
+    frames_per_micro = sum(frames_of(nb) for nb in lengths) if lengths else cfg['batch'] * frames_of(n)
     from padertorch_amd import _lib
 
     if args.dry:
@@ -389,7 +405,7 @@ def main():
             assert float(got.min()) == float(got.max()) == expect, (float(got.min()), float(got.max()), expect)
             trainer._flat.flat.zero_()
     else:
-        data = synthetic_batch(1000 + rank, cfg['batch'], K, n, device)
+        data = synthetic_batch(1000 + rank, cfg['batch'], K, n, device, lengths)
         timers = []
 
         counted = [0, 0]              # timed steps so far / of which with kernel events
@@ -592,7 +608,7 @@ def main():
             'dtype': 'fp16/bf16 operands, f32 accumulate (reduced precision)' if args.bf16 else 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': f'{cfg["label"]}, {cfg["batch"]} x {SECONDS} s {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
+                'workload': f'{cfg["label"]}, {cfg["batch"]} x {"3-6 s (ragged, U[3 s, 6 s])" if args.ragged else str(SECONDS) + " s"} {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
                             f'micro-step ({frames_per_micro} frames), {micro} micro-step(s) per optimizer step, STFT '
                             f'{SIZE}/{SHIFT} on device, full optimizer step (Adam, clip 1)',
                 'global_batch': cfg['batch'] * world * micro,
@@ -613,8 +629,9 @@ def main():
             out['dry'] = True
             out['roofline'] = None
         else:
-            kernels = kernel_report(timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro,
-                                    1 if args.bf16 else 3)
+            # (ragged batches: the per-kernel figures assume frames_per_step / batch time steps per launch - a reported mode without them)
+            kernels = [] if args.ragged else kernel_report(timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro,
+                                                           1 if args.bf16 else 3)
             out['kernel_event_steps'] = counted[1]
             out['roofline'] = kernels[0] if kernels else None
             out['other_kernels'] = kernels[1:]

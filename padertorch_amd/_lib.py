@@ -173,6 +173,18 @@ def timed(name, fn, *args):
     return rc
 
 
+def host_to_device(values, dtype, device):
+    """A small host list / ndarray as a device tensor WITHOUT a host synchronisation: pinned staging buffer + non-blocking copy.
+    (``torch.tensor(values, device='cuda')`` copies from pageable memory, which blocks the host until the stream has drained: with
+    one such call per step - the lengths of a ragged batch - the host never runs ahead of the GPU and every launch gap of the step
+    becomes visible: 12.7 instead of 10.2 ms per step for 32 examples of 3-6 s)"""
+    t = torch.as_tensor(values, dtype=dtype)
+    device = torch.device(device)
+    if device.type != 'cuda' or t.numel() == 0:
+        return t.to(device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def strides4(*vals):
     return (c_int64 * 4)(*vals)
 

@@ -91,7 +91,7 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
     F = stft.size // 2 + 1
     dev = y.device
     ragged = any(n != N for n in num_samples)
-    ns_dev = torch.tensor(num_samples, dtype=torch.int32, device=dev) if ragged else None
+    ns_dev = _lib.host_to_device(num_samples, torch.int32, dev) if ragged else None
     tb = stft._tables.get(dev)
     g = stft._geom
     geom = [g.size, g.shift, g.window_length, g.pad_left, g.pad_right, g.pad]
@@ -118,7 +118,7 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
         packed = PackedLog1p(lp, bs, entry, None if entry is None else entry[1])
     else:
         Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features(y, s, ns_dev, tb['window'], tb['twiddle'], geom, T)
-    fl = torch.tensor(frames, dtype=torch.int32, device=dev) if ragged else None
+    fl = _lib.host_to_device(frames, torch.int32, dev) if ragged else None
     out = dict(Y_abs=PaddedList(Y_abs, frames, True, fl), num_frames=frames)
     #: consumed by PermutationInvariantTrainingModel.forward / DeepClusteringModel.forward when the list is handed on untouched
     out['Y_abs'].packed_log1p = packed

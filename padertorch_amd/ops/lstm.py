@@ -41,8 +41,8 @@ class _PackMeta:
         self.bs_host = np.ascontiguousarray(bs, dtype=np.int32)
         self.offs_host = np.ascontiguousarray(offs[:-1], dtype=np.int64)
         # device copies for the persistent kernels (read in-kernel, step by step)
-        self.bs_dev = torch.from_numpy(self.bs_host).to(device)
-        self.offs_dev = torch.from_numpy(self.offs_host).to(device)
+        self.bs_dev = _lib.host_to_device(self.bs_host, torch.int32, device)          # (no host synchronisation: _lib.host_to_device)
+        self.offs_dev = _lib.host_to_device(self.offs_host, torch.int64, device)
         # index of the predecessor row (forward sense) per direction; `rows` = "no predecessor"
         prev = np.full((2, self.rows), self.rows, dtype=np.int64)
         for t in range(self.T):
@@ -50,7 +50,7 @@ class _PackMeta:
                 prev[0, offs[t]:offs[t] + bs[t]] = offs[t - 1] + np.arange(bs[t])
             if t + 1 < self.T:
                 prev[1, offs[t]:offs[t] + bs[t + 1]] = offs[t + 1] + np.arange(bs[t + 1])
-        self.prev_dev = torch.tensor(prev, device=device)
+        self.prev_dev = _lib.host_to_device(prev, torch.int64, device)
         # equal-length batch: the predecessor of packed row r is row r - bs[0] (forward direction) or
         # r + bs[0] (reverse direction), which `_LstmLayerFn` turns into shifted views of a padded buffer
         self.bs0 = int(bs[0]) if self.T else 0
@@ -60,14 +60,18 @@ class _PackMeta:
         lens = (bs[None, :] > np.arange(self.max_batch)[:, None]).sum(1) if self.T else np.zeros(0, np.int64)
         b_idx = np.arange(self.max_batch)
         end_rows = offs[np.maximum(lens - 1, 0)] + b_idx
-        self.first_rows = torch.tensor(np.stack([b_idx, end_rows]), device=device)
-        self.last_rows = torch.tensor(np.stack([end_rows, b_idx]), device=device)
+        self.first_rows = _lib.host_to_device(np.stack([b_idx, end_rows]), torch.int64, device)
+        self.last_rows = _lib.host_to_device(np.stack([end_rows, b_idx]), torch.int64, device)
         prev_h0 = prev.copy()
         row_b = np.concatenate([np.arange(n) for n in bs]) if self.T else np.zeros(0, np.int64)
         for d in range(2):
             fresh = prev[d] == self.rows
             prev_h0[d, fresh] = self.rows + 1 + row_b[fresh]
-        self.prev_h0_dev = torch.tensor(prev_h0, device=device)
+        self.prev_h0_dev = _lib.host_to_device(prev_h0, torch.int64, device)
+        # packed row (t, b) -> row t * max_batch + b of the time-major padded tensor (ops.sequence.unpack_sequence)
+        self.padded_rows = _lib.host_to_device(
+            np.concatenate([t * self.max_batch + np.arange(n) for t, n in enumerate(bs)]) if self.T else np.zeros(0, np.int64),
+            torch.int64, device)
 
 
 @functools.lru_cache(maxsize=64)

@@ -85,6 +85,29 @@ def test_trainer_deferred_checks_match_golden(g6, tmp_path):
     assert np.isfinite(scalars['loss']) and np.isfinite(scalars['grad_norm']), scalars
 
 
+def test_unpack_sequence_ragged_is_one_scatter_and_matches_torch():
+    """``ops.unpack_sequence`` of a ragged PackedSequence on the GPU (reference ``pack_module.py:29-30``): values, zero padding, lengths
+    and the gradient equal ``torch.nn.utils.rnn.pad_packed_sequence``'s."""
+    from torch.nn.utils.rnn import pack_sequence, pad_packed_sequence
+    from padertorch_amd import ops
+    torch.manual_seed(5)
+    lens = [37, 30, 30, 12, 5, 1]
+    seqs = [torch.randn(n, 2, 7, device=DEV) for n in lens]
+    a = pack_sequence(seqs)
+    data1 = a.data.clone().requires_grad_(True)
+    data2 = a.data.clone().requires_grad_(True)
+    out = ops.unpack_sequence(a._replace(data=data1))
+    ref, ref_lens = pad_packed_sequence(a._replace(data=data2))
+    assert out.lengths == ref_lens.tolist() == lens and not out.batch_first
+    assert torch.equal(out.padded, ref)
+    for b, n in enumerate(lens):
+        assert torch.equal(out[b], seqs[b])
+    w = torch.randn_like(ref)
+    (out.padded * w).sum().backward()
+    (ref * w).sum().backward()
+    assert torch.equal(data1.grad, data2.grad)
+
+
 def test_trainer_prefetched_weight_forms_change_nothing(g6, tmp_path, monkeypatch):
     """From the second optimizer step on, the dense layers' operand forms (maximum, planes) and the later LSTM layers' are made on the
     preparation stream behind the optimizer kernel (ops.gemm.note_update / prefetch_known, ops.lstm._stacked_weights): the cache
