@@ -431,6 +431,10 @@ def main():
                 if buckets is not None:
                     buckets.active = m + 1 == micro
                 src = data
+                if args.ragged:
+                    # real data brings a new length pattern every step: the per-pattern bookkeeping (ops.lstm.pack_meta: index tables,
+                    # their transfers) is rebuilt every step although this bench repeats one batch
+                    _lstm._meta.cache_clear()
                 if source is not None:        # waveforms start in pinned host memory
                     src = dict(y=source['y'].to(device, non_blocking=True), s=source['s'].to(device, non_blocking=True),
                                num_samples=source['num_samples'])

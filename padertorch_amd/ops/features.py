@@ -7,6 +7,7 @@ Replaces the numpy data-pipeline transform ``pre_batch_transform``
 directly in HBM - the H2D copy shrinks from (1+2K) feature maps to (1+K) waveforms
  and the STFTs never leave the device.
 """
+import numpy as np
 import torch
 
 from .. import _lib
@@ -99,7 +100,8 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
     if packed_log1p and T > 0 and all(a >= b for a, b in zip(frames, frames[1:])):
         # the model's first-layer input on the way out: log1p(Y_abs) in PackedSequence order, fp32 and as fp16 planes
         from . import gemm as _gemm, lstm as _lstm
-        bs = torch.tensor([sum(1 for f in frames if f > t) for t in range(T)], dtype=torch.int64) if ragged else \
+        # (numpy, not torch: a CPU tensor op over T x B elements wakes torch's whole intra-op thread pool - tens of ms on a 256-core host)
+        bs = torch.from_numpy((np.asarray(frames)[None, :] > np.arange(T)[:, None]).sum(1).astype(np.int64)) if ragged else \
             torch.full((T,), B, dtype=torch.int64)
         meta = _lstm.pack_meta(bs, dev)
         lp = torch.empty((meta.rows, F), dtype=torch.float32, device=dev)

@@ -44,12 +44,14 @@ class _PackMeta:
         self.bs_dev = _lib.host_to_device(self.bs_host, torch.int32, device)          # (no host synchronisation: _lib.host_to_device)
         self.offs_dev = _lib.host_to_device(self.offs_host, torch.int64, device)
         # index of the predecessor row (forward sense) per direction; `rows` = "no predecessor"
+        # (vectorised: a new length pattern every step - real training data - must not cost the host milliseconds)
+        t_row = np.repeat(np.arange(self.T), bs)                      # time step / batch index of every packed row
+        b_row = np.arange(self.rows) - offs[t_row] if self.T else np.zeros(0, np.int64)
+        bs_next = np.append(bs[1:], 0) if self.T else bs
         prev = np.full((2, self.rows), self.rows, dtype=np.int64)
-        for t in range(self.T):
-            if t > 0:
-                prev[0, offs[t]:offs[t] + bs[t]] = offs[t - 1] + np.arange(bs[t])
-            if t + 1 < self.T:
-                prev[1, offs[t]:offs[t] + bs[t + 1]] = offs[t + 1] + np.arange(bs[t + 1])
+        if self.T:
+            prev[0] = np.where(t_row > 0, offs[np.maximum(t_row - 1, 0)] + b_row, self.rows)
+            prev[1] = np.where(b_row < bs_next[t_row], offs[t_row + 1] + b_row, self.rows)
         self.prev_dev = _lib.host_to_device(prev, torch.int64, device)
         # equal-length batch: the predecessor of packed row r is row r - bs[0] (forward direction) or
         # r + bs[0] (reverse direction), which `_LstmLayerFn` turns into shifted views of a padded buffer
@@ -63,15 +65,13 @@ class _PackMeta:
         self.first_rows = _lib.host_to_device(np.stack([b_idx, end_rows]), torch.int64, device)
         self.last_rows = _lib.host_to_device(np.stack([end_rows, b_idx]), torch.int64, device)
         prev_h0 = prev.copy()
-        row_b = np.concatenate([np.arange(n) for n in bs]) if self.T else np.zeros(0, np.int64)
+        row_b = b_row
         for d in range(2):
             fresh = prev[d] == self.rows
             prev_h0[d, fresh] = self.rows + 1 + row_b[fresh]
         self.prev_h0_dev = _lib.host_to_device(prev_h0, torch.int64, device)
         # packed row (t, b) -> row t * max_batch + b of the time-major padded tensor (ops.sequence.unpack_sequence)
-        self.padded_rows = _lib.host_to_device(
-            np.concatenate([t * self.max_batch + np.arange(n) for t, n in enumerate(bs)]) if self.T else np.zeros(0, np.int64),
-            torch.int64, device)
+        self.padded_rows = _lib.host_to_device(t_row * self.max_batch + b_row, torch.int64, device)
 
 
 @functools.lru_cache(maxsize=64)

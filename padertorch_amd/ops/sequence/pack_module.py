@@ -4,6 +4,7 @@ Same public names as ``padertorch/ops/sequence/pack_module.py:17-34`` (pure data
 torch ``rnn`` utilities are the implementation in the reference too), plus :class:`PaddedList`,
 the container this package uses to hand a ragged batch to the HIP kernels without re-padding.
 """
+import numpy as np
 import torch
 from torch.nn.utils.rnn import PackedSequence  # noqa: F401
 from torch.nn.utils.rnn import pad_packed_sequence
@@ -103,7 +104,7 @@ def unpack_sequence(packed_sequence: PackedSequence) -> list:
         from .. import lstm as _lstm
         meta = _lstm.pack_meta(bs, data.device)
         padded = _PackedToPadded.apply(data, meta.padded_rows, meta.T, meta.max_batch)
-        lengths = (bs[None, :] > torch.arange(meta.max_batch)[:, None]).sum(1).tolist()
+        lengths = (meta.bs_host[None, :] > np.arange(meta.max_batch)[:, None]).sum(1).tolist()       # (numpy: see ops.features)
         return PaddedList(padded, lengths, batch_first=False)
     padded, lengths = pad_packed_sequence(packed_sequence)
     return PaddedList(padded, lengths.tolist(), batch_first=False)
