@@ -41,6 +41,9 @@ rm -rf /tmp/kt3; timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace -d /tm
 db3=$(find /tmp/kt3 -name "*.db" 2>/dev/null | head -1)
 [ -n "$db3" ] && python $repo/scripts/hip_api_between_launches.py "$db3" --min 2 > $out/${tag}_hip_api_between_launches.txt 2>&1 </dev/null
 [ -x $repo/scripts/mb/pack_t ] && { cd $repo/scripts/mb; { ./pack_t 8096 2400 4800; ./pack_t 32192 2400 4800; ./pack_t 32192 1200 1200; } > $out/${tag}_mb_pack_t.txt 2>&1; cd /tmp; }
+# ragged batches (lengths U[3 s, 6 s], bookkeeping rebuilt every step): a reported mode
+( for a in "" "--config c3" "--config c5"; do timeout 600 python $repo/bench.py $a --ragged --steps 60 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ragged $a: %.2f ms/step, %d frames/s, %d frames/step' % (d['ms_per_step'], d['value'], d['config']['frames_per_step']))"; done
+  timeout 300 python $repo/scripts/phase_events.py --ragged 2>/dev/null | grep -E '^#|^[ms] ' ) > $out/${tag}_ragged.txt
 timeout 600 python $repo/scripts/bf16_delta.py 2>/dev/null | tail -1 > $out/${tag}_bf16_delta.json
 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' > $out/${tag}_lstm_us_per_step.txt
 PTMI_LSTM_F32=1 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' | sed 's/^/exact-fp32 kernels: /' >> $out/${tag}_lstm_us_per_step.txt
