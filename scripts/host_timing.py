@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How far ahead of the GPU is the host in the bench step?  Per step: host time spent enqueuing (step start -> the
-deferred check of the previous step), time blocked in that check (0 = the host is the bottleneck), host time per phase."""
+deferred check of the previous step), time blocked in that check (0 = the host is the bottleneck), host time per phase.
+    python scripts/host_timing.py [c2|c3] [ragged]   (ragged: lengths U[3 s, 6 s], the per-pattern bookkeeping rebuilt every step)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,7 +12,8 @@ import bench
 
 dev = torch.device('cuda', 0)
 torch.manual_seed(0)
-cfg = bench.CONFIGS['c2']
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in bench.CONFIGS else 'c2']
+RAGGED = 'ragged' in sys.argv
 model = PermutationInvariantTrainingModel()
 trainer = pt.Trainer(model, '/tmp/ptmi_ht', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=bench.LOSS_WEIGHTS,
                      virtual_minibatch_size=1, deferred_checks=True)
@@ -21,7 +23,13 @@ model.train()
 _lstm.DEFER_WGRAD = True
 _lstm.warm_side_stream(dev)
 n = cfg['fs'] * bench.SECONDS
-data = bench.synthetic_batch(1000, cfg['batch'], cfg['K'], n, dev)
+lengths = None
+if RAGGED:
+    import random
+    rnd = random.Random(1234)
+    lengths = sorted((rnd.randint(3 * cfg['fs'], 6 * cfg['fs']) for _ in range(cfg['batch'])), reverse=True)
+    n = lengths[0]
+data = bench.synthetic_batch(1000, cfg['batch'], cfg['K'], n, dev, lengths)
 
 marks = {}
 def add(k, dt):
@@ -33,6 +41,8 @@ def timed_check(flush=False):
 trainer._check_pending = timed_check
 
 def step():
+    if RAGGED:
+        _lstm._meta.cache_clear()
     t0 = time.perf_counter()
     feats = pt.ops.pit_features(data['y'], data['s'], data['num_samples'])
     t1 = time.perf_counter()

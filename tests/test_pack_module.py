@@ -51,3 +51,34 @@ def test_pad_direction_blocks_matches_the_hand_off_plane_layout():
     x = torch.randint(-4, 5, (4, 10)).to(torch.float32)                  # integer-valued: both products are exact in fp32
     xp = pad_direction_blocks(x, 2, 5, 8)
     assert torch.equal(xp @ p.t(), x @ w.t())                             # padded operands: same product
+
+
+def test_pack_meta_index_tables_match_the_per_step_definition():
+    """``ops.lstm._PackMeta`` (vectorised): the predecessor row of every packed row per direction, the h0 variant, the rows of every
+    sequence's first / last processed step and the packed -> padded row map equal their per-time-step definitions."""
+    import random
+    import numpy as np
+    from padertorch_amd.ops.lstm import _PackMeta
+    rnd = random.Random(7)
+    for _ in range(25):
+        B = rnd.randint(1, 9)
+        lens = sorted((rnd.randint(1, 30) for _ in range(B)), reverse=True)
+        T = lens[0]
+        bs = [sum(1 for n in lens if n > t) for t in range(T)]
+        m = _PackMeta(tuple(bs), torch.device('cpu'))
+        offs = np.concatenate([[0], np.cumsum(bs)])
+        rows = int(offs[-1])
+        prev = np.full((2, rows), rows, dtype=np.int64)
+        prev_h0 = prev.copy()
+        for t in range(T):
+            for b in range(bs[t]):
+                r = offs[t] + b
+                prev[0, r] = offs[t - 1] + b if t > 0 else rows
+                prev[1, r] = offs[t + 1] + b if (t + 1 < T and b < bs[t + 1]) else rows
+                for d in range(2):
+                    prev_h0[d, r] = prev[d, r] if prev[d, r] != rows else rows + 1 + b
+        assert np.array_equal(m.prev_dev.numpy(), prev) and np.array_equal(m.prev_h0_dev.numpy(), prev_h0)
+        assert m.padded_rows.tolist() == [t * B + b for t in range(T) for b in range(bs[t])]
+        last = [offs[n - 1] + b for b, n in enumerate(lens)]
+        assert m.first_rows.tolist() == [list(range(B)), last] and m.last_rows.tolist() == [last, list(range(B))]
+        assert m.rows == rows and m.T == T and m.max_batch == B and m.equal_lengths == (len(set(lens)) == 1)
