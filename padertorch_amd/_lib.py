@@ -184,7 +184,8 @@ class _Staging:
         self.half = half_bytes
         self.buf = torch.empty(2 * half_bytes, dtype=torch.uint8, pin_memory=True)
         self.which, self.off = 0, 0
-        self.events = [None, None]
+        self.events = [[], []]           # per half: events behind the copies out of it (one per stream that copied)
+        self.streams = [{}, {}]          # per half: the streams that have copied out of it since it was entered
         self.lock = threading.Lock()
 
     def put(self, t, device):
@@ -193,17 +194,21 @@ class _Staging:
             return t.pin_memory().to(device, non_blocking=True)
         with self.lock:
             if self.off + n > self.half:                       # leave this half: an event behind everything copied out of it
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(device))
-                self.events[self.which] = ev
+                for stream in self.streams[self.which].values():
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    self.events[self.which].append(ev)
+                self.streams[self.which] = {}
                 self.which, self.off = self.which ^ 1, 0
-                if self.events[self.which] is not None:
-                    self.events[self.which].synchronize()
-                    self.events[self.which] = None
+                for ev in self.events[self.which]:
+                    ev.synchronize()
+                self.events[self.which] = []
             start = self.which * self.half + self.off
             self.off += (n + 63) // 64 * 64
             stage = self.buf[start:start + n].view(t.dtype).view(t.shape)
             stage.copy_(t)
+            cur = torch.cuda.current_stream(device)
+            self.streams[self.which][cur.cuda_stream] = cur
             return stage.to(device, non_blocking=True)
 
 

@@ -85,6 +85,29 @@ def test_trainer_deferred_checks_match_golden(g6, tmp_path):
     assert np.isfinite(scalars['loss']) and np.isfinite(scalars['grad_norm']), scalars
 
 
+def test_host_to_device_staging_wraps_without_losing_values(monkeypatch):
+    """``_lib.host_to_device``: small host arrays through two pinned halves, many laps, two streams: every device tensor holds its values
+    (a half is rewritten only behind the event of the copies out of it); large arrays take their own pinned buffer."""
+    from padertorch_amd import _lib
+    monkeypatch.setattr(_lib, '_STAGING', {0: _lib._Staging(half_bytes=1 << 12)})
+    rng = np.random.RandomState(0)
+    side = torch.cuda.Stream()
+    keep = []
+    for i in range(400):
+        a = rng.randint(-1000, 1000, size=rng.randint(1, 120)).astype(np.int64)
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                keep.append((a, _lib.host_to_device(a, torch.int64, DEV)))
+        else:
+            keep.append((a, _lib.host_to_device(a.tolist(), torch.int32, torch.device(DEV))))
+    big = rng.randint(0, 9, size=5000).astype(np.int32)
+    keep.append((big, _lib.host_to_device(big, torch.int32, DEV)))
+    torch.cuda.synchronize()
+    for a, d in keep:
+        assert d.is_cuda and d.cpu().numpy().tolist() == a.tolist()
+    assert _lib.host_to_device([], torch.int32, DEV).numel() == 0
+
+
 def test_unpack_sequence_ragged_is_one_scatter_and_matches_torch():
     """``ops.unpack_sequence`` of a ragged PackedSequence on the GPU (reference ``pack_module.py:29-30``): values, zero padding, lengths
     and the gradient equal ``torch.nn.utils.rnn.pad_packed_sequence``'s."""
