@@ -339,6 +339,9 @@ def main():
     from padertorch_amd.ops import lstm as _lstm
 
     torch.manual_seed(0)
+    # the host side of the step is a few small CPU tensor operations; with the default (one intra-op thread per core: 256 here) each
+    # of them that exceeds torch's grain size wakes the whole pool - milliseconds on a box that other tenants load
+    torch.set_num_threads(min(8, os.cpu_count() or 8))
     if args.library_gemms:
         _gemm.ENABLED = False
         if not args.dry:

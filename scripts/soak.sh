@@ -19,4 +19,9 @@ run --config c4 --steps 100 --warmup 2
 run --config c5 --steps 600 --warmup 5
 run --config c2 --steps 500 --warmup 5 --bf16
 run --config c2 --steps 300 --warmup 5 --sync-checks
+# ragged batches (lengths U[3 s, 6 s], the per-pattern bookkeeping rebuilt every step): cold starts and long runs
+for cfg in c2 c3 c5; do run --config $cfg --ragged --steps 8 --warmup 0; done
+run --config c2 --ragged --steps 1500 --warmup 10
+run --config c3 --ragged --steps 300 --warmup 5
+run --config c5 --ragged --steps 300 --warmup 5
 cat $out
