@@ -418,8 +418,11 @@ def main():
             if cfg['model'] == 'pit':
                 return feats
             X = feats['X_abs'].padded                                  # [B, T, K, F]: ideal binary masks as targets
-            target = torch.nn.functional.one_hot(X.argmax(2), K).permute(0, 1, 3, 2).to(torch.float32)
-            return dict(Y_abs=feats['Y_abs'], target_mask=list(target.unbind(0)), num_frames=feats['num_frames'])
+            target = torch.nn.functional.one_hot(X.argmax(2), K).permute(0, 1, 3, 2).to(torch.float32, memory_format=torch.contiguous_format)
+            # (a list of per-example views of ONE padded tensor, like the features themselves: the review pads nothing)
+            from padertorch_amd.ops.sequence.pack_module import PaddedList
+            return dict(Y_abs=feats['Y_abs'], target_mask=PaddedList(target, feats['num_frames'], True, feats['Y_abs'].lengths_dev),
+                        num_frames=feats['num_frames'])
 
         def step(timed, source=None):
             # the STFT feature front-end is part of the step; inside the timed region every launch of a ptmi kernel is
