@@ -210,14 +210,15 @@ def pack_t(x, amax=None):
     """``x [k, c]`` (fp32 CUDA, unit inner stride; any row stride) -> ``(planes, amax word or None)`` of the operand whose
     rows are ``x``'s columns and whose reduction axis is ``k`` (``torch.ops.ptmi.pack_planes_t``).  ``amax``: the device
     word from :func:`absmax` (measured here when ``None``) or :data:`UNIT_RANGE`."""
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32, (x.shape, x.stride(), x.dtype)
+    # (a single column has no inner stride to speak of: torch leaves whatever stride it had, .contiguous() included)
+    assert x.dim() == 2 and (x.stride(1) == 1 or x.shape[1] == 1) and x.dtype == torch.float32, (x.shape, x.stride(), x.dtype)
     ax = None if amax is UNIT_RANGE else (absmax(x) if amax is None else amax)
     return torch.ops.ptmi.pack_planes_t(x, ax), ax
 
 
 def pack_n(x, amax=None):
     """``x [r, k]`` (reduction axis contiguous) -> ``(planes, amax word or None)`` of that ``r x k`` operand."""
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32, (x.shape, x.stride(), x.dtype)
+    assert x.dim() == 2 and (x.stride(1) == 1 or x.shape[1] == 1) and x.dtype == torch.float32, (x.shape, x.stride(), x.dtype)
     ax = None if amax is UNIT_RANGE else (absmax(x) if amax is None else amax)
     return torch.ops.ptmi.pack_planes_n(x, ax), ax
 

@@ -264,7 +264,7 @@ def pack_planes_t(x, amax):
     lib = _lib.load()
     k, c = x.shape
     out = torch.empty(int(lib.ptmi_planes_elems(c, k)), dtype=torch.float16, device=x.device)
-    _lib.check(_lib.timed(f'pack_planes_t:{k}x{c}', lib.ptmi_pack_planes_t, x.data_ptr(), k, c, x.stride(0), _lib.ptr(amax), out.data_ptr(),
+    _lib.check(_lib.timed(f'pack_planes_t:{k}x{c}', lib.ptmi_pack_planes_t, x.data_ptr(), k, c, _ld(x), _lib.ptr(amax), out.data_ptr(),
                           _lib.stream(x.device)), 'ptmi_pack_planes_t')
     return out
 
@@ -275,7 +275,7 @@ def pack_planes_n(x, amax):
     lib = _lib.load()
     r, k = x.shape
     out = torch.empty(int(lib.ptmi_planes_elems(r, k)), dtype=torch.float16, device=x.device)
-    _lib.check(_lib.timed(f'pack_planes_n:{r}x{k}', lib.ptmi_pack_planes_n, x.data_ptr(), r, k, x.stride(0), _lib.ptr(amax), out.data_ptr(),
+    _lib.check(_lib.timed(f'pack_planes_n:{r}x{k}', lib.ptmi_pack_planes_n, x.data_ptr(), r, k, _ld(x), _lib.ptr(amax), out.data_ptr(),
                           _lib.stream(x.device)), 'ptmi_pack_planes_n')
     return out
 
@@ -289,6 +289,11 @@ def gemm_planes_(out, a, amax_a, b, amax_b, bias, M, N, K, accumulate, split_k):
     _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}:{split_k}', lib.ptmi_gemm_planes, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
                           _lib.ptr(amax_b), _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, int(accumulate), split_k,
                           _products(), _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes')
+
+
+def _ld(x):
+    """Row stride of a 2-D source with unit inner stride (a single row has none to speak of)."""
+    return x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
 
 
 def _products():
@@ -307,7 +312,7 @@ def pack_planes_bf16(x, transposed):
     rows, k = (b, a) if transposed else (a, b)
     out = torch.empty(int(lib.ptmi_planes_elems(rows, k)), dtype=torch.bfloat16, device=x.device)
     fn = lib.ptmi_pack_planes_t_bf16 if transposed else lib.ptmi_pack_planes_n_bf16
-    _lib.check(_lib.timed(f'pack_planes_bf16:{a}x{b}', fn, x.data_ptr(), a, b, x.stride(0), out.data_ptr(), _lib.stream(x.device)),
+    _lib.check(_lib.timed(f'pack_planes_bf16:{a}x{b}', fn, x.data_ptr(), a, b, _ld(x), out.data_ptr(), _lib.stream(x.device)),
                'ptmi_pack_planes_bf16')
     return out
 
@@ -320,7 +325,7 @@ def pack_planes_into_(out, x, amax, transposed, kb_total, kb_offset, kb_count):
     a, b = x.shape
     rows = b if transposed else a
     assert out.dtype in (torch.float16, torch.bfloat16) and out.numel() >= (rows + 15) // 16 * kb_total * 1024, (out.dtype, out.numel())
-    _lib.check(_lib.timed(f'pack_planes_into:{a}x{b}', lib.ptmi_pack_planes_into, x.data_ptr(), a, b, x.stride(0), int(transposed),
+    _lib.check(_lib.timed(f'pack_planes_into:{a}x{b}', lib.ptmi_pack_planes_into, x.data_ptr(), a, b, _ld(x), int(transposed),
                           int(out.dtype == torch.bfloat16), _lib.ptr(amax), out.data_ptr(), kb_total, kb_offset, kb_count,
                           _lib.stream(x.device)), 'ptmi_pack_planes_into')
 

@@ -159,6 +159,24 @@ def test_planes_pack_layout_and_unit_range():
     assert float(p[1, :, :, :, 4:, :].abs().sum()) == 0 and float(p[:, 2, :, 0, :, 6:].abs().sum()) == 0      # past the matrix
 
 
+def test_mm_with_a_single_column_or_row_operand():
+    """``ops.gemm.mm`` with K = 1 / N = 1 / M = 1: a size-1 axis keeps whatever stride it had (``.contiguous()`` does not touch it), the
+    pack passes must not take it for the inner stride (found by scripts/fuzz_lstm.py: an LSTM with ONE input feature)."""
+    from padertorch_amd.ops import gemm as G
+    torch.manual_seed(2)
+    x = torch.randn(8192, 3, device='cuda')[:, 1:2]                  # [8192, 1], strides (3, 1)
+    xt = torch.randn(1, 8192, device='cuda').t()                     # [8192, 1], strides (1, 8192)
+    w = torch.randn(1, 40, device='cuda')
+    for a in (x, xt):
+        assert float((G.mm(a, w).double() - a.double() @ w.double()).abs().max()) < 1e-5
+    v = torch.randn(300, 1, device='cuda')
+    m = torch.randn(70, 300, device='cuda')
+    assert float((G.mm(m, v).double() - m.double() @ v.double()).abs().max()) < 1e-4
+    r = torch.randn(1, 300, device='cuda')
+    assert float((G.mm(r, m.t().contiguous()).double() - r.double() @ m.double().t()).abs().max()) < 1e-4
+    assert float((G.mm(r.expand(1, 300), m.t()).double() - r.double() @ m.double().t()).abs().max()) < 1e-4
+
+
 def test_absmax_words_and_running_maximum():
     """``ops.gemm.absmax``: the float bits of max |x| in a word of a buffer zeroed once (no zeroing launch per call; every call its
     own word, per stream), for either unit stride; ``ptmi_absmax_accumulate`` keeps a running maximum; ``ptmi_absmax`` zeroes."""
