@@ -40,19 +40,19 @@ def _grad_check(model, ref, tol=2e-4):
     return worst
 
 
-def _pit_case(B, fs, lens=None, seed=0):
+def _pit_case(B, fs, lens=None, seed=0, n=None, **model_kw):
     import padertorch_amd as pt
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
     from padertorch_amd.ops import lstm as _lstm
     from oracle import torch_ref
-    n = 4 * fs
+    n = n or 4 * fs
     lens = lens or [n] * B
     torch.manual_seed(seed)
-    model = PermutationInvariantTrainingModel()
-    ref = torch_ref.PITModelRef()
+    model = PermutationInvariantTrainingModel(**model_kw)
+    ref = torch_ref.PITModelRef(**model_kw)
     ref.load_state_dict(model.state_dict())
     model.to(DEV).train()
-    s = _waveforms(B, 2, n, lens, seed + 1).to(DEV)
+    s = _waveforms(B, model_kw.get('K', 2), n, lens, seed + 1).to(DEV)
     feats = pt.ops.pit_features(s.sum(1), s, lens)
     _lstm.CHECK_PERSISTENT_ERRORS = True
     try:
@@ -79,6 +79,21 @@ def test_pit_step_config2_size_vs_oracle():
     _pit_case(32, 8000)
 
 
+@pytest.mark.parametrize('seed', range(16))
+def test_pit_step_random_small_configurations_vs_oracle(seed):
+    """Random model sizes (units, layers, K, output activation), batch sizes 1 ... 40 and ragged / equal lengths of 0.1 ... 0.6 s: the
+    whole step (packed feature output, recurrences of every tile shape, dense layers, unpack scatter, PIT loss, every gradient)
+    against the oracle - the corners the three BASELINE shapes do not touch."""
+    rng = np.random.RandomState(1000 + seed)
+    B = int(rng.randint(1, 41))
+    n = int(rng.randint(800, 4800))
+    ragged = bool(rng.randint(0, 2))
+    lens = sorted((int(x) for x in rng.randint(n // 3, n + 1, B)), reverse=True) if ragged else [n] * B
+    lens[0] = n
+    _pit_case(B, 8000, lens=lens, seed=seed, n=n, units=int(rng.choice([4, 24, 100, 600])), recurrent_layers=int(rng.randint(1, 4)),
+              K=int(rng.randint(2, 4)), output_activation=str(rng.choice(['relu', 'sigmoid'])))
+
+
 def test_pit_step_config3_rows_and_steps_vs_oracle():
     """More than 32 sequences x 503 steps: the 32-row chains (two row tiles per workgroup) of the config-3 kernels; a few
     shorter examples make the batch ragged at the end (the hand-off bookkeeping of shrinking steps)."""
@@ -87,22 +102,26 @@ def test_pit_step_config3_rows_and_steps_vs_oracle():
     _pit_case(40, 16000, lens=lens, seed=3)
 
 
-def test_dc_step_config5_shape_vs_oracle():
+def _dc_case(B, K, n, lens, seed, padded_target=False, **model_kw):
     import padertorch_amd as pt
     from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
     from padertorch_amd.ops import lstm as _lstm
+    from padertorch_amd.ops.sequence.pack_module import PaddedList
     from oracle import torch_ref
-    B, K, n = 34, 3, 64000
-    lens = [n] * 30 + [n - 128 * 3, n - 128 * 90, n - 128 * 91, n - 128 * 300]
-    torch.manual_seed(5)
-    model = DeepClusteringModel()
-    ref = torch_ref.DCModelRef()
+    torch.manual_seed(seed)
+    model = DeepClusteringModel(**model_kw)
+    ref = torch_ref.DCModelRef(**model_kw)
     ref.load_state_dict(model.state_dict())
     model.to(DEV).train()
-    s = _waveforms(B, K, n, lens, 6).to(DEV)
+    s = _waveforms(B, K, n, lens, seed + 1).to(DEV)
     feats = pt.ops.pit_features(s.sum(1), s, lens)
     target = [torch.nn.functional.one_hot(x.argmax(1), K).permute(0, 2, 1).to(torch.float32) for x in feats['X_abs']]
-    batch = dict(Y_abs=feats['Y_abs'], target_mask=target, num_frames=feats['num_frames'])
+    given = target
+    if padded_target:        # what bench.py hands over: per-example views of ONE padded tensor
+        X = feats['X_abs'].padded
+        whole = torch.nn.functional.one_hot(X.argmax(2), K).permute(0, 1, 3, 2).to(torch.float32, memory_format=torch.contiguous_format)
+        given = PaddedList(whole, feats['num_frames'], True, feats['Y_abs'].lengths_dev)
+    batch = dict(Y_abs=feats['Y_abs'], target_mask=given, num_frames=feats['num_frames'])
     _lstm.CHECK_PERSISTENT_ERRORS = True
     try:
         emb = model(batch)
@@ -120,6 +139,23 @@ def test_dc_step_config5_shape_vs_oracle():
     assert worst < 1e-5, worst
     assert abs(float(loss) - float(rloss)) < 1e-4 * max(1., abs(float(rloss))), (float(loss), float(rloss))
     _grad_check(model, ref)
+
+
+def test_dc_step_config5_shape_vs_oracle():
+    n = 64000
+    _dc_case(34, 3, n, [n] * 30 + [n - 128 * 3, n - 128 * 90, n - 128 * 91, n - 128 * 300], 5)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_dc_step_random_small_configurations_vs_oracle(seed):
+    """Random batch sizes, ragged / equal lengths, target masks as a plain list or as the bench's PaddedList over one tensor."""
+    rng = np.random.RandomState(2000 + seed)
+    B = int(rng.randint(1, 41))
+    n = int(rng.randint(800, 4800))
+    ragged = bool(rng.randint(0, 2))
+    lens = sorted((int(x) for x in rng.randint(n // 3, n + 1, B)), reverse=True) if ragged else [n] * B
+    lens[0] = n
+    _dc_case(B, 3, n, lens, 40 + seed, padded_target=bool(seed % 2))
 
 
 def test_pit_step_config1_batch4_vs_oracle():
@@ -134,38 +170,10 @@ def test_pit_step_config3_full_batch_vs_oracle():
 
 
 def test_dc_step_config5_full_batch_vs_oracle():
-    """BASELINE configs[4] at its full batch (64 x 4 s at 16 kHz, K = 3, equal lengths): `bench.py --config c5`."""
-    import padertorch_amd as pt
-    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
-    from padertorch_amd.ops import lstm as _lstm
-    from oracle import torch_ref
-    B, K, n = 64, 3, 64000
-    torch.manual_seed(15)
-    model = DeepClusteringModel()
-    ref = torch_ref.DCModelRef()
-    ref.load_state_dict(model.state_dict())
-    model.to(DEV).train()
-    s = _waveforms(B, K, n, [n] * B, 16).to(DEV)
-    feats = pt.ops.pit_features(s.sum(1), s, [n] * B)
-    target = [torch.nn.functional.one_hot(x.argmax(1), K).permute(0, 2, 1).to(torch.float32) for x in feats['X_abs']]
-    batch = dict(Y_abs=feats['Y_abs'], target_mask=target, num_frames=feats['num_frames'])
-    _lstm.CHECK_PERSISTENT_ERRORS = True
-    try:
-        emb = model(batch)
-        loss = model.review(batch, emb)['losses']['dc_loss']
-        loss.backward()
-    finally:
-        _lstm.CHECK_PERSISTENT_ERRORS = False
-    torch.cuda.synchronize()
-    torch.set_num_threads(min(16, torch.get_num_threads() or 16))
-    rb = dict(Y_abs=[t.detach().cpu() for t in feats['Y_abs']], target_mask=[t.cpu() for t in target])
-    remb = ref(rb)
-    rloss = ref.review(rb, remb)['losses']['dc_loss']
-    rloss.backward()
-    worst = max(float((m.detach().cpu() - r.detach()).abs().max()) for m, r in zip(emb, remb))
-    assert worst < 1e-5, worst
-    assert abs(float(loss) - float(rloss)) < 1e-4 * max(1., abs(float(rloss))), (float(loss), float(rloss))
-    _grad_check(model, ref)
+    """BASELINE configs[4] at its full batch (64 x 4 s at 16 kHz, K = 3, equal lengths): `bench.py --config c5` (incl. its PaddedList of
+    target masks)."""
+    n = 64000
+    _dc_case(64, 3, n, [n] * 64, 15, padded_target=True)
 
 
 def test_config4_four_micro_steps_one_optimizer_step_vs_oracle(tmp_path):
