@@ -57,6 +57,37 @@ def test_generic_sizes_vs_oracle(size, shift, wl):
     np.testing.assert_allclose(xi.cpu().numpy()[..., :x.shape[-1]], x, atol=2e-4)
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_random_options_vs_oracle(seed):
+    """Random (size, shift, window_length, window, fading, pad, batch, signal length) against the numpy oracle: shapes, values, the
+    frame bookkeeping, and the inverse where the options reconstruct (fading 'full' / True with pad)."""
+    from padertorch_amd.ops import STFT
+    rng = np.random.RandomState(500 + seed)
+    size = int(rng.choice([32, 64, 100, 128, 256, 400, 512, 1024]))
+    wl = int(rng.choice([size, size, max(8, size // 2), max(8, int(size * 0.8))]))
+    shift = int(rng.randint(max(1, wl // 8), wl // 2 + 1))
+    fading = [None, 'full', 'half', True, False][int(rng.randint(0, 5))]
+    pad = bool(rng.randint(0, 2))
+    window = str(rng.choice(['hann', 'blackman', 'hamming']))
+    n = int(rng.randint(wl if not pad else 1, 6 * size + 50))
+    B = int(rng.randint(1, 5))
+    x = rng.standard_normal((B, n)).astype(np.float32)
+    st = STFT(size, shift, window=window, window_length=wl, fading=fading, pad=pad)
+    ref = stft_np.stft(x, size, shift, window=window, window_length=wl, fading=fading, pad=pad)
+    X = st(torch.from_numpy(x).to(DEV))
+    assert tuple(X.shape) == ref.shape, (X.shape, ref.shape)
+    # (the frame bookkeeping is paderbox's formula, which - like the reference - counts 0 frames for a signal shorter than the window
+    # although the padded transform yields one: equal to the oracle always, to the transform from one window on)
+    assert st.samples_to_frames(n) == stft_np.samples_to_frames(n, wl, shift, pad=pad, fading=fading)
+    padded_n = n + (0 if fading in (None, False) else (1 + (fading != 'half')) * (wl - shift))
+    assert padded_n < wl or st.samples_to_frames(n) == ref.shape[-2]
+    np.testing.assert_allclose(X.cpu().numpy(), ref, atol=2e-4 * max(np.abs(ref).max(), 1e-3))
+    xi = st.inverse(X).cpu().numpy()
+    ri = stft_np.istft(ref, size, shift, window=window, window_length=wl, fading=fading)
+    assert xi.shape == ri.shape and st.frames_to_samples(ref.shape[-2]) == ri.shape[-1]
+    np.testing.assert_allclose(xi, ri, atol=3e-4 * max(np.abs(ri).max(), 1e-3))
+
+
 def test_representations(g2):
     from padertorch_amd.ops import STFT
     x = torch.from_numpy(g2['x_s512_h128'].astype(np.float32)).to(DEV)
