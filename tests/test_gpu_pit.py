@@ -41,12 +41,13 @@ def test_vs_reference_goldens(g4):
     np.testing.assert_allclose(est.grad.cpu().numpy(), g4['b_grad'], atol=1e-6)
 
 
-@pytest.mark.parametrize('K', [2, 3, 4, 5])
-def test_fused_review_vs_oracle(K):
-    """pit/model.py:117-140 fused over a ragged batch, batch- and time-major masks, + gradients."""
+@pytest.mark.parametrize('K,F,lens', [(2, 33, [19, 17, 17, 4]), (3, 33, [19, 17, 17, 4]), (4, 33, [19, 17, 17, 4]), (5, 33, [19, 17, 17, 4])] + [
+    (int(r.randint(2, 6)), int(r.choice([1, 7, 64, 257, 300])), sorted((int(x) for x in r.randint(1, 60, int(r.randint(1, 12)))), reverse=True))
+    for r in (np.random.RandomState(900 + i) for i in range(14))])
+def test_fused_review_vs_oracle(K, F, lens):
+    """pit/model.py:117-140 fused over a ragged batch, batch- and time-major masks, + gradients (fixed cases and random K / F / lengths)."""
     from padertorch_amd.ops.losses import pit_mse_ips_losses
     rng = np.random.RandomState(K)
-    F, lens = 33, [19, 17, 17, 4]
     B, T = len(lens), max(lens)
     mask = np.abs(rng.standard_normal((B, T, K, F))).astype(np.float32)
     Y = np.abs(rng.standard_normal((B, T, F))).astype(np.float32)
