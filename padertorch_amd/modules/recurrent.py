@@ -40,6 +40,12 @@ class StatefulLSTM(torch.nn.Module):
         self._states = states
 
     def forward(self, x):
+        if isinstance(x, PackedSequence):           # torch.nn.LSTM takes either form (contrib/jensheit's MaskEstimator packs)
+            out, states = packed_lstm(self.lstm, x, hx=self.states, return_state=True)
+            self.states = tuple(s.detach() for s in states)
+            if not self.save_states:
+                del self.states
+            return out
         assert x.dim() == 3, x.shape
         xt = x.transpose(0, 1) if self.batch_first else x            # [T, B, F]
         T, B = xt.shape[:2]

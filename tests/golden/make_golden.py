@@ -23,6 +23,9 @@ Fixtures:
   g9_norm.npz             modules/normalization.py: normalize() outputs + reference-autograd gradients over
                           a grid of formats / axes / shift / scale / lengths; Normalization and
                           InputNormalization training steps + eval; SimpleMaskEstimator forward / loss / grads
+  g11_mask_estimator.npz  contrib/jensheit/mask_estimator_example/modul.py MaskEstimator built through the reference's own
+                          Configurable defaults (finalize_dogmatic_config): state_dict, ragged multi-channel inputs, every output
+                          key, gradients of all parameters; with and without the VAD head / the normalisation
   g10_summary_data.npz    summary/tbx_utils.py mask_to_image / stft_to_image / spectrogram_to_image over batch_first x colour x
                           origin; data/batch.py Sorter and data/utils.py collate_fn results
   g8_logmel.npz           contrib/je/modules/features.py MelTransform (forward / inverse / maxima) and
@@ -557,10 +560,69 @@ def g10():
     np.savez_compressed(HERE / 'g10_summary_data.npz', **out)
 
 
+def g11():
+    """contrib/jensheit MaskEstimator (modul.py:45-158): Normalization -> StatefulLSTM -> fully_connected_stack -> masks."""
+    from padertorch.contrib.jensheit.mask_estimator_example.modul import MaskEstimator
+    rng = np.random.RandomState(11)
+    out, cases = {}, []
+    F = 9
+    grid = [
+        dict(key='default', C=2, frames=[9, 7, 4], updates={}),
+        dict(key='vad', C=1, frames=[8, 8, 5, 2], updates=dict(vad=True)),
+        dict(key='nonorm_uni', C=3, frames=[6], updates=dict(normalization=None, separate_masks=False, output_activation='tanh',
+                                                            recurrent=dict(bidirectional=False))),
+    ]
+    for case in grid:
+        key, C, frames = case['key'], case['C'], case['frames']
+        torch.manual_seed(11)
+        upd = dict(num_features=F, recurrent=dict(hidden_size=8), fully_connected=dict(hidden_size=[16, 12, 16], dropout=0.))
+        for k, v in case['updates'].items():
+            if isinstance(v, dict):
+                upd[k] = {**upd.get(k, {}), **v}
+            else:
+                upd[k] = v
+        upd['fully_connected']['input_size'] = 16 if upd.get('recurrent', {}).get('bidirectional', True) else 8
+        # (Configurable.get_config needs `sacred`, which this image lacks: the reference's own finalize_dogmatic_config fills
+        #  the defaults, the update entries override them, the factories are called as from_config would)
+        cfg = dict(num_features=F)
+        MaskEstimator.finalize_dogmatic_config(cfg)
+        for k, v in upd.items():
+            if isinstance(v, dict) and isinstance(cfg.get(k), dict):
+                cfg[k].update(v)
+            else:
+                cfg[k] = v
+
+        def build(node):
+            if isinstance(node, dict) and 'factory' in node:
+                return node['factory'](**{k: build(v) for k, v in node.items() if k != 'factory'})
+            return node
+        me = MaskEstimator(**{k: build(v) for k, v in cfg.items()})
+        me.eval()
+        for k, v in me.state_dict().items():
+            out[f'{key}/sd/{k}'] = v.numpy()
+        x = [torch.tensor(np.abs(rng.randn(C, n, F)).astype(np.float32) * 2) for n in frames]
+        o = me(x, frames)
+        loss = 0.
+        for i, (k, v) in enumerate(sorted(o.items())):
+            w = torch.tensor(rng.randn(*v.shape).astype(np.float32))
+            out[f'{key}/w/{k}'] = w.numpy()
+            out[f'{key}/out/{k}'] = v.detach().numpy()
+            loss = loss + (v * w).sum()
+        loss.backward()
+        for b, t in enumerate(x):
+            out[f'{key}/x{b}'] = t.numpy()
+        out[f'{key}/loss'] = loss.detach().numpy()
+        for k, p_ in me.named_parameters():
+            out[f'{key}/grad/{k}'] = p_.grad.numpy() if p_.grad is not None else np.zeros(0, np.float32)
+        cases.append(dict(key=key, C=C, frames=frames, updates=case['updates'], F=F))
+    out['cases'] = np.array(json.dumps(cases))
+    np.savez_compressed(HERE / 'g11_mask_estimator.npz', **out)
+
+
 if __name__ == '__main__':
     assert os.path.isdir('/root/reference'), 'run in the build container'
     only = sys.argv[1:]
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10):
+    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9, g10, g11):
         if only and fn.__name__ not in only:
             continue
         fn()
