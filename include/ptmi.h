@@ -487,6 +487,25 @@ int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const in
                    const float* step, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t zero_grad,
                    ptmi_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Data parallelism: the gradient exchange of padertorch/train/trainer.py:396-442 (parallel_apply over the devices of ONE
+ * process, gradients of the replicas summed at :426-428 - accumulated, NOT averaged) as one process per GPU and one RCCL
+ * all_reduce(SUM) over xGMI on the flat fp32 gradient bucket.  librccl is opened on first use (dlopen).
+ *
+ * ptmi_comm_unique_id : rank 0 draws the 128-byte rendezvous id and hands it to the other ranks (file, socket, MPI, env).
+ * ptmi_comm_create    : collective over all ranks; binds the device that is CURRENT in the calling thread.
+ * ptmi_allreduce_sum  : buffer[0:n] (device fp32) <- sum over ranks, in place, enqueued on `stream`; no division by the
+ *                       world size.  Call it for the same n in the same order on every rank.
+ * Errors: PTMI_E_UNSUPPORTED when librccl cannot be opened; RCCL's own result r is returned as -100 - r.
+ * ------------------------------------------------------------------------------------------- */
+#define PTMI_COMM_ID_BYTES 128
+typedef struct ptmi_comm ptmi_comm;
+int32_t ptmi_comm_rccl_version(void);                  /* e.g. 22105 for 2.21.5; 0: librccl not available */
+int ptmi_comm_unique_id(uint8_t* id_out /* [PTMI_COMM_ID_BYTES] */);
+int ptmi_comm_create(ptmi_comm** comm, int32_t world_size, int32_t rank, const uint8_t* id);
+int ptmi_allreduce_sum(ptmi_comm* comm, float* buffer, int64_t n, ptmi_stream_t stream);
+int ptmi_comm_destroy(ptmi_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,16 +45,12 @@ class PermutationInvariantTrainingModel(base.Model):
             dropout_linear=0.,
             output_activation='relu'
     ):
-        """
-        Args:
-            F: Number of frequency bins, fft_size / 2 + 1
-            recurrent_layers:
-            units: results in `units` forward and `units` backward units
-            K: Number of output streams/ speakers
-            dropout_input: Dropout forget ratio before first recurrent layer
-            dropout_hidden: Vertical forget ratio dropout between each recurrent layer
-            dropout_linear: Dropout forget ratio before first linear layer
-            output_activation: Different activations. Default is 'ReLU'.
+        """Constructor schema of the reference (``pit/model.py:27-66``; the names are the config keys of its checkpoints).
+
+        ``F`` frequency bins per frame (``size // 2 + 1`` of the STFT) go through ``recurrent_layers`` BLSTM layers of ``units``
+        cells per direction and two dense layers to ``K`` masks per bin, squashed by ``output_activation`` (a key of
+        ``ACTIVATION_FN_MAP``).  The three dropout probabilities (each at most 0.5) act on the network input, between the
+        BLSTM layers (``torch.nn.LSTM``'s own ``dropout``) and in front of the first dense layer.
         """
         super().__init__()
         self.K = K
@@ -93,6 +89,8 @@ class PermutationInvariantTrainingModel(base.Model):
         """
         batch = self.prepare_batch(batch)
         packed = getattr(batch['Y_abs'], 'packed_log1p', None)
+        if packed is not None and not packed.matches(batch['Y_abs']):
+            packed = None             # the list was edited since the feature kernel wrote its log-magnitudes: recompute from it
         input_planes = None
         if packed is not None and not (self.training and self.dropout_input.p > 0):
             # the feature kernel has written log1p(Y_abs) in PackedSequence order itself (and as fp16 planes for the first
@@ -178,11 +176,13 @@ class PermutationInvariantTrainingModel(base.Model):
         review = dict(losses={'pit_mse_loss': loss[0], 'pit_ips_loss': loss[1]})
 
         if self.create_snapshot:
-            b = 0   # only print image of first example in a batch
-            images = dict()
-            images['observation'] = stft_to_image(batch['Y_abs'][b])
-            for i in range(model_out[b].shape[1]):
-                images[f'mask_{i}'] = mask_to_image(model_out[b][:, i, :])
-                images[f'estimation_{i}'] = stft_to_image(batch['X_abs'][b][:, 0, :])
-            review['images'] = images
+            # tensorboard images of the batch's first example (reference :141-150; note its quirk: every 'estimation_<k>' shows
+            # source 0 of the targets)
+            first = 0
+            masks = model_out[first]
+            review['images'] = {
+                'observation': stft_to_image(batch['Y_abs'][first]),
+                **{f'mask_{k}': mask_to_image(masks[:, k, :]) for k in range(masks.shape[1])},
+                **{f'estimation_{k}': stft_to_image(batch['X_abs'][first][:, 0, :]) for k in range(masks.shape[1])},
+            }
         return review

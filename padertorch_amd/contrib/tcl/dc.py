@@ -20,13 +20,9 @@ class DeepClusteringModel(base.Model):
             E=20,
             input_feature_transform='identity'
     ):
-        """
-        Args:
-            F: Number of frequency bins, fft_size / 2 + 1
-            recurrent_layers:
-            units: results in `units` forward and `units` backward units
-            E: Dimensionality of the embedding
-        """
+        """Constructor schema of the reference (``contrib/tcl/dc.py:8-37``): ``recurrent_layers`` BLSTM layers of ``units`` cells
+        per direction over ``F``-bin magnitude frames (optionally through ``input_feature_transform``: ``'identity'``,
+        ``'log1p'`` or ``'log'``), then one dense layer to an ``E``-dimensional embedding per time-frequency bin."""
         super().__init__()
         self.E = E
         self.F = F
@@ -55,6 +51,8 @@ class DeepClusteringModel(base.Model):
         except KeyError:
             raise NotImplementedError(self.input_feature_transform) from None
         packed = getattr(batch['Y_abs'], 'packed_log1p', None)
+        if packed is not None and not packed.matches(batch['Y_abs']):
+            packed = None             # the list was edited since the feature kernel wrote its log-magnitudes: recompute from it
         input_planes = None
         if packed is not None and self.input_feature_transform == 'log1p':
             # written by the feature kernel itself (ops.pit_features): PackedSequence rows of log1p(Y_abs) + their fp16 planes

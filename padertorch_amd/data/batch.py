@@ -25,33 +25,36 @@ def _nested(func, value):
     return func(value)
 
 
-def example_to_device(example, device=None, memo=None):
-    """Moves a nested structure to the device; numpy arrays become tensors.
-
-    Objects already moved are tracked by ``id`` like ``copy.deepcopy`` so that an array referenced
-    twice is transferred once (``data/batch.py:56-81``).  H2D copies are issued non-blocking.
-    """
+def _to_device(value, device):
+    """One leaf of an example on ``device``.  numpy arrays become tensors first (complex ones included; a dtype torch has no
+    counterpart for - strings, objects - raises ``torch.from_numpy``'s ``TypeError`` as in the reference), tensors cross with
+    a non-blocking copy, a ``PaddedList`` moves its ONE padded buffer; everything else is not device data and stays."""
     from ..ops.sequence.pack_module import PaddedList
-    if memo is None:
-        memo = {}
+    if isinstance(value, PaddedList):
+        return value.to(device)
+    if isinstance(value, np.ndarray):
+        value = torch.from_numpy(value)
+    if isinstance(value, torch.Tensor):
+        return value.to(device=device, non_blocking=True)
+    return value
 
-    def convert(value):
-        id_ = id(value)
-        if id_ in memo:
-            return memo[id_]
-        if isinstance(value, np.ndarray):
-            try:
-                value = torch.from_numpy(value)
-            except TypeError:
-                if value.dtype not in [np.complex64, np.complex128]:
-                    raise
-        if isinstance(value, (torch.Tensor, PaddedList)):
-            value = value.to(device) if isinstance(value, PaddedList) else \
-                value.to(device=device, non_blocking=True)
-        memo[id_] = value
-        return value
 
-    return _nested(convert, example)
+def example_to_device(example, device=None, memo=None):
+    """Moves a nested structure to the device; numpy arrays become tensors (``data/batch.py:16-81``).
+
+    ``memo`` maps ``id(host object) -> moved object`` across calls like ``copy.deepcopy``'s: an array that is referenced
+    twice (inside one example, or by two examples that share the memo) crosses PCIe once and both places get the SAME
+    tensor.  H2D copies are issued non-blocking.
+    """
+    seen = {} if memo is None else memo
+
+    def moved(leaf):
+        key = id(leaf)
+        if key not in seen:
+            seen[key] = _to_device(leaf, device)
+        return seen[key]
+
+    return _nested(moved, example)
 
 
 @dataclass

@@ -37,6 +37,30 @@ class PackedLog1p:
         self.batch_sizes = batch_sizes
         self._entry = planes_entry
         self._generation = generation
+        self._source = None
+
+    def bind(self, source: PaddedList):
+        """Remember what ``source`` (the ``Y_abs`` list this was computed with) looks like right now: its buffer, the version
+        counter the buffer shares with all its views, its lengths."""
+        self._source = (source.padded.data_ptr(), source.padded._version, tuple(source.padded.shape), tuple(source.lengths),
+                        self.data._version)
+        return self
+
+    def matches(self, source) -> bool:
+        """Is ``source`` still the list this was computed from, element for element and value for value?  False after an
+        in-place edit of the padded buffer or of any of its views (they bump the shared version counter), after a list entry
+        was replaced or the list re-ordered, after a device move, or after an in-place edit of ``data``: the consumer then
+        packs ``source`` and takes ``log1p`` itself, as the reference always does (``pit/model.py:91-94``)."""
+        if self._source is None or not isinstance(source, PaddedList) or not source.batch_first:
+            return False
+        ptr, version, shape, lengths, data_version = self._source
+        pad = source.padded
+        if (pad.data_ptr() != ptr or pad._version != version or tuple(pad.shape) != shape or tuple(source.lengths) != lengths
+                or self.data._version != data_version or len(source) != len(lengths)):
+            return False
+        step = pad.stride(0) * pad.element_size()
+        return all(torch.is_tensor(v) and v.data_ptr() == ptr + b * step and v.shape[0] == n and v._version == version
+                   and v.stride() == pad.stride()[1:] for b, (v, n) in enumerate(zip(source, lengths)))
 
     def planes(self):
         if self._entry is not None and self._entry[1] == self._generation:
@@ -123,7 +147,7 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
     fl = _lib.host_to_device(frames, torch.int32, dev) if ragged else None
     out = dict(Y_abs=PaddedList(Y_abs, frames, True, fl), num_frames=frames)
     #: consumed by PermutationInvariantTrainingModel.forward / DeepClusteringModel.forward when the list is handed on untouched
-    out['Y_abs'].packed_log1p = packed
+    out['Y_abs'].packed_log1p = None if packed is None else packed.bind(out['Y_abs'])
     if K:
         out['X_abs'] = PaddedList(X_abs, frames, True, fl)
         out['cos_phase_difference'] = PaddedList(cos_pd, frames, True, fl)

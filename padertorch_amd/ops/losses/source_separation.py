@@ -214,17 +214,15 @@ def pit_loss(
             return min_loss, tuple(int(p) for p in perm[0].tolist())
         return min_loss
 
-    # generic loss_fn: the reference's brute-force algorithm, evaluated with torch ops on the device
-    candidates = []
-    indexer = [slice(None), ] * estimate.ndim
-    permutations = list(itertools.permutations(range(sources)))
-    for permutation in permutations:
-        indexer[axis] = permutation
-        candidates.append(loss_fn(estimate[tuple(indexer)], target))
-    min_loss, idx = torch.min(torch.stack(candidates), dim=0)
+    # any other loss_fn: one evaluation per permutation of the estimates (torch ops on the device); the FIRST minimum in
+    # itertools.permutations order wins, as torch.min picks it in the reference (source_separation.py:113-124)
+    perms = tuple(itertools.permutations(range(sources)))
+    values = torch.stack([loss_fn(estimate.index_select(axis, torch.as_tensor(perm, device=estimate.device)), target)
+                          for perm in perms])
+    best, where = values.min(dim=0)             # no host sync unless the permutation itself is asked for
     if return_permutation:
-        return min_loss, permutations[int(idx)]
-    return min_loss
+        return best, perms[int(where)]
+    return best
 
 
 def compute_pairwise_losses(
@@ -273,15 +271,11 @@ def compute_pairwise_losses(
                 0, sources * inner, 0, 0, 0, sources * inner), sources, inner, None,
             ws.data_ptr(), sse.data_ptr(), _lib.stream(est.device)), 'ptmi_pit_pairwise_sse')
         return (sse[0, 0] / (outer * inner)).to(torch.float32)
-    indexer_e = [slice(None), ] * estimate.ndim
-    indexer_t = [slice(None), ] * target.ndim
-    pair_wise_loss_matrix = []
-    for i in range(sources):
-        indexer_e[axis] = i
-        for j in range(0, sources):
-            indexer_t[axis] = j
-            pair_wise_loss_matrix.append(loss_fn(estimate[tuple(indexer_e)], target[tuple(indexer_t)]))
-    return torch.stack(pair_wise_loss_matrix, 0).reshape(sources, sources)
+    # any other loss_fn: K * K evaluations on slices, row i = estimate i, column j = target j
+    est_i = estimate.unbind(axis)
+    tgt_j = target.unbind(axis)
+    rows = [torch.stack([loss_fn(e, t) for t in tgt_j]) for e in est_i]
+    return torch.stack(rows)
 
 
 def pit_loss_from_loss_matrix(
@@ -320,14 +314,11 @@ def pit_loss_from_loss_matrix(
         row_ind = np.arange(sources)
     else:
         raise ValueError(algorithm)
-    if reduction is None:
-        min_loss = pair_wise_loss_matrix[row_ind, col_ind]
-    elif reduction == 'mean':
-        min_loss = pair_wise_loss_matrix[row_ind, col_ind].mean()
-    elif reduction == 'sum':
-        min_loss = pair_wise_loss_matrix[row_ind, col_ind].sum()
-    else:
+    picked = pair_wise_loss_matrix[row_ind, col_ind]             # the assigned entries (a gather: the gradient flows into them)
+    reducers = {None: lambda v: v, 'mean': torch.mean, 'sum': torch.sum}
+    if reduction not in reducers:
         raise ValueError(reduction)
+    min_loss = reducers[reduction](picked)
     if return_permutation:
         return min_loss, col_ind
     return min_loss

@@ -27,6 +27,6 @@ ACTIVATION_FN_MAP = _CallableDispatcher(
     elu=torch.nn.ELU,
     tanh=torch.nn.Tanh,
     sigmoid=torch.nn.Sigmoid,
-    softmax=torch.nn.Softmax,  # Defaults to softmax along last dimension
+    softmax=torch.nn.Softmax,
     identity=torch.nn.Identity,
 )

@@ -10,7 +10,7 @@ __all__ = ['sequence_elementwise', 'abs', 'ceil', 'clamp', 'exp', 'log', 'log1p'
 
 
 def sequence_elementwise(function, x, *args, **kwargs):
-    """Expects the desired function and a `Tensor` or `PackedSequence`."""
+    """``function(x, ...)`` on a tensor, or on the ``.data`` rows of a ``PackedSequence`` (the packing is kept)."""
     if isinstance(x, torch.nn.utils.rnn.PackedSequence):
         return torch.nn.utils.rnn.PackedSequence(function(x.data, *args, **kwargs), x.batch_sizes)
     return function(x, *args, **kwargs)

@@ -92,29 +92,34 @@ class Optimizer:
             return total_norm
         return torch.nn.utils.clip_grad_norm_(self.parameters, self.gradient_clipping)
 
-    def to(self, device):
-        if device is None:
-            return
+    # -- device placement / checkpointing of the wrapped torch optimizer (reference API: to / cpu / cuda / state_dict / load_state_dict,
+    #    ``optimizer.py:44-70``); the moments live in ``self.optimizer.state``
+    def _state_tensors(self):
         self.check_if_set()
-        for state in self.optimizer.state.values():
-            for k, v in state.items():
-                if torch.is_tensor(v):
-                    state[k] = v.to(device)
+        for per_param in self.optimizer.state.values():
+            for name, value in per_param.items():
+                if torch.is_tensor(value):
+                    yield per_param, name, value
+
+    def to(self, device):
+        if device is not None:
+            for per_param, name, value in list(self._state_tensors()):
+                per_param[name] = value.to(device)
 
     def cpu(self):
         return self.to('cpu')
 
     def cuda(self, device=None):
         assert device is None or isinstance(device, int), device
-        return self.to(torch.device('cuda') if device is None else device)
-
-    def load_state_dict(self, state_dict):
-        self.check_if_set()
-        return self.optimizer.load_state_dict(state_dict)
+        return self.to(torch.device('cuda', device) if isinstance(device, int) else torch.device('cuda'))
 
     def state_dict(self):
         self.check_if_set()
         return self.optimizer.state_dict()
+
+    def load_state_dict(self, state_dict):
+        self.check_if_set()
+        return self.optimizer.load_state_dict(state_dict)
 
 
 class Adam(Optimizer):

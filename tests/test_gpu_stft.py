@@ -294,3 +294,39 @@ def test_models_take_the_packed_log_magnitude_when_the_list_is_untouched():
         plain = model(dict(Y_abs=list(f['Y_abs'])))          # a plain list: pack_sequence + log1p + measured scale
     for a, b in zip(fused, plain):
         torch.testing.assert_close(a, b, atol=1e-6, rtol=0)
+
+
+@pytest.mark.gpu
+def test_edited_feature_list_is_not_served_from_the_packed_log_magnitude():
+    """anything that edits ``Y_abs`` between ``ops.pit_features`` and ``forward`` - an in-place gain on the padded
+    buffer or on one example's view, a replaced list entry - must reach the model (the reference always packs the list it is
+    given, pit/model.py:91-94): ``PackedLog1p.matches`` notices, and both models recompute from the list."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
+    rng = np.random.RandomState(4)
+    exs = [features_np.synthetic_mixture(rng, n) for n in (3000, 3000, 2400)]
+    ys = [torch.from_numpy(y).to(DEV) for _, y in exs]
+    torch.manual_seed(1)
+    for model in (PermutationInvariantTrainingModel(F=257, recurrent_layers=1, units=16, K=2).to(DEV).eval(),
+                  DeepClusteringModel(F=257, recurrent_layers=1, units=16, E=4, input_feature_transform='log1p').to(DEV).eval()):
+        def run(edit):
+            f = pt.ops.pit_features(ys)
+            assert f['Y_abs'].packed_log1p.matches(f['Y_abs'])
+            edit(f['Y_abs'])
+            stale = not f['Y_abs'].packed_log1p.matches(f['Y_abs'])
+            with torch.no_grad():
+                got = model(dict(Y_abs=f['Y_abs']))
+                want = model(dict(Y_abs=[t.clone() for t in f['Y_abs']]))      # plain list of the edited values: the generic path
+            return stale, got, want
+
+        def gain(lst): lst.padded.mul_(3.)
+        def view_gain(lst): lst[1].mul_(0.25)
+        def replace(lst): lst[2] = lst[2] * 2.
+        for edit in (gain, view_gain, replace):
+            stale, got, want = run(edit)
+            assert stale, edit.__name__
+            for a, b in zip(got, want):
+                assert torch.equal(a, b), edit.__name__          # the same generic path on the same values: bit-identical
+        stale, got, want = run(lambda lst: None)
+        assert not stale
