@@ -161,7 +161,7 @@ class PermutationInvariantTrainingModel(base.Model):
 
     def review(self, batch, model_out):
         batch = self.prepare_batch(batch)
-        if isinstance(model_out, PaddedList):
+        if isinstance(model_out, PaddedList) and model_out.intact():
             mask, mask_bf = model_out.padded, model_out.batch_first
             lengths_dev = model_out.lengths_dev
         else:

@@ -73,7 +73,7 @@ class DeepClusteringModel(base.Model):
         """Mean deep-clustering loss of the batch (reference ``dc.py:73-84``: per-example loop over
         re-laid-out copies).  A :class:`PaddedList` output is consumed in place by ONE fused HIP
         pass; anything else follows the reference loop through ``deep_clustering_loss``."""
-        if isinstance(model_out, PaddedList):
+        if isinstance(model_out, PaddedList) and model_out.intact():
             tm, _, _ = as_padded(batch['target_mask'])
             loss, _ = ops.losses.dc_loss_batched(
                 model_out.padded, tm, model_out.lengths_dev,

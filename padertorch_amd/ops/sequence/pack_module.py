@@ -52,6 +52,20 @@ class PaddedList(list):
         #: int32 device tensor [B], or None when every example fills the padded length
         self.lengths_dev = lengths_dev
 
+    def intact(self):
+        """Are the list's entries still the views into ``padded`` it was built with?  A caller may treat the object as the
+        plain ``list`` of the reference's batch contract and replace, drop or re-order entries; consumers that read ``padded``
+        instead of the entries ask first and fall back to the entries otherwise.  (In-place edits of an entry ARE edits of
+        ``padded``: they need no check.)"""
+        pad, bf = self.padded, self.batch_first
+        if len(self) != len(self.lengths):
+            return False
+        step = pad.stride(0 if bf else 1) * pad.element_size()
+        inner = pad.stride()[1:] if bf else pad.stride()[:1] + pad.stride()[2:]
+        base = pad.data_ptr()
+        return all(torch.is_tensor(v) and v.data_ptr() == base + b * step and v.shape[0] == n and v.stride() == inner
+                   for b, (v, n) in enumerate(zip(self, self.lengths)))
+
     def to(self, device):
         if device is None:
             return self
@@ -65,9 +79,9 @@ class PaddedList(list):
 
 def as_padded(seq, batch_first=True):
     """list of tensors (descending length) or :class:`PaddedList` -> (padded, lengths, lengths_dev)."""
-    if isinstance(seq, PaddedList) and seq.batch_first == batch_first:
-        return seq.padded, seq.lengths, seq.lengths_dev
-    if isinstance(seq, PaddedList):
+    if isinstance(seq, PaddedList) and seq.intact():
+        if seq.batch_first == batch_first:
+            return seq.padded, seq.lengths, seq.lengths_dev
         return seq.padded.transpose(0, 1).contiguous(), seq.lengths, seq.lengths_dev
     lengths = [int(t.shape[0]) for t in seq]
     padded = pad_sequence(list(seq), batch_first=batch_first)
@@ -77,6 +91,8 @@ def as_padded(seq, batch_first=True):
 
 def pack_sequence(sequences, enforce_sorted=True):
     """``torch.nn.utils.rnn.pack_sequence`` (``pack_module.py:14``); PaddedList skips the re-pad."""
+    if isinstance(sequences, PaddedList) and not sequences.intact():
+        sequences = list(sequences)                    # entries were replaced: what the caller sees in the list is the data
     if isinstance(sequences, PaddedList) and not sequences.ragged and not sequences.batch_first \
             and sequences.padded.is_contiguous():
         padded = sequences.padded                      # time-major, equal lengths: a view

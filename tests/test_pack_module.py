@@ -82,3 +82,26 @@ def test_pack_meta_index_tables_match_the_per_step_definition():
         last = [offs[n - 1] + b for b, n in enumerate(lens)]
         assert m.first_rows.tolist() == [list(range(B)), last] and m.last_rows.tolist() == [last, list(range(B))]
         assert m.rows == rows and m.T == T and m.max_batch == B and m.equal_lengths == (len(set(lens)) == 1)
+
+
+def test_padded_list_notices_replaced_entries():
+    """A PaddedList is a plain ``list`` to its callers (the reference's batch contract): once an entry has been replaced or
+    dropped, consumers must read the entries, not the padded buffer (``intact``); in-place edits go through to the buffer."""
+    from padertorch_amd.ops.sequence.pack_module import PaddedList, as_padded, pack_sequence
+    for bf in (True, False):
+        lens = [5, 4, 2]
+        pad = torch.arange(3 * 5 * 2, dtype=torch.float32).view(3, 5, 2) if bf else \
+            torch.arange(5 * 3 * 2, dtype=torch.float32).view(5, 3, 2)
+        pl = PaddedList(pad.clone(), lens, batch_first=bf)
+        assert pl.intact()
+        pl[1].mul_(2.)                                  # in place: the buffer changes with it
+        assert pl.intact()
+        assert torch.equal(pack_sequence(pl).data, torch.nn.utils.rnn.pack_sequence(list(pl)).data)
+        pl[2] = pl[2] + 100.                            # replaced: the list is the data now
+        assert not pl.intact()
+        want = torch.nn.utils.rnn.pack_sequence(list(pl))
+        assert torch.equal(pack_sequence(pl).data, want.data)
+        padded, lengths, _ = as_padded(pl, batch_first=True)
+        assert lengths == lens and torch.equal(padded[2, :2], pl[2])
+        del pl[2]
+        assert not pl.intact()
