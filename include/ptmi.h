@@ -274,6 +274,23 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream);
+/* The same launch with the gate gradients ALSO (or only) leaving the kernel as the operand of the weight-gradient GEMMs
+ * dW_ih = dgates^T x, dW_hh = dgates^T h_prev (torch.nn.LSTM backward inside pit/model.py:60-66,97): bf16 (hi, lo) planes of
+ * dgates^T per direction, [ndir][4H / 16 column tiles][ceil(rows / 32) k blocks][hi | lo][64 chunks of 8 values] = exactly what
+ * ptmi_pack_planes_t_bf16 makes of one direction's [rows, 4H] block, i.e. operand A of ptmi_gemm_planes_bf16(m = 4H, k = rows)
+ * at byte offset direction * ptmi_planes_elems(4H, rows) * 2.  No row-major fp32 store, no transposing pack pass.
+ *   dgates_t   ndir * ptmi_planes_elems(4H, range_rows) uint16 (16-byte aligned) or NULL, range_rows = (s_end - s_begin) *
+ *              max_batch: the rows of THIS launch's step range (all rows for [0, T)) - for the forward direction the time
+ *              indices T - s_end .. T - s_begin - 1, for the reverse direction s_begin .. s_end - 1 -; the call writes every value
+ *   dgates     may be NULL when dgates_t is given (the hand-off copy in `flags` still serves dx = dgates W_ih)
+ * Only for batches of equal-length sequences whose size is a multiple of 16 on the split kernels:
+ * ptmi_lstm_backward_planes_ok(...) != 0; PTMI_E_UNSUPPORTED otherwise. */
+int32_t ptmi_lstm_backward_planes_ok(int32_t T, int32_t ndir, int32_t max_batch, int64_t rows, int32_t H);
+int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, const float* c0, const float* dhy,
+                                         const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
+                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
+                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin, int32_t s_end,
+                                         int32_t prefilled, ptmi_stream_t stream);
 /* Data-as-flag hand-off (the split kernels' protocol wherever their tile shapes allow it): the planes at the
  * start of the scratch start out as 0xFFFF in every 16-bit value - a pattern no conversion to fp16 / bf16 produces -, producers
  * only store, consumers re-request an operand tile until none of the values they are going to use is the pattern.  The

@@ -1080,8 +1080,37 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin, int32_t s_end,
                                         int32_t prefilled, ptmi_stream_t stream) {
-    PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || !dgates || !batch_sizes_dev || !offsets_dev || !flags,
+    PTMI_RETURN_IF(!dgates, PTMI_E_INVALID);
+    return ptmi_lstm_backward_persistent_planes(gates, c, c0, dhy, w_hh_t, dgates, nullptr, batch_sizes_dev, offsets_dev, flags, dc_carry,
+                                                T, max_batch, rows, H, ndir, s_begin, s_end, prefilled, stream);
+}
+
+int32_t ptmi_lstm_backward_planes_ok(int32_t T, int32_t ndir, int32_t max_batch, int64_t rows, int32_t H) {
+    if (T < 1 || max_batch < 1 || H < 1 || H % 4 != 0 || (ndir != 1 && ndir != 2) || !ptmi_lstm_split_enabled()) return 0;
+    if (rows != (int64_t)T * max_batch || max_batch % 16 != 0) return 0;             // equal lengths, whole 16-row tiles
+    const int G32 = (4 * H + 31) / 32 * 32;
+    if ((G32 / 32 + 7) / 8 > 10 || !bwd_daf_applies()) return 0;                     // the data-as-flag split kernels run
+    const int nx = (H + 15) / 16;
+    return ((long long)nx * ndir <= cu_count() - 16 && nx <= kSlots) ? 1 : 0;
+}
+
+// the half k block behind the last packed row (rows % 32 == 16) of every column tile and plane: zero
+__global__ void zero_tp_tail_kernel(uint4* planes, long long tiles, int kb_total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // (tile, plane, chunk 32..63)
+    if (i >= tiles * 64) return;
+    const long long tile = i >> 6;
+    const int plane = (int)(i >> 5) & 1, ch = 32 + (int)(i & 31);
+    planes[((tile * kb_total + kb_total - 1) * 2 + plane) * 64 + ch] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, const float* c0, const float* dhy,
+                                         const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
+                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
+                                         int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin, int32_t s_end,
+                                         int32_t prefilled, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || (!dgates && !dgates_t) || !batch_sizes_dev || !offsets_dev || !flags,
                    PTMI_E_INVALID);
+    PTMI_RETURN_IF(dgates_t && (reinterpret_cast<uintptr_t>(dgates_t) & 15) != 0, PTMI_E_INVALID);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(s_begin < 0 || s_end > T || s_begin >= s_end, PTMI_E_INVALID);
     const bool whole = s_begin == 0 && s_end == T;
@@ -1134,6 +1163,23 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
     A.s_begin = s_begin;
     A.s_end = s_end;
     A.dc_carry = dc_carry;
+    if (dgates_t) {
+        PTMI_RETURN_IF(!split || !ptmi_lstm_backward_planes_ok(T, ndir, max_batch, rows, H), PTMI_E_UNSUPPORTED);
+        // the planes hold the rows of THIS launch's step range: (s_end - s_begin) * max_batch packed rows per direction, from
+        // time index T - s_end on (forward direction: processed last to first) / s_begin on (reverse direction)
+        const int64_t range_rows = (int64_t)(s_end - s_begin) * max_batch;
+        A.dgtp = reinterpret_cast<uint4*>(dgates_t);
+        A.tp_kb = (int)((range_rows + 31) / 32);
+        A.tp_dir_stride = (long long)(4 * H / 16) * A.tp_kb * 2 * 64;
+        A.tp_row0[0] = (long long)(T - s_end) * max_batch;
+        A.tp_row0[1] = (long long)s_begin * max_batch;
+        if (range_rows % 32 != 0) {
+            const long long tiles = (long long)ndir * (4 * H / 16);
+            hipLaunchKernelGGL(zero_tp_tail_kernel, dim3((unsigned)((tiles * 64 + 255) / 256)), dim3(256), 0, st, A.dgtp, tiles, A.tp_kb);
+            int rc = launch_status();
+            if (rc) return rc;
+        }
+    }
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);

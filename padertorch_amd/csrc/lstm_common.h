@@ -112,6 +112,12 @@ struct LstmPersistBwdArgs {
     int s_begin = 0, s_end = -1;
     float* dc_carry = nullptr;
     int uniform = 0;         // as in LstmPersistArgs
+    // split kernels, equal lengths, batch a multiple of 16: dgates^T as bf16 (hi, lo) planes for the weight-gradient GEMMs
+    // ([ndir][4H / 16][tp_kb][2][64] chunks of 16 B; null: not written); with them `dg` may be null
+    uint4* dgtp = nullptr;
+    long long tp_dir_stride = 0;      // chunks per direction
+    int tp_kb = 0;                    // k blocks (32 packed rows) per column tile
+    long long tp_row0[2] = {0, 0};    // first packed row of this launch's step range per direction: the planes' k index 0
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)

@@ -654,8 +654,19 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
 // ---------------------------------------------------------------------------------------------------------------
 // Backward-through-time.  8 wavefronts, CB = 32-wide k blocks of K = 4H per wavefront (even split), CAB blocks in
 // flight per wavefront (re-requested as soon as their MFMAs have consumed them, as in lstm_bwd_persistent_kernel).
-template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false>
+//
+// TP (equal-length batches whose size is a multiple of 16): the gate gradients leave the kernel a second time as bf16 (hi, lo)
+// planes of dgates^T - the operand [4H gate columns][packed rows] of the weight-gradient GEMMs dW = dgates^T [x | h_prev]
+// (ptmi_gemm_planes_bf16), in the layout ptmi_pack_planes_t_bf16 would produce from the row-major fp32 tensor: per direction
+// [4H / 16 column tiles][rows / 32 k blocks][hi | lo][64 chunks], chunk (k group g, column r) = 8 consecutive packed rows of one
+// gate column.  A workgroup's step produces 16 MTL rows x 64 columns; the owners park their halves in LDS as [plane][8-row
+// group][column][row], and BEHIND THE NEXT STEP'S BARRIER (no barrier of its own; double-buffered by step parity) every thread
+// stores one 16-byte chunk.  With the planes, the hand-off copy (the LSTM input gradient's operand) and the in-kernel bias sums,
+// nobody reads the row-major fp32 gate gradients any more: A.dg may be null, and the 155 MB store + two transposing pack
+// passes per layer of the B = 32 step go away.
+template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false, bool TP = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
+    static_assert(!TP || (UNI && DAF), "transposed planes: equal-length data-as-flag instantiations only");
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
     const int n0 = bx * 16;
@@ -668,6 +679,23 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
     __shared__ float red[DAF ? 2 : 1][NW][MR][DAF ? 20 : 17];       // DAF: double-buffered by step parity (one barrier per step); pitch 20: conflict-free accumulator writes
+    __shared__ unsigned short tbuf[TP ? 2 : 1][2][TP ? MR / 8 : 1][TP ? 64 : 1][8];      // TP: [step parity][plane][8-row group][gate-major column][row]
+    int t_pend = -1;                                   // TP: time index whose chunks lie in tbuf[(its step) & 1], not stored yet
+    auto flush_tp = [&](int par, int tt) {
+        // 2 planes x MR / 8 row groups x 64 columns = 16 MR chunks of 16 B: one per thread; a wavefront reads 1 KB of LDS lane-linear
+        // and writes runs of 16 chunks (256 B: the 16 units of one gate) into the planes
+        if (TP && tid < 16 * MR) {
+            const int unit = tid & 15, gate = (tid >> 4) & 3, plane = (tid >> 6) & 1, rg = tid >> 7;
+            if (n0 + unit < H && m0 + rg * 8 < A.max_batch) {
+                const int col = gate * H + n0 + unit;
+                const long long prow = (long long)tt * A.max_batch + m0 + rg * 8 - A.tp_row0[dir];
+                const long long kb = prow >> 5;
+                const int kg = (int)(prow & 31) >> 3;
+                uint4* dst = A.dgtp + (long long)dir * A.tp_dir_stride + ((((long long)(col >> 4) * A.tp_kb + kb) * 2 + plane) * 64 + kg * 16 + (col & 15));
+                *dst = *reinterpret_cast<const uint4*>(&tbuf[par][plane][rg][gate * 16 + unit][0]);
+            }
+        }
+    };
     const bool uniform = UNI || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
     auto bs_at = [&](int t) { if (UNI) return A.max_batch; return uniform ? A.max_batch : A.bs[t]; };
     auto offs_at = [&](int t) { if (UNI) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
@@ -912,6 +940,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                 for (int w = 0; w < NW; ++w) sum += red[s & 1][w][bl_][jl];
                 dh += sum;
             }
+            if (TP && t_pend >= 0) {        // the previous step's chunks (parked in front of this barrier)
+                flush_tp((s - 1) & 1, t_pend);
+                t_pend = -1;
+            }
         }
         float gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f;
         if (act) {
@@ -940,6 +972,17 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const unsigned w1 = pair_word<true>(gf, lane, &plane);
             const unsigned w2 = pair_word<true>(gc, lane, &plane);
             const unsigned w3 = pair_word<true>(go, lane, &plane);
+            if (TP && tid < 16 * MR) {       // every row of the tile (rows past the batch / units past H carry zeros; flush_tp skips them)
+                const float gv[4] = {gi, gf, gc, go};
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    unsigned hi, lo;
+                    split1<true>(gv[g], &hi, &lo);
+                    tbuf[s & 1][0][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)hi;
+                    tbuf[s & 1][1][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)lo;
+                }
+                t_pend = t;
+            }
             if (act) {
                 unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
                 const int je = j & ~1;
@@ -966,7 +1009,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             if (tid == 0)
                 __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (act) {                                    // row-major dgates (what the GEMMs read): nobody in this launch waits for them
+        if (act && (!TP || A.dg)) {                   // row-major dgates (what the GEMMs read): nobody in this launch waits for them
             float* dgp = A.dg + og_;
             dgp[0] = gi;
             dgp[H] = gf;
@@ -980,6 +1023,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     // bias gradient = sum of dgates over all rows; max |dgates| for the GEMMs that follow (operand scale)
     float* const fold = &red[0][0][0][0];
     __syncthreads();
+    if (TP && t_pend >= 0) flush_tp((s1 - 1) & 1, t_pend);       // the last step's chunks
     if (tid < 16 * MR) {
         fold[(0 * MR + bl_) * 16 + jl] = sb0;
         fold[(1 * MR + bl_) * 16 + jl] = sb1;
@@ -1039,6 +1083,13 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
     // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
     const bool uni = A.uniform != 0;
+    if (A.dgtp) {          // + dgates^T as bf16 planes (host checked: equal lengths, batch a multiple of 16)
+        if (mtl == 2)
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, true, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        return launch_status();
+    }
     if (mtl == 2 && uni)
         hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true>), dim3(nwg), dim3(512), 0, st, A);
     else if (mtl == 2)

@@ -189,6 +189,10 @@ DX_FROM_HANDOFF = True
 #: the top layer's backward recurrence in two launches for batches of at least this many packed rows (see _LstmLayerFn.backward)
 SPLIT_TOP_BACKWARD = True
 SPLIT_TOP_BACKWARD_ROWS = 16384
+#: the backward recurrence hands its gate gradients to the weight-gradient GEMMs itself, as bf16 planes of dgates^T
+#: (ptmi_lstm_backward_persistent_planes): no row-major fp32 store, no transposing pack pass per direction (equal-length batches
+#: whose size is a multiple of 16, in-place weight gradients)
+DG_PLANES_FROM_KERNEL = True
 _WGRAD_DONE = {}
 # (Measured in round 2 and not kept - DESIGN.md sections 3.9 / 4 have the numbers -: the pattern fill ahead of time on a side stream,
 # the weight gradients' forward-data operand planes packed during the forward pass, a layer's weight gradients started behind its
@@ -647,9 +651,10 @@ class _LstmLayerFn(torch.autograd.Function):
 
         dgplanes = {}
 
-        def wgrad_rows(dg, ranges, amax_dg, both_queues=False):
+        def wgrad_rows(dg, ranges, amax_dg, both_queues=False, dg_t=None):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
-            (both_queues: all but the forward direction's dW_hh on the main stream - see TAIL_ON_BOTH_QUEUES)."""
+            (both_queues: all but the forward direction's dW_hh on the main stream - see TAIL_ON_BOTH_QUEUES).
+            dg_t: the kernel's bf16 planes of dgates^T for exactly these row ranges (then `dg` is None)."""
             for d, ((p_wih, p_whh, _, _), (r0, r1)) in enumerate(zip(params, ranges)):
                 q_ih = main if both_queues else side
                 q_hh = main if both_queues and d == 1 else side
@@ -658,6 +663,20 @@ class _LstmLayerFn(torch.autograd.Function):
                         operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
                     dgd, h_prev = operands[0][d]
                     if r1 <= r0:
+                        continue
+                    if dg_t is not None:
+                        # both operands reduce over the packed rows: dgates^T comes from the recurrence as bf16 planes; the layer
+                        # input (once for both directions) and the previous hidden state are packed to match (bf16: no scale)
+                        k = r1 - r0
+                        key = (r0, r1)
+                        a_off = d * int(lib.ptmi_planes_elems(G, k)) * 2
+                        if key not in xplanes:
+                            xplanes[key] = torch.ops.ptmi.pack_planes_bf16(x[r0:r1], True)
+                        torch.ops.ptmi.gemm_planes_bf16_(p_wih.grad, dg_t, a_off, xplanes[key], None, G, x.shape[1], k, True,
+                                                         _gemm.auto_split_k(G, x.shape[1], k))
+                        with torch.cuda.stream(q_hh):
+                            hpl = torch.ops.ptmi.pack_planes_bf16(h_prev[r0:r1], True)
+                            torch.ops.ptmi.gemm_planes_bf16_(p_whh.grad, dg_t, a_off, hpl, None, G, H, k, True, _gemm.auto_split_k(G, H, k))
                         continue
                     dgt = dgd[r0:r1].t()
                     if gm is not None and _gemm.planes_enabled():
@@ -683,6 +702,7 @@ class _LstmLayerFn(torch.autograd.Function):
                         p_whh.grad.addmm_(dgt, h_prev[r0:r1])
 
         todo = [(0, meta.rows)] * ndir                  # row ranges whose weight gradients are still to be accumulated
+        use_tp, dg_t = False, None
         if lease is None:
             dhy = dhy.contiguous()
             w_t = ctx.forms['w_t'] if ctx.forms is not None else w_hh.transpose(1, 2).contiguous()      # [ndir, H, 4H]
@@ -704,7 +724,47 @@ class _LstmLayerFn(torch.autograd.Function):
             chunks = 2 if (SPLIT_TOP_BACKWARD and getattr(ctx, 'top', False) and PERSISTENT and use_side and gm is not None
                            and _gemm.planes_enabled() and lib.ptmi_lstm_split_enabled() and T >= 128
                            and meta.rows >= SPLIT_TOP_BACKWARD_ROWS) else 1
-            if chunks > 1 or state_grad:
+            # the gate gradients as bf16 planes of dgates^T straight from the kernel (no row-major fp32 tensor at all when the
+            # input gradient takes the hand-off planes, or is not needed)
+            cols_dx = int(lib.ptmi_lstm_handoff_cols(H, 1)) if DX_FROM_HANDOFF else 0
+            dx_needs_rows = ctx.needs_input_grad[0] and not (cols_dx and meta.equal_lengths and meta.bs0 % 16 == 0)
+            use_tp = bool(DG_PLANES_FROM_KERNEL and PERSISTENT and in_place and gm is not None and _gemm.planes_enabled()
+                          and not state_grad and not dx_needs_rows
+                          and lib.ptmi_lstm_backward_planes_ok(T, ndir, meta.max_batch, meta.rows, H))
+            if use_tp:
+                flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
+                    int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
+                pre = bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0])
+                cuts = [T * i // chunks for i in range(chunks + 1)]
+                carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device) if chunks > 1 else None
+                B_ = meta.max_batch
+
+                def launch_tp(i):
+                    n_rows = (cuts[i + 1] - cuts[i]) * B_
+                    planes = torch.empty(ndir * int(lib.ptmi_planes_elems(G, n_rows)), dtype=torch.bfloat16, device=dhy.device)
+                    ok = torch.ops.ptmi.lstm_recurrence_backward_planes(
+                        gates, c, c0, dhy, w_t, None, planes, flags, carry, meta.bs_dev, meta.offs_dev, T, B_, meta.rows, H, ndir,
+                        cuts[i], cuts[i + 1], pre)
+                    # rows of this range per direction (forward direction: processed from the last time index down)
+                    part = [((T - cuts[i + 1]) * B_, (T - cuts[i]) * B_), (cuts[i] * B_, cuts[i + 1] * B_)][:ndir]
+                    return ok, planes, part
+                ok, dg_t, part_t = launch_tp(0)
+                if ok:
+                    for i in range(1, chunks):
+                        done = torch.cuda.Event()
+                        done.record(main)
+                        side.wait_event(done)
+                        wgrad_rows(None, part_t, None, dg_t=dg_t)        # the finished range, under the next launch
+                        dg_t.record_stream(side)
+                        ok, dg_t, part_t = launch_tp(i)
+                        if not ok:
+                            raise RuntimeError('ptmi_lstm_backward_persistent_planes: a later range was refused')
+                    todo = part_t
+                else:
+                    use_tp, dg_t, flags = False, None, None
+            else:
+                dg_t = None
+            if not use_tp and (chunks > 1 or state_grad):
                 dg = torch.empty_like(gates)
                 flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
                     int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
@@ -738,7 +798,7 @@ class _LstmLayerFn(torch.autograd.Function):
                     if state_grad:
                         raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
                                                   'persistent kernels')
-            if dg is None:
+            if dg is None and not use_tp:
                 dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                     gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
                     T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1])
@@ -754,7 +814,7 @@ class _LstmLayerFn(torch.autograd.Function):
         if gm is not None:
             amax_x, amax_w = gm
             # one scale for the whole gate-gradient tensor (both directions): the backward kernel tracked its maximum
-            amax_dg = amax_kernel if amax_kernel is not None else _gemm.absmax(dg)
+            amax_dg = amax_kernel if (amax_kernel is not None or dg is None) else _gemm.absmax(dg)
             cols = int(lib.ptmi_lstm_handoff_cols(H, 1)) if (DX_FROM_HANDOFF and flags is not None and amax_kernel is not None) else 0
             if not ctx.needs_input_grad[0]:
                 dx = None
@@ -764,7 +824,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 pdx = ctx.forms.get('w_ih_planes_dx') if ctx.forms is not None else None
                 wplanes = pdx[0] if (pdx is not None and pdx[1] == cols) else _gemm.stacked_planes_t_bf16(
                     w_ih, ndir, cols, None if params is None else [ps[0] for ps in params])
-                dx = torch.empty((meta.rows, w_ih.shape[1]), dtype=torch.float32, device=dg.device)
+                dx = torch.empty((meta.rows, w_ih.shape[1]), dtype=torch.float32, device=dhy.device)
                 torch.ops.ptmi.gemm_planes_bf16_(dx, flags, 0, wplanes, None, meta.rows, w_ih.shape[1], ndir * cols, False,
                                                  _gemm.auto_split_k(meta.rows, w_ih.shape[1], ndir * cols))
             else:
@@ -786,13 +846,16 @@ class _LstmLayerFn(torch.autograd.Function):
                         main.wait_event(ev)
                 operands[0] = _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)
                 # shared between the queues: packed before they part
-                xplanes[todo[0]] = _gemm.pack_t(x, gm[0])
-                dgplanes[(0, todo[0])] = _gemm.pack_t(operands[0][0][0], amax_dg)
+                if dg_t is not None:
+                    xplanes[todo[0]] = torch.ops.ptmi.pack_planes_bf16(x, True)
+                else:
+                    xplanes[todo[0]] = _gemm.pack_t(x, gm[0])
+                    dgplanes[(0, todo[0])] = _gemm.pack_t(operands[0][0][0], amax_dg)
             if use_side:
                 side.wait_stream(main)
             else:
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
-            wgrad_rows(dg, todo, amax_dg, both_queues=both)
+            wgrad_rows(dg, todo, amax_dg, both_queues=both, dg_t=dg_t)
             with torch.cuda.stream(side):
                 for d, (_, _, p_bih, p_bhh) in enumerate(params):
                     db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
@@ -806,12 +869,12 @@ class _LstmLayerFn(torch.autograd.Function):
                         _WGRAD_DONE[id(p)] = done
             if both:
                 main.wait_event(done)                          # the main queue is now behind both
-                for t in dgplanes[(0, todo[0])][:1]:
+                for t in (dgplanes[(0, todo[0])][:1] if dg_t is None else (xplanes[todo[0]],)):
                     t.record_stream(side)
                 if GRAD_READY_HOOK is not None:
                     side.wait_stream(main)                     # whoever orders itself after `side` sees every gradient
             if use_side:
-                for t in (dg, x, hy) + tuple(v for v in (h0, ctx.ext, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
+                for t in (x, hy) + tuple(v for v in (dg, dg_t, h0, ctx.ext, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
                         + tuple(h_prev for _, h_prev in operands[0]):
                     t.record_stream(side)           # keep the operands alive until the side stream is done
             if GRAD_READY_HOOK is not None:

@@ -463,3 +463,58 @@ def test_recurrences_next_to_a_cu_occupying_kernel(wgs, threads, lds, monkeypatc
     assert torch.equal(base[0], got[0])
     for a, b in zip(base[1] + base[2], got[1] + got[2]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,T,H,ndir', [(32, 21, 600, 2), (16, 9, 40, 2), (64, 11, 600, 2), (48, 7, 100, 1), (16, 5, 20, 1)])
+def test_backward_recurrence_hands_the_weight_gradient_operand_on(B, T, H, ndir):
+    """``ptmi_lstm_backward_persistent_planes``: the gate gradients leave the backward recurrence as bf16 (hi, lo) planes of
+    ``dgates^T`` - bit for bit what ``ptmi_pack_planes_t_bf16`` makes of the row-major fp32 gate gradients of the plain launch
+    (both are the same two roundings of the same fp32 values), with and without the row-major tensor next to them, for the whole
+    recurrence and for two launches over step ranges (each range's planes hold that range's rows per direction); odd row counts
+    (rows % 32 == 16) get their half k block zeroed."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import lstm as L
+    lib = _lib.load()
+    rows, G = T * B, 4 * H
+    if not lib.ptmi_lstm_backward_planes_ok(T, ndir, B, rows, H):
+        pytest.skip('split recurrence kernels not active')
+    assert not lib.ptmi_lstm_backward_planes_ok(T, ndir, B, rows - 1, H)          # ragged batches keep the row-major route
+    assert not lib.ptmi_lstm_backward_planes_ok(T, ndir, B + 8, T * (B + 8), H)   # so do batches that are no multiple of 16
+    meta = L.pack_meta(torch.full((T,), B, dtype=torch.int64), torch.device(DEV))
+    torch.manual_seed(B + T + H)
+    gates = torch.rand(rows, ndir * G, device=DEV)
+    c = torch.randn(rows, ndir * H, device=DEV)
+    dhy = torch.randn(rows, ndir * H, device=DEV)
+    w_t = (torch.randn(ndir, H, G, device=DEV) * 0.05).contiguous()
+    n_scratch = int(lib.ptmi_lstm_scratch_elems(T, ndir, B, H, 1))
+
+    dg_ref, _ = torch.ops.ptmi.lstm_recurrence_backward(gates, c, None, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data,
+                                                        meta.offs_host.ctypes.data, T, B, rows, H, ndir, True)
+    torch.cuda.synchronize()
+
+    def planes_of(rows_d):           # per direction: the transposing bf16 pack of its [n, 4H] block
+        return torch.cat([torch.ops.ptmi.pack_planes_bf16(r, True).view(torch.int16) for r in rows_d])
+
+    dgv = dg_ref.view(rows, ndir, G)
+    for with_rows in (True, False):
+        for cuts in ([0, T], [0, T // 2, T]):
+            dg = torch.full_like(gates, float('nan')) if with_rows else None
+            flags = torch.empty(n_scratch, dtype=torch.int32, device=DEV)
+            carry = torch.empty(ndir, B, H, device=DEV)
+            for a, b in zip(cuts, cuts[1:]):
+                n = (b - a) * B
+                planes = torch.full((ndir * int(lib.ptmi_planes_elems(G, n)),), -1, dtype=torch.int16, device=DEV).view(torch.bfloat16)
+                assert torch.ops.ptmi.lstm_recurrence_backward_planes(gates, c, None, dhy, w_t, dg, planes, flags, carry, meta.bs_dev,
+                                                                      meta.offs_dev, T, B, rows, H, ndir, a, b, False)
+                torch.cuda.synchronize()
+                L.check_errors()
+                part = [((T - b) * B, (T - a) * B), (a * B, b * B)][:ndir]
+                want = planes_of([dgv[r0:r1, d] for d, (r0, r1) in enumerate(part)])
+                assert torch.equal(planes.view(torch.int16), want), (with_rows, cuts, a, b)
+            if with_rows:
+                assert torch.equal(dg, dg_ref)
+    # the bias gradient and max |dgates| still come out of the launch (scratch tail)
+    nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, B)) + 8
+    db = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
+    torch.testing.assert_close(db, dg_ref.sum(0), rtol=2e-5, atol=2e-5 * float(dg_ref.abs().sum(0).max()))
