@@ -431,8 +431,11 @@ int ptmi_absmax_accumulate(const float* x, int64_t rows, int64_t cols, int64_t l
  * ptmi_gemm_planes:  C[m, n] (+)= sum_k A[m, k] B[n, k] / (scale_a scale_b) + bias[n]  with A, B as planes of m x k and n x k
  *   operands (same amax words as at packing), fp32 accumulation; products = 3: hi hi + hi lo + lo hi (fp32-equivalent), 1: the
  *   hi planes only (plain 16-bit operands: the reduced-precision mode of BASELINE configs[1]);
- *   split_k > 1: that many k ranges, summed in order by a second kernel (workspace:
- *   ptmi_gemm_planes_workspace_elems floats). */
+ *   split_k > 1: AT MOST that many k ranges (what the workspace of ptmi_gemm_planes_workspace_elems floats holds); how many are used,
+ *   and on which workgroup tile (persistent big-tile kernel: work item = (k range, tile)), is a cost model's choice that depends on
+ *   the shape alone; the ranges' partial products are summed in range order by a second kernel (reproducible, no atomics).
+ *   split_k < -1: exactly -split_k ranges on the 128 x 128 kernel, whose workgroups fit on a CU next to a workgroup of the
+ *   persistent recurrence kernels (callers whose GEMM runs beside a recurrence). */
 int64_t ptmi_planes_elems(int64_t rows, int64_t k);
 int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
                        ptmi_stream_t stream);

@@ -197,6 +197,11 @@ struct BigArgs {
     int accumulate;
     int tiles_m, tiles_n, band;
     unsigned a_bytes, b_bytes;  // extent of the planes (buffer descriptors; < 2 GB: launch_big)
+    // split K (weight-gradient shapes: few output tiles, K = all rows of the batch): work item = (k range, tile), range-major, so
+    // that the items an XCD runs at a time share their operand panels' k range; item (z, tile) leaves its partial product in slab z of
+    // `slabs` [splits][M][N], summed in slab order by planes_reduce_kernel (reproducible, no atomics, nobody waits for anybody)
+    int splits = 1, kb_per_split = 0;
+    float* slabs = nullptr;
 };
 
 template <bool BF16, int MT, int NT, bool ONE>
@@ -216,21 +221,26 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
     const int rta = (G.M + 15) / 16, rtb = (G.N + 15) / 16;
     const float inv = 1.f / (plane_scale(G.amax_a) * plane_scale(G.amax_b));
 
-    // this workgroup's tiles: workgroup id b runs on XCD b % 8; every XCD owns one contiguous range of the band-major tile list
-    // (bands of G.band tile rows, column by column), of which its j-th workgroup takes every (grid / 8)-th
-    const int T = G.tiles_m * G.tiles_n;
+    // this workgroup's work items: workgroup id b runs on XCD b % 8; every XCD owns one contiguous range of the item list - k range
+    // by k range the band-major tile list (bands of G.band tile rows, column by column) -, of which its j-th workgroup takes every
+    // (grid / 8)-th
+    const int TT = G.tiles_m * G.tiles_n;
+    const int T = TT * G.splits;
     const int xcd = blockIdx.x & 7, j0 = blockIdx.x >> 3, per = gridDim.x >> 3;
     const int q = T / 8, r8 = T % 8;
     const int cnt = xcd < r8 ? q + 1 : q;
     const int first = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
     if (j0 >= cnt) return;
     const int band_tiles = G.band * G.tiles_n;
-    auto tile_rc = [&](int idx, int& tm, int& tn) {
+    auto tile_rc = [&](int item, int& tm, int& tn, int& z) {
+        z = item / TT;
+        const int idx = item - z * TT;
         const int b = idx / band_tiles, rem = idx - b * band_tiles;
         const int h = min(G.band, G.tiles_m - b * G.band);
         tn = rem / h;
         tm = b * G.band + (rem - tn * h);
     };
+    const int KBS = G.splits > 1 ? G.kb_per_split : KB;        // k blocks per work item (the last range may be shorter)
     auto issue = [&](int i, int tm, int tn, int kb, int st) {            // piece i of this wavefront for (tile, k step) into stage st
         if (i < PA) {
             const int f = wave * PA + i;
@@ -251,24 +261,25 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 
-    int idx = j0, tm, tn;
-    tile_rc(first + idx, tm, tn);
+    int idx = j0, tm, tn, tz;
+    tile_rc(first + idx, tm, tn, tz);
 #pragma unroll
-    for (int i = 0; i < PW; ++i) issue(i, tm, tn, 0, 0);
+    for (int i = 0; i < PW; ++i) issue(i, tm, tn, tz * KBS, 0);
     int st = 0;
     constexpr int PPI = (PW + MT - 1) / MT;             // pieces issued per row-tile iteration
     while (true) {
         const int nidx = idx + per;
         const bool has_next_tile = nidx < cnt;
-        int ntm = tm, ntn = tn;
-        if (has_next_tile) tile_rc(first + nidx, ntm, ntn);
-        for (int kb = 0; kb < KB; ++kb) {
+        int ntm = tm, ntn = tn, ntz = tz;
+        if (has_next_tile) tile_rc(first + nidx, ntm, ntn, ntz);
+        const int kb_lo = tz * KBS, kb_hi = min(KB, kb_lo + KBS);
+        for (int kb = kb_lo; kb < kb_hi; ++kb) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wavefront's pieces of stage `st` have landed
             __builtin_amdgcn_s_barrier();                             // everybody's have; everybody is done reading stage st ^ 1
             // the stage requested during this step: the next k step of this tile, or the first one of the next tile (behind the
             // very last step: this tile's first stage once more - never read, keeps the loop free of branches)
-            const bool last = kb + 1 == KB;
-            const int ptm = last ? ntm : tm, ptn = last ? ntn : tn, pkb = last ? 0 : kb + 1;
+            const bool last = kb + 1 == kb_hi;
+            const int ptm = last ? ntm : tm, ptn = last ? ntn : tn, pkb = last ? ntz * KBS : kb + 1;
             const uint4* sa = &lds[(st * PIECES + wm * MT * 2) * FR + lane];
             const uint4* sb = &lds[(st * PIECES + 2 * RA + wn * NT * 2) * FR + lane];
             h8 bh[NT], bl[NT];
@@ -318,6 +329,34 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                 }
             }
             const int mrow = (tm * WM + wm) * MT * 16 + r;
+            if (G.splits > 1) {         // the partial product of this k range: slab tz, row stride N (planes_reduce_kernel adds bias / C)
+                float* const srow = G.slabs + ((long long)tz * G.M + mrow) * G.N + n0;
+                const bool svec = (G.N & 3) == 0 && (reinterpret_cast<unsigned long long>(G.slabs) & 15) == 0;
+                const bool sfull = svec && (tn * WN + wn + 1) * NT * 16 <= G.N;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const bool ok = mrow + i * 16 < G.M;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const f4 v = acc[i][j] * inv;
+                        acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+                        float* o = srow + (long long)i * 16 * G.N + j * 16;
+                        if (sfull) {
+                            if (ok) *reinterpret_cast<f4*>(o) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ok && n0 + j * 16 + e < G.N) o[e] = v[e];
+                        }
+                    }
+                }
+                if (!has_next_tile) break;
+                idx = nidx;
+                tm = ntm;
+                tn = ntn;
+                tz = ntz;
+                continue;
+            }
             float* const crow = G.C + (long long)mrow * G.ldc + n0;
             if (full && !G.accumulate) {
 #pragma unroll
@@ -364,6 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
         idx = nidx;
         tm = ntm;
         tn = ntn;
+        tz = ntz;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -801,6 +841,7 @@ int ptmi_pack_planes_into(const float* x, int64_t rows_or_k, int64_t cols, int64
 
 int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_t split_k) {
     const int KB = (k + 31) / 32;
+    if (split_k < 0) split_k = -split_k;
     const int splits = std::max(1, std::min<int>(split_k, KB));
     return splits > 1 ? (int64_t)splits * m * n : 0;
 }
@@ -827,37 +868,64 @@ static void launch_big_inst(const BigArgs& G0, hipStream_t st) {
     BigArgs G = G0;
     G.tiles_m = (G.M + 32 * MT - 1) / (32 * MT);
     G.tiles_n = (G.N + 64 * NT - 1) / (64 * NT);
-    const int T = G.tiles_m * G.tiles_n;
+    const int T = G.tiles_m * G.tiles_n * G.splits;
     const int grid = std::min((T + 7) / 8 * 8, cu_count() / 8 * 8);
     hipLaunchKernelGGL((gemm_planes_big_kernel<BF16, MT, NT, ONE>), dim3((unsigned)grid), dim3(512), 0, st, G);
 }
 
-// Picks the tile by a cost model fitted to scripts/mb/gemm_big.hip's measurements (profiles/r3_mb_gemm_big.txt): time ~ rounds of
-// the CUs x tile area / efficiency of the tile shape; the 128 x 128 kernel (two workgroups per CU at half speed each) is one of the
-// candidates.  Returns false when that one wins or the planes do not fit a buffer descriptor.
-static bool launch_big(bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias,
-                       float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st) {
-    if (g_tile_override == 5) return false;
-    const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
-    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return false;      // piece offsets are formed in 32-bit signed arithmetic
+// Picks the tile - and, for calls that allow split K, the number of k ranges - by a cost model fitted to scripts/mb/gemm_big.hip's
+// and scripts/exp_wgrad_big.py's measurements (profiles/r3_mb_gemm_big.txt, profiles/r4_wgrad_big_split.txt):
+//   time ~ rounds of the CUs x (k blocks per item x tile area / efficiency of the tile shape + an epilogue worth ~10 k blocks)
+//          + the slab traffic of the reduction pass ((S + 2) M N floats at ~4 TB/s) + its launch
+// with the 128 x 128 kernel (two workgroups per CU at half speed each) as one of the candidates.  Weight-gradient shapes land on
+// 128 x 320 / 256 x 320 tiles with as many k ranges as fill ONE round of the CUs (2400 x 1200 x 8096: 76 tiles x 3 ranges, 127 us
+// against 148 for the 128 x 128 slabs; x 32192: 40 tiles x 6, 448 against 531 = 0.50 of the 16-bit peak / 3).
+struct BigPick { int tile; int splits; };       // tile -1: the 128 x 128 kernel
+
+static BigPick pick_big(int32_t m, int32_t n, int KB, int max_splits) {
     struct Cand { int mt, nt; double eff; };
     static const Cand cands[] = {{8, 5, 1.0}, {8, 4, 1.0}, {8, 3, 0.92}, {4, 5, 0.86}, {4, 4, 0.85}};
     const int cus = cu_count();
-    const long long t128 = (long long)((m + 127) / 128) * ((n + 127) / 128);
-    double best = (double)((t128 + 2 * cus - 1) / (2 * cus)) * 2.0 * 128 * 128 / 0.79;
-    int pick = -1;
-    for (int i = 0; i < 5; ++i) {
-        const long long tiles = (long long)((m + 32 * cands[i].mt - 1) / (32 * cands[i].mt)) * ((n + 64 * cands[i].nt - 1) / (64 * cands[i].nt));
-        const double cost = (double)((tiles + cus - 1) / cus) * (32.0 * cands[i].mt) * (64.0 * cands[i].nt) / cands[i].eff;
-        if (cost < best) {
-            best = cost;
-            pick = i;
+    const double unit = 3.1e-5;                  // us per (k block x output element) of a 256-row tile on one CU
+    BigPick best{-1, 1};
+    double best_cost = 1e300;
+    const int smax = std::max(1, std::min(max_splits, KB / 4));
+    for (int i = -1; i < 5; ++i) {
+        if (g_tile_override >= 0 && g_tile_override != (i < 0 ? 5 : i)) continue;
+        const double area = i < 0 ? 128.0 * 128 : 32.0 * cands[i].mt * 64.0 * cands[i].nt;
+        const double eff = i < 0 ? 0.79 : cands[i].eff;
+        const long long tiles = i < 0 ? (long long)((m + 127) / 128) * ((n + 127) / 128)
+                                      : (long long)((m + 32 * cands[i].mt - 1) / (32 * cands[i].mt)) * ((n + 64 * cands[i].nt - 1) / (64 * cands[i].nt));
+        const int slots = i < 0 ? 2 * cus : cus;                 // 128 x 128: two workgroups per CU, each at half the rate
+        const double rate = i < 0 ? 2.0 : 1.0;
+        for (int S = 1; S <= smax; ++S) {
+            const int per = (KB + S - 1) / S;
+            if ((KB + per - 1) / per != S) continue;             // this S does not exist (ranges are whole k blocks)
+            const long long rounds = (tiles * S + slots - 1) / slots;
+            // (calls without split K keep round 3's model - rounds x area / efficiency -, which its measurements were fitted with)
+            double cost = max_splits <= 1 ? (double)rounds * rate * area / eff * KB * unit
+                                          : (double)rounds * rate * (per * area * unit / eff + 10.0 * area * unit);
+            if (S > 1) cost += (double)(S + 2) * m * n * 4.0 / 4.0e6 + 8.0;
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = BigPick{i, S};
+            }
         }
     }
-    if (g_tile_override >= 0 && g_tile_override < 5) pick = g_tile_override;
-    if (pick < 0) return false;
+    return best;
+}
+
+// splits > 1: `splits` k ranges of `per` k blocks, partial products into `slabs` (the caller runs planes_reduce_kernel behind the launch)
+static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
+                       const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st,
+                       int splits = 1, int per = 0, float* slabs = nullptr) {
+    const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
+    if (pick < 0 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return false;      // piece offsets are formed in 32-bit signed arithmetic
     BigArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, amax_a, amax_b, bias, m, n, KB, (long long)ldc,
               accumulate ? 1 : 0, 0, 0, 4, (unsigned)a_bytes, (unsigned)b_bytes};
+    G.splits = splits;
+    G.kb_per_split = per;
+    G.slabs = slabs;
 #define PTMI_BIG_CASE(I, MT_, NT_)                                    \
     case I:                                                           \
         if (bf16 && one) launch_big_inst<true, MT_, NT_, true>(G, st);        \
@@ -882,12 +950,37 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
     PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
     const int KB = (k + 31) / 32;
+    // split_k = the most k ranges the caller's workspace holds; how many are used (and on which tile) is the cost model's choice - a
+    // function of the shape alone, so a call is reproducible bit for bit.  A pinned tile (ptmi_gemm_planes_select_tile: tests, sweeps)
+    // takes split_k as it is.
+    // split_k < 0: exactly -split_k ranges on the 128 x 128 kernel - its workgroups (4 wavefronts, 64 KB of LDS) fit on a CU NEXT TO a
+    // persistent recurrence workgroup, a big tile needs a whole CU and only gets the ~100 the recurrence leaves free: what a caller
+    // asks for whose GEMM runs beside a recurrence and is short (measured in the B = 32 step: 7.15 against 7.18 ms with the big tiles)
+    const bool co_resident = split_k < 0;
+    if (co_resident) split_k = -split_k;
     int splits = std::max(1, std::min<int>(split_k, KB));
-    const int per = (KB + splits - 1) / splits;
+    int per = (KB + splits - 1) / splits;
     splits = (KB + per - 1) / per;
     PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (splits == 1 && launch_big(bf16, one, a, amax_a, b, amax_b, bias, c, ldc, m, n, KB, accumulate, st)) return launch_status();
+    static const bool big_split = !(getenv("PTMI_GEMM_BIG_SPLIT") && atoi(getenv("PTMI_GEMM_BIG_SPLIT")) == 0);
+    BigPick pk = pick_big(m, n, KB, ((big_split && !co_resident) || g_tile_override >= 0) ? splits : 1);
+    if (g_tile_override >= 0) pk.splits = splits;
+    else if ((!big_split || co_resident) && splits > 1) pk = BigPick{-1, splits};    // 128 x 128 slabs as asked for
+    if (pk.splits != splits) {
+        splits = pk.splits;
+        per = (KB + splits - 1) / splits;
+    }
+    if (pk.tile >= 0 && launch_big(pk.tile, bf16, one, a, amax_a, b, amax_b, splits > 1 ? nullptr : bias, c, ldc, m, n, KB,
+                                   splits > 1 ? 0 : accumulate, st, splits, per, workspace)) {
+        int rc = launch_status();
+        if (rc != PTMI_OK || splits == 1) return rc;
+        const long long total = (long long)m * n;
+        const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
+                           accumulate ? 1 : 0);
+        return launch_status();
+    }
     PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, bias, m, n, KB,
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
     const int tiles = G.tiles_m * G.tiles_n;

@@ -327,13 +327,32 @@ def usable(*tensors):
 
 
 def auto_split_k(M, N, K):
-    """K ranges per output tile: weight-gradient shapes (few 128 x 128 tiles, K = all rows of the batch) are cut until
-    about two workgroups per CU exist (measured at the step's shapes: 2400 x 1200 x 8096 311 / 274 / 262 / 254 us with 1 / 2 / 4 / 8
-    ranges, 2400 x 600 x 8096 295 / 165 / 150 / 144); every range keeps at least 16 k-steps."""
+    """The MOST K ranges a call may use (what its slab workspace is sized for): weight-gradient shapes - few output tiles, K = all
+    rows of the batch - may be cut into up to 12; how many ranges and which tile run is the cost model's choice in
+    ``csrc/gemm_planes.hip`` (``pick_big``: e.g. 2400 x 1200 x 8096 -> 76 tiles of 128 x 320 x 3 ranges = one round of the CUs, 127 us
+    against 148 on round 3's 128 x 128 slabs; x 32192 -> 40 tiles of 256 x 320 x 6 ranges, 448 against 531 us), a function of the
+    shape alone.  Shapes with many output tiles run without a split."""
     tiles = -(-M // 128) * -(-N // 128)
     if tiles >= 384:
         return 1
-    return max(1, min(512 // tiles, K // 512, 8))
+    return max(1, min(12, K // 256))
+
+
+#: weight-gradient GEMMs that run BESIDE a persistent recurrence: up to this many reduction rows on the 128 x 128 kernel, whose
+#: workgroups share a CU with the recurrence's (``co_resident_split_k``); longer ones on big tiles on the CUs the recurrence leaves free
+CO_RESIDENT_MAX_K = 16384
+
+
+def co_resident_split_k(M, N, K):
+    """``split_k`` of a weight-gradient GEMM that runs next to a recurrence (``ptmi_gemm_planes``: negative = exactly that many k ranges
+    on the 128 x 128 kernel, measured: until about two workgroups per CU exist, every range at least 16 k steps)."""
+    if K > CO_RESIDENT_MAX_K:
+        return auto_split_k(M, N, K)
+    tiles = -(-M // 128) * -(-N // 128)
+    if tiles >= 384:
+        return 1
+    s = max(1, min(512 // tiles, K // 512, 8))
+    return -s if s > 1 else 1
 
 
 def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, split_k=None):

@@ -71,8 +71,9 @@ class _LinearFn(torch.autograd.Function):
             main.wait_stream(_lstm._wgrad_stream(x.device))
         with torch.cuda.stream(side):
             if _gemm.planes_enabled() and x.stride(1) == 1:
+                # (beside the top BLSTM layer's backward recurrence: co_resident_split_k)
                 _gemm.mm_planes_(mod.weight.grad, _gemm.pack_t(g, amax_g), _gemm.pack_t(x, amax_x), g.shape[1], x.shape[1],
-                                 x.shape[0], accumulate=True)
+                                 x.shape[0], accumulate=True, split_k=_gemm.co_resident_split_k(g.shape[1], x.shape[1], x.shape[0]))
             else:
                 _gemm.mm(g.t(), x, out=mod.weight.grad, accumulate=True, amax_x=amax_g, amax_y=amax_x)
             if ctx.has_bias:

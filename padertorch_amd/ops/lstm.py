@@ -655,6 +655,9 @@ class _LstmLayerFn(torch.autograd.Function):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
             (both_queues: all but the forward direction's dW_hh on the main stream - see TAIL_ON_BOTH_QUEUES).
             dg_t: the kernel's bf16 planes of dgates^T for exactly these row ranges (then `dg` is None)."""
+            # the first layer's weight gradients have the chip to themselves (the step's tail): big tiles; every other layer's run
+            # beside the next recurrence: short ones on the kernel whose workgroups share CUs with the recurrence's
+            split_of = _gemm.auto_split_k if not ctx.needs_input_grad[0] else _gemm.co_resident_split_k
             for d, ((p_wih, p_whh, _, _), (r0, r1)) in enumerate(zip(params, ranges)):
                 q_ih = main if both_queues else side
                 q_hh = main if both_queues and d == 1 else side
@@ -673,10 +676,10 @@ class _LstmLayerFn(torch.autograd.Function):
                         if key not in xplanes:
                             xplanes[key] = torch.ops.ptmi.pack_planes_bf16(x[r0:r1], True)
                         torch.ops.ptmi.gemm_planes_bf16_(p_wih.grad, dg_t, a_off, xplanes[key], None, G, x.shape[1], k, True,
-                                                         _gemm.auto_split_k(G, x.shape[1], k))
+                                                         split_of(G, x.shape[1], k))
                         with torch.cuda.stream(q_hh):
                             hpl = torch.ops.ptmi.pack_planes_bf16(h_prev[r0:r1], True)
-                            torch.ops.ptmi.gemm_planes_bf16_(p_whh.grad, dg_t, a_off, hpl, None, G, H, k, True, _gemm.auto_split_k(G, H, k))
+                            torch.ops.ptmi.gemm_planes_bf16_(p_whh.grad, dg_t, a_off, hpl, None, G, H, k, True, split_of(G, H, k))
                         continue
                     dgt = dgd[r0:r1].t()
                     if gm is not None and _gemm.planes_enabled():
@@ -689,10 +692,10 @@ class _LstmLayerFn(torch.autograd.Function):
                             dgp = _gemm.pack_t(dgd[r0:r1], amax_dg)
                         if key not in xplanes:
                             xplanes[key] = _gemm.pack_t(x[r0:r1], gm[0])
-                        _gemm.mm_planes_(p_wih.grad, dgp, xplanes[key], G, x.shape[1], k, accumulate=True)
+                        _gemm.mm_planes_(p_wih.grad, dgp, xplanes[key], G, x.shape[1], k, accumulate=True, split_k=split_of(G, x.shape[1], k))
                         with torch.cuda.stream(q_hh):
                             hpl = _gemm.pack_t(h_prev[r0:r1], _gemm.UNIT_RANGE if h0 is None else None)
-                            _gemm.mm_planes_(p_whh.grad, dgp, hpl, G, H, k, accumulate=True)
+                            _gemm.mm_planes_(p_whh.grad, dgp, hpl, G, H, k, accumulate=True, split_k=split_of(G, H, k))
                     elif gm is not None:
                         _gemm.mm(dgt, x[r0:r1], out=p_wih.grad, accumulate=True, amax_x=amax_dg, amax_y=gm[0])
                         _gemm.mm(dgt, h_prev[r0:r1], out=p_whh.grad, accumulate=True, amax_x=amax_dg,

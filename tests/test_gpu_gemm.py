@@ -319,6 +319,47 @@ def test_planes_big_tiles_vs_fp64(tile, M, N, K, acc, bias):
         _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
 
 
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, -1])
+@pytest.mark.parametrize('M,N,K,split,acc,bias,bf16', [
+    (2400, 600, 2080, 5, True, False, True), (530, 257, 1000, 3, False, True, False), (300, 70, 4111, 12, True, True, True),
+    (2400, 1200, 8096, 12, True, False, True), (129, 321, 96, 2, False, False, False)])
+def test_planes_big_tiles_with_split_k_vs_fp64(tile, M, N, K, split, acc, bias, bf16):
+    """Round 4: split K on the persistent big-tile kernel - work item = (k range, tile), partial products into slabs, summed in slab
+    order by the reduction pass (weight-gradient shapes: dW = dgates^T [x | h_prev]).  Every tile pinned (split K as asked for) and the
+    cost model's own choice of tile and number of ranges (-1): ragged last k range, more items than CUs per XCD range, rows / columns
+    ending inside tiles, bias, accumulation into a strided C, both plane flavours; bit-identical between two calls."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import gemm as G
+    lib = _lib.load()
+    torch.manual_seed(M + N + K + tile)
+    a = torch.randn(K, M, device='cuda') * 0.3            # both operands reduce over their outer axis (the weight-gradient form)
+    x = torch.randn(K, N, device='cuda')
+    b = torch.randn(N, device='cuda') if bias else None
+    cbuf = torch.randn(M, N + 3, device='cuda')
+    c0 = cbuf.clone()
+    c = cbuf[:, :N]
+    want = a.double().t() @ x.double() + (b.double() if bias else 0) + (c.double() if acc else 0)
+    mag = a.double().abs().t() @ x.double().abs() + (b.double().abs() if bias else 0) + (c.double().abs() if acc else 0)
+
+    def run(out):
+        if bf16:
+            torch.ops.ptmi.gemm_planes_bf16_(out, torch.ops.ptmi.pack_planes_bf16(a, True), 0, torch.ops.ptmi.pack_planes_bf16(x, True), b,
+                                             M, N, K, acc, split)
+        else:
+            G.mm_planes_(out, G.pack_t(a), G.pack_t(x), M, N, K, accumulate=acc, split_k=split, bias=b)
+    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    try:
+        run(c)
+        torch.cuda.synchronize()
+        assert float(((c.double() - want).abs() / mag).max()) < (4e-6 if bf16 else 4e-7)
+        assert torch.equal(cbuf[:, N:], c0[:, N:])
+        again = c0.clone()
+        run(again[:, :N])
+        assert torch.equal(again, cbuf)
+    finally:
+        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+
+
 def test_planes_big_tile_many_tiles_per_workgroup():
     """More tiles than CUs: every workgroup of the persistent kernel walks several tiles (the next tile's first stage is requested
     during the last k step of the current one); 128 x 256 tiles at 4100 x 4100 = 33 x 17 = 561 tiles."""
