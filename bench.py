@@ -18,9 +18,11 @@ Other configurations of BASELINE.json (parity / scaling cases, not the default l
   virtual_minibatch_size = 4 x devices);  c5  deep-clustering model, K = 3, batch 64, 16 kHz.
 
 The JSON line also carries
-  roofline        the kernel family with the most GPU time per step, HIP-event time of its launches inside the
-                  timed steps against the peak that bounds it; other_kernels lists every other hand-written
-                  kernel family of the step the same way;
+  roofline        the ONE kernel with the most GPU time per step (as rocprofv3's summary of the same command names it), HIP-event
+                  time of its launches inside the timed steps minus the bracket of an empty launch, against the peak that bounds
+                  it; other_kernels lists every other hand-written kernel of the step the same way, plus the stand-alone STFT /
+                  iSTFT op at a chip-filling batch; roofline_family = all planes GEMM launches of the step together;
+  value_ragged    the same step on SURVEY 8d's training distribution (example lengths ~ U[3 s, 6 s]) in frames/s, ms_per_step_ragged;
   cpu_baseline    the oracle's torch-CPU port of the reference step (oracle/torch_ref.py) timed on this box's host
                   cores on a bounded sample (rank 0, N = 1 only), at 1 thread, 16 threads and all cores;
   ms_per_step_sync_checks   the same step with the reference's two host syncs per step (loss / grad-norm checks
@@ -190,10 +192,74 @@ def measured_traffic(kernel):
     return json.loads(f.read_text()).get(kernel, {}).get('hbm_bytes_per_launch')
 
 
-def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_mode=3):
-    """One entry per hand-written kernel family seen in the timed steps: HIP-event time of every launch (events
-    recorded on the launch stream around the C-ABI call), algorithmic bytes or flops per launch."""
+TILE_NAMES = {0: '8, 5 (256 x 320)', 1: '8, 4 (256 x 256)', 2: '8, 3 (256 x 192)', 3: '4, 5 (128 x 320)', 4: '4, 4 (128 x 256)'}
+
+
+def event_bracket_overhead_ms(device, n=200):
+    """What two HIP events around ONE launch measure when the kernel does nothing: the launch's own dispatch latency sits
+    inside every event bracket, rocprofv3's kernel durations do not contain it.  A 30 us HBM kernel priced on the raw
+    bracket looks ~20 % slower than in the profile of the same command; `kernel_report` subtracts this figure so that the
+    two tools quote one number (the raw bracket stays in the entry as ``avg_launch_ms_events``)."""
+    import torch
+    from padertorch_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream(device)
+    for _ in range(20):
+        lib.ptmi_debug_occupy(1, 64, 0, 0, st)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record()
+        lib.ptmi_debug_occupy(1, 64, 0, 0, st)
+        b.record()
+    torch.cuda.synchronize()
+    v = sorted(a.elapsed_time(b) for a, b in ev)
+    return v[len(v) // 2]
+
+
+def standalone_front_end(device, overhead_ms, rows=192, samples=64000):
+    """north_star prices 'the STFT kernel' against the HBM peak: the forward and inverse STFT op alone on a batch that fills the
+    chip (192 x 8 s @ 8 kHz: 97 k frames, 2568 algorithmic bytes per frame each way), HIP events per launch minus the empty-launch
+    bracket.  Not part of the training step (its fused front-end is pit_features): reported as stand-alone rows."""
+    import torch
+    import padertorch_amd as pt
+    stft = pt.ops.STFT(SIZE, SHIFT, complex_representation='stacked')
+    x = torch.randn(rows, samples, device=device)
+    out = []
+    with torch.no_grad():
+        spec = stft(x)
+        frames = spec.shape[1] * rows
+        for name, label, fn in (('stft_fwd', 'stft_fwd_kernel<Plan<16,16>> (ptmi_stft_forward, stand-alone)', lambda: stft(x)),
+                                ('istft', 'istft_kernel<Plan<16,16>> (ptmi_istft_forward, stand-alone)', lambda: stft.inverse(spec))):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            ms = []
+            for _ in range(10):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                b.record()
+                torch.cuda.synchronize()
+                ms.append(a.elapsed_time(b))
+            raw = sorted(ms)[len(ms) // 2]
+            t = max(raw - overhead_ms, 1e-6)
+            work = (SHIFT * 4 + (SIZE // 2 + 1) * 8) * frames
+            out.append(dict(kernel=label, bound='hbm', achieved=work / (t * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                            frac=work / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None, avg_launch_ms=t, avg_launch_ms_events=raw,
+                            standalone=True, frames_per_launch=frames, algorithmic_bytes_per_launch=work,
+                            workload=f'{rows} x {samples} samples, STFT {SIZE}/{SHIFT}'))
+    return out
+
+
+def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_mode=3, overhead_ms=0.):
+    """One entry per hand-written KERNEL seen in the timed steps, named as rocprofv3's summary of the same command names it (the
+    planes GEMMs by kernel, plane type and workgroup tile: ``ptmi_gemm_planes_plan`` tells which one a call runs as): HIP-event time
+    of every launch (events recorded on the launch stream around the C-ABI call) minus the bracket of an empty launch, against the
+    algorithmic bytes or flops of the launch.  Sorted by GPU time per step: the first entry is the step's top kernel."""
     import numpy as np
+    from padertorch_amd import _lib
+    lib = _lib.load()
     by_name = {}
     for name, a, b in timers:
         by_name.setdefault(name, []).append(a.elapsed_time(b))
@@ -206,49 +272,61 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
     # itself: F fp32 log-magnitudes in PackedSequence order + their fp16 (hi, lo) planes (F rounded up to 32-wide blocks)
     feature_bytes = ((1 + K) * SHIFT * 4 + (1 + 2 * K) * F * 4 + F * 4 + (F + 31) // 32 * 32 * 2 * 2) * fpl
     pit_bytes = (1 + 3 * K) * F * 4 * fpl
+    rec_note = ('fp16/bf16 MFMA dense peak 2500 TFLOP/s / 3 products.  What bounds the kernel is the serial per-timestep hand-off (stores '
+                'becoming visible, then the gather of the chain\'s rows: 39 KB forward, 154 KB backward per CU and step = the CU\'s '
+                'vector-memory issue rate, independent of the batch), not the matrix cores (DESIGN.md section 3.3)')
     spec = {
         'pit_features': ('pit_features_kernel<Plan<16,16>> (fused STFT front-end incl. the packed log-magnitude input of the first layer)', 'hbm', feature_bytes),
         'pit_pairwise_sse': ('pit_pairwise_kernel (PIT mse+ips pairwise SSE)', 'hbm', pit_bytes),
         'pit_backward': ('pit_backward_kernel (d loss / d mask)', 'hbm', pit_bytes + K * F * 4 * fpl),
         'lstm_forward': ('lstm_fwd_daf_kernel (BLSTM recurrence, one persistent launch per layer, fp16 hi/lo MFMA products, data-as-flag '
-                         'hand-off)',
-                         'mfma16x3', rec_flop),
+                         'hand-off)', 'mfma16x3', rec_flop),
         'lstm_backward': ('lstm_bwd_split_kernel<DAF> (BLSTM backward-through-time, one persistent launch per layer, bf16 hi/lo MFMA '
-                          'products, data-as-flag hand-off)', 'mfma16x3', rec_flop),
+                          'products, data-as-flag hand-off; hands dgates^T on as bf16 planes)', 'mfma16x3', rec_flop),
     }
     kernels = []
     gemm, packs = {}, {}
+    family = dict(flop=0., ms=0., launches=0)
     for n, v in by_name.items():
-        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:', 'gemm_planes_tn:')):          # gemm_planes[_bf16|_tn]:MxNxK
+        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:', 'gemm_planes_tn:')):          # gemm_planes[_bf16|_tn]:MxNxK:split
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
-            key = (('planes_tn', 3) if n.startswith('gemm_planes_tn') else
-                   ('planes_bf16', products_mode) if n.startswith('gemm_planes_bf16') else ('planes', products_mode))
-            e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0, members={}))
+            bf16 = n.startswith('gemm_planes_bf16')
+            if n.startswith('gemm_planes_tn'):
+                key = ('gemm_planes_tn_kernel<bf16>', 3, 'weight gradients on row-major planes (LDS transpose reads)')
+            else:
+                split = int(parts[2]) if len(parts) > 2 and parts[2].lstrip('-').isdigit() else 1
+                plan = int(lib.ptmi_gemm_planes_plan(M, N, Kd, split))
+                tile, ranges = plan // 100, plan % 100
+                dt = 'bf16' if bf16 else 'fp16'
+                one = ', one product' if products_mode == 1 else ''
+                if tile == 5:
+                    key = (f'gemm_planes_kernel<{dt}{one}> (128 x 128, slab split K' + (', co-resident with a recurrence' if split < 0 else '') + ')',
+                           products_mode, 'weight gradients beside a backward recurrence')
+                else:
+                    key = (f'gemm_planes_big_kernel<{dt}, {TILE_NAMES[tile]}{one}>' + (' split K + planes_reduce_kernel' if ranges > 1 else ''),
+                           products_mode, 'persistent big-tile kernel')
+            e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0, shapes=set()))
             e['flop'] += 2.0 * M * N * Kd * len(v)
-            e['ms'] += float(np.sum(v))
+            e['ms'] += float(np.sum(v)) - overhead_ms * len(v)
             e['launches'] += len(v)
-            # the kernel behind the call (csrc/gemm_planes.hip): split K > 1 -> gemm_planes_kernel (128 x 128, slabs), else the
-            # persistent big-tile kernel; per kernel: what rocprofv3's summary of the same command lists
-            split = int(parts[2]) if len(parts) > 2 and parts[2].lstrip('-').isdigit() else 1
-            kname = ('gemm_planes_tn_kernel' if key[0] == 'planes_tn' else
-                     'gemm_planes_kernel (128 x 128, slab split K)' if split > 1 else 'gemm_planes_big_kernel (persistent, tile per problem)')
-            mem = e['members'].setdefault(kname, dict(flop=0., ms=0., launches=0))
-            mem['flop'] += 2.0 * M * N * Kd * len(v)
-            mem['ms'] += float(np.sum(v))
-            mem['launches'] += len(v)
+            e['shapes'].add(f'{M}x{N}x{Kd}')
+            family['flop'] += 2.0 * M * N * Kd * len(v)
+            family['ms'] += float(np.sum(v)) - overhead_ms * len(v)
+            family['launches'] += len(v)
             continue
         if n.startswith('pack_planes'):          # pack_planes_t:KxC / pack_planes_n:RxK: 4 B read + 4 B written per element
             a_, b_ = (int(x) for x in n.split(':')[1].split('x'))
             e = packs.setdefault('pack', dict(bytes=0., ms=0., launches=0))
             e['bytes'] += 8.0 * a_ * b_ * len(v)
-            e['ms'] += float(np.sum(v))
+            e['ms'] += float(np.sum(v)) - overhead_ms * len(v)
             e['launches'] += len(v)
             continue
         if n not in spec:
             continue
         label, bound, work = spec[n]
-        ms = float(np.mean(v))
+        raw = float(np.mean(v))
+        ms = max(raw - overhead_ms, 1e-6)
         if bound == 'hbm':
             achieved, peak, unit = work / (ms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s'
         else:
@@ -256,49 +334,44 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
             # 16-bit dense peak / 3 (its real bound is the per-timestep hand-off chain)
             achieved, peak, unit = work / (ms * 1e-3) / 1e12, FP16_MFMA_PEAK_TFLOPS / 3, 'TFLOP/s'
         e = dict(kernel=label, bound='hbm' if bound == 'hbm' else 'mfma', achieved=achieved, peak=peak, unit=unit,
-                 frac=achieved / peak, traffic=measured_traffic(n), avg_launch_ms=ms,
-                 launches_per_step=len(v) / steps, ms_per_step=float(np.sum(v)) / steps)
+                 frac=achieved / peak, traffic=measured_traffic(n), avg_launch_ms=ms, avg_launch_ms_events=raw,
+                 launches_per_step=len(v) / steps, ms_per_step=ms * len(v) / steps)
         if bound == 'hbm':
             e['algorithmic_bytes_per_launch'] = work
         else:
             e['algorithmic_flop_per_launch'] = work
             e['us_per_timestep'] = ms * 1e3 / T
             e['frac_of_fp32_mfma_peak'] = achieved / FP32_MFMA_PEAK_TFLOPS       # the measure of round 1 (exact-fp32 MFMA kernels)
-            e['peak_note'] = ('fp16/bf16 MFMA dense peak 2500 TFLOP/s / 3 products; the kernel is bound by the serial per-timestep '
-                              'hand-off (stores becoming visible + operand gather), not by the matrix cores')
+            e['peak_note'] = rec_note
         kernels.append(e)
-    for (kind, products), e in gemm.items():
+    for (label, products, what), e in gemm.items():
         if not e['launches']:
             continue
         achieved = e['flop'] / (e['ms'] * 1e-3) / 1e12
         peak = FP16_MFMA_PEAK_TFLOPS / products
-        label = ('gemm_planes_big_kernel / gemm_planes_kernel <fp16> (LSTM input projections, linears, their input and weight '
-                 f'gradients: operands pre-split into fp16 (hi, lo) planes, {products} fp16 MFMA product(s) per product; persistent '
-                 'big-tile kernel without split K, 128 x 128 kernel with slabs for the linears\' weight gradients)' if kind == 'planes' else
-                 'gemm_planes_tn_kernel<bf16> (LSTM weight gradients dgates^T [x | h_prev] reduced over the ROW tiles of the bf16 planes the '
-                 'backward recurrence hands on, LDS transpose reads; 3 bf16 MFMA products per product, slab split K)' if kind == 'planes_tn' else
-                 'gemm_planes_big_kernel<bf16> (LSTM input gradients dgates W_ih on the bf16 (hi, lo) planes the backward recurrence hands '
-                 f'on, {products} bf16 MFMA product(s) per product)')
         kernels.append(dict(
-            kernel=label, bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak,
+            kernel=f'{label}: {what}', bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak,
             traffic=measured_traffic('gemm_planes'),
-            peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = '
-                      f'algorithmic 2MNK flop of all launches / their HIP-event time (main and weight-gradient stream, i.e. '
-                      f'mostly next to a running recurrence)',
+            peak_note=f'fp16/bf16 MFMA dense peak {FP16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} products; achieved = algorithmic 2MNK flop '
+                      f'of the launches / their HIP-event time inside the step (weight gradients run beside a recurrence)',
             avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
-            algorithmic_flop_per_step=e['flop'] / steps,
-            members=[dict(kernel=k, launches_per_step=m['launches'] / steps, avg_launch_ms=m['ms'] / m['launches'],
-                          ms_per_step=m['ms'] / steps, achieved=m['flop'] / (m['ms'] * 1e-3) / 1e12,
-                          frac=m['flop'] / (m['ms'] * 1e-3) / 1e12 / peak) for k, m in e['members'].items()]))
+            algorithmic_flop_per_step=e['flop'] / steps, shapes=sorted(e['shapes'])))
     for e in packs.values():
         achieved = e['bytes'] / (e['ms'] * 1e-3) / 1e9
         kernels.append(dict(
-            kernel='pack_planes_t_kernel / pack_planes_n_kernel (fp32 operand -> fp16 (hi, lo) planes in MFMA fragment order)',
+            kernel='pack_planes_t_kernel / pack_planes_n_kernel (fp32 operand -> 16-bit (hi, lo) planes in MFMA fragment order)',
             bound='hbm', achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS, traffic=None,
             avg_launch_ms=e['ms'] / e['launches'], launches_per_step=e['launches'] / steps, ms_per_step=e['ms'] / steps,
             algorithmic_bytes_per_step=e['bytes'] / steps))
     kernels.sort(key=lambda e: -e['ms_per_step'])
-    return kernels
+    fam = None
+    if family['launches']:
+        achieved = family['flop'] / (family['ms'] * 1e-3) / 1e12
+        peak = FP16_MFMA_PEAK_TFLOPS / products_mode
+        fam = dict(kernel='all planes GEMM launches of the step (gemm_planes_big_kernel + gemm_planes_kernel, both queues)', bound='mfma',
+                   achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, launches_per_step=family['launches'] / steps,
+                   ms_per_step=family['ms'] / steps, algorithmic_flop_per_step=family['flop'] / steps)
+    return kernels, fam
 
 
 def main():
@@ -380,6 +453,8 @@ def main():
         n = lengths[0]
     frames_per_micro = sum(frames_of(nb) for nb in lengths) if lengths else cfg['batch'] * frames_of(n)
     from padertorch_amd import _lib
+    # what step() runs on: the headline's batch, or (value_ragged) a batch of SURVEY 8d's length distribution
+    variant = dict(ragged=bool(args.ragged), frames=frames_per_micro, data=None)
 
     if args.dry:
         data = None
@@ -409,6 +484,7 @@ def main():
             trainer._flat.flat.zero_()
     else:
         data = synthetic_batch(1000 + rank, cfg['batch'], K, n, device, lengths)
+        variant['data'] = data
         timers = []
 
         counted = [0, 0]              # timed steps so far / of which with kernel events
@@ -436,8 +512,8 @@ def main():
             for m in range(micro):
                 if buckets is not None:
                     buckets.active = m + 1 == micro
-                src = data
-                if args.ragged:
+                src = variant['data']
+                if variant['ragged']:
                     # real data brings a new length pattern every step: the per-pattern bookkeeping (ops.lstm.pack_meta: index tables,
                     # their transfers) is rebuilt every step although this bench repeats one batch
                     _lstm._meta.cache_clear()
@@ -445,7 +521,7 @@ def main():
                     src = dict(y=source['y'].to(device, non_blocking=True), s=source['s'].to(device, non_blocking=True),
                                num_samples=source['num_samples'])
                 feats = features(src)
-                assert sum(feats['num_frames']) == frames_per_micro, (sum(feats['num_frames']), frames_per_micro)
+                assert sum(feats['num_frames']) == variant['frames'], (sum(feats['num_frames']), variant['frames'])
                 loss, _, _, _ = trainer.train_step(model, feats, device)
                 loss.backward()
             trainer.optimizer_step()
@@ -584,6 +660,20 @@ def main():
                 return time.perf_counter() - t0
             prefetched_loop(3)
             extras['ms_per_step_h2d_prefetched'] = prefetched_loop(nx) / nx * 1e3
+        if not args.ragged and micro == 1:
+            # SURVEY 8d's training distribution: lengths ~ U[3 s, 6 s] (the same draw as --ragged), zero-padded waveforms, the
+            # per-pattern bookkeeping rebuilt every step as with real data
+            import random
+            rnd = random.Random(1234)
+            rl = sorted((rnd.randint(3 * cfg['fs'], 6 * cfg['fs']) for _ in range(cfg['batch'])), reverse=True)
+            variant.update(ragged=True, frames=sum(frames_of(nb) for nb in rl),
+                           data=synthetic_batch(1000 + rank, cfg['batch'], K, rl[0], device, rl))
+            for _ in range(3):
+                step(False)
+            extras['ms_per_step_ragged'] = timed_loop(nx) / nx * 1e3
+            extras['value_ragged'] = variant['frames'] * world / (extras['ms_per_step_ragged'] * 1e-3)
+            extras['ragged_frames_per_step'] = variant['frames'] * world
+            variant.update(ragged=False, frames=frames_per_micro, data=data)
     rccl = None
     if world > 1:
         flat = trainer._flat.flat
@@ -640,11 +730,18 @@ def main():
             out['roofline'] = None
         else:
             # (ragged batches: the per-kernel figures assume frames_per_step / batch time steps per launch - a reported mode without them)
-            kernels = [] if args.ragged else kernel_report(timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro,
-                                                           1 if args.bf16 else 3)
+            overhead = event_bracket_overhead_ms(device)
+            kernels, family = ([], None) if args.ragged else kernel_report(
+                timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro, 1 if args.bf16 else 3, overhead)
             out['kernel_event_steps'] = counted[1]
+            out['event_bracket_overhead_us'] = overhead * 1e3
+            # `roofline`: the ONE kernel with the most GPU time per step - what leads rocprofv3's summary of this command
+            # (profiles/r4_kernel_trace_bench.txt); `roofline_family`: all planes GEMM launches together (round 3's headline entry)
             out['roofline'] = kernels[0] if kernels else None
+            out['roofline_family'] = family
             out['other_kernels'] = kernels[1:]
+            if not args.no_extras and world == 1:
+                out['other_kernels'] += standalone_front_end(device, overhead)
         out.update(extras)
         # `value` is taken with the waveform batch resident in HBM (the bench contract).  SURVEY 8(d) counts example_to_device
         # inside the step: that figure, with the next batch's transfer issued one step ahead (data.DevicePrefetcher), is

@@ -480,6 +480,8 @@ int ptmi_gemm_planes_tn_bf16(const uint16_t* a, int32_t a_col_blocks, int32_t a_
  * 0 = 256 x 320, 1 = 256 x 256, 2 = 256 x 192, 3 = 128 x 320, 4 = 128 x 256) or on the 128 x 128 kernel (5) that also carries
  * every split-K call.  ptmi_gemm_planes_select_tile pins that choice for the process (tests, A/B timing); -1 = the cost model. */
 int ptmi_gemm_planes_select_tile(int32_t tile);
+/* What a ptmi_gemm_planes[_bf16] call of this shape runs as: 100 * tile + k ranges (tile as above; measurement / labelling only). */
+int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimizer step on the Trainer's flat gradient bucket (csrc/optim.hip): replaces, on the step path of

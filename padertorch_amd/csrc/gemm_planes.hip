@@ -1047,6 +1047,24 @@ int ptmi_gemm_planes_tn_bf16(const uint16_t* a, int32_t a_col_blocks, int32_t a_
     return launch_status();
 }
 
+int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k) {
+    // the choice gemm_planes_impl makes for this call: 100 * tile + k ranges (tile 0..4: the big-tile instantiations, 5: 128 x 128)
+    if (m < 1 || n < 1 || k < 1) return -1;
+    const int KB = (k + 31) / 32;
+    const bool co_resident = split_k < 0;
+    if (co_resident) split_k = -split_k;
+    int splits = std::max(1, std::min<int>(split_k, KB));
+    const int per0 = (KB + splits - 1) / splits;
+    splits = (KB + per0 - 1) / per0;
+    static const bool big_split = !(getenv("PTMI_GEMM_BIG_SPLIT") && atoi(getenv("PTMI_GEMM_BIG_SPLIT")) == 0);
+    BigPick pk = pick_big(m, n, KB, ((big_split && !co_resident) || g_tile_override >= 0) ? splits : 1);
+    if (g_tile_override >= 0) pk.splits = splits;
+    else if ((!big_split || co_resident) && splits > 1) pk = BigPick{-1, splits};
+    const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
+    if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) pk.tile = -1;
+    return (pk.tile < 0 ? 5 : pk.tile) * 100 + pk.splits;
+}
+
 int ptmi_gemm_planes_select_tile(int32_t tile) {
     PTMI_RETURN_IF(tile < -1 || tile > 5, PTMI_E_INVALID);
     g_tile_override = tile;
