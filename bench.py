@@ -77,7 +77,7 @@ def parse_args(argv=None):
     ap.add_argument('--cpu-baseline-batch', type=int, default=4, help=argparse.SUPPRESS)
     ap.add_argument('--no-extras', action='store_true', help='skip the sync-checks / host-to-device / all-reduce side measurements')
     ap.add_argument('--library-gemms', action='store_true',
-                    help='dense layers on the BLAS library (TunableOp selections of padertorch_amd/tuned) instead of csrc/gemm.hip')
+                    help='dense layers on the BLAS library (TunableOp selections of scripts/tuned) instead of csrc/gemm.hip')
     ap.add_argument('--bf16', action='store_true',
                     help="BASELINE configs[1]'s reduced-precision run: plain 16-bit operands in the dense layers (the hi halves only: fp16 "
                          'for activations and weights, bf16 for the gate gradients), fp32 accumulation; not the default')
@@ -418,7 +418,8 @@ def main():
     if args.library_gemms:
         _gemm.ENABLED = False
         if not args.dry:
-            from padertorch_amd import tuning
+            sys.path.insert(0, str(REPO / 'scripts'))
+            import library_gemm_tuning as tuning        # A/B tooling outside the package
             tuning.use_tuned_gemms()
     if args.bf16:
         _gemm.PRODUCTS = 1
@@ -436,8 +437,8 @@ def main():
     buckets = trainer._buckets
     model.train()
     if not args.dry:
-        _lstm.DEFER_WGRAD = not args.no_overlap      # what Trainer.train() sets
-        if _lstm.DEFER_WGRAD:
+        trainer.op_context.defer_wgrad = not args.no_overlap      # what Trainer.train() sets
+        if trainer.op_context.defer_wgrad:
             _lstm.warm_side_stream(device)
 
     n = cfg['fs'] * SECONDS
@@ -553,8 +554,8 @@ def main():
         """Bucketed all-reduce under the backward pass (True) or one all-reduce of the flat buffer in optimizer_step (False)."""
         for h in state['hooks']:
             h.remove()
-        _lstm.GRAD_READY_HOOK = None
-        _lstm.GRAD_USE_HOOK = None
+        trainer.op_context.grad_ready_hook = None
+        trainer.op_context.grad_use_hook = None
         trainer.overlap_allreduce = bool(flag)
         state['hooks'] = trainer.enable_bucketed_allreduce()
 
@@ -686,7 +687,32 @@ def main():
         ar_ms = (time.perf_counter() - t0) / reps * 1e3
         flat.zero_()
         nbytes = flat.numel() * 4
+        # which GPU every rank is bound to (one process per GPU: the ranks must sit on DISTINCT devices - two ranks on one GPU would
+        # halve the recurrences' CUs under each other and deadlock RCCL's intra-node transport)
+        if args.dry:
+            me = dict(rank=rank, local_rank=local_rank, device='cpu', uuid=f'cpu-{rank}', hip_visible_devices=os.environ.get('HIP_VISIBLE_DEVICES'))
+        else:
+            prop = torch.cuda.get_device_properties(device)
+            me = dict(rank=rank, local_rank=local_rank, device=str(device), name=prop.name, uuid=str(getattr(prop, 'uuid', '')) or f'{device}',
+                      pci_bus_id=getattr(prop, 'pci_bus_id', None), hip_visible_devices=os.environ.get('HIP_VISIBLE_DEVICES'),
+                      rocr_visible_devices=os.environ.get('ROCR_VISIBLE_DEVICES'))
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        ids = [(r.get('uuid'), r.get('pci_bus_id')) for r in ranks]
+        assert len(set(ids)) == world, f'ranks share a GPU: {ranks}'
+        try:
+            rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version()) if not args.dry else None
+        except Exception:       # (a build without the binding)
+            rccl_version = None
         rccl = dict(world_size=dist.get_world_size(), backend=backend, overlap_allreduce=buckets is not None, schedule=schedule,
+                    rccl_version=rccl_version, ranks=ranks,
+                    # what to read the measured figures against: a ring all-reduce over xGMI moves 2 (W - 1) / W x bytes per rank and is
+                    # bound by ONE link's ~153 GB/s per direction between neighbours (MI355X_MICROARCH.md); with 7 links per GPU RCCL
+                    # runs several rings in parallel, so the bus bandwidth of a 94 MB buffer at W = 8 is expected between ~150 (one
+                    # ring) and ~600 GB/s, i.e. 0.3 - 1.1 ms per all-reduce, under 15 % of the B = 32 step and overlappable with the
+                    # backward pass (layer buckets)
+                    expected=dict(bus_bandwidth_gbs=[150., 600.], blocking_all_reduce_ms_at_w8=[0.27, 1.1],
+                                  weak_scaling_efficiency_floor=0.85),
                     buckets=[b[1] - b[0] for b in buckets.buckets] if buckets is not None else [flat.numel()],
                     flat_gradient_bytes=nbytes, blocking_all_reduce_ms=ar_ms,
                     bus_bandwidth_gbs=2. * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9,
@@ -715,7 +741,7 @@ def main():
                 'frames_per_step': frames_per_step * world,
                 'parallelism': f'dp{world}',
                 'blstm': 'HIP recurrence (csrc/lstm_split.hip)',
-                'gemms': ('hipBLASLt/rocBLAS fp32, TunableOp selections (padertorch_amd/tuned)' if args.library_gemms else
+                'gemms': ('hipBLASLt/rocBLAS fp32, TunableOp selections (scripts/tuned)' if args.library_gemms else
                           'csrc/gemm_planes.hip, the hi planes only: plain 16-bit operands (reduced precision)' if args.bf16 else
                           'csrc/gemm_planes.hip: fp32 in / out, 3 16-bit MFMA products per product (fp32-equivalent accuracy); projections, '
                           'linears and weight gradients on operands pre-split into fp16 planes, LSTM input gradients on the bf16 planes the '

@@ -252,3 +252,21 @@ def strides6(*vals):
 
 def strides8(*vals):
     return (c_int64 * 8)(*vals)
+
+
+#: PTMI_STRICT=1 (or ``padertorch_amd._lib.STRICT = True``): a request that would leave the hand-written HIP path - an LSTM the
+#: recurrence kernels do not cover, a dense layer handed to the BLAS library - raises instead of warning.  The GPU test suite runs strict.
+STRICT = bool(int(os.environ.get('PTMI_STRICT', '0') or 0))
+_WARNED = set()
+
+
+def leaving_native_path(what, reason):
+    """``what`` is about to run on a library kernel (MIOpen / rocBLAS through torch) instead of this package's HIP kernels because
+    of ``reason``: said once per (what, reason) as a ``RuntimeWarning``, or raised under :data:`STRICT` - never silently."""
+    msg = f'padertorch_amd: {what} runs on the torch / library path, not on the HIP kernels: {reason}'
+    if STRICT:
+        raise RuntimeError(msg + ' (PTMI_STRICT)')
+    if (what, reason) not in _WARNED:
+        _WARNED.add((what, reason))
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)

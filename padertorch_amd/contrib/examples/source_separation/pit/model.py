@@ -19,6 +19,7 @@ What changed underneath:
 import torch
 from torch.nn.utils.rnn import PackedSequence
 
+from padertorch_amd import _lib
 from padertorch_amd import base
 from padertorch_amd import ops
 from padertorch_amd.ops.mappings import ACTIVATION_FN_MAP
@@ -111,9 +112,12 @@ class PermutationInvariantTrainingModel(base.Model):
             h = PackedSequence(h_data, h.batch_sizes)
 
         # Returns tensor with shape (t, b, num_directions * hidden_size)
-        if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
-            h = ops.packed_lstm(self.blstm, h, input_planes=input_planes)        # HIP time recurrence (csrc/lstm.hip)
+        why = 'hip_blstm = False' if not self.hip_blstm else ops.lstm.unsupported_reason(self.blstm, h.data)
+        if why is None:
+            h = ops.packed_lstm(self.blstm, h, input_planes=input_planes)        # HIP time recurrence (csrc/lstm_split.hip)
         else:
+            if h.data.is_cuda:                        # (CPU tensors - the reference Trainer's test_run on the host - are torch's business)
+                _lib.leaving_native_path('the BLSTM of PermutationInvariantTrainingModel', why)
             h, _ = self.blstm(h)                      # library LSTM (MIOpen)
 
         h_data = self.dropout_linear(h.data)

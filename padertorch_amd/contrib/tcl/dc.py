@@ -3,6 +3,7 @@
 import torch
 from torch.nn.utils.rnn import PackedSequence
 
+from padertorch_amd import _lib
 from padertorch_amd import base
 from padertorch_amd import ops
 from padertorch_amd.ops.sequence.pack_module import PaddedList, as_padded
@@ -63,9 +64,12 @@ class DeepClusteringModel(base.Model):
             h = transform(ops.pack_sequence(batch['Y_abs']))
         F = h.data.shape[1]
         assert F == self.F, f'self.F = {self.F} != F = {F}'
-        if self.hip_blstm and ops.lstm.supported(self.blstm, h.data):
-            h = ops.packed_lstm(self.blstm, h, input_planes=input_planes)        # HIP time recurrence (csrc/lstm.hip)
+        why = 'hip_blstm = False' if not self.hip_blstm else ops.lstm.unsupported_reason(self.blstm, h.data)
+        if why is None:
+            h = ops.packed_lstm(self.blstm, h, input_planes=input_planes)        # HIP time recurrence (csrc/lstm_split.hip)
         else:
+            if h.data.is_cuda:
+                _lib.leaving_native_path('the BLSTM of DeepClusteringModel', why)
             h = self.blstm(h)[0]
         return ops.unpack_sequence(PackedSequence(self._embed_rows(h.data), h.batch_sizes))
 

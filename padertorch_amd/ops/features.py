@@ -23,7 +23,7 @@ _default_stft = None
 #: exponent makes ptmi_gemm_planes take that scale (2^13 / 16)
 LOG1P_SCALE_WORD_VALUE = 16.0
 
-_PLANES = {}        # (device, rows, F) -> [zero-initialised planes buffer, generation]
+_PLANES = {}        # (device, rows, F, stream) -> [zero-initialised planes buffer, generation]
 
 
 class PackedLog1p:
@@ -131,7 +131,9 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
         lp = torch.empty((meta.rows, F), dtype=torch.float32, device=dev)
         entry = None
         if _gemm.planes_enabled():
-            key = (dev.type, dev.index, meta.rows, F)
+            # (one buffer per shape AND stream: a call on another stream - a prefetching copy stream, a second host thread - must not
+            #  overwrite planes that a GEMM queued on this stream has not read yet)
+            key = (dev.type, dev.index, meta.rows, F, torch.cuda.current_stream(dev).cuda_stream)
             entry = _PLANES.get(key)
             if entry is None:
                 if len(_PLANES) > 8:

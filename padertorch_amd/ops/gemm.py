@@ -12,6 +12,7 @@ gradients the backward recurrence hands on), fp32 accumulation: BASELINE's "bf16
 as a delta, never the default.
 """
 import os
+import threading
 import weakref
 
 import torch
@@ -103,7 +104,21 @@ def absmax(x):
 #: :func:`prefetch_known` re-makes after an optimizer step
 _KNOWN = {}
 _WAITED = {}                # stream -> the prefetch event it has waited for last
-_PREFETCHING = [None]      # the event new cache entries carry while prefetch_known fills the caches on a side stream
+
+
+class _Prefetching(threading.local):
+    """The event new cache entries carry while :func:`prefetch_known` fills the caches on a side stream - per host thread (a model
+    per thread: another thread's ordinary cache fills must not be tagged with this thread's prefetch event)."""
+    event = None
+
+    def __getitem__(self, _):
+        return self.event
+
+    def __setitem__(self, _, value):
+        self.event = value
+
+
+_PREFETCHING = _Prefetching()
 
 
 def _cached(cache, key, p, make, limit, form=None):
@@ -141,12 +156,19 @@ def prefetch_known(device):
     has made stale: a handful of small launches (~5 us each, 45 us per step of the PIT model) that otherwise sit in front of the
     first use on the main stream, between the last recurrence and the loss."""
     todo = []
+    # only parameters the optimizer kernel behind this stream's wait has written, at the version it left them with: anything else
+    # (a parameter another writer has touched since - weight clipping, an EMA copy-in - or one this event does not cover) is packed
+    # lazily on its consumer's stream, behind its writer (ADVICE r3)
+    updated = _UPDATED.get(device)
+    covered = updated[1] if updated is not None else {}
     for pid, (ref, forms) in list(_KNOWN.items()):
         q = ref()
         if q is None:
             del _KNOWN[pid]
         elif q.device == device and q.dim() == 2:
-            todo.append((q, sorted(forms, key=str)))
+            e = covered.get(id(q))
+            if e is not None and e[0]() is q and e[1] == q._version:
+                todo.append((q, sorted(forms, key=str)))
     if not todo or _PREFETCHING[0] is not None:
         return
     ev = _PREFETCHING[0] = torch.cuda.Event()

@@ -10,6 +10,7 @@ non-fp32 / CPU tensors) this is ``module(x)``.
 """
 import torch
 
+from . import context as _context
 from . import gemm as _gemm
 from . import lstm as _lstm
 
@@ -28,11 +29,10 @@ class _LinearFn(torch.autograd.Function):
         if _gemm.planes_enabled() and x.stride(1) == 1:
             # both operands as fp16 planes (the weight's cached per optimizer step): csrc/gemm_planes.hip
             y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
-            lh = _lstm.LAST_HANDOFF
-            if (lh is not None and _lstm.INPUT_FROM_HANDOFF and lh[0].data_ptr() == x.data_ptr() and lh[0].shape == x.shape
-                    and lh[0].stride() == x.stride() and lh[1] == x._version == lh[0]._version):
+            lh = _lstm.handoff_planes_of(x) if _lstm.INPUT_FROM_HANDOFF else None
+            if lh is not None and x.is_contiguous() and x.shape[1] == lh[1] * lh[2]:
                 # x is the BLSTM output whose recurrence has left it as fp16 planes of 2^10 h: operand A as it lies
-                (scratch, cols), ndir, H = lh[2], lh[3], lh[4]
+                (scratch, cols), ndir, H = lh
                 wpl = _gemm.weight_planes_h(module.weight, ndir, H, cols)
                 kh = ndir * cols
                 torch.ops.ptmi.gemm_planes_(y, scratch, _gemm.scale_word(x.device), wpl[0], wpl[1], bias, x.shape[0], weight.shape[0], kh,
@@ -57,14 +57,15 @@ class _LinearFn(torch.autograd.Function):
                                   _gemm.weight_planes_t(mod.weight), g.shape[0], weight.shape[1], weight.shape[0])
         else:
             dx = _gemm.mm(g, weight, amax_x=amax_g, amax_y=amax_w)
-        in_place = (_lstm.DEFER_WGRAD and mod.weight.grad is not None and mod.weight.requires_grad
+        oc = _context.effective(mod)
+        in_place = (oc.defer_wgrad and mod.weight.grad is not None and mod.weight.requires_grad
                     and (not ctx.has_bias or mod.bias.grad is not None))
         if not in_place:
             dw = _gemm.mm(g.t(), x, amax_x=amax_g, amax_y=amax_x) if ctx.needs_input_grad[1] else None
             db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
             return dx, dw, db, None, None
         main = torch.cuda.current_stream(x.device)
-        side = _lstm._wgrad_stream(x.device) if _lstm.WGRAD_SIDE_STREAM else main
+        side = _lstm._wgrad_stream(x.device) if oc.wgrad_side_stream else main
         if side is not main:
             side.wait_stream(main)
         else:
@@ -81,8 +82,8 @@ class _LinearFn(torch.autograd.Function):
         if side is not main:
             for t in (g, x, amax_g) + ((amax_x,) if torch.is_tensor(amax_x) else ()):
                 t.record_stream(side)
-        if _lstm.GRAD_READY_HOOK is not None:
-            _lstm.GRAD_READY_HOOK([mod.weight] + ([mod.bias] if ctx.has_bias else []))
+        if oc.grad_ready_hook is not None:
+            oc.grad_ready_hook([mod.weight] + ([mod.bias] if ctx.has_bias else []))
         return dx, None, None, None, None
 
 
@@ -90,8 +91,14 @@ def linear(module: torch.nn.Linear, x, x_range=None):
     """``module(x)`` for a 2-D ``x``.  ``x_range=ops.gemm.UNIT_RANGE`` when ``x`` is known to lie in a range fp16
     covers without scaling (e.g. LSTM outputs); by default its maximum is measured."""
     if x.dim() == 2 and _gemm.usable(x, module.weight):
-        if (_lstm.GRAD_USE_HOOK is not None and torch.is_grad_enabled() and _lstm.DEFER_WGRAD and module.weight.requires_grad
+        oc = _context.effective(module)
+        if (oc.grad_use_hook is not None and torch.is_grad_enabled() and oc.defer_wgrad and module.weight.requires_grad
                 and module.weight.grad is not None and (module.bias is None or module.bias.grad is not None)):
-            _lstm.GRAD_USE_HOOK([module.weight] + ([module.bias] if module.bias is not None else []))
+            oc.grad_use_hook([module.weight] + ([module.bias] if module.bias is not None else []))
         return _LinearFn.apply(x, module.weight, module.bias, module, x_range)
+    if x.is_cuda:
+        from .. import _lib
+        _lib.leaving_native_path(f'a Linear({module.in_features}, {module.out_features}) layer',
+                                 'ops.gemm.ENABLED = False (library-GEMM A/B mode)' if not _gemm.ENABLED else
+                                 f'input of rank {x.dim()} / dtype {x.dtype} (2-D fp32 only)')
     return module(x)

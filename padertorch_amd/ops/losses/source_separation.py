@@ -66,6 +66,7 @@ def deep_clustering_loss(x, t):
     assert t.shape[0] == N, (x.shape, t.shape)
     if E + K > 32 or x.dtype != torch.float32:
         # wider than one 32x32 matrix-core tile: the reference's three products on the device BLAS
+        _lib.leaving_native_path('deep_clustering_loss', f'E + K = {E + K} > 32 columns' if E + K > 32 else f'dtype {x.dtype} (fp32 only)')
         t = t.to(x.dtype)
         return (torch.sum((x.t() @ x) ** 2) - 2 * torch.sum((x.t() @ t) ** 2)
                 + torch.sum((t.t() @ t) ** 2)) / N ** 2

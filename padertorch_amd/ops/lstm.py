@@ -20,6 +20,7 @@ import torch
 from torch.nn.utils.rnn import PackedSequence
 
 from .. import _lib
+from . import context as _context
 from . import gemm as _gemm
 from . import library  # noqa: F401  (registers torch.ops.ptmi.*)
 
@@ -182,8 +183,17 @@ TAIL_ON_BOTH_QUEUES = True
 FILL_IN_FORWARD = True
 #: the forward recurrence's hand-off planes as operand A of the next projection / of the dense layer behind the BLSTM (no pack pass)
 INPUT_FROM_HANDOFF = True
-#: (output tensor, its version, (scratch, cols), ndir, H) of the last packed_lstm call when its planes are valid, or None
-LAST_HANDOFF = None
+#: attribute of a packed_lstm output tensor whose recurrence has left it as hand-off planes: (version, (scratch, cols), ndir, H)
+HANDOFF_ATTR = '_ptmi_handoff_planes'
+
+
+def handoff_planes_of(x):
+    """``((scratch, cols), ndir, H)`` when ``x`` is an output tensor of :func:`packed_lstm` that still holds what its recurrence
+    wrote (same object, no in-place edit since), else ``None``."""
+    rec = getattr(x, HANDOFF_ATTR, None)
+    if rec is None or rec[0] != x._version:
+        return None
+    return rec[1:]
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
 DX_FROM_HANDOFF = True
 #: the top layer's backward recurrence in two launches for batches of at least this many packed rows (see _LstmLayerFn.backward)
@@ -200,7 +210,13 @@ _WGRAD_DONE = {}
 
 
 def _wgrad_stream(device):
-    key = (device.type, device.index)
+    """The weight-gradient side stream that belongs to the CURRENT stream of ``device``: one per (device, main stream), so that
+    two host threads that drive their own models on their own streams (reference ``trainer.py:412-420``) do not serialise on, or
+    order themselves through, one shared side queue.  (The backward pass runs on autograd's thread with the forward pass' stream
+    current, i.e. it finds the forward pass' side stream.)"""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WGRAD_STREAMS:
         _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
     return _WGRAD_STREAMS[key]
@@ -264,8 +280,12 @@ def warm_side_stream(device, nbytes=1 << 30):
 
 def sync_deferred(device=None):
     """Make the current stream wait for every deferred weight-gradient accumulation."""
-    for (typ, idx), side in _WGRAD_STREAMS.items():
-        if device is None or (torch.device(device).type, torch.device(device).index) == (typ, idx):
+    want = None
+    if device is not None:
+        device = torch.device(device)
+        want = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    for (typ, idx, _main), side in list(_WGRAD_STREAMS.items()):
+        if want is None or want == (typ, idx):
             torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(side)
 
 
@@ -465,7 +485,8 @@ class _LstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_ih, bias, w_hh, meta, h0=None, c0=None, params=None, x_unit=False, anchor=None, forms=None, prev=None,
-                handoff=None, top=False):
+                handoff=None, top=False, oc=None):
+        # oc: ops.context.Effective of the LSTM module this layer belongs to (None: the process defaults)
         # prev: {'planes': (scratch, cols)} of the layer whose output `x` is (its hand-off planes as this projection's operand);
         # handoff: dict this call leaves its own planes in
         # anchor: a Parameter of the layer when (w_ih, bias, w_hh) are the cached detached forms (`forms`), so that the
@@ -605,6 +626,7 @@ class _LstmLayerFn(torch.autograd.Function):
         ctx.params = params
         ctx.forms = forms
         ctx.top = bool(top)          # the layer whose backward pass runs first (nothing else is on the weight-gradient queue then)
+        ctx.oc = oc if oc is not None else _context.effective(None)
         if stateful:
             ctx.mark_non_differentiable(c)
             return hy, c
@@ -642,8 +664,9 @@ class _LstmLayerFn(torch.autograd.Function):
         # weight gradients accumulated in place (see DEFER_WGRAD), on the side stream where that is safe: the split GEMM
         # kernels never wait for sibling workgroups - always safe next to a persistent recurrence -, library kernels only
         # when their shape is pinned to a rocBLAS solution
-        in_place = (DEFER_WGRAD or ctx.forms is not None) and lease is None and has_grads
-        use_side = in_place and WGRAD_SIDE_STREAM and (
+        oc = ctx.oc
+        in_place = (oc.defer_wgrad or ctx.forms is not None) and lease is None and has_grads
+        use_side = in_place and oc.wgrad_side_stream and (
             gm is not None or _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
         main = torch.cuda.current_stream(x.device) if in_place else None
         side = _wgrad_stream(x.device) if use_side else main
@@ -874,18 +897,18 @@ class _LstmLayerFn(torch.autograd.Function):
                 main.wait_event(done)                          # the main queue is now behind both
                 for t in (dgplanes[(0, todo[0])][:1] if dg_t is None else (xplanes[todo[0]],)):
                     t.record_stream(side)
-                if GRAD_READY_HOOK is not None:
+                if oc.grad_ready_hook is not None:
                     side.wait_stream(main)                     # whoever orders itself after `side` sees every gradient
             if use_side:
                 for t in (x, hy) + tuple(v for v in (dg, dg_t, h0, ctx.ext, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
                         + tuple(h_prev for _, h_prev in operands[0]):
                     t.record_stream(side)           # keep the operands alive until the side stream is done
-            if GRAD_READY_HOOK is not None:
-                GRAD_READY_HOOK([p for ps in params for p in ps])
+            if oc.grad_ready_hook is not None:
+                oc.grad_ready_hook([p for ps in params for p in ps])
             gh0 = gc0 = None
             if state_grad:
                 gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
-            return (dx, None, None, None, None, gh0, gc0) + (None,) * 7
+            return (dx, None, None, None, None, gh0, gc0) + (None,) * 8
         db = dg.sum(0) if db_kernel is None else db_kernel
         if gm is not None:
             dw_ih = _gemm.mm(dg.t(), x, amax_x=amax_dg, amax_y=amax_x)
@@ -899,7 +922,7 @@ class _LstmLayerFn(torch.autograd.Function):
         gh0 = gc0 = None
         if lease is None and state_grad:
             gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
-        return (dx, dw_ih, db, dw_hh, None, gh0, gc0) + (None,) * 7
+        return (dx, dw_ih, db, dw_hh, None, gh0, gc0) + (None,) * 8
 
 
 def _state_grads(meta, dg, w_hh, carry, ndir, G, needs):
@@ -930,9 +953,25 @@ def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
     return [(dgv[:, d], hy_pad[:, d].index_select(0, prev[d])) for d in range(ndir)]
 
 
+def unsupported_reason(lstm, data):
+    """Why :func:`packed_lstm` cannot evaluate ``lstm`` on ``data`` (``None``: it can)."""
+    if not isinstance(lstm, torch.nn.LSTM):
+        return f'{type(lstm).__name__} is not a torch.nn.LSTM'
+    if lstm.hidden_size % 4 != 0:
+        return f'hidden_size {lstm.hidden_size} is not a multiple of 4'
+    if lstm.proj_size != 0:
+        return 'proj_size != 0'
+    if not lstm.bias:
+        return 'bias=False'
+    if not data.is_cuda:
+        return 'the input is not on the GPU'
+    if data.dtype != torch.float32:
+        return f'input dtype {data.dtype} (fp32 only)'
+    return None
+
+
 def supported(lstm, data):
-    return (isinstance(lstm, torch.nn.LSTM) and lstm.hidden_size % 4 == 0 and lstm.proj_size == 0
-            and lstm.bias and data.is_cuda and data.dtype == torch.float32)
+    return unsupported_reason(lstm, data) is None
 
 
 def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False, input_planes=None):
@@ -953,6 +992,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             'packed_lstm needs an fp32 torch.nn.LSTM with bias, proj_size=0 and hidden_size % 4 == 0')
     assert packed.sorted_indices is None, 'sequences must be sorted by length (enforce_sorted=True)'
     training = lstm.training if training is None else training
+    oc = _context.effective(lstm)
     meta = pack_meta(packed.batch_sizes, data.device)
     sfx = ['', '_reverse'] if lstm.bidirectional else ['']
     ndir, H = len(sfx), lstm.hidden_size
@@ -969,7 +1009,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     if (CACHE_STACKED_WEIGHTS and data.is_cuda and any(_stacked_stale(ps_) for ps_ in all_params)
             and all(p.is_cuda and p.dtype == torch.float32 for p in flat_params)
             and (not (torch.is_grad_enabled() and any(p.requires_grad for p in flat_params))
-                 or (DEFER_WGRAD and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for p in flat_params)))):
+                 or (oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for p in flat_params)))):
         # after an optimizer step: the operand forms of ALL layers on a side stream, next to whatever the main stream is
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
         pre = _prep_stream(data.device)
@@ -993,7 +1033,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
         # runs on the cached stacked / padded / transposed forms of its parameters
         graph = torch.is_grad_enabled() and any(p.requires_grad for ps in params for p in ps)
-        in_place = DEFER_WGRAD and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for ps in params for p in ps)
+        in_place = oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for ps in params for p in ps)
         forms = anchor = None
         if CACHE_STACKED_WEIGHTS and data.is_cuda and (not graph or in_place):
             forms = _stacked_weights(params, (H + 15) // 16 * 16)
@@ -1009,21 +1049,21 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
             sl = slice(layer * ndir, (layer + 1) * ndir)
             h0 = hx[0][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
             c0 = hx[1][sl] if hx is not None else data.new_zeros(ndir, meta.max_batch, H)
-            if GRAD_USE_HOOK is not None and graph and in_place:
-                GRAD_USE_HOOK([p for ps in params for p in ps])
-            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0, anchor, forms)
+            if oc.grad_use_hook is not None and graph and in_place:
+                oc.grad_use_hook([p for ps in params for p in ps])
+            h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0, anchor, forms, None, None, False, oc)
             prev_handoff = None
             hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
             h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:
             out_handoff = {}
-            if GRAD_USE_HOOK is not None and graph and in_place:
-                GRAD_USE_HOOK([p for ps in params for p in ps])
+            if oc.grad_use_hook is not None and graph and in_place:
+                oc.grad_use_hook([p for ps in params for p in ps])
             if layer == 0 and input_planes is not None and prev_handoff is None:
                 prev_handoff = {'xplanes': input_planes}
             h = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, None, None, params, layer > 0, anchor, forms, prev_handoff, out_handoff,
-                                   layer + 1 == lstm.num_layers)
+                                   layer + 1 == lstm.num_layers, oc)
             prev_handoff = out_handoff
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
@@ -1032,14 +1072,11 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # inference: nobody will run Trainer.clip_grad (which reads the watchdog words of the persistent kernels during
         # training) - check them here, so that results of a timed-out launch are never returned silently
         check_errors()
-    global LAST_HANDOFF
-    LAST_HANDOFF = None
     if prev_handoff and prev_handoff.get('planes') is not None:
-        # (ops.linear takes these planes as operand A when its input is this very tensor)
-        # (the tensor itself is held: its memory cannot be handed to another tensor while the entry could still match)
-        # (detached: the entry must not keep this step's autograd graph - every layer's context with its operand forms and
-        # scratch - alive until the next forward pass lets go of it in the middle of its critical path)
-        LAST_HANDOFF = (h.detach(), h._version, prev_handoff['planes'], ndir, H)
+        # the recurrence has left this very tensor as fp16 planes too: ops.linear takes them as operand A when it is handed the SAME
+        # tensor object, unmodified (the record travels WITH the tensor - until round 3 it was a process global naming "the last
+        # call's output", a side channel between two ops that two models or two host threads would have shared)
+        setattr(h, HANDOFF_ATTR, (h._version, prev_handoff['planes'], ndir, H))
     out = PackedSequence(h, packed.batch_sizes)
     if want_state:
         return out, (torch.stack(h_n), torch.stack(c_n))

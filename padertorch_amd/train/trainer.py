@@ -192,6 +192,10 @@ class Trainer:
         #: micro-step of the optimizer step are complete, under the rest of the backward pass (False: one all-reduce
         #: of the whole flat buffer in optimizer_step)
         self.overlap_allreduce = overlap_allreduce
+        #: this Trainer's switches / hooks of the in-place weight-gradient path, attached to every module of its model
+        #: (ops.context): nothing process-global is set or reset around train()
+        from ..ops import context as _context
+        self.op_context = _context.attach(self.model, _context.OpContext())
         self._buckets = None
         self._pending = []           # [(what, event, host tensor, context, optimizer step)]
         self._stage_queue = []       # staged scalars whose copies are not enqueued yet (_flush_stage)
@@ -265,9 +269,12 @@ class Trainer:
             self._broadcast_parameters()
         self.optimizer.zero_grad()
         from ..ops import lstm as _lstm
-        defer_before = _lstm.DEFER_WGRAD
-        _lstm.DEFER_WGRAD = bool(self.overlap_wgrad) and self._flat.flat.is_cuda
-        if _lstm.DEFER_WGRAD:
+        # this model's own switches and hooks (ops.context): another Trainer in the same process - a second model trained
+        # alternately, an EMA / validation copy, a model per host thread - has its own
+        oc = self.op_context
+        defer_before = oc.defer_wgrad
+        oc.defer_wgrad = bool(self.overlap_wgrad) and self._flat.flat.is_cuda
+        if oc.defer_wgrad:
             _lstm.warm_side_stream(self._flat.flat.device)
         hooks = self.enable_bucketed_allreduce()
 
@@ -320,11 +327,11 @@ class Trainer:
         finally:
             for h in hooks:
                 h.remove()
-            _lstm.GRAD_READY_HOOK = None
-            _lstm.GRAD_USE_HOOK = None
+            oc.grad_ready_hook = None
+            oc.grad_use_hook = None
             self._buckets = None
             _lstm.sync_deferred()
-            _lstm.DEFER_WGRAD = defer_before
+            oc.defer_wgrad = defer_before
             opt = self.optimizer.optimizer
             if getattr(opt, 'found_inf', None) is not None:
                 opt.found_inf = None
@@ -662,8 +669,8 @@ class Trainer:
         def on_grad(p):
             buckets.ready((p,), side)
 
-        _lstm.GRAD_READY_HOOK = lambda params: buckets.ready(params, side)
-        _lstm.GRAD_USE_HOOK = buckets.expect
+        self.op_context.grad_ready_hook = lambda params: buckets.ready(params, side)
+        self.op_context.grad_use_hook = buckets.expect
         return [p.register_post_accumulate_grad_hook(on_grad) for p in self._flat.params]
 
     def _all_ranks_finite(self, mine):

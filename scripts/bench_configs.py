@@ -14,7 +14,8 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch  # noqa: E402
 
 import padertorch_amd as pt  # noqa: E402
-from padertorch_amd import tuning  # noqa: E402
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import library_gemm_tuning as tuning  # noqa: E402  (A/B tooling outside the package)
 from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel  # noqa: E402
 from padertorch_amd.contrib.tcl.dc import DeepClusteringModel  # noqa: E402
 

@@ -3,7 +3,8 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
 import torch.cuda.tunable as tunable
-from padertorch_amd import tuning
+import sys; from pathlib import Path; sys.path.insert(0, str(Path(__file__).resolve().parent))
+import library_gemm_tuning as tuning
 dev = torch.device('cuda:0')
 x = torch.randn(8096, 1200, device=dev)
 lin = torch.nn.Linear(1200, 4800).to(dev)

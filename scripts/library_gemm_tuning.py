@@ -1,4 +1,5 @@
-"""GEMM solution selection for the dense layers around the HIP kernels.
+"""A/B tooling, NOT part of the package (moved out of padertorch_amd/ in round 4): GEMM solution selection for the round-1 route of
+the dense layers through the BLAS library (``bench.py --library-gemms``, ``padertorch_amd.ops.gemm.ENABLED = False``).
 
 The input-projection / linear / weight-gradient GEMMs run in rocBLAS / hipBLASLt through torch
 (DESIGN.md section 3.5).  Their default heuristics pick fp32 kernels that reach 65-70 % of the fp32 MFMA
@@ -6,7 +7,7 @@ peak at the PIT shapes; PyTorch's TunableOp finds solutions at 85-91 % (one-off 
 This module applies a committed result file for the benchmark shapes and offers the online search
 for other shapes.  Nothing here changes what is computed - only which library kernel computes it.
 
-    from padertorch_amd import tuning
+    from scripts import library_gemm_tuning as tuning
     tuning.use_tuned_gemms()                 # committed selections for the PIT shapes (ignored, with
                                              # a warning from TunableOp, when the library versions differ)
     tuning.use_tuned_gemms(search=True)      # additionally search new shapes on first use

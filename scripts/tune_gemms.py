@@ -4,7 +4,7 @@
     python scripts/tune_gemms.py gpurun_out/tune/gfx950.csv
 
 Starts from the committed selections, runs a few optimizer steps of every configuration with the
-search enabled and writes the merged result file (commit it as padertorch_amd/tuned/<name>.csv).
+search enabled and writes the merged result file (commit it as scripts/tuned/<name>.csv).
 """
 import os
 import sys

@@ -15,6 +15,24 @@ GOLDEN = Path(__file__).resolve().parent / 'golden'
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run through gpurun)')
+    config.addinivalue_line('markers', 'library_path: the test drives a torch / library path on purpose (A/B against the HIP kernels)')
+
+
+@pytest.fixture(autouse=True)
+def _native_path_only(request):
+    """GPU tests run STRICT: a model or op that would leave the hand-written HIP path (an LSTM the recurrence kernels do not
+    cover, a dense layer on the BLAS library, ...) raises instead of falling back (padertorch_amd._lib.leaving_native_path) -
+    unless the test says it compares against such a path on purpose (``@pytest.mark.library_path``)."""
+    if 'gpu' not in request.keywords or 'library_path' in request.keywords:
+        yield
+        return
+    from padertorch_amd import _lib
+    before = _lib.STRICT
+    _lib.STRICT = True
+    try:
+        yield
+    finally:
+        _lib.STRICT = before
 
 
 def pytest_collection_modifyitems(config, items):

@@ -83,6 +83,7 @@ def test_graph_plan_path_matches_eager_and_reference(monkeypatch):
     assert all(not ws.busy for ws in L._POOL[key][1])
 
 
+@pytest.mark.library_path
 def test_model_uses_hip_lstm_and_matches_library_lstm():
     """Same weights, HIP recurrence vs torch.nn.LSTM (MIOpen) inside the PIT model."""
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel

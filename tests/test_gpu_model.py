@@ -407,3 +407,74 @@ def test_device_prefetcher_overlaps_and_preserves_batches():
         z = ex['y'] * 2 + 1                       # consumer work on the current stream
         seen.append((ex['tag'], float(z.min()), float(z.max())))
     assert seen == [(i, 2.0 * i + 1, 2.0 * i + 1) for i in range(6)]
+
+
+@pytest.mark.gpu
+def test_config4_size_step_on_the_rccl_path_next_to_a_cu_occupying_kernel(tmp_path):
+    """Pre-flight of BASELINE configs[3] for the first real 8-GPU run, as far as ONE GPU can take it: the full
+    model (3 x BLSTM-600) at the full per-GPU batch (64 x 4 s @ 16 kHz), 4 micro-steps per optimizer step, process group 'nccl'
+    (world size 1), layer buckets all-reduced under the last micro-step's backward pass - while a third queue keeps 256 workgroups
+    resident in 1.5 ms pieces (the stand-in for RCCL's channel kernels, which hold CUs beside the persistent recurrence launches).
+    Two optimizer steps: no recurrence watchdog timeout, finite losses, every bucket reduced once per step, parameters moved."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import padertorch_amd as pt
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import lstm as L
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    lib = _lib.load()
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        torch.manual_seed(4)
+        model = PermutationInvariantTrainingModel()
+        t = pt.Trainer(model, tmp_path / 'c4', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.),
+                       virtual_minibatch_size=4, overlap_allreduce=True, deferred_checks=True)
+        t.to(torch.device(DEV))
+        t._flat = t.optimizer.use_flat_grads()
+        hooks = t.enable_bucketed_allreduce()
+        buckets = t._buckets
+        assert buckets is not None and len(buckets.buckets) >= 4
+        model.train()
+        t.op_context.defer_wgrad = True          # what Trainer.train() sets
+        L.warm_side_stream(torch.device(DEV))
+        g = torch.Generator().manual_seed(0)
+        y = (0.1 * torch.randn(64, 64000, generator=g)).to(DEV)
+        s_ = (0.1 * torch.randn(64, 2, 64000, generator=g)).to(DEV)
+        before = model.linear2.weight.detach().clone()
+        issued = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda tensor, *a, **k: (issued.append(tensor.numel()), real(tensor, *a, **k))[1]
+        occupy = torch.cuda.Stream()
+        losses = []
+        try:
+            for step in range(2):
+                with torch.cuda.stream(occupy):
+                    for _ in range(80):          # ~120 ms of occupancy: covers the optimizer step's four micro-steps
+                        _lib.check(lib.ptmi_debug_occupy(256, 256, 0, 150000, _lib.stream(torch.device(DEV))), 'occupy')
+                for m in range(4):
+                    buckets.active = m == 3
+                    feats = pt.ops.pit_features(y, s_)
+                    loss, _, _, _ = t.train_step(model, feats, torch.device(DEV))
+                    loss.backward()
+                    losses.append(loss.detach())
+                t.optimizer_step()
+            t._check_pending(flush=True)             # raises on a timed-out recurrence launch or a non-finite step
+            torch.cuda.synchronize()
+        finally:
+            dist.all_reduce = real
+            for h in hooks:
+                h.remove()
+        L.check_errors()
+        assert L.DEFER_WGRAD is False and L.GRAD_READY_HOOK is None and L.GRAD_USE_HOOK is None      # nothing process-global was touched
+        assert all(bool(torch.isfinite(v)) for v in losses)
+        nflat = t._flat.flat.numel()
+        big = [n for n in issued if n > 8]
+        assert sum(big) == 2 * nflat and len(big) == 2 * len(buckets.buckets), (big, nflat)
+        assert float((model.linear2.weight.detach() - before).abs().max()) > 0.
+    finally:
+        dist.destroy_process_group()
