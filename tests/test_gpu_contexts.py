@@ -84,14 +84,16 @@ def test_two_host_threads_on_two_streams_equal_the_single_model_runs(tmp_path):
     ref = {k: _alone(k, tmp_path) for k in 'ab'}
     out, errors = {}, []
     barrier = threading.Barrier(2)
+    build = threading.Lock()             # torch's global RNG seeds the models: one construction at a time
 
     def work(kind):
         try:
             torch.cuda.set_device(DEV)
             stream = torch.cuda.Stream()
             with torch.cuda.stream(stream):
-                t, batch = _make(kind, tmp_path, 'thr')
-                L.warm_side_stream(DEV)              # this stream's own weight-gradient side stream
+                with build:
+                    t, batch = _make(kind, tmp_path, 'thr')
+                    L.warm_side_stream(DEV)          # this stream's own weight-gradient side stream
                 barrier.wait()
                 losses = []
                 for _ in range(3):
