@@ -285,6 +285,24 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
  *   dgates     may be NULL when dgates_t is given (the hand-off copy in `flags` still serves dx = dgates W_ih)
  * Only for batches of equal-length sequences whose size is a multiple of 16 on the split kernels:
  * ptmi_lstm_backward_planes_ok(...) != 0; PTMI_E_UNSUPPORTED otherwise. */
+/* Row-slot batches: several sequences lie END TO END in one row slot, so that every one of the (at most 64) row slots works in
+ * (nearly) every time step - a recurrence costs its number of steps, whatever the number of rows up to 32 (64) per step, so a ragged
+ * batch packed this way takes total frames / slots steps instead of the longest sequence's.  Layout: uniform, row(t, slot) = t *
+ * max_batch + slot, every such row exists in all buffers; step_masks [T][3] uint64 (device): rows alive at time index t, rows whose
+ * sequence STARTS at t, rows whose sequence ENDS at t (bit b = slot b).  A sequence start resets (h, c) to zero in the forward
+ * direction, a sequence end in the reverse direction; idle rows are neither computed nor handed on (hy / c of idle rows are not
+ * written: hand in zeroed buffers; their gate gradients come out as zeros).  Same results per sequence as one sequence per row
+ * (torch.nn.LSTM on a PackedSequence, pit/model.py:60-66,97).  Data-as-flag split kernels only (PTMI_E_UNSUPPORTED otherwise); no
+ * initial states. */
+int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
+                                       const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                       const uint64_t* step_masks, uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows,
+                                       int32_t H, int32_t KP, int32_t ndir, int32_t prefilled, uint32_t* backward_scratch,
+                                       ptmi_stream_t stream);
+int ptmi_lstm_backward_persistent_slots(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
+                                        const int32_t* batch_sizes_dev, const int64_t* offsets_dev, const uint64_t* step_masks,
+                                        uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir,
+                                        int32_t prefilled, ptmi_stream_t stream);
 int32_t ptmi_lstm_backward_planes_ok(int32_t T, int32_t ndir, int32_t max_batch, int64_t rows, int32_t H);
 int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, const float* c0, const float* dhy,
                                          const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,

@@ -34,6 +34,10 @@ class PermutationInvariantTrainingModel(base.Model):
     """
     #: run the BLSTM time recurrence in the hand-written HIP kernels (False: torch.nn.LSTM / MIOpen)
     hip_blstm = True
+    #: ragged batches on the GPU: place the examples END TO END into this many row slots (16 / 32 / 64; ops.sequence.SlotLayout) so that
+    #: the recurrences run ~ sum(frames) / row_slots steps instead of the longest example's - worth it when the batch has more
+    #: examples than slots (the data pipeline forms batches of ~1.4 x row_slots examples of the U[3 s, 6 s] distribution); None: off
+    row_slots = None
 
     def __init__(
             self,
@@ -89,6 +93,10 @@ class PermutationInvariantTrainingModel(base.Model):
         Returns: List of mask tensors, each list element has shape (T, K, F)
         """
         batch = self.prepare_batch(batch)
+        if self.row_slots and self.hip_blstm:
+            out = self._forward_row_slots(batch['Y_abs'])
+            if out is not None:
+                return out
         packed = getattr(batch['Y_abs'], 'packed_log1p', None)
         if packed is not None and not packed.matches(batch['Y_abs']):
             packed = None             # the list was edited since the feature kernel wrote its log-magnitudes: recompute from it
@@ -129,6 +137,25 @@ class PermutationInvariantTrainingModel(base.Model):
 
         mask = PackedSequence(h_data.view(-1, self.K, self.F), h.batch_sizes)  # 'tb (k f) -> tb k f'
         return ops.unpack_sequence(mask)
+
+    def _forward_row_slots(self, Y_abs):
+        """``forward`` for a ragged batch on the row-slot layout (``row_slots``): the same network, rows = [T, slots] with the
+        examples end to end in the slots; returns the masks as a batch-major :class:`PaddedList` (what ``review`` consumes), or
+        ``None`` when the layout does not apply (CPU tensors, equal lengths, an LSTM the kernels do not cover)."""
+        padded, lengths, lengths_dev = as_padded(Y_abs)                          # [B, T_max, F], zero padded
+        if not padded.is_cuda or len(set(lengths)) == 1 or ops.lstm.unsupported_reason(self.blstm, padded) is not None:
+            return None
+        layout = ops.sequence.SlotLayout.cached(tuple(lengths), int(self.row_slots), padded.device)
+        F = padded.shape[-1]
+        assert F == self.F, f'self.F = {self.F} != F = {F}'
+        x = ops.sequence.log1p(self.dropout_input(layout.scatter_rows(padded)))   # log1p(0) = 0: idle rows stay zero
+        T, S = layout.T, layout.slots
+        h = ops.packed_lstm(self.blstm, PackedSequence(x, torch.full((T,), S, dtype=torch.int64)), meta=layout.meta).data
+        h = self.dropout_linear(h)
+        h = self.relu(ops.linear.linear(self.linear1, h, ops.gemm.UNIT_RANGE))
+        h = self.output_activation(ops.linear.linear(self.linear2, h))
+        masks = layout.gather_rows(h.view(-1, self.K, self.F), padded.shape[1])   # 'tb (k f) -> tb k f', back to one example per row
+        return PaddedList(masks, lengths, True, lengths_dev)
 
     @torch.no_grad()
     def separate(self, y, num_samples=None, stft=None):

@@ -848,6 +848,12 @@ static unsigned* error_sink() {
     return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) ? g_error_sink[dev] : nullptr;
 }
 
+static int lstm_backward_persistent_impl(const float* gates, const float* c, const float* c0, const float* dhy,
+                                         const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
+                                         const int64_t* offsets_dev, const uint64_t* step_masks, uint32_t* flags, float* dc_carry,
+                                         int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
+                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream);
+
 extern "C" {
 
 int ptmi_lstm_forward(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad, const int32_t* batch_sizes,
@@ -975,7 +981,18 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                                  const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                  uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t KP,
                                  int32_t ndir, int32_t prefilled, uint32_t* backward_scratch, ptmi_stream_t stream) {
+    return ptmi_lstm_forward_persistent_slots(gates, hy, c, c0, w_hh_pad, w_hh_amax, batch_sizes_dev, offsets_dev, nullptr, flags, T,
+                                              max_batch, rows, H, KP, ndir, prefilled, backward_scratch, stream);
+}
+
+int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
+                                       const uint32_t* w_hh_amax, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                       const uint64_t* step_masks, uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows,
+                                       int32_t H, int32_t KP, int32_t ndir, int32_t prefilled, uint32_t* backward_scratch,
+                                       ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !hy || !c || !w_hh_pad || !batch_sizes_dev || !offsets_dev || !flags, PTMI_E_INVALID);
+    // row slots: every (time index, slot) row exists in the buffers; at most 64 slots (one mask word per step and kind)
+    PTMI_RETURN_IF(step_masks && (rows != (int64_t)T * max_batch || max_batch > 64 || c0), PTMI_E_UNSUPPORTED);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
     constexpr int NW = 8, CH = 5;
@@ -1009,6 +1026,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
     float* const hyt = reinterpret_cast<float*>(flags);
     flags += lstm_tile_elems(T, ndir, max_batch, KP32);
     const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
+    PTMI_RETURN_IF(step_masks && !daf, PTMI_E_UNSUPPORTED);          // the data-as-flag kernels carry the row masks
     if (daf && !prefilled) {        // every 16-bit value of the planes = 0xFFFF (no value can be), the counters behind them zero: one launch
         int fe = daf_prefill_and_zero(hyt, (size_t)lstm_tile_elems(T, ndir, max_batch, KP32), flags, (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
         if (fe) return fe;
@@ -1023,6 +1041,7 @@ int ptmi_lstm_forward_persistent(float* gates, float* hy, float* c, const float*
                       w_hh_amax, KP32};
     A.err_sink = error_sink();
     A.uniform = (rows == (int64_t)T * max_batch) ? 1 : 0;      // batch sizes never grow: equal lengths
+    A.masks = reinterpret_cast<const unsigned long long*>(step_masks);
     if (backward_scratch && ptmi_lstm_forward_fills(T, ndir, max_batch, H)) {     // this layer's backward planes get their pattern here
         const int G32 = (4 * H + 31) / 32 * 32;
         A.fill_ptr = reinterpret_cast<uint4*>(backward_scratch);
@@ -1108,6 +1127,27 @@ int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, con
                                          const int64_t* offsets_dev, uint32_t* flags, float* dc_carry, int32_t T,
                                          int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin, int32_t s_end,
                                          int32_t prefilled, ptmi_stream_t stream) {
+    return lstm_backward_persistent_impl(gates, c, c0, dhy, w_hh_t, dgates, dgates_t, batch_sizes_dev, offsets_dev, nullptr, flags, dc_carry,
+                                         T, max_batch, rows, H, ndir, s_begin, s_end, prefilled, stream);
+}
+
+int ptmi_lstm_backward_persistent_slots(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
+                                        const int32_t* batch_sizes_dev, const int64_t* offsets_dev, const uint64_t* step_masks,
+                                        uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir,
+                                        int32_t prefilled, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!step_masks || !dgates, PTMI_E_INVALID);
+    PTMI_RETURN_IF(rows != (int64_t)T * max_batch || max_batch > 64, PTMI_E_UNSUPPORTED);
+    return lstm_backward_persistent_impl(gates, c, nullptr, dhy, w_hh_t, dgates, nullptr, batch_sizes_dev, offsets_dev, step_masks, flags,
+                                         nullptr, T, max_batch, rows, H, ndir, 0, T, prefilled, stream);
+}
+
+}  // extern "C"
+
+static int lstm_backward_persistent_impl(const float* gates, const float* c, const float* c0, const float* dhy,
+                                         const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
+                                         const int64_t* offsets_dev, const uint64_t* step_masks, uint32_t* flags, float* dc_carry,
+                                         int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
+                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream) {
     PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || (!dgates && !dgates_t) || !batch_sizes_dev || !offsets_dev || !flags,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(dgates_t && (reinterpret_cast<uintptr_t>(dgates_t) & 15) != 0, PTMI_E_INVALID);
@@ -1160,6 +1200,8 @@ int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, con
                          split ? dg_amax : nullptr, G32};
     A.err_sink = error_sink();
     A.uniform = (rows == (int64_t)T * max_batch) ? 1 : 0;
+    A.masks = reinterpret_cast<const unsigned long long*>(step_masks);
+    PTMI_RETURN_IF(step_masks && !(split && bwd_daf_applies()), PTMI_E_UNSUPPORTED);
     A.s_begin = s_begin;
     A.s_end = s_end;
     A.dc_carry = dc_carry;
@@ -1204,6 +1246,8 @@ int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, con
     }
     return PTMI_OK;
 }
+
+extern "C" {
 
 int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float* c, const float* w_hh_pad,
                           const float* dhy, const float* w_hh_t, float* dgates, float* dc_state,

@@ -48,6 +48,11 @@ struct LstmPersistArgs {
     // scratch) get the fill pattern from an otherwise idle wavefront, a slice per workgroup and step
     uint4* fill_ptr = nullptr;
     unsigned long long fill_n16 = 0;
+    // Row-slot batches (data-as-flag kernels; layout = uniform [T][max_batch] rows, max_batch <= 64 slots): several sequences lie END TO
+    // END in one row slot, so "row b is alive at step t" and "row b has a predecessor" are no prefix rules any more.  masks[3 t + 0]
+    // = rows alive at time index t, + 1 = rows whose sequence STARTS at t (no predecessor in the forward direction), + 2 = rows whose
+    // sequence ENDS at t (no predecessor in the reverse direction); bit b = row b.  Null: the PackedSequence rules (bs / offs).
+    const unsigned long long* masks = nullptr;
 };
 
 // Hand-off flags: every workgroup of a chain owns ONE slot and stores the number of steps it has
@@ -118,6 +123,7 @@ struct LstmPersistBwdArgs {
     long long tp_dir_stride = 0;      // chunks per direction
     int tp_kb = 0;                    // k blocks (32 packed rows) per column tile
     long long tp_row0[2] = {0, 0};    // first packed row of this launch's step range per direction: the planes' k index 0
+    const unsigned long long* masks = nullptr;      // row-slot batches: as in LstmPersistArgs
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)

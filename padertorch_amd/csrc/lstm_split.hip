@@ -452,6 +452,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     const bool uniform = A.uniform != 0;
     auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
     auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
+    // row-slot batches: per-step row masks instead of the prefix rules "b < bs[t]" / "b < bs[t -+ 1]" (LstmPersistArgs::masks)
+    const bool masked = A.masks != nullptr;
+    typedef unsigned long long u64;
+    auto alive_at = [&](int t) -> u64 { return masked ? A.masks[3 * t] : ~0ull; };
+    auto bit = [](u64 m, int i) { return ((m >> (i & 63)) & 1ull) != 0ull; };
     const int nblk = A.KP32 >> 5;
     const int base = nblk / NW, extra = nblk - base * NW;
     const int kb0 = __builtin_amdgcn_readfirstlane(wave * base + min(wave, extra));
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     float c_reg = 0.f;
     {
         const int t0 = dir == 0 ? 0 : A.T - 1;
-        if (tid < MR * JT && b < bs_at(t0) && j0 + u < H) {
+        if (tid < MR * JT && b < bs_at(t0) && bit(alive_at(t0), b) && j0 + u < H) {
             const float* np = A.gx + (offs_at(t0) + b) * ld_g + (long long)dir * G + j0 + u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
@@ -516,18 +521,23 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
         const long long row0 = offs_at(t);
         const int tp = dir == 0 ? t - 1 : t + 1;
         const int nprev = (tp >= 0 && tp < A.T) ? min(bs_at(tp), nb) : 0;
-        const bool has_rec = nprev > m0;
-        const bool act = tid < MR * JT && b < nb && j0 + u < H;
+        // rows of this step that continue a sequence (their hidden / cell state of the previous step counts)
+        const u64 amask = alive_at(t);
+        const u64 pmask = masked ? ((tp >= 0 && tp < A.T) ? amask & ~A.masks[3 * t + (dir == 0 ? 1 : 2)] : 0ull) : ~0ull;
+        auto has_pred = [&](int row) { return row < nprev && bit(pmask, row); };
+        const bool has_rec = masked ? ((pmask >> m0) & ((1ull << MR) - 1ull)) != 0ull : nprev > m0;
+        const bool act = tid < MR * JT && b < nb && bit(amask, b) && j0 + u < H;
         float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
         float cprev = 0.f;
         float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
-        if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
+        if (act && !has_pred(b) && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
         const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
         const bool more = s + 1 < A.T;
         const int nb1 = more ? bs_at(t1) : 0;
         const long long row1 = more ? offs_at(t1) : 0;
+        const u64 amask1 = more ? alive_at(t1) : 0ull;
         auto prefetch = [&]() {
-            if (tid < MR * JT && b < nb1 && j0 + u < H) {
+            if (tid < MR * JT && b < nb1 && bit(amask1, b) && j0 + u < H) {
                 const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
@@ -538,15 +548,15 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             fill_some(s + 1 == A.T);
         }
         if (has_rec) {
-            if (act && b < nprev) cprev = c_reg;
+            if (act && has_pred(b)) cprev = c_reg;
             constexpr int NF = MTL * CB * 2;                 // fragments: (row tile mt, k block i, plane p)
             const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
                 A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
             const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
                 A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
             const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
-            const unsigned vb0 = m0 + r < nprev ? vin : 0x80000000u;
-            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev) ? vin : 0x80000000u;
+            const unsigned vb0 = has_pred(m0 + r) ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && has_pred(m0 + 16 + r)) ? vin : 0x80000000u;
             uint4 a[NF];
             if (!(A.dbg & 8192)) dd.wait();
             unsigned polls = 0;
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             const int pw2 = (A.KP32 - H) >> 1;
             for (int e = tid; e < MR * pw2 * 2 && tid < ACTW * 64; e += ACTW * 64) {
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = H + 2 * (rem - plane * pw2);
-                if (m0 + rl < nb) {
+                if (m0 + rl < nb && bit(amask, m0 + rl)) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
                     __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -699,6 +709,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const bool uniform = UNI || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
     auto bs_at = [&](int t) { if (UNI) return A.max_batch; return uniform ? A.max_batch : A.bs[t]; };
     auto offs_at = [&](int t) { if (UNI) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
+    // row-slot batches (LstmPersistBwdArgs::masks; not in the UNI instantiations): per-step row masks instead of the prefix rules
+    typedef unsigned long long u64;
+    const bool masked = !UNI && A.masks != nullptr;
+    auto bit = [](u64 m, int i) { return ((m >> (i & 63)) & 1ull) != 0ull; };
 
     const int nblk = A.G32 >> 5;
     const int base = nblk / NW, extra = nblk - base * NW;
@@ -767,8 +781,19 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             nb_f = bs_at(t2);
             row_f = offs_at(t2);
         }
-        const bool has_rec = nnext > m0;
-        const bool act = tid < 16 * MR && b < nb && j < H;
+        // masks of this step: rows alive; rows whose NEXT processed... whose previously processed step (time index tn) belongs to the
+        // same sequence (its gate gradients reach this step through W_hh; the cell-state gradient carries over); rows whose cell
+        // state c_{t-1} (forward sense of this direction) exists
+        u64 amask = ~0ull, smask = ~0ull, cmask = ~0ull;
+        if (masked) {
+            amask = A.masks[3 * t];
+            const bool tn_ok = tn >= 0 && tn < A.T;
+            smask = tn_ok ? A.masks[3 * tn] & ~A.masks[3 * tn + (dir == 0 ? 1 : 2)] : 0ull;
+            cmask = amask & ~A.masks[3 * t + (dir == 0 ? 1 : 2)];
+        }
+        auto has_succ = [&](int row) { return row < nnext && bit(smask, row); };
+        const bool has_rec = masked ? ((smask >> m0) & ((1ull << MR) - 1ull)) != 0ull && nnext > m0 : nnext > m0;
+        const bool act = tid < 16 * MR && b < nb && bit(amask, b) && j < H;
         // The saved activations of this thread's element: UNCONDITIONAL loads from clamped addresses in the wavefronts that own
         // elements (a wave-uniform branch).  With `if (act) x = load` the compiler zero-initialises the destination registers at
         // the loop head and, to protect them, waits there for every memory operation of the previous step (s_waitcnt
@@ -792,7 +817,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                         // where it brings the wait back)
             asm volatile("" : "=v"(dh), "=v"(ig), "=v"(fg), "=v"(gg), "=v"(og), "=v"(cn), "=v"(cprev));
         }
-        const bool has_prev_c = b < npv;
+        const bool has_prev_c = b < npv && bit(cmask, b);
         float c0v = 0.f;
         if (A.c0 && act && !has_prev_c) c0v = A.c0[((long long)dir * A.max_batch + b) * H + j];
         if (!DAF && has_rec) {
@@ -865,8 +890,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, A.G32 * 64, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(tbase + (MTL > 1 ? (size_t)A.ndir * tile_elems : 0)), 0, A.G32 * 64, 0x00020000);
-            const unsigned vb0 = m0 + r < nnext ? vin : 0x80000000u;
-            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nnext) ? vin : 0x80000000u;
+            const unsigned vb0 = has_succ(m0 + r) ? vin : 0x80000000u;
+            const unsigned vb1 = (MTL > 1 && has_succ(m0 + 16 + r)) ? vin : 0x80000000u;
             constexpr int NB = MTL * CB;
             constexpr int CAB = CABW < NB ? CABW : NB;
             constexpr int NP = (NB + CAB - 1) / CAB;
@@ -934,7 +959,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                 for (int q = 0; q < 4; ++q) red[s & 1][wave][mt * 16 + g4 * 4 + q][r] = (acc3[mt][0][q] + acc3[mt][1][q]) + acc3[mt][2][q];
             __syncthreads();
             dd.mark();
-            if (tid < 16 * MR && b < nnext) {
+            if (tid < 16 * MR && has_succ(b)) {
                 float sum = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) sum += red[s & 1][w][bl_][jl];
@@ -947,7 +972,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         }
         float gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f;
         if (act) {
-            float dc = b < nnext ? dc_state : 0.f;
+            float dc = has_succ(b) ? dc_state : 0.f;
             const float tc = tanhf_(cn);
             const float d_o = dh * tc;
             dc += dh * og * (1.f - tc * tc);
@@ -996,7 +1021,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const int pw2 = (A.G32 - G) >> 1;
             for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = G + 2 * (rem - plane * pw2);
-                if (m0 + rl < nb) {
+                if (m0 + rl < nb && bit(amask, m0 + rl)) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
                     __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -1008,6 +1033,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             __syncthreads();
             if (tid == 0)
                 __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (masked && !act && tid < 16 * MR && b < nb && j < H) {       // a slot's idle step: its row exists in the buffers - zeros
+            float* dgp = A.dg + og_;
+            dgp[0] = dgp[H] = dgp[2 * H] = dgp[3 * H] = 0.f;
         }
         if (act && (!TP || A.dg)) {                   // row-major dgates (what the GEMMs read): nobody in this launch waits for them
             float* dgp = A.dg + og_;
@@ -1082,7 +1111,7 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
     // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
-    const bool uni = A.uniform != 0;
+    const bool uni = A.uniform != 0 && !A.masks;         // (row-slot batches: the instantiation that reads the per-step masks)
     if (A.dgtp) {          // + dgates^T as bf16 planes (host checked: equal lengths, batch a multiple of 16)
         if (mtl == 2)
             hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true, true>), dim3(nwg), dim3(512), 0, st, A);

@@ -403,9 +403,9 @@ def unit_norm_backward(gy, y, inv, eps):
 # ------------------------------------------------------------------------------------------------ (B)LSTM recurrence
 @_register('lstm_recurrence_forward(Tensor(a!) gates, Tensor(b!) hy, Tensor? c0, Tensor w_hh_pad, Tensor? w_amax, Tensor bs_dev, '
            'Tensor offs_dev, int bs_host, int offs_host, int T, int max_batch, int rows, int H, int KP, int ndir, bool persistent, '
-           'Tensor(c!)? scratch=None, bool prefilled=False, Tensor(d!)? backward_scratch=None) -> (Tensor, Tensor?)')
+           'Tensor(c!)? scratch=None, bool prefilled=False, Tensor(d!)? backward_scratch=None, Tensor? step_masks=None) -> (Tensor, Tensor?)')
 def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, KP, ndir,
-                            persistent, scratch=None, prefilled=False, backward_scratch=None):
+                            persistent, scratch=None, prefilled=False, backward_scratch=None, step_masks=None):
     """gates: pre-activations in, activations out (in place); hy: output rows (a view into the caller's padded buffer).
     Returns (c, scratch): scratch = the persistent kernel's flag / hand-off buffer (its last 8 words are the watchdog
     words), None when the one-launch-per-timestep kernels ran.  bs_host / offs_host: addresses of the HOST copies of the
@@ -413,18 +413,26 @@ def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, b
     lib = _lib.load()
     dev = gates.device
     st = _lib.stream(dev)
-    c = torch.empty((rows, ndir * H), dtype=torch.float32, device=dev)
+    # row-slot batches (step_masks: ptmi_lstm_forward_persistent_slots): idle rows are not written - they must read as zeros
+    c = (torch.zeros if step_masks is not None else torch.empty)((rows, ndir * H), dtype=torch.float32, device=dev)
     rc = -2
     flags = None
     if persistent:
         n = int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 0))
         flags = scratch if scratch is not None else torch.empty(n, dtype=torch.int32, device=dev)
         assert flags.numel() >= n and flags.dtype == torch.int32
-        rc = _lib.timed('lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
-                        _lib.ptr(c0), w_hh_pad.data_ptr(), _lib.ptr(w_amax), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        flags.data_ptr(), T, max_batch, rows, H, KP, ndir, int(bool(prefilled and scratch is not None)),
-                        _lib.ptr(backward_scratch), st)
-        if rc not in (0, -2):
+        if step_masks is not None:
+            assert step_masks.dtype == torch.int64 and step_masks.numel() == 3 * T and c0 is None
+            rc = _lib.timed('lstm_forward', lib.ptmi_lstm_forward_persistent_slots, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
+                            None, w_hh_pad.data_ptr(), _lib.ptr(w_amax), bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
+                            flags.data_ptr(), T, max_batch, rows, H, KP, ndir, int(bool(prefilled and scratch is not None)),
+                            _lib.ptr(backward_scratch), st)
+        else:
+            rc = _lib.timed('lstm_forward', lib.ptmi_lstm_forward_persistent, gates.data_ptr(), hy.data_ptr(), c.data_ptr(),
+                            _lib.ptr(c0), w_hh_pad.data_ptr(), _lib.ptr(w_amax), bs_dev.data_ptr(), offs_dev.data_ptr(),
+                            flags.data_ptr(), T, max_batch, rows, H, KP, ndir, int(bool(prefilled and scratch is not None)),
+                            _lib.ptr(backward_scratch), st)
+        if rc not in (0, -2) or (step_masks is not None and rc != 0):
             _lib.check(rc, 'ptmi_lstm_forward_persistent')
     if rc == -2:        # configuration not resident-able: one launch per timestep
         flags = None
@@ -436,9 +444,9 @@ def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, b
 
 @_register('lstm_recurrence_backward(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor bs_dev, Tensor offs_dev, '
            'int bs_host, int offs_host, int T, int max_batch, int rows, int H, int ndir, bool persistent, Tensor(a!)? scratch=None, '
-           'bool prefilled=False) -> (Tensor, Tensor?)')
+           'bool prefilled=False, Tensor? step_masks=None) -> (Tensor, Tensor?)')
 def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, ndir, persistent,
-                             scratch=None, prefilled=False):
+                             scratch=None, prefilled=False, step_masks=None):
     """Returns (dgates, scratch): scratch as above; behind its tile-major copy it carries the bias gradient [ndir * 4H]
     and, for the split kernels, the word with max |dgates| (see ``ops.lstm``)."""
     lib = _lib.load()
@@ -451,10 +459,16 @@ def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_hos
         n = int(lib.ptmi_lstm_scratch_elems(T, ndir, max_batch, H, 1))
         flags = scratch if scratch is not None else torch.empty(n, dtype=torch.int32, device=dev)
         assert flags.numel() >= n and flags.dtype == torch.int32
-        rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
-                        dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
-        if rc not in (0, -2):
+        if step_masks is not None:      # row-slot batch
+            assert c0 is None
+            rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent_slots, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
+                            w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
+                            flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
+        else:
+            rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                            dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
+                            flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
+        if rc not in (0, -2) or (step_masks is not None and rc != 0):
             _lib.check(rc, 'ptmi_lstm_backward_persistent')
     if rc == -2:
         flags = None

@@ -588,7 +588,9 @@ class _LstmLayerFn(torch.autograd.Function):
             # equal-length batch: bs[0] rows of "state before the first step" (zero or h0) in front of and
             # behind the output rows, so that the backward pass reads h_{t-1} as a shifted view (no gather)
             pad = meta.bs0 if meta.equal_lengths else 0
-            ext = torch.empty((meta.rows + 2 * pad, ndir * H), dtype=torch.float32, device=x.device)
+            masks = getattr(meta, 'masks_dev', None)          # row-slot batch (ops.sequence.SlotLayout): idle rows stay zero
+            assert masks is None or not stateful, 'row-slot batches take no initial states'
+            ext = (torch.zeros if masks is not None else torch.empty)((meta.rows + 2 * pad, ndir * H), dtype=torch.float32, device=x.device)
             hy = ext[pad:pad + meta.rows]
             if pad:
                 # (both ends in ONE fill launch: a [2, pad, C] view over the first and the last `pad` rows)
@@ -608,7 +610,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 _error_sink(x.device)           # the word a timed-out launch reports to (set before the first launch)
             c, flags = torch.ops.ptmi.lstm_recurrence_forward(
                 gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b)
+                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b, masks)
             if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
                 pre_b = False
             if handoff is not None and flags is not None and not stateful and meta.equal_lengths and meta.bs0 % 16 == 0:
@@ -747,15 +749,16 @@ class _LstmLayerFn(torch.autograd.Function):
             # start under the second launch (ptmi_lstm_backward_persistent_range).  For every layer, or at B = 32 / T = 253,
             # the same cut measured neutral to slower (a recurrence next to GEMMs loses what the GEMMs gain): c3 23.97 -> 23.55 ms
             # with the top layer in two launches, 23.35 / 23.33 in three / four, 23.70 with every layer in two.
+            masks = getattr(meta, 'masks_dev', None)          # row-slot batch
             chunks = 2 if (SPLIT_TOP_BACKWARD and getattr(ctx, 'top', False) and PERSISTENT and use_side and gm is not None
                            and _gemm.planes_enabled() and lib.ptmi_lstm_split_enabled() and T >= 128
-                           and meta.rows >= SPLIT_TOP_BACKWARD_ROWS) else 1
+                           and meta.rows >= SPLIT_TOP_BACKWARD_ROWS and masks is None) else 1
             # the gate gradients as bf16 planes of dgates^T straight from the kernel (no row-major fp32 tensor at all when the
             # input gradient takes the hand-off planes, or is not needed)
             cols_dx = int(lib.ptmi_lstm_handoff_cols(H, 1)) if DX_FROM_HANDOFF else 0
             dx_needs_rows = ctx.needs_input_grad[0] and not (cols_dx and meta.equal_lengths and meta.bs0 % 16 == 0)
             use_tp = bool(DG_PLANES_FROM_KERNEL and PERSISTENT and in_place and gm is not None and _gemm.planes_enabled()
-                          and not state_grad and not dx_needs_rows
+                          and not state_grad and not dx_needs_rows and masks is None
                           and lib.ptmi_lstm_backward_planes_ok(T, ndir, meta.max_batch, meta.rows, H))
             if use_tp:
                 flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
@@ -827,7 +830,7 @@ class _LstmLayerFn(torch.autograd.Function):
             if dg is None and not use_tp:
                 dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                     gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                    T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1])
+                    T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1], masks)
             if flags is not None:
                 if CHECK_PERSISTENT_ERRORS:
                     check_errors()
@@ -974,7 +977,7 @@ def supported(lstm, data):
     return unsupported_reason(lstm, data) is None
 
 
-def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False, input_planes=None):
+def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False, input_planes=None, meta=None):
     """``lstm(packed, hx)`` through the HIP recurrence.
 
     ``input_planes = (planes, scale value)``: ``packed.data`` once more as fp16 (hi, lo) planes in the layout of
@@ -993,7 +996,12 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     assert packed.sorted_indices is None, 'sequences must be sorted by length (enforce_sorted=True)'
     training = lstm.training if training is None else training
     oc = _context.effective(lstm)
-    meta = pack_meta(packed.batch_sizes, data.device)
+    if meta is None:
+        meta = pack_meta(packed.batch_sizes, data.device)
+    else:       # a row-slot layout (ops.sequence.SlotLayout.meta): rows = [T, slots], several sequences end to end per slot
+        assert meta.rows == data.shape[0] and hx is None and not return_state and input_planes is None, 'row-slot batches: plain calls only'
+        if not (PERSISTENT and _lib.load().ptmi_lstm_split_enabled()):
+            raise NotImplementedError('row-slot batches need the persistent split recurrence kernels')
     sfx = ['', '_reverse'] if lstm.bidirectional else ['']
     ndir, H = len(sfx), lstm.hidden_size
     want_state = return_state or hx is not None

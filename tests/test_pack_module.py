@@ -105,3 +105,44 @@ def test_padded_list_notices_replaced_entries():
         assert lengths == lens and torch.equal(padded[2, :2], pl[2])
         del pl[2]
         assert not pl.intact()
+
+
+def test_slot_layout_places_sequences_end_to_end():
+    """ops.sequence.SlotLayout (host logic): longest-first packing into the emptiest slot, masks, predecessor tables, and the
+    scatter / gather pair round-trips a batch-major padded tensor (idle rows zero)."""
+    import numpy as np
+    from padertorch_amd.ops.sequence import SlotLayout
+    lengths = [9, 7, 7, 5, 4, 3, 3, 2]
+    L = SlotLayout(lengths, slots=4)
+    assert L.T == 11 and sorted(np.bincount(L.slot)) == [2, 2, 2, 2]
+    total = np.zeros(4, int)
+    for n, s in zip(lengths, L.slot):
+        total[s] += n
+    assert total.max() == L.T and abs(L.occupancy - sum(lengths) / 44.) < 1e-12
+    for b, (n, s, t0) in enumerate(zip(lengths, L.slot, L.t0)):      # every sequence: contiguous, starts / ends flagged, nothing overlaps
+        assert L.alive[t0:t0 + n, s].all() and L.first[t0, s] and L.last[t0 + n - 1, s]
+        assert L.first[t0:t0 + n, s].sum() == 1 and L.last[t0:t0 + n, s].sum() == 1
+    assert int(L.alive.sum()) == sum(lengths) and len(set(L.rows_host.tolist())) == sum(lengths)
+    m = L.meta
+    masks = m.masks_dev.view(-1, 3).numpy().view(np.uint64)
+    for t in range(L.T):
+        for k, arr in enumerate((L.alive, L.first, L.last)):
+            assert int(masks[t, k]) == sum(1 << s for s in range(4) if arr[t, s])
+    prev = m.prev_dev.numpy()
+    for t in range(L.T):
+        for s in range(4):
+            r = t * 4 + s
+            assert prev[0, r] == (r - 4 if L.alive[t, s] and not L.first[t, s] else m.rows)
+            assert prev[1, r] == (r + 4 if L.alive[t, s] and not L.last[t, s] else m.rows)
+    x = torch.arange(8 * 10 * 3, dtype=torch.float32).view(8, 10, 3) + 1.
+    for b, n in enumerate(lengths):
+        x[b, n:] = 0
+    g = L.scatter_rows(x)
+    assert g.shape == (44, 3) and int((g.abs().sum(1) > 0).sum()) == sum(lengths)
+    assert torch.equal(L.gather_rows(g, 10), x)
+    xr = x.clone().requires_grad_()
+    (L.gather_rows(L.scatter_rows(xr) * 2., 10) * x).sum().backward()
+    assert torch.equal(xr.grad, 2. * x)
+    one = SlotLayout([5, 3, 2], slots=1)               # a single slot: plain concatenation
+    assert one.T == 10 and one.t0 == [0, 5, 8]
+    assert SlotLayout.cached((5, 3, 2), 1, 'cpu') is SlotLayout.cached([5, 3, 2], 1, torch.device('cpu'))
