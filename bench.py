@@ -376,6 +376,9 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
 
 def main():
     args = parse_args()
+    if os.environ.get('PTMI_BENCH_TRACE'):
+        import faulthandler
+        faulthandler.dump_traceback_later(40, repeat=True, file=sys.stderr)
     if args.cpu_baseline_variant:
         print(json.dumps(cpu_baseline_variant(args.cpu_baseline_variant, b=args.cpu_baseline_batch)), flush=True)
         return
@@ -518,6 +521,8 @@ def main():
                     # real data brings a new length pattern every step: the per-pattern bookkeeping (ops.lstm.pack_meta: index tables,
                     # their transfers) is rebuilt every step although this bench repeats one batch
                     _lstm._meta.cache_clear()
+                    from padertorch_amd.ops.sequence import slots as _slots
+                    _slots._cached_layout.cache_clear()
                 if source is not None:        # waveforms start in pinned host memory
                     src = dict(y=source['y'].to(device, non_blocking=True), s=source['s'].to(device, non_blocking=True),
                                num_samples=source['num_samples'])
@@ -627,6 +632,12 @@ def main():
     frames_per_step = frames_per_micro * micro
 
     extras = {}
+    t_trace = time.perf_counter()
+
+    def trace(what):          # PTMI_BENCH_TRACE=1: where the wall-clock of a run goes, on stderr
+        if os.environ.get('PTMI_BENCH_TRACE'):
+            print(f'[bench {time.perf_counter() - t_trace:8.2f} s] {what}', file=sys.stderr, flush=True)
+    trace('timed steps done')
     if not args.dry and not args.no_extras:
         nx = max(5, min(args.steps, 50))
         if not args.sync_checks:
@@ -638,6 +649,7 @@ def main():
                 step(False)
             extras['ms_per_step_sync_checks'] = timed_loop(nx) / nx * 1e3
             trainer.deferred_checks = True
+        trace('sync-checks variant done')
         host = dict(y=data['y'].cpu().pin_memory(), s=data['s'].cpu().pin_memory(), num_samples=data['num_samples'])
         for _ in range(3):
             step(False, host)
@@ -661,6 +673,7 @@ def main():
                 return time.perf_counter() - t0
             prefetched_loop(3)
             extras['ms_per_step_h2d_prefetched'] = prefetched_loop(nx) / nx * 1e3
+        trace('host-to-device variants done')
         if not args.ragged and micro == 1:
             # SURVEY 8d's training distribution: lengths ~ U[3 s, 6 s] (the same draw as --ragged), zero-padded waveforms, the
             # per-pattern bookkeeping rebuilt every step as with real data
@@ -674,6 +687,26 @@ def main():
             extras['ms_per_step_ragged'] = timed_loop(nx) / nx * 1e3
             extras['value_ragged'] = variant['frames'] * world / (extras['ms_per_step_ragged'] * 1e-3)
             extras['ragged_frames_per_step'] = variant['frames'] * world
+            trace('ragged variant done')
+            # the same distribution on ROW SLOTS (model.row_slots; ops.sequence.SlotLayout): a recurrence costs its number of time steps,
+            # not its rows, so a ragged batch only pays off with >= 2 sequences end to end per row slot - 2 x batch examples in `batch`
+            # slots (occupancy 0.97 instead of 0.72); the optimizer step then covers twice the examples
+            if cfg['model'] == 'pit' and cfg['batch'] <= 64:
+                rnd = random.Random(4321)
+                rl2 = sorted((rnd.randint(3 * cfg['fs'], 6 * cfg['fs']) for _ in range(2 * cfg['batch'])), reverse=True)
+                model.row_slots = cfg['batch']
+                variant.update(ragged=True, frames=sum(frames_of(nb) for nb in rl2),
+                               data=synthetic_batch(2000 + rank, 2 * cfg['batch'], K, rl2[0], device, rl2))
+                try:
+                    for _ in range(3):
+                        step(False)
+                    extras['ms_per_step_ragged_row_slots'] = timed_loop(nx) / nx * 1e3
+                    extras['value_ragged_row_slots'] = variant['frames'] * world / (extras['ms_per_step_ragged_row_slots'] * 1e-3)
+                    extras['ragged_row_slots'] = dict(examples_per_step=2 * cfg['batch'] * world, row_slots=cfg['batch'],
+                                                      frames_per_step=variant['frames'] * world)
+                finally:
+                    model.row_slots = None
+                trace('row-slot variant done')
             variant.update(ragged=False, frames=frames_per_micro, data=data)
     rccl = None
     if world > 1:
@@ -756,6 +789,7 @@ def main():
             out['roofline'] = None
         else:
             # (ragged batches: the per-kernel figures assume frames_per_step / batch time steps per launch - a reported mode without them)
+            trace('extras done')
             overhead = event_bracket_overhead_ms(device)
             kernels, family = ([], None) if args.ragged else kernel_report(
                 timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro, 1 if args.bf16 else 3, overhead)
@@ -766,8 +800,10 @@ def main():
             out['roofline'] = kernels[0] if kernels else None
             out['roofline_family'] = family
             out['other_kernels'] = kernels[1:]
+            trace('kernel report done')
             if not args.no_extras and world == 1:
                 out['other_kernels'] += standalone_front_end(device, overhead)
+            trace('stand-alone front-end done')
         out.update(extras)
         # `value` is taken with the waveform batch resident in HBM (the bench contract).  SURVEY 8(d) counts example_to_device
         # inside the step: that figure, with the next batch's transfer issued one step ahead (data.DevicePrefetcher), is
