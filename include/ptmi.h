@@ -24,7 +24,8 @@ extern "C" {
 typedef void* ptmi_stream_t; /* hipStream_t */
 
 const char* ptmi_version(void);
-/* Test utility: `workgroups` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for `ticks_100mhz`
+/* DEBUG / TEST ONLY (not part of the hot path's contract; ptmi_gemm_planes_select_tile below is the other such entry: a process-wide,
+ * not thread-safe override for sweeps and tests).  `workgroups` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for `ticks_100mhz`
  * ticks of the 100 MHz clock - a stand-in for a communication kernel holding CUs next to the persistent recurrence kernels
  * (the RCCL all-reduce of padertorch/train/trainer.py:396-442's data-parallel branch runs beside them). */
 int ptmi_debug_occupy(int32_t workgroups, int32_t threads, int32_t lds_bytes, int64_t ticks_100mhz, ptmi_stream_t stream);
@@ -291,7 +292,9 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
  * max_batch + slot, every such row exists in all buffers; step_masks [T][3] uint64 (device): rows alive at time index t, rows whose
  * sequence STARTS at t, rows whose sequence ENDS at t (bit b = slot b).  A sequence start resets (h, c) to zero in the forward
  * direction, a sequence end in the reverse direction; idle rows are neither computed nor handed on (hy / c of idle rows are not
- * written: hand in zeroed buffers; their gate gradients come out as zeros).  Same results per sequence as one sequence per row
+ * written: hand in zeroed buffers; their gate gradients come out as zeros, and their rows of the hand-off planes as zeros too, so
+ * that for max_batch % 16 == 0 the planes are the GEMM operands they are for equal-length batches: ptmi_lstm_handoff_cols; the
+ * backward call takes dgates_t like ptmi_lstm_backward_persistent_planes, dgates may then be NULL).  Same results per sequence as one sequence per row
  * (torch.nn.LSTM on a PackedSequence, pit/model.py:60-66,97).  Data-as-flag split kernels only (PTMI_E_UNSUPPORTED otherwise); no
  * initial states. */
 int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const float* c0, const float* w_hh_pad,
@@ -300,9 +303,9 @@ int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const 
                                        int32_t H, int32_t KP, int32_t ndir, int32_t prefilled, uint32_t* backward_scratch,
                                        ptmi_stream_t stream);
 int ptmi_lstm_backward_persistent_slots(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
-                                        const int32_t* batch_sizes_dev, const int64_t* offsets_dev, const uint64_t* step_masks,
-                                        uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir,
-                                        int32_t prefilled, ptmi_stream_t stream);
+                                        uint16_t* dgates_t, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                        const uint64_t* step_masks, uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows,
+                                        int32_t H, int32_t ndir, int32_t prefilled, ptmi_stream_t stream);
 int32_t ptmi_lstm_backward_planes_ok(int32_t T, int32_t ndir, int32_t max_batch, int64_t rows, int32_t H);
 int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, const float* c0, const float* dhy,
                                          const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
@@ -497,7 +500,7 @@ int ptmi_gemm_planes_tn_bf16(const uint16_t* a, int32_t a_col_blocks, int32_t a_
 /* Calls without split K run on a persistent big-tile kernel (8 wavefronts, workgroup tile picked per problem by a cost model:
  * 0 = 256 x 320, 1 = 256 x 256, 2 = 256 x 192, 3 = 128 x 320, 4 = 128 x 256) or on the 128 x 128 kernel (5) that also carries
  * every split-K call.  ptmi_gemm_planes_select_tile pins that choice for the process (tests, A/B timing); -1 = the cost model. */
-int ptmi_gemm_planes_select_tile(int32_t tile);
+int ptmi_gemm_planes_select_tile(int32_t tile);     /* DEBUG / TEST ONLY: process-wide, not thread-safe */
 /* What a ptmi_gemm_planes[_bf16] call of this shape runs as: 100 * tile + k ranges (tile as above; measurement / labelling only). */
 int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k);
 

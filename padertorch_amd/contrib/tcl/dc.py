@@ -12,6 +12,8 @@ from padertorch_amd.ops.sequence.pack_module import PaddedList, as_padded
 class DeepClusteringModel(base.Model):
     #: run the BLSTM time recurrence in the hand-written HIP kernels (False: torch.nn.LSTM / MIOpen)
     hip_blstm = True
+    #: ragged GPU batches on row slots (see PermutationInvariantTrainingModel.row_slots); None: off
+    row_slots = None
 
     def __init__(
             self,
@@ -51,6 +53,10 @@ class DeepClusteringModel(base.Model):
             transform = self._TRANSFORMS[self.input_feature_transform]
         except KeyError:
             raise NotImplementedError(self.input_feature_transform) from None
+        if self.row_slots and self.hip_blstm:
+            out = self._forward_row_slots(batch['Y_abs'], transform)
+            if out is not None:
+                return out
         packed = getattr(batch['Y_abs'], 'packed_log1p', None)
         if packed is not None and not packed.matches(batch['Y_abs']):
             packed = None             # the list was edited since the feature kernel wrote its log-magnitudes: recompute from it
@@ -72,6 +78,22 @@ class DeepClusteringModel(base.Model):
                 _lib.leaving_native_path('the BLSTM of DeepClusteringModel', why)
             h = self.blstm(h)[0]
         return ops.unpack_sequence(PackedSequence(self._embed_rows(h.data), h.batch_sizes))
+
+    def _forward_row_slots(self, Y_abs, transform):
+        """``forward`` on the row-slot layout (``ops.sequence.SlotLayout``: the examples end to end in ``row_slots`` rows); ``None``
+        when it does not apply (CPU tensors, equal lengths, an LSTM the kernels do not cover)."""
+        padded, lengths, lengths_dev = as_padded(Y_abs)                          # [B, T_max, F], zero padded
+        if not padded.is_cuda or len(set(lengths)) == 1 or ops.lstm.unsupported_reason(self.blstm, padded) is not None:
+            return None
+        if self.input_feature_transform == 'log':
+            return None                                 # log(0 + 1e-10) of the idle rows is not zero: the PackedSequence path
+        layout = ops.sequence.SlotLayout.cached(tuple(lengths), int(self.row_slots), padded.device)
+        assert padded.shape[-1] == self.F, f'self.F = {self.F} != F = {padded.shape[-1]}'
+        T, S = layout.T, layout.slots
+        x = transform(PackedSequence(layout.scatter_rows(padded), torch.full((T,), S, dtype=torch.int64)))     # identity / log1p: 0 -> 0
+        h = ops.packed_lstm(self.blstm, x, meta=layout.meta).data
+        e = layout.gather_rows(self._embed_rows(h), padded.shape[1])                                             # [B, T_max, E, F]
+        return PaddedList(e, lengths, True, lengths_dev)
 
     def review(self, batch, model_out):
         """Mean deep-clustering loss of the batch (reference ``dc.py:73-84``: per-example loop over

@@ -1132,12 +1132,12 @@ int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, con
 }
 
 int ptmi_lstm_backward_persistent_slots(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
-                                        const int32_t* batch_sizes_dev, const int64_t* offsets_dev, const uint64_t* step_masks,
-                                        uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir,
-                                        int32_t prefilled, ptmi_stream_t stream) {
-    PTMI_RETURN_IF(!step_masks || !dgates, PTMI_E_INVALID);
+                                        uint16_t* dgates_t, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
+                                        const uint64_t* step_masks, uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows,
+                                        int32_t H, int32_t ndir, int32_t prefilled, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!step_masks || (!dgates && !dgates_t), PTMI_E_INVALID);
     PTMI_RETURN_IF(rows != (int64_t)T * max_batch || max_batch > 64, PTMI_E_UNSUPPORTED);
-    return lstm_backward_persistent_impl(gates, c, nullptr, dhy, w_hh_t, dgates, nullptr, batch_sizes_dev, offsets_dev, step_masks, flags,
+    return lstm_backward_persistent_impl(gates, c, nullptr, dhy, w_hh_t, dgates, dgates_t, batch_sizes_dev, offsets_dev, step_masks, flags,
                                          nullptr, T, max_batch, rows, H, ndir, 0, T, prefilled, stream);
 }
 

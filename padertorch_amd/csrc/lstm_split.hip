@@ -633,7 +633,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
         {
             int plane;
             const unsigned word = pair_word<false>(h * kHScale, lane, &plane);
-            if (act) {
+            // (row-slot batches: an idle slot step writes ZEROS - nobody in this launch waits for them, but the planes then are a
+            //  valid operand of the GEMMs that follow, like those of an equal-length batch)
+            if (act || (masked && tid < MR * JT && b < nb && j0 + u < H)) {
                 const int ce = (j0 + u) & ~1;
                 unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
                 __hip_atomic_store(tq + handoff_index(ce, plane, bl_ & 15) / 2, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             const int pw2 = (A.KP32 - H) >> 1;
             for (int e = tid; e < MR * pw2 * 2 && tid < ACTW * 64; e += ACTW * 64) {
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = H + 2 * (rem - plane * pw2);
-                if (m0 + rl < nb && bit(amask, m0 + rl)) {
+                if (m0 + rl < nb && (masked || bit(amask, m0 + rl))) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
                     __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
 // passes per layer of the B = 32 step go away.
 template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false, bool TP = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
-    static_assert(!TP || (UNI && DAF), "transposed planes: equal-length data-as-flag instantiations only");
+    static_assert(!TP || DAF, "transposed planes: data-as-flag instantiations only (equal lengths, or row slots with their masks)");
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
     const int n0 = bx * 16;
@@ -970,6 +972,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                 t_pend = -1;
             }
         }
+        if (TP && !has_rec && t_pend >= 0) {       // a step without the chain's barrier (row slots: no row of the tile continues a sequence)
+            __syncthreads();
+            flush_tp((s - 1) & 1, t_pend);
+            t_pend = -1;
+        }
         float gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f;
         if (act) {
             float dc = has_succ(b) ? dc_state : 0.f;
@@ -1008,7 +1015,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                 }
                 t_pend = t;
             }
-            if (act) {
+            if (act || (masked && tid < 16 * MR && b < nb && j < H)) {       // (row slots: zeros for an idle slot step, see the forward kernel)
                 unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
                 const int je = j & ~1;
                 const unsigned ws_[4] = {w0, w1, w2, w3};
@@ -1021,7 +1028,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const int pw2 = (A.G32 - G) >> 1;
             for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = G + 2 * (rem - plane * pw2);
-                if (m0 + rl < nb && bit(amask, m0 + rl)) {
+                if (m0 + rl < nb && (masked || bit(amask, m0 + rl))) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
                     __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
@@ -1034,7 +1041,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             if (tid == 0)
                 __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (masked && !act && tid < 16 * MR && b < nb && j < H) {       // a slot's idle step: its row exists in the buffers - zeros
+        if (masked && !act && tid < 16 * MR && b < nb && j < H && A.dg) {       // a slot's idle step: its row exists in the buffers - zeros
             float* dgp = A.dg + og_;
             dgp[0] = dgp[H] = dgp[2 * H] = dgp[3 * H] = 0.f;
         }
@@ -1112,6 +1119,13 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
     // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
     const bool uni = A.uniform != 0 && !A.masks;         // (row-slot batches: the instantiation that reads the per-step masks)
+    if (A.dgtp && A.masks) {          // row slots + dgates^T planes
+        if (mtl == 2)
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, false, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, false, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        return launch_status();
+    }
     if (A.dgtp) {          // + dgates^T as bf16 planes (host checked: equal lengths, batch a multiple of 16)
         if (mtl == 2)
             hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, true, true, true>), dim3(nwg), dim3(512), 0, st, A);

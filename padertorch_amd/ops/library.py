@@ -215,19 +215,25 @@ def lstm_recurrence_backward_range(gates, c, c0, dhy, w_hh_t, dg, scratch, dc_ca
 
 @_register('lstm_recurrence_backward_planes(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!)? dg, '
            'Tensor(b!) dg_t, Tensor(c!) scratch, Tensor(d!)? dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, '
-           'int H, int ndir, int s_begin, int s_end, bool prefilled=False) -> bool')
+           'int H, int ndir, int s_begin, int s_end, bool prefilled=False, Tensor? step_masks=None) -> bool')
 def lstm_recurrence_backward_planes(gates, c, c0, dhy, w_hh_t, dg, dg_t, scratch, dc_carry, bs_dev, offs_dev, T, max_batch, rows, H, ndir,
-                                    s_begin, s_end, prefilled=False):
+                                    s_begin, s_end, prefilled=False, step_masks=None):
     """``ptmi_lstm_backward_persistent_planes``: the persistent backward recurrence over the processing steps [s_begin, s_end) with
     the gate gradients leaving as bf16 planes of ``dgates^T`` (``dg_t``: ``ndir * ptmi_planes_elems(4H, range rows)`` bf16 values, the
     operand of the weight-gradient GEMMs) and, only when ``dg`` is given, as the row-major fp32 tensor too.  False: the launch
     cannot be resident (nothing was run)."""
     need = ndir * int(_lib.load().ptmi_planes_elems(4 * H, (s_end - s_begin) * max_batch))       # this step range's rows
     assert dg_t.dtype == torch.bfloat16 and dg_t.numel() >= need, (dg_t.dtype, dg_t.numel(), need)
-    rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_planes, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
-                    dhy.data_ptr(), w_hh_t.data_ptr(), _lib.ptr(dg), dg_t.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                    scratch.data_ptr(), _lib.ptr(dc_carry), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)),
-                    _lib.stream(gates.device))
+    if step_masks is not None:          # a row-slot batch (ptmi_lstm_backward_persistent_slots): the whole recurrence in one launch
+        assert c0 is None and s_begin == 0 and s_end == T, 'row-slot batches: no initial states, no step ranges'
+        rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_slots, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
+                        w_hh_t.data_ptr(), _lib.ptr(dg), dg_t.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
+                        scratch.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled)), _lib.stream(gates.device))
+    else:
+        rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_planes, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                        dhy.data_ptr(), w_hh_t.data_ptr(), _lib.ptr(dg), dg_t.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
+                        scratch.data_ptr(), _lib.ptr(dc_carry), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)),
+                        _lib.stream(gates.device))
     if rc == -2:
         return False
     _lib.check(rc, 'ptmi_lstm_backward_persistent_planes')
@@ -462,7 +468,7 @@ def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_hos
         if step_masks is not None:      # row-slot batch
             assert c0 is None
             rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent_slots, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
-                            w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
+                            w_hh_t.data_ptr(), dg.data_ptr(), None, bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
                             flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
         else:
             rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),

@@ -613,7 +613,8 @@ class _LstmLayerFn(torch.autograd.Function):
                 meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b, masks)
             if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
                 pre_b = False
-            if handoff is not None and flags is not None and not stateful and meta.equal_lengths and meta.bs0 % 16 == 0:
+            # (a row-slot batch's planes are operands as well: its kernels write zeros for the idle slot steps)
+            if handoff is not None and flags is not None and not stateful and (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0:
                 cols_out = int(lib.ptmi_lstm_handoff_cols(H, 0))
                 if cols_out:
                     handoff['planes'] = (flags, cols_out)
@@ -756,9 +757,10 @@ class _LstmLayerFn(torch.autograd.Function):
             # the gate gradients as bf16 planes of dgates^T straight from the kernel (no row-major fp32 tensor at all when the
             # input gradient takes the hand-off planes, or is not needed)
             cols_dx = int(lib.ptmi_lstm_handoff_cols(H, 1)) if DX_FROM_HANDOFF else 0
-            dx_needs_rows = ctx.needs_input_grad[0] and not (cols_dx and meta.equal_lengths and meta.bs0 % 16 == 0)
+            uniform_rows = (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0        # rows = [T, batch]: the planes are operands
+            dx_needs_rows = ctx.needs_input_grad[0] and not (cols_dx and uniform_rows)
             use_tp = bool(DG_PLANES_FROM_KERNEL and PERSISTENT and in_place and gm is not None and _gemm.planes_enabled()
-                          and not state_grad and not dx_needs_rows and masks is None
+                          and not state_grad and not dx_needs_rows
                           and lib.ptmi_lstm_backward_planes_ok(T, ndir, meta.max_batch, meta.rows, H))
             if use_tp:
                 flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
@@ -773,7 +775,7 @@ class _LstmLayerFn(torch.autograd.Function):
                     planes = torch.empty(ndir * int(lib.ptmi_planes_elems(G, n_rows)), dtype=torch.bfloat16, device=dhy.device)
                     ok = torch.ops.ptmi.lstm_recurrence_backward_planes(
                         gates, c, c0, dhy, w_t, None, planes, flags, carry, meta.bs_dev, meta.offs_dev, T, B_, meta.rows, H, ndir,
-                        cuts[i], cuts[i + 1], pre)
+                        cuts[i], cuts[i + 1], pre, masks)
                     # rows of this range per direction (forward direction: processed from the last time index down)
                     part = [((T - cuts[i + 1]) * B_, (T - cuts[i]) * B_), (cuts[i] * B_, cuts[i + 1] * B_)][:ndir]
                     return ok, planes, part
@@ -847,7 +849,7 @@ class _LstmLayerFn(torch.autograd.Function):
             cols = int(lib.ptmi_lstm_handoff_cols(H, 1)) if (DX_FROM_HANDOFF and flags is not None and amax_kernel is not None) else 0
             if not ctx.needs_input_grad[0]:
                 dx = None
-            elif cols and _gemm.planes_enabled() and meta.equal_lengths and meta.bs0 % 16 == 0:
+            elif cols and _gemm.planes_enabled() and (meta.equal_lengths or getattr(meta, 'masks_dev', None) is not None) and meta.bs0 % 16 == 0:
                 # the recurrence has left its gate gradients as bf16 (hi, lo) planes in fragment order at the start of its
                 # scratch (the hand-off copy): for a batch of equal lengths they ARE operand A of dx = dgates W_ih
                 pdx = ctx.forms.get('w_ih_planes_dx') if ctx.forms is not None else None
@@ -953,7 +955,7 @@ def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
         parts.append(h0.transpose(0, 1))
         prev = meta.prev_h0_dev
     hy_pad = torch.cat(parts, 0)
-    return [(dgv[:, d], hy_pad[:, d].index_select(0, prev[d])) for d in range(ndir)]
+    return [(dgv[:, d] if dgv is not None else None, hy_pad[:, d].index_select(0, prev[d])) for d in range(ndir)]
 
 
 def unsupported_reason(lstm, data):

@@ -594,15 +594,23 @@ class Trainer:
         """Asynchronous device -> pinned host copy of a few scalars (a tensor, or a list of tensors that each keep their
         dtype); ``_check_pending`` inspects them later.  The copies themselves are enqueued by ``_flush_stage`` behind the
         optimizer kernel: in front of it (loss values between the loss and the backward pass, the gradient norm between the norm
-        and the update) every copy is a blit launch of ~5 us on the step's critical path."""
+        and the update) every copy is a blit launch of ~5 us on the step's critical path.
+        The returned host tensors are valid only behind ``_check_pending(flush=True)`` (or the next ``optimizer_step``): until
+        their copy has run they read NaN (floating point) / the type's minimum (integers), never stale memory, and the
+        queue is bounded - code that calls ``train_step`` without ever reaching ``optimizer_step`` has its oldest entries flushed."""
+        def blank(shape, dtype):
+            h = torch.empty(shape, dtype=dtype, pin_memory=True)
+            return h.fill_(float('nan')) if dtype.is_floating_point else h.fill_(torch.iinfo(dtype).min)
+        if len(self._stage_queue) >= 64:
+            self._flush_stage()
         if isinstance(vals, (list, tuple)):
             vals = [v.detach() for v in vals]
-            host = [torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for v in vals]
+            host = [blank(v.shape, v.dtype) for v in vals]
         else:
             vals = vals.detach().to(torch.float32)
             if what == 'loss':      # a non-finite loss makes the sum non-finite: what the optimizer update is gated on
                 self._loss_acc = vals[-1] if self._loss_acc is None else self._loss_acc + vals[-1]
-            host = torch.empty(vals.shape, dtype=torch.float32, pin_memory=True)
+            host = blank(vals.shape, torch.float32)
         self._stage_queue.append((what, vals, host, context, self._opt_step))
         return host
 

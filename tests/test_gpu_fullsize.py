@@ -40,7 +40,7 @@ def _grad_check(model, ref, tol=2e-4):
     return worst
 
 
-def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, **model_kw):
+def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, in_place=False, **model_kw):
     import padertorch_amd as pt
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
     from padertorch_amd.ops import lstm as _lstm
@@ -56,10 +56,17 @@ def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, *
     s = _waveforms(B, model_kw.get('K', 2), n, lens, seed + 1).to(DEV)
     feats = pt.ops.pit_features(s.sum(1), s, lens)
     _lstm.CHECK_PERSISTENT_ERRORS = True
+    if in_place:        # the Trainer's route: weight gradients accumulated into existing .grad buffers on the side stream (ops.context)
+        from padertorch_amd.ops import context as _context
+        for p in model.parameters():
+            p.grad = torch.zeros_like(p)
+        _context.attach(model, _context.OpContext(defer_wgrad=True))
+        _lstm.warm_side_stream(torch.device(DEV))
     try:
         masks = model(feats)
         losses = model.review(feats, masks)['losses']
         losses['pit_ips_loss'].backward()
+        _lstm.sync_deferred()
     finally:
         _lstm.CHECK_PERSISTENT_ERRORS = False
     torch.cuda.synchronize()
@@ -95,13 +102,16 @@ def test_pit_step_random_small_configurations_vs_oracle(seed):
               K=int(rng.randint(2, 4)), output_activation=str(rng.choice(['relu', 'sigmoid'])))
 
 
+@pytest.mark.parametrize('in_place', [False, True])
 @pytest.mark.parametrize('B,slots,units,layers', [(10, 4, 24, 2), (40, 16, 100, 1), (70, 32, 600, 2), (100, 64, 64, 3), (33, 32, 600, 1),
                                                   (5, 1, 8, 2)])
-def test_pit_step_on_row_slots_vs_oracle(B, slots, units, layers):
+def test_pit_step_on_row_slots_vs_oracle(B, slots, units, layers, in_place):
     """Ragged batches on the row-slot layout (model.row_slots; ops.sequence.SlotLayout): 2 - 5 sequences lie end to end in every
     row slot, the recurrences reset (h, c) at the boundaries in both directions (ptmi_lstm_forward / backward_persistent_slots), idle
     slot steps contribute nothing.  The whole step - masks of every example, both losses, every parameter gradient - against the
-    oracle, which knows nothing of slots (one sequence per row, torch.nn.LSTM on the PackedSequence)."""
+    oracle, which knows nothing of slots (one sequence per row, torch.nn.LSTM on the PackedSequence).  in_place: the Trainer's route
+    (weight gradients accumulated in place on the side stream); with 16 / 32 / 64 slots the recurrences' planes then serve the
+    projections, the input gradients and - as dgates^T - the weight gradients, as for equal-length batches."""
     from padertorch_amd.ops.sequence import SlotLayout
     rng = np.random.RandomState(B + slots)
     n = 4400
@@ -113,8 +123,8 @@ def test_pit_step_on_row_slots_vs_oracle(B, slots, units, layers):
     assert per_slot.max() >= 2 and layout.T == max(np.bincount(layout.slot, weights=frames, minlength=slots)), (per_slot, layout.T)
     # (B = 100: linear1.weight's gradient differs from the oracle's by 3.3e-4 of its largest entry with OR WITHOUT slots - the same
     #  6.896e-7 in both, fp32 summation order over 28 k rows against a 2e-3 gradient - so this case is held to 5e-4)
-    _pit_case(B, 8000, lens=lens, seed=B, n=n, row_slots=slots, grad_tol=5e-4 if B == 100 else 2e-4, units=units, recurrent_layers=layers,
-              K=2 + B % 2)
+    _pit_case(B, 8000, lens=lens, seed=B, n=n, row_slots=slots, grad_tol=5e-4 if B == 100 else 2e-4, in_place=in_place, units=units,
+              recurrent_layers=layers, K=2 + B % 2)
 
 
 def test_row_slot_masks_equal_the_packed_sequence_path():
@@ -146,7 +156,7 @@ def test_pit_step_config3_rows_and_steps_vs_oracle():
     _pit_case(40, 16000, lens=lens, seed=3)
 
 
-def _dc_case(B, K, n, lens, seed, padded_target=False, **model_kw):
+def _dc_case(B, K, n, lens, seed, padded_target=False, row_slots=None, **model_kw):
     import padertorch_amd as pt
     from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
     from padertorch_amd.ops import lstm as _lstm
@@ -157,6 +167,7 @@ def _dc_case(B, K, n, lens, seed, padded_target=False, **model_kw):
     ref = torch_ref.DCModelRef(**model_kw)
     ref.load_state_dict(model.state_dict())
     model.to(DEV).train()
+    model.row_slots = row_slots
     s = _waveforms(B, K, n, lens, seed + 1).to(DEV)
     feats = pt.ops.pit_features(s.sum(1), s, lens)
     target = [torch.nn.functional.one_hot(x.argmax(1), K).permute(0, 2, 1).to(torch.float32) for x in feats['X_abs']]
@@ -183,6 +194,17 @@ def _dc_case(B, K, n, lens, seed, padded_target=False, **model_kw):
     assert worst < 1e-5, worst
     assert abs(float(loss) - float(rloss)) < 1e-4 * max(1., abs(float(rloss))), (float(loss), float(rloss))
     _grad_check(model, ref)
+
+
+@pytest.mark.parametrize('B,slots,transform', [(36, 16, 'log1p'), (9, 4, 'identity')])
+def test_dc_step_on_row_slots_vs_oracle(B, slots, transform):
+    """The deep-clustering model on row slots (2-3 sequences end to end per slot): embeddings, loss and every gradient against the
+    oracle (one sequence per row), with the bench's PaddedList targets."""
+    rng = np.random.RandomState(B)
+    n = 4000
+    lens = sorted((int(x) for x in rng.randint(900, n + 1, B)), reverse=True)
+    lens[0] = n
+    _dc_case(B, 3, n, lens, seed=B, padded_target=True, row_slots=slots, units=40, recurrent_layers=2, E=8, input_feature_transform=transform)
 
 
 def test_dc_step_config5_shape_vs_oracle():
