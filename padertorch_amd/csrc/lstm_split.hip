@@ -1013,8 +1013,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                     tbuf[s & 1][0][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)hi;
                     tbuf[s & 1][1][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)lo;
                 }
-                t_pend = t;
             }
+            if (TP) t_pend = t;          // (every thread: the flush in a step without the chain's barrier brings its own barrier)
             if (act || (masked && tid < 16 * MR && b < nb && j < H)) {       // (row slots: zeros for an idle slot step, see the forward kernel)
                 unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
                 const int je = j & ~1;
