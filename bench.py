@@ -648,6 +648,11 @@ def main():
             for _ in range(3):
                 step(False)
             extras['ms_per_step_sync_checks'] = timed_loop(nx) / nx * 1e3
+            # ... and with the checks at the END of the same step (Trainer(deferred_checks='step'): device-gated update, one sync)
+            trainer.deferred_checks = 'step'
+            for _ in range(3):
+                step(False)
+            extras['ms_per_step_end_of_step_checks'] = timed_loop(nx) / nx * 1e3
             trainer.deferred_checks = True
         trace('sync-checks variant done')
         host = dict(y=data['y'].cpu().pin_memory(), s=data['s'].cpu().pin_memory(), num_samples=data['num_samples'])

@@ -187,6 +187,8 @@ class Trainer:
         #: optimizer step later; the optimizer update itself is gated ON THE DEVICE by their finiteness
         #: (fused optimizers' ``found_inf``), so a non-finite step still leaves the parameters untouched and
         #: raises the reference's RuntimeError -- one iteration late.  The host then runs ahead of the GPU.
+        #: 'step': the same staging and device gating, inspected at the END of the same optimizer step (one host sync per step, behind
+        #: the update's launch): the error surfaces in the iteration it belongs to, as in the reference.
         self.deferred_checks = deferred_checks
         #: data parallel: the gradient bucket of a layer is all-reduced as soon as that layer's gradients of the LAST
         #: micro-step of the optimizer step are complete, under the rest of the backward pass (False: one all-reduce
@@ -431,6 +433,12 @@ class Trainer:
             self.optimizer.zero_grad()
         self._flush_stage()            # this step's staged scalars (deferred_checks): copied behind the update
         self._opt_step += 1
+        if self.deferred_checks == 'step':
+            # ONE host sync per optimizer step, behind everything the step has enqueued: the loss / gradient-norm / watchdog
+            # checks raise in the iteration they belong to, like the reference's (whose two syncs sit in the MIDDLE of the step:
+            # after the loss and after the norm); the update itself was gated on the device, so the parameters are what the
+            # reference leaves behind when it raises before optimizer.step()
+            self._check_pending(flush=True)
         return summary
 
     def clip_grad(self, summary: dict):

@@ -165,11 +165,11 @@ def test_trainer_prefetched_weight_forms_change_nothing(g6, tmp_path, monkeypatc
         assert torch.equal(v, got[k]), k
 
 
-@pytest.mark.parametrize('deferred', [False, True])
+@pytest.mark.parametrize('deferred', [False, True, 'step'])
 def test_trainer_non_finite_loss_raises_and_keeps_parameters(g6, tmp_path, deferred):
     """A NaN in the third optimizer step's input: RuntimeError('The loss (nan) is not finite...') as in
     trainer.py:620-638, the parameters are those after step two (the deferred mode skips the update on
-    the device and raises one iteration late)."""
+    the device and raises one iteration late; 'step': device-gated too, but inspected at the end of the SAME optimizer step)."""
     import padertorch_amd as pt
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
     batch = _batch(g6, ['Y_abs', 'X_abs', 'cos_phase_difference'])
@@ -187,7 +187,7 @@ def test_trainer_non_finite_loss_raises_and_keeps_parameters(g6, tmp_path, defer
                    deferred_checks=deferred, **kw)
     with pytest.raises(RuntimeError, match='is not finite'):
         t.train(bad, device=DEV)
-    assert t.iteration == (3 if deferred else 2), t.iteration        # optimizer steps gone through (the third one skipped on the device)
+    assert t.iteration == (3 if deferred is True else 2), t.iteration    # optimizer steps gone through (deferred: the third one skipped on the device)
     for (k, v), (_, r) in zip(model.state_dict().items(), ref.state_dict().items()):
         np.testing.assert_array_equal(v.cpu().numpy(), r.cpu().numpy(), err_msg=k)
 
