@@ -112,3 +112,15 @@ def test_device_prefetcher_yields_what_example_to_device_would():
         want = example_to_device(batches[i], torch.device('cpu'))
         assert torch.equal(g['y'], want['y']) and g['meta']['n'] == [3, 3] and int(g['meta']['t']) == i
     assert list(DevicePrefetcher([], 'cpu')) == []
+
+
+def test_row_slot_batches_groups_and_sorts():
+    """data.row_slot_batches: round(fill * row_slots) examples per batch, sorted by descending length, collated; the tail batch
+    takes what is left; a stream (generator) works."""
+    from padertorch_amd.data import row_slot_batches
+    exs = [dict(num_samples=n, tag=i) for i, n in enumerate((5, 9, 2, 7, 3, 8, 1))]
+    got = list(row_slot_batches(iter(exs), row_slots=2, fill=1.5))
+    assert [b['num_samples'] for b in got] == [[9, 5, 2], [8, 7, 3], [1]]
+    assert got[0]['tag'] == [1, 0, 2]
+    raw = list(row_slot_batches(exs, row_slots=4, fill=1.0, key=lambda e: -e['tag'], collate=False))
+    assert [[e['tag'] for e in b] for b in raw] == [[0, 1, 2, 3], [4, 5, 6]]
