@@ -179,9 +179,9 @@ def _plain(rows_fn, estimate, target, reduction, **kw):
     halve_n = False
     if isinstance(estimate, torch.Tensor) and isinstance(target, torch.Tensor) and (estimate.is_complex() or target.is_complex()):
         # the error-energy losses are defined through |.| (reference ``regression.py:4-18``: torch.abs) and take complex
-        # signals; the scale-invariant ones use an unconjugated product there and stay real-only here
+        # signals; si_sdr_loss has its own complex form (_si_sdr_complex: the reference's unconjugated scaling factor)
         if rows_fn not in (_rows_mse, _rows_log_mse, _rows_log1p_mse, _rows_sdr):
-            raise NotImplementedError('complex signals: mse / log_mse / log1p_mse / sdr losses only')
+            raise NotImplementedError('complex signals: mse / log_mse / log1p_mse / sdr / si_sdr losses only')
         assert estimate.is_complex() and target.is_complex(), (estimate.dtype, target.dtype)
         estimate, target = _complex_as_real(estimate), _complex_as_real(target)
         halve_n = True                                  # the time mean runs over T complex samples, not 2 T real ones
@@ -221,8 +221,44 @@ def si_sdr_loss(estimate, target, reduction='mean', offset_invariant=False, grad
     assert len(estimate.shape) >= 1, estimate.shape
     assert len(estimate.shape) == 1 or estimate.shape[-2] < 10, (
         f'Number of speakers should be small (<10, not {estimate.shape[-2]})!')
+    if isinstance(estimate, torch.Tensor) and isinstance(target, torch.Tensor) and (estimate.is_complex() or target.is_complex()):
+        return _si_sdr_complex(estimate, target, reduction, offset_invariant, grad_stop, soft_sdr_max)
     return _plain(_rows_si_sdr, estimate, target, reduction, offset_invariant=offset_invariant,
                   grad_stop=grad_stop, soft_sdr_max=soft_sdr_max)
+
+
+def _si_sdr_complex(estimate, target, reduction, offset_invariant, grad_stop, soft_sdr_max):
+    """SI-SDR of complex64 signals as the reference defines it (``regression.py:21-24,178-296``): the scaling factor is the
+    UNCONJUGATED product ``alpha = sum(e t) / sum |t|^2`` - a complex number -, ``s = alpha t``, loss ``-10 log10(sum |s|^2 / sum |e -
+    s|^2)``.  Real and imaginary parts are taken as the two rows of a [2, T] real signal: ONE pass of ``ptmi_td_pair_stats`` gives
+    the four real products ``sum er tr, sum er ti, sum ei tr, sum ei ti`` (its 2 x 2 pair matrix) and the energies, everything else
+    is scalar arithmetic per signal under autograd (the gradient w.r.t. the signals is one more streaming pass)."""
+    assert estimate.is_complex() and target.is_complex(), (estimate.dtype, target.dtype)
+    lead, T = estimate.shape[:-1], estimate.shape[-1]
+
+    def parts(x):       # complex64 [..., T] -> float32 [rows, 2, T] (real row, imaginary row)
+        if x.dtype != torch.complex64:
+            raise NotImplementedError(f'complex64 signals only, got {x.dtype}')
+        return torch.view_as_real(x.contiguous()).reshape(-1, T, 2).transpose(1, 2).contiguous()
+    q = pair_stats(parts(estimate), parts(target))
+    n = q['n'][:, 0]
+    a, c, d, b = q['set'][:, 0, 0], q['set'][:, 0, 1], q['set'][:, 1, 0], q['set'][:, 1, 1]      # er tr, er ti, ei tr, ei ti
+    see, stt = q['see'].sum(1), q['stt'].sum(1)
+    if offset_invariant:        # statistics of the signals minus their (complex) time means
+        (ser, sei), (str_, sti) = q['se'].unbind(1), q['st'].unbind(1)
+        a, b, c, d = a - ser * str_ / n, b - sei * sti / n, c - ser * sti / n, d - sei * str_ / n
+        see = see - (ser * ser + sei * sei) / n
+        stt = stt - (str_ * str_ + sti * sti) / n
+    al_re, al_im = (a - b) / stt, (c + d) / stt              # alpha = sum(e t) / sum |t|^2
+    if grad_stop:
+        al_re, al_im = al_re.detach(), al_im.detach()
+    s_norm = (al_re * al_re + al_im * al_im) * stt           # sum |alpha t|^2
+    cross = al_re * (a + b) + al_im * (d - c)                # Re(conj(alpha) sum(e conj(t))) = Re sum(e conj(s))
+    den = see - 2 * cross + s_norm                           # sum |e - s|^2
+    if soft_sdr_max is not None:
+        den = den + _get_threshold(soft_sdr_max) * s_norm
+    loss = (-10 * torch.log10(s_norm / den)).reshape(lead)
+    return _reduce(loss, reduction).to(torch.float32)
 
 
 def log1p_mse_loss(estimate: torch.Tensor, target: torch.Tensor, reduction: str = 'sum'):

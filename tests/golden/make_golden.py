@@ -387,6 +387,24 @@ def g7():
     enc2 = StftEncoder(window_length=16, feature_size=66, stride=4)
     out['coder/encoded_16_66_4'] = enc2(mixture).numpy()
     out['coder/roundtrip_16_66_4'] = IstftDecoder(window_length=16, feature_size=66, stride=4)(enc2(mixture)).numpy()
+    # complex signals through the scale-invariant loss (regression.py:21-24,178-296: the scaling factor is the UNCONJUGATED
+    # product sum(e t) / sum |t|^2, a complex number): values and the reference-autograd gradient w.r.t. the estimate
+    rng_c = np.random.RandomState(77)         # (its own stream: everything above keeps its values)
+    ec = (rng_c.randn(3, 2, 333) + 1j * rng_c.randn(3, 2, 333)).astype(np.complex64)
+    tc = (rng_c.randn(3, 2, 333) + 1j * rng_c.randn(3, 2, 333)).astype(np.complex64)
+    tc = (tc + 0.6 * ec).astype(np.complex64)
+    out['complex/estimate'], out['complex/target'] = ec, tc
+    cnames = []
+    for name, kw in (('plain', {}), ('offset', dict(offset_invariant=True)), ('grad_stop', dict(grad_stop=True)),
+                     ('soft30', dict(soft_sdr_max=30)), ('all', dict(offset_invariant=True, grad_stop=True, soft_sdr_max=20, reduction='sum')),
+                     ('none', dict(reduction=None))):
+        e_ = torch.tensor(ec, requires_grad=True)
+        val = R.si_sdr_loss(e_, torch.tensor(tc), **kw)
+        val.sum().backward()
+        out[f'complex/si_sdr/{name}/value'] = val.detach().numpy()
+        out[f'complex/si_sdr/{name}/grad'] = e_.grad.numpy()
+        cnames.append(dict(name=name, kwargs=kw))
+    out['complex/cases'] = np.array(json.dumps(cnames))
     np.savez_compressed(HERE / 'g7_td_losses.npz', **out)
 
 

@@ -220,5 +220,24 @@ def test_complex_signals_error_energy_losses():
         got.backward()
         assert abs(float(got) - float(want)) < 2e-5 * max(1., abs(float(want))), (name, kw, float(got), float(want))
         assert torch.allclose(eg.grad.cpu().to(torch.complex128), ed.grad, atol=2e-6, rtol=2e-4), (name, kw)
+
+
+def test_complex_si_sdr_vs_reference(g7):
+    """si_sdr_loss on complex64 signals against the REFERENCE's own values and autograd gradients (golden g7 ``complex/*``, generated
+    by importing padertorch's regression.py): its scaling factor is the unconjugated product sum(e t) / sum |t|^2 (regression.py:21-24);
+    plain, offset invariant, grad_stop, soft threshold, all at once, reduction None."""
+    import json
+    import torch
+    from padertorch_amd.ops.losses import regression as R
+    e, t = torch.from_numpy(g7['complex/estimate']), torch.from_numpy(g7['complex/target'])
+    for case in json.loads(str(g7['complex/cases'])):
+        name, kw = case['name'], case['kwargs']
+        eg = e.cuda().requires_grad_(True)
+        got = R.si_sdr_loss(eg, t.cuda(), **kw)
+        got.sum().backward()
+        want, wgrad = g7[f'complex/si_sdr/{name}/value'], g7[f'complex/si_sdr/{name}/grad']
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-5, atol=2e-5, err_msg=name)
+        np.testing.assert_allclose(eg.grad.cpu().numpy(), wgrad, rtol=2e-4, atol=2e-6 * float(np.abs(wgrad).max() / 1e-3 + 1), err_msg=name)
     with pytest.raises(NotImplementedError):
-        R.si_sdr_loss(e.cuda(), t.cuda())
+        R.source_aggregated_sdr_loss(e.cuda(), t.cuda())
