@@ -286,6 +286,15 @@ int ptmi_lstm_backward_persistent_range(const float* gates, const float* c, cons
  *   dgates     may be NULL when dgates_t is given (the hand-off copy in `flags` still serves dx = dgates W_ih)
  * Only for batches of equal-length sequences whose size is a multiple of 16 on the split kernels:
  * ptmi_lstm_backward_planes_ok(...) != 0; PTMI_E_UNSUPPORTED otherwise. */
+/* The whole backward recurrence with gradients through BOTH ends of the state (torch.nn.LSTM returns (h_n, c_n) with their graph,
+ * padertorch/modules/recurrent.py:42 carries them): dc_n [ndir][max_batch][H] (or NULL) = gradient w.r.t. the final cell state, added
+ * to the cell-state gradient at every sequence's last step; dc_0 [ndir][max_batch][H] (or NULL) receives the gradient w.r.t. the
+ * initial cell state.  (The final / initial HIDDEN states' gradients travel through dhy resp. dgates W_hh on the caller's side.)
+ * Split kernels only. */
+int ptmi_lstm_backward_persistent_states(const float* gates, const float* c, const float* c0, const float* dhy, const float* dc_n,
+                                         const float* w_hh_t, float* dgates, const int32_t* batch_sizes_dev,
+                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_0, int32_t T, int32_t max_batch,
+                                         int64_t rows, int32_t H, int32_t ndir, int32_t prefilled, ptmi_stream_t stream);
 /* Row-slot batches: several sequences lie END TO END in one row slot, so that every one of the (at most 64) row slots works in
  * (nearly) every time step - a recurrence costs its number of steps, whatever the number of rows up to 32 (64) per step, so a ragged
  * batch packed this way takes total frames / slots steps instead of the longest sequence's.  Layout: uniform, row(t, slot) = t *

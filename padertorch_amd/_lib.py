@@ -88,6 +88,8 @@ SIGNATURES = {
                                                    c_int32, c_int32, _P, _P]),
     'ptmi_lstm_backward_persistent_slots': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32, c_int32,
                                                     c_int32, _P]),
+    'ptmi_lstm_backward_persistent_states': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
+                                                     c_int32, c_int32, _P]),
     'ptmi_lstm_backward_planes_ok': (c_int32, [c_int32, c_int32, c_int32, c_int64, c_int32]),
     'ptmi_lstm_backward_persistent_planes': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
                                                      c_int32, c_int32, c_int32, c_int32, _P]),

@@ -852,7 +852,7 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
                                          const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
                                          const int64_t* offsets_dev, const uint64_t* step_masks, uint32_t* flags, float* dc_carry,
                                          int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
-                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream);
+                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream, const float* dc_n = nullptr);
 
 extern "C" {
 
@@ -1131,6 +1131,15 @@ int ptmi_lstm_backward_persistent_planes(const float* gates, const float* c, con
                                          T, max_batch, rows, H, ndir, s_begin, s_end, prefilled, stream);
 }
 
+int ptmi_lstm_backward_persistent_states(const float* gates, const float* c, const float* c0, const float* dhy, const float* dc_n,
+                                         const float* w_hh_t, float* dgates, const int32_t* batch_sizes_dev,
+                                         const int64_t* offsets_dev, uint32_t* flags, float* dc_0, int32_t T, int32_t max_batch,
+                                         int64_t rows, int32_t H, int32_t ndir, int32_t prefilled, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!dgates, PTMI_E_INVALID);
+    return lstm_backward_persistent_impl(gates, c, c0, dhy, w_hh_t, dgates, nullptr, batch_sizes_dev, offsets_dev, nullptr, flags, dc_0, T,
+                                         max_batch, rows, H, ndir, 0, T, prefilled, stream, dc_n);
+}
+
 int ptmi_lstm_backward_persistent_slots(const float* gates, const float* c, const float* dhy, const float* w_hh_t, float* dgates,
                                         uint16_t* dgates_t, const int32_t* batch_sizes_dev, const int64_t* offsets_dev,
                                         const uint64_t* step_masks, uint32_t* flags, int32_t T, int32_t max_batch, int64_t rows,
@@ -1147,7 +1156,7 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
                                          const float* w_hh_t, float* dgates, uint16_t* dgates_t, const int32_t* batch_sizes_dev,
                                          const int64_t* offsets_dev, const uint64_t* step_masks, uint32_t* flags, float* dc_carry,
                                          int32_t T, int32_t max_batch, int64_t rows, int32_t H, int32_t ndir, int32_t s_begin,
-                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream) {
+                                         int32_t s_end, int32_t prefilled, ptmi_stream_t stream, const float* dc_n) {
     PTMI_RETURN_IF(!gates || !c || !dhy || !w_hh_t || (!dgates && !dgates_t) || !batch_sizes_dev || !offsets_dev || !flags,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(dgates_t && (reinterpret_cast<uintptr_t>(dgates_t) & 15) != 0, PTMI_E_INVALID);
@@ -1202,6 +1211,8 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
     A.uniform = (rows == (int64_t)T * max_batch) ? 1 : 0;
     A.masks = reinterpret_cast<const unsigned long long*>(step_masks);
     PTMI_RETURN_IF(step_masks && !(split && bwd_daf_applies()), PTMI_E_UNSUPPORTED);
+    PTMI_RETURN_IF(dc_n && (!split || step_masks), PTMI_E_UNSUPPORTED);
+    A.dcn = dc_n;
     A.s_begin = s_begin;
     A.s_end = s_end;
     A.dc_carry = dc_carry;

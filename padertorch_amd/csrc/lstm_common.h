@@ -124,6 +124,9 @@ struct LstmPersistBwdArgs {
     int tp_kb = 0;                    // k blocks (32 packed rows) per column tile
     long long tp_row0[2] = {0, 0};    // first packed row of this launch's step range per direction: the planes' k index 0
     const unsigned long long* masks = nullptr;      // row-slot batches: as in LstmPersistArgs
+    // gradient w.r.t. the FINAL cell state c_n [ndir][max_batch][H] (or null): enters the cell-state gradient of every sequence's
+    // last step in the direction's forward sense = the first step this pass processes for it
+    const float* dcn = nullptr;
 };
 
 // Workgroup L of a 1-D grid runs on XCD L % 8 (round-robin dispatch).  A chain = (direction, row tile)

@@ -979,7 +979,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         }
         float gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f;
         if (act) {
-            float dc = has_succ(b) ? dc_state : 0.f;
+            float dc = has_succ(b) ? dc_state : (A.dcn ? A.dcn[((size_t)dir * A.max_batch + b) * H + j] : 0.f);
             const float tc = tanhf_(cn);
             const float d_o = dh * tc;
             dc += dh * og * (1.f - tc * tc);

@@ -199,14 +199,20 @@ def absmax(x, rows, cols, ld):
 
 @_register('lstm_recurrence_backward_range(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!) dg, '
            'Tensor(b!) scratch, Tensor(c!) dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, int H, '
-           'int ndir, int s_begin, int s_end, bool prefilled=False) -> bool')
+           'int ndir, int s_begin, int s_end, bool prefilled=False, Tensor? dc_n=None) -> bool')
 def lstm_recurrence_backward_range(gates, c, c0, dhy, w_hh_t, dg, scratch, dc_carry, bs_dev, offs_dev, T, max_batch, rows, H, ndir,
-                                   s_begin, s_end, prefilled=False):
+                                   s_begin, s_end, prefilled=False, dc_n=None):
     """The persistent backward recurrence over the processing steps [s_begin, s_end) (``ptmi_lstm_backward_persistent_range``;
     ranges in order, same ``dg`` / ``scratch`` / ``dc_carry``).  False: the launch cannot be resident (nothing was run)."""
-    rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_range, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
-                    dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), scratch.data_ptr(),
-                    dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)), _lib.stream(gates.device))
+    if dc_n is not None:        # + the gradient w.r.t. the final cell state (ptmi_lstm_backward_persistent_states; whole recurrence)
+        assert s_begin == 0 and s_end == T and dc_n.shape == (ndir, max_batch, H) and dc_n.is_contiguous(), (s_begin, s_end, dc_n.shape)
+        rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_states, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                        dhy.data_ptr(), dc_n.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
+                        scratch.data_ptr(), dc_carry.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled)), _lib.stream(gates.device))
+    else:
+        rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_range, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
+                        dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), scratch.data_ptr(),
+                        dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)), _lib.stream(gates.device))
     if rc == -2:
         return False
     _lib.check(rc, 'ptmi_lstm_backward_persistent_range')

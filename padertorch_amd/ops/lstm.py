@@ -495,6 +495,7 @@ class _LstmLayerFn(torch.autograd.Function):
         ndir, G, H = w_hh.shape
         assert G == 4 * H
         KP = (H + 15) // 16 * 16
+        ctx.set_materialize_grads(False)         # an unused output (the cell states of a call whose c_n nobody differentiates) comes back as None
         stateful = h0 is not None or c0 is not None
         if stateful:            # [ndir, B, H]; their gradients: see backward (persistent split kernels)
             h0 = torch.zeros_like(c0) if h0 is None else h0.detach().to(torch.float32).contiguous()
@@ -631,13 +632,15 @@ class _LstmLayerFn(torch.autograd.Function):
         ctx.top = bool(top)          # the layer whose backward pass runs first (nothing else is on the weight-gradient queue then)
         ctx.oc = oc if oc is not None else _context.effective(None)
         if stateful:
-            ctx.mark_non_differentiable(c)
-            return hy, c
+            return hy, c            # (c: differentiable too - the gradient of the FINAL cell state comes back through it, see backward)
         return hy
 
     @staticmethod
     def backward(ctx, dhy, _dc=None):
         meta, lease = ctx.meta, ctx.lease
+        if dhy is None:             # only the cell states were used
+            dhy = torch.zeros((meta.rows, ctx.saved_tensors[2].shape[0] * ctx.saved_tensors[2].shape[2]), dtype=torch.float32,
+                              device=ctx.saved_tensors[0].device)
         h0 = c0 = db_kernel = amax_kernel = None
         lib = _lib.load()
         st = _lib.stream(dhy.device)
@@ -741,8 +744,16 @@ class _LstmLayerFn(torch.autograd.Function):
             T = meta.T
             # gradients w.r.t. the initial state: the range entry point leaves the cell-state gradient behind the last step
             state_grad = h0 is not None and any(ctx.needs_input_grad[5:7])
+            # gradient w.r.t. the FINAL cell state: `_dc` is the gradient of the cell-state tensor this layer returned; packed_lstm
+            # exposes only each sequence's last row of it (c_n), so only those rows can carry a gradient: gathered into [ndir, B, H]
+            # and handed to the kernel, which adds it to the cell-state gradient at each sequence's last step
+            dcn = None
+            if _dc is not None and h0 is not None:
+                dcv = _dc.reshape(meta.rows, ndir, H)
+                dcn = torch.stack([dcv[meta.last_rows[d], d] for d in range(ndir)]).contiguous()
+                state_grad = True                    # (the states entry point of the range launcher)
             if state_grad and not (PERSISTENT and lib.ptmi_lstm_split_enabled()):
-                raise NotImplementedError('gradients w.r.t. the initial LSTM state need the persistent split kernels')
+                raise NotImplementedError('gradients w.r.t. the LSTM states need the persistent split kernels')
             carry = None
             # The TOP layer's backward recurrence runs while the weight-gradient queue is still empty; for long batches, where
             # that queue is the critical one of the backward phase (16 kHz configurations: 11.9 ms of GEMMs and pack passes
@@ -808,7 +819,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 def launch(i):
                     return torch.ops.ptmi.lstm_recurrence_backward_range(
                         gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
-                        ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]))
+                        ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]), dcn)
                 if launch(0):
                     for i in range(1, chunks):
                         snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
@@ -986,8 +997,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     ``ptmi_pack_planes_n`` (written by the producer of the data, e.g. ``ops.pit_features``), with the float whose exponent gives
     their operand scale (``ops.gemm.scale_word``): the first layer's projection takes them as they lie.
 
-    ``hx = (h_0, c_0)``, each ``[num_layers * num_directions, B, H]`` like ``torch.nn.LSTM``, are taken
-    as constants (no gradient flows into the initial state).  Returns the output PackedSequence, or
+    ``hx = (h_0, c_0)``, each ``[num_layers * num_directions, B, H]`` like ``torch.nn.LSTM``; gradients flow into the initial
+    state and back from the final one ``(h_n, c_n)`` (persistent split kernels).  Returns the output PackedSequence, or
     ``(output, (h_n, c_n))`` when ``hx`` is given or ``return_state`` is set.
     """
     data = packed.data
@@ -1063,7 +1074,9 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
                 oc.grad_use_hook([p for ps in params for p in ps])
             h, c = _LstmLayerFn.apply(h, w_ih, bias, w_hh, meta, h0, c0, params, layer > 0, anchor, forms, None, None, False, oc)
             prev_handoff = None
-            hv, cv = h.detach().view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
+            # (h_n / c_n keep their graph, like torch.nn.LSTM's: the gradient of h_n joins this layer's output gradient, that of c_n
+            #  reaches the backward kernel through `c`; modules.StatefulLSTM detaches what it carries between calls)
+            hv, cv = h.view(meta.rows, ndir, H), c.view(meta.rows, ndir, H)
             h_n += [hv[meta.last_rows[d], d] for d in range(ndir)]
             c_n += [cv[meta.last_rows[d], d] for d in range(ndir)]
         else:

@@ -120,8 +120,8 @@ def test_initial_and_final_states_vs_torch_cpu(persistent, lens, monkeypatch):
     yr, (hr, cr) = ref(pack_sequence(xr), (h0, c0))
     yd, (hd, cd) = packed_lstm(dut, pack_sequence(xd), hx=(h0.to(DEV), c0.to(DEV)))
     np.testing.assert_allclose(yd.data.detach().cpu().numpy(), yr.data.detach().numpy(), atol=3e-6)
-    np.testing.assert_allclose(hd.cpu().numpy(), hr.detach().numpy(), atol=3e-6)
-    np.testing.assert_allclose(cd.cpu().numpy(), cr.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(hd.detach().cpu().numpy(), hr.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(cd.detach().cpu().numpy(), cr.detach().numpy(), atol=3e-6)
     g = torch.randn(yr.data.shape)
     (yr.data * g).sum().backward()
     (yd.data * g.to(DEV)).sum().backward()
@@ -133,8 +133,8 @@ def test_initial_and_final_states_vs_torch_cpu(persistent, lens, monkeypatch):
     # zero-state call with return_state == plain call + states
     y0, (hn0, cn0) = packed_lstm(dut, pack_sequence([x.detach() for x in xd]), return_state=True)
     yr0, (hr0, cr0) = ref(pack_sequence(xs))
-    np.testing.assert_allclose(hn0.cpu().numpy(), hr0.detach().numpy(), atol=3e-6)
-    np.testing.assert_allclose(cn0.cpu().numpy(), cr0.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(hn0.detach().cpu().numpy(), hr0.detach().numpy(), atol=3e-6)
+    np.testing.assert_allclose(cn0.detach().cpu().numpy(), cr0.detach().numpy(), atol=3e-6)
     # a state that requires a gradient: served by the persistent split kernels (test_gradients_wrt_the_initial_state), refused -
     # in the backward pass - by the one-launch-per-timestep kernels
     out = packed_lstm(dut, pack_sequence([x.detach() for x in xd]), hx=(h0.to(DEV).requires_grad_(True), c0.to(DEV)))
@@ -367,6 +367,46 @@ def test_input_gradient_from_handoff_planes(B, T, H, monkeypatch):
     yc, _ = ref(torch.nn.utils.rnn.PackedSequence(xc, torch.full((T,), B, dtype=torch.int64)))
     (yc.data * w.cpu()).sum().backward()
     assert float((dx_planes.cpu() - xc.grad).abs().max()) < 1e-4 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('lens', [[9, 9, 9, 9], [12, 10, 7, 7, 3]])
+@pytest.mark.parametrize('with_hx', [True, False])
+def test_gradients_through_the_final_state(lens, with_hx):
+    """``packed_lstm(..., return_state=True)`` returns ``(h_n, c_n)`` WITH their graph, like ``torch.nn.LSTM`` (the reference's
+    StatefulLSTM hands them on, modules/recurrent.py:42): a loss on the output, on h_n and on c_n - parameter, input and initial-state
+    gradients against torch's CPU LSTM (the gradient of c_n enters the backward kernel at every sequence's last step:
+    ptmi_lstm_backward_persistent_states), two layers, both directions, equal and ragged lengths."""
+    from padertorch_amd.ops import lstm as L
+    torch.manual_seed(21)
+    I, H, layers = 10, 12, 2
+    B = len(lens)
+    lstm = torch.nn.LSTM(I, H, layers, bidirectional=True).cuda()
+    ref = torch.nn.LSTM(I, H, layers, bidirectional=True)
+    ref.load_state_dict(lstm.state_dict())
+    xs = [torch.randn(n, I) for n in lens]
+    h0 = torch.randn(2 * layers, B, H) * 0.5
+    c0 = torch.randn(2 * layers, B, H) * 0.5
+    w = torch.randn(sum(lens), 2 * H)
+    wh, wc = torch.randn(2 * layers, B, H), torch.randn(2 * layers, B, H)
+
+    def run(mod, dev, fn):
+        mod.zero_grad()
+        xd = [x.to(dev).requires_grad_(True) for x in xs]
+        hh = h0.to(dev).requires_grad_(True)
+        cc = c0.to(dev).requires_grad_(True)
+        out, (hn, cn) = fn(mod, pack_sequence(xd), (hh, cc) if with_hx else None)
+        ((out.data * w.to(dev)).sum() + (hn * wh.to(dev)).sum() + (cn * wc.to(dev)).sum()).backward()
+        states = (hh.grad.cpu(), cc.grad.cpu()) if with_hx else ()
+        return (out.data.detach().cpu(), hn.detach().cpu(), cn.detach().cpu(), [x.grad.cpu() for x in xd],
+                [p.grad.cpu().clone() for p in mod.parameters()], states)
+
+    got = run(lstm, 'cuda', lambda m, p, hx: L.packed_lstm(m, p, hx=hx, return_state=True))
+    want = run(ref, 'cpu', lambda m, p, hx: m(p, hx))
+    for a, b in zip(got[:3], want[:3]):
+        assert float((a - b).abs().max()) < 2e-5
+    for a, b in zip(got[3] + got[4] + list(got[5]), want[3] + want[4] + list(want[5])):
+        assert float((a - b).abs().max()) < 1e-4 * max(1., float(b.abs().max())), float((a - b).abs().max())
 
 
 @pytest.mark.gpu
