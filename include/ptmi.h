@@ -464,7 +464,7 @@ int ptmi_absmax_accumulate(const float* x, int64_t rows, int64_t cols, int64_t l
  *   split_k > 1: AT MOST that many k ranges (what the workspace of ptmi_gemm_planes_workspace_elems floats holds); how many are used,
  *   and on which workgroup tile (persistent big-tile kernel: work item = (k range, tile)), is a cost model's choice that depends on
  *   the shape alone; the ranges' partial products are summed in range order by a second kernel (reproducible, no atomics).
- *   split_k < -1: exactly -split_k ranges on the 128 x 128 kernel, whose workgroups fit on a CU next to a workgroup of the
+ *   split_k < 0: exactly -split_k ranges (-1: no split) on the 128 x 128 kernel, whose workgroups fit on a CU next to a workgroup of the
  *   persistent recurrence kernels (callers whose GEMM runs beside a recurrence). */
 int64_t ptmi_planes_elems(int64_t rows, int64_t k);
 int ptmi_pack_planes_t(const float* x, int64_t k_rows, int64_t cols, int64_t ld, const uint32_t* amax, uint16_t* out,
@@ -490,6 +490,13 @@ int ptmi_pack_planes_into(const float* x, int64_t rows_or_k, int64_t cols, int64
                           uint16_t* out, int64_t kb_total, int64_t kb_offset, int64_t kb_count, ptmi_stream_t stream);
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,
                           int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace, ptmi_stream_t stream);
+/* ptmi_gemm_planes_bf16 with a TWO-PART output: rows m < m_split of the product go to c, rows m >= m_split to c2 (row m - m_split;
+ * same row stride ldc; m_split a multiple of 16; c and c2 equally aligned).  Both directions' dW_ih = [dgates_f | dgates_r]^T x of a
+ * BLSTM layer (torch.nn.LSTM backward, pit/model.py:60-66: weight_ih_l<k> and weight_ih_l<k>_reverse are separate parameters) as
+ * ONE launch over the operand the backward recurrence hands on (both directions' dgates^T planes lie behind each other). */
+int ptmi_gemm_planes_bf16_two(const uint16_t* a, const uint16_t* b, float* c, float* c2, int32_t m_split, int64_t ldc, int32_t m,
+                              int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace,
+                              ptmi_stream_t stream);
 /* The weight-gradient form on the SAME planes: C[m, n] (+)= sum over rows r of A[r, m] B[r, n], both operands bf16 planes of
  * matrices whose rows are r (ptmi_pack_planes_n_bf16 of the layer input / output; the backward recurrence's hand-off planes of the
  * gate gradients): the reduction runs over the planes' ROW tiles, the MFMA fragments are read with the LDS transpose read, and no

@@ -115,6 +115,7 @@ SIGNATURES = {
                                          c_int64, c_int32, c_int32, _P, _P]),
     'ptmi_gemm_planes_select_tile': (c_int, [c_int32]),
     'ptmi_debug_occupy': (c_int, [c_int32, c_int32, c_int32, c_int64, _P]),
+    'ptmi_gemm_planes_bf16_two': (c_int, [_P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'ptmi_gemm_planes_plan': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_comm_rccl_version': (c_int32, []),
     'ptmi_comm_unique_id': (c_int, [_P]),

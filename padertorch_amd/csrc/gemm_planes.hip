@@ -57,6 +57,10 @@ struct PlanesArgs {
     int accumulate;
     int kb_per_split;
     int tiles_m, tiles_n;
+    // two-part output: rows m >= m_split go to C2 (row m - m_split, same row stride): both directions' dW_ih = [dgates_f | dgates_r]^T x
+    // as ONE launch into the two parameters' gradient buffers (m_split a multiple of 16; null: one output)
+    float* C2 = nullptr;
+    int m_split = 0;
 };
 
 // BF16: the planes hold bf16 halves (fp32's exponent range: no operand scale) - the backward recurrence's hand-off copy of the
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
     const bool slab = gridDim.z > 1;
     float* const Cz = slab ? G.workspace + (long long)blockIdx.z * G.M * G.N : G.C;
     const long long ldc = slab ? G.N : G.ldc;
-    const bool vec = (ldc & 3) == 0 && (reinterpret_cast<unsigned long long>(Cz) & 15) == 0;
+    const bool vec = (ldc & 3) == 0 && ((reinterpret_cast<unsigned long long>(Cz) | reinterpret_cast<unsigned long long>(G.C2)) & 15) == 0;
     const bool add = G.accumulate && !slab;
     const int r = lane & 15, g = lane >> 4;
     // this lane's four bias groups (one per column tile j), all requested before any is used
@@ -167,10 +171,12 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
     for (int i = 0; i < 4; ++i) {
         const int m = tm * PBM + wm * 64 + i * 16 + r;
         if (m >= G.M) continue;
+        const bool second = !slab && G.C2 != nullptr && m >= G.m_split;
+        float* const rowp = second ? G.C2 + (long long)(m - G.m_split) * ldc : Cz + (long long)m * ldc;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
-            float* o = Cz + (long long)m * ldc + n;
+            float* o = rowp + n;
             const f4 v = acc[i][j] * inv + bv[j];
             if (vec && n + 3 < G.N) {
                 f4* o4 = reinterpret_cast<f4*>(o);
@@ -202,6 +208,8 @@ struct BigArgs {
     // `slabs` [splits][M][N], summed in slab order by planes_reduce_kernel (reproducible, no atomics, nobody waits for anybody)
     int splits = 1, kb_per_split = 0;
     float* slabs = nullptr;
+    float* C2 = nullptr;        // two-part output, as in PlanesArgs
+    int m_split = 0;
 };
 
 template <bool BF16, int MT, int NT, bool ONE>
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
         {
             const int r = lane & 15, g = lane >> 4;
             const int n0 = (tn * WN + wn) * NT * 16 + g * 4;
-            const bool vec = (G.ldc & 3) == 0 && (reinterpret_cast<unsigned long long>(G.C) & 15) == 0;
+            const bool vec = (G.ldc & 3) == 0 && ((reinterpret_cast<unsigned long long>(G.C) | reinterpret_cast<unsigned long long>(G.C2)) & 15) == 0;
             const bool full = vec && (tn * WN + wn + 1) * NT * 16 <= G.N;           // wave-uniform: every column of this wave's tile exists
             f4 bv[NT];
 #pragma unroll
@@ -357,7 +365,11 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                 tz = ntz;
                 continue;
             }
-            float* const crow = G.C + (long long)mrow * G.ldc + n0;
+            // row of subtile i (two-part output: rows from m_split on live in C2)
+            auto rowp = [&](int i) {
+                const int m = mrow + i * 16;
+                return (G.C2 != nullptr && m >= G.m_split ? G.C2 + (long long)(m - G.m_split) * G.ldc : G.C + (long long)m * G.ldc) + n0;
+            };
             if (full && !G.accumulate) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
@@ -365,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                     for (int j = 0; j < NT; ++j) {
                         const f4 v = acc[i][j] * inv + bv[j];
                         acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-                        if (mrow + i * 16 < G.M) *reinterpret_cast<f4*>(crow + (long long)i * 16 * G.ldc + j * 16) = v;
+                        if (mrow + i * 16 < G.M) *reinterpret_cast<f4*>(rowp(i) + j * 16) = v;
                     }
                 }
             } else if (full) {
@@ -375,12 +387,12 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                     f4 old[NT];                         // all of a row tile's loads in flight before the first add
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        old[j] = ok ? *reinterpret_cast<const f4*>(crow + (long long)i * 16 * G.ldc + j * 16) : f4{0.f, 0.f, 0.f, 0.f};
+                        old[j] = ok ? *reinterpret_cast<const f4*>(rowp(i) + j * 16) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const f4 v = acc[i][j] * inv + bv[j] + old[j];
                         acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-                        if (ok) *reinterpret_cast<f4*>(crow + (long long)i * 16 * G.ldc + j * 16) = v;
+                        if (ok) *reinterpret_cast<f4*>(rowp(i) + j * 16) = v;
                     }
                 }
             } else {
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                     for (int j = 0; j < NT; ++j) {
                         const f4 v = acc[i][j] * inv + bv[j];
                         acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-                        float* o = crow + (long long)i * 16 * G.ldc + j * 16;
+                        float* o = rowp(i) + j * 16;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (ok && n0 + j * 16 + e < G.N) o[e] = G.accumulate ? o[e] + v[e] : v[e];
@@ -618,14 +630,15 @@ __device__ __forceinline__ void split_chunk(const float (&v)[8], uint4* hi_out, 
 
 // split K, second pass: C (+)= sum over the slabs in slab order (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long long ldc,
-                                                            const float* __restrict__ bias, int M, int N, int accumulate) {
+                                                            const float* __restrict__ bias, int M, int N, int accumulate,
+                                                            float* __restrict__ C2 = nullptr, int m_split = 0) {
     const long long total = (long long)M * N;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / N), c = (int)(i - (long long)r * N);
         float sum = 0.f;
         for (int z = 0; z < splits; ++z) sum += ws[(long long)z * total + i];
         if (bias) sum += bias[c];
-        float* o = C + (long long)r * ldc + c;
+        float* o = (C2 != nullptr && r >= m_split) ? C2 + (long long)(r - m_split) * ldc + c : C + (long long)r * ldc + c;
         *o = accumulate ? *o + sum : sum;
     }
 }
@@ -918,7 +931,7 @@ static BigPick pick_big(int32_t m, int32_t n, int KB, int max_splits) {
 // splits > 1: `splits` k ranges of `per` k blocks, partial products into `slabs` (the caller runs planes_reduce_kernel behind the launch)
 static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
                        const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st,
-                       int splits = 1, int per = 0, float* slabs = nullptr) {
+                       int splits = 1, int per = 0, float* slabs = nullptr, float* c2 = nullptr, int m_split = 0) {
     const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
     if (pick < 0 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return false;      // piece offsets are formed in 32-bit signed arithmetic
     BigArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, amax_a, amax_b, bias, m, n, KB, (long long)ldc,
@@ -926,6 +939,8 @@ static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const u
     G.splits = splits;
     G.kb_per_split = per;
     G.slabs = slabs;
+    G.C2 = c2;
+    G.m_split = m_split;
 #define PTMI_BIG_CASE(I, MT_, NT_)                                    \
     case I:                                                           \
         if (bf16 && one) launch_big_inst<true, MT_, NT_, true>(G, st);        \
@@ -946,8 +961,9 @@ static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const u
 
 static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
                             const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate,
-                            int32_t split_k, float* workspace, ptmi_stream_t stream) {
+                            int32_t split_k, float* workspace, ptmi_stream_t stream, float* c2 = nullptr, int32_t m_split = 0) {
     PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
+    PTMI_RETURN_IF(c2 && (m_split < 16 || m_split >= m || m_split % 16 != 0), PTMI_E_INVALID);
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
     const int KB = (k + 31) / 32;
     // split_k = the most k ranges the caller's workspace holds; how many are used (and on which tile) is the cost model's choice - a
@@ -966,23 +982,25 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
     static const bool big_split = !(getenv("PTMI_GEMM_BIG_SPLIT") && atoi(getenv("PTMI_GEMM_BIG_SPLIT")) == 0);
     BigPick pk = pick_big(m, n, KB, ((big_split && !co_resident) || g_tile_override >= 0) ? splits : 1);
     if (g_tile_override >= 0) pk.splits = splits;
-    else if ((!big_split || co_resident) && splits > 1) pk = BigPick{-1, splits};    // 128 x 128 slabs as asked for
+    else if (co_resident || (!big_split && splits > 1)) pk = BigPick{-1, splits};    // 128 x 128 (slabs) as asked for
     if (pk.splits != splits) {
         splits = pk.splits;
         per = (KB + splits - 1) / splits;
     }
     if (pk.tile >= 0 && launch_big(pk.tile, bf16, one, a, amax_a, b, amax_b, splits > 1 ? nullptr : bias, c, ldc, m, n, KB,
-                                   splits > 1 ? 0 : accumulate, st, splits, per, workspace)) {
+                                   splits > 1 ? 0 : accumulate, st, splits, per, workspace, c2, m_split)) {
         int rc = launch_status();
         if (rc != PTMI_OK || splits == 1) return rc;
         const long long total = (long long)m * n;
         const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
-                           accumulate ? 1 : 0);
+                           accumulate ? 1 : 0, c2, m_split);
         return launch_status();
     }
     PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, bias, m, n, KB,
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
+    G.C2 = c2;
+    G.m_split = m_split;
     const int tiles = G.tiles_m * G.tiles_n;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
     if (bf16 && one)
@@ -998,7 +1016,7 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
     const long long total = (long long)m * n;
     const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
-                       accumulate ? 1 : 0);
+                       accumulate ? 1 : 0, c2, m_split);
     return launch_status();
 }
 
@@ -1059,7 +1077,7 @@ int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k) 
     static const bool big_split = !(getenv("PTMI_GEMM_BIG_SPLIT") && atoi(getenv("PTMI_GEMM_BIG_SPLIT")) == 0);
     BigPick pk = pick_big(m, n, KB, ((big_split && !co_resident) || g_tile_override >= 0) ? splits : 1);
     if (g_tile_override >= 0) pk.splits = splits;
-    else if ((!big_split || co_resident) && splits > 1) pk = BigPick{-1, splits};
+    else if (co_resident || (!big_split && splits > 1)) pk = BigPick{-1, splits};
     const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) pk.tile = -1;
     return (pk.tile < 0 ? 5 : pk.tile) * 100 + pk.splits;
@@ -1075,6 +1093,15 @@ int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bia
                           int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace, ptmi_stream_t stream) {
     PTMI_RETURN_IF(products != 3 && products != 1, PTMI_E_INVALID);
     return gemm_planes_impl(true, products == 1, a, nullptr, b, nullptr, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
+}
+
+int ptmi_gemm_planes_bf16_two(const uint16_t* a, const uint16_t* b, float* c, float* c2, int32_t m_split, int64_t ldc, int32_t m,
+                              int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace,
+                              ptmi_stream_t stream) {
+    PTMI_RETURN_IF((products != 3 && products != 1) || !c2, PTMI_E_INVALID);
+    PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(c) ^ reinterpret_cast<uintptr_t>(c2)) & 15, PTMI_E_INVALID);       // one alignment class
+    return gemm_planes_impl(true, products == 1, a, nullptr, b, nullptr, nullptr, c, ldc, m, n, k, accumulate, split_k, workspace, stream,
+                            c2, m_split);
 }
 
 }  // extern "C"

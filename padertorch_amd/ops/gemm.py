@@ -371,10 +371,9 @@ def co_resident_split_k(M, N, K):
     if K > CO_RESIDENT_MAX_K:
         return auto_split_k(M, N, K)
     tiles = -(-M // 128) * -(-N // 128)
-    if tiles >= 384:
+    if tiles >= 1024:
         return 1
-    s = max(1, min(512 // tiles, K // 512, 8))
-    return -s if s > 1 else 1
+    return -max(1, min(512 // tiles, K // 512, 8))
 
 
 def mm(x, y, bias=None, out=None, accumulate=False, amax_x=None, amax_y=None, split_k=None):

@@ -376,6 +376,20 @@ def gemm_planes_bf16_(out, a, a_offset, b, bias, M, N, K, accumulate, split_k):
                           _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes_bf16')
 
 
+@_register('gemm_planes_bf16_two_(Tensor(a!) out, Tensor(b!) out2, Tensor a, int a_offset, Tensor b, int M, int N, int K, bool accumulate, '
+           'int split_k) -> ()')
+def gemm_planes_bf16_two_(out, out2, a, a_offset, b, M, N, K, accumulate, split_k):
+    """``[out; out2] (+)= A B^T`` (``ptmi_gemm_planes_bf16_two``): ``out`` takes the first ``out.shape[0]`` rows of the M x N product,
+    ``out2`` the rest - two parameters' gradient buffers with one row stride (both directions' ``dW_ih`` of a BLSTM layer)."""
+    lib = _lib.load()
+    assert out.shape[0] + out2.shape[0] == M and out.shape[1] == out2.shape[1] == N and out.stride(0) == out2.stride(0), (out.shape, out2.shape)
+    nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
+    ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
+    _lib.check(_lib.timed(f'gemm_planes_bf16:{M}x{N}x{K}:{split_k}', lib.ptmi_gemm_planes_bf16_two, a.data_ptr() + a_offset, b.data_ptr(),
+                          out.data_ptr(), out2.data_ptr(), out.shape[0], max(out.stride(0), N), M, N, K, int(accumulate), split_k,
+                          _products(), _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes_bf16_two')
+
+
 @_register('gemm_planes_tn_bf16_(Tensor(a!) out, Tensor a, int a_offset, int a_col_blocks, int a_col_block0, int a_row_tile0, '
            'Tensor b, int b_offset, int b_col_blocks, int b_col_block0, int b_row_tile0, int M, int N, int rows, bool accumulate, '
            'int split_k) -> ()')

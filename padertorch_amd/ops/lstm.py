@@ -203,6 +203,8 @@ SPLIT_TOP_BACKWARD_ROWS = 16384
 #: (ptmi_lstm_backward_persistent_planes): no row-major fp32 store, no transposing pack pass per direction (equal-length batches
 #: whose size is a multiple of 16, in-place weight gradients)
 DG_PLANES_FROM_KERNEL = True
+#: both directions' dW_ih of a BLSTM layer as one GEMM launch with a two-part output (with DG_PLANES_FROM_KERNEL)
+FUSE_DW_IH = True
 _WGRAD_DONE = {}
 # (Measured in round 2 and not kept - DESIGN.md sections 3.9 / 4 have the numbers -: the pattern fill ahead of time on a side stream,
 # the weight gradients' forward-data operand planes packed during the forward pass, a layer's weight gradients started behind its
@@ -687,6 +689,20 @@ class _LstmLayerFn(torch.autograd.Function):
             # the first layer's weight gradients have the chip to themselves (the step's tail): big tiles; every other layer's run
             # beside the next recurrence: short ones on the kernel whose workgroups share CUs with the recurrence's
             split_of = _gemm.auto_split_k if not ctx.needs_input_grad[0] else _gemm.co_resident_split_k
+            # both directions' dW_ih = [dgates_f | dgates_r]^T x share the operand x and the kernel's planes of dgates^T lie behind each
+            # other: ONE launch with a two-part output (ptmi_gemm_planes_bf16_two) instead of two GEMMs + two slab reductions
+            fused_ih = False
+            if (dg_t is not None and FUSE_DW_IH and ndir == 2 and ranges[0] == ranges[1] and ranges[0][1] > ranges[0][0]):
+                ga, gb = params[0][0].grad, params[1][0].grad
+                if ga.stride() == gb.stride() and (ga.data_ptr() ^ gb.data_ptr()) & 15 == 0 and ga.is_contiguous():
+                    r0, r1 = ranges[0]
+                    with torch.cuda.stream(main if both_queues else side):
+                        key = (r0, r1)
+                        if key not in xplanes:
+                            xplanes[key] = torch.ops.ptmi.pack_planes_bf16(x[r0:r1], True)
+                        torch.ops.ptmi.gemm_planes_bf16_two_(ga, gb, dg_t, 0, xplanes[key], 2 * G, x.shape[1], r1 - r0, True,
+                                                             split_of(2 * G, x.shape[1], r1 - r0))
+                    fused_ih = True
             for d, ((p_wih, p_whh, _, _), (r0, r1)) in enumerate(zip(params, ranges)):
                 q_ih = main if both_queues else side
                 q_hh = main if both_queues and d == 1 else side
@@ -702,10 +718,11 @@ class _LstmLayerFn(torch.autograd.Function):
                         k = r1 - r0
                         key = (r0, r1)
                         a_off = d * int(lib.ptmi_planes_elems(G, k)) * 2
-                        if key not in xplanes:
+                        if key not in xplanes and not fused_ih:
                             xplanes[key] = torch.ops.ptmi.pack_planes_bf16(x[r0:r1], True)
-                        torch.ops.ptmi.gemm_planes_bf16_(p_wih.grad, dg_t, a_off, xplanes[key], None, G, x.shape[1], k, True,
-                                                         split_of(G, x.shape[1], k))
+                        if not fused_ih:
+                            torch.ops.ptmi.gemm_planes_bf16_(p_wih.grad, dg_t, a_off, xplanes[key], None, G, x.shape[1], k, True,
+                                                             split_of(G, x.shape[1], k))
                         with torch.cuda.stream(q_hh):
                             hpl = torch.ops.ptmi.pack_planes_bf16(h_prev[r0:r1], True)
                             torch.ops.ptmi.gemm_planes_bf16_(p_whh.grad, dg_t, a_off, hpl, None, G, H, k, True, split_of(G, H, k))

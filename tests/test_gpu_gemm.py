@@ -360,6 +360,43 @@ def test_planes_big_tiles_with_split_k_vs_fp64(tile, M, N, K, split, acc, bias, 
         _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
 
 
+@pytest.mark.parametrize('tile', [-1, 0, 3, 5])
+@pytest.mark.parametrize('M,split_at,N,K,split,acc', [(4800, 2400, 257, 2080, 8, True), (4800, 2400, 1200, 1000, -1, True),
+                                                      (80, 32, 70, 333, 3, False), (272, 256, 321, 96, 1, True)])
+def test_planes_gemm_with_a_two_part_output_vs_fp64(tile, M, split_at, N, K, split, acc):
+    """ptmi_gemm_planes_bf16_two: rows < split_at of the product land in one buffer, the rest in another (both directions' dW_ih of a
+    BLSTM layer in one launch) - every route (cost model, pinned big tiles with and without split K, the 128 x 128 kernel incl. its
+    co-resident form), accumulation, strided outputs; equal to two separate calls bit for bit."""
+    from padertorch_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + N + K + tile)
+    a = torch.randn(K, M, device='cuda') * 0.3
+    x = torch.randn(K, N, device='cuda')
+    pa, px = torch.ops.ptmi.pack_planes_bf16(a, True), torch.ops.ptmi.pack_planes_bf16(x, True)
+    buf = torch.randn(M + 4, (N + 7) // 4 * 4, device='cuda')          # (both parts in one alignment class: row stride and gap multiples of 16 B)
+    c1, c2 = buf[:split_at, :N], buf[split_at + 4:, :N]
+    ref = buf.clone()
+    want = a.double().t() @ x.double()
+    mag = a.double().abs().t() @ x.double().abs()
+    before = torch.cat([c1, c2]).double() if acc else 0
+    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    try:
+        torch.ops.ptmi.gemm_planes_bf16_two_(c1, c2, pa, 0, px, M, N, K, acc, split)
+        torch.cuda.synchronize()
+        got = torch.cat([c1, c2]).double()
+        assert float(((got - want - before).abs() / (mag + (before.abs() if acc else 0))).max()) < 8e-6       # bf16 (hi, lo) operands: 2^-17 per product
+        assert torch.equal(buf[split_at:split_at + 4], ref[split_at:split_at + 4]) and torch.equal(buf[:, N:], ref[:, N:])
+        # two separate calls on the two halves of the operand give the same bits
+        r1, r2 = ref[:split_at, :N], ref[split_at + 4:, :N]
+        half = int(lib.ptmi_planes_elems(split_at, K)) * 2
+        if split_at % 16 == 0 and tile in (-1, 5) and split == 1:
+            torch.ops.ptmi.gemm_planes_bf16_(r1, pa, 0, px, None, split_at, N, K, acc, split)
+            torch.ops.ptmi.gemm_planes_bf16_(r2, pa, half, px, None, M - split_at, N, K, acc, split)
+            assert float((torch.cat([r1, r2]) - torch.cat([c1, c2])).abs().max()) <= 1e-6 * float(torch.cat([c1, c2]).abs().max())
+    finally:
+        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+
+
 def test_planes_big_tile_many_tiles_per_workgroup():
     """More tiles than CUs: every workgroup of the persistent kernel walks several tiles (the next tile's first stage is requested
     during the last k step of the current one); 128 x 256 tiles at 4100 x 4100 = 33 x 17 = 561 tiles."""
