@@ -539,6 +539,11 @@ int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k);
  *   step's losses) or norm[0] is not finite; applied (device fp32 scalar or NULL) receives 1 / 0 = applied / skipped.  segments = device int64 [nseg][3]: parameter pointer, first flat
  *   index, element count, ascending and dense over [0, n).  exp_avg / exp_avg_sq: flat fp32 [n].  The caller
  *   advances `step` (a device fp32 scalar) afterwards. */
+/* ptmi_lstm_bias_grad_add: bias_ih_grad[d][i] += db[d][i] and bias_hh_grad[d][i] += db[d][i] for every direction d (HOST arrays of
+ * ndir device pointers; db [ndir][n] = the bias gradient the persistent backward recurrence leaves in its scratch): torch.nn.LSTM
+ * keeps two bias vectors per direction (pit/model.py:60-66) that receive the same gradient - one launch instead of 2 ndir. */
+int ptmi_lstm_bias_grad_add(const float* db, int32_t ndir, int32_t n, float* const* bias_ih_grad, float* const* bias_hh_grad,
+                            ptmi_stream_t stream);
 int64_t ptmi_grad_norm_workspace_elems(void);
 int ptmi_grad_norm(const float* flat, int64_t n, double* workspace, float* norm_out, ptmi_stream_t stream);
 int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const int64_t* segments, int32_t nseg, int64_t n,

@@ -122,6 +122,7 @@ SIGNATURES = {
     'ptmi_comm_create': (c_int, [_P, c_int32, c_int32, _P]),
     'ptmi_allreduce_sum': (c_int, [_P, _P, c_int64, _P]),
     'ptmi_comm_destroy': (c_int, [_P]),
+    'ptmi_lstm_bias_grad_add': (c_int, [_P, c_int32, c_int32, _P, _P, _P]),
     'ptmi_grad_norm_workspace_elems': (c_int64, []),
     'ptmi_grad_norm': (c_int32, [_P, c_int64, _P, _P, _P]),
     'ptmi_adam_flat': (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, c_double, c_double, c_double,

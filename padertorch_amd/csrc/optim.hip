@@ -164,6 +164,42 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
     }
 }
 
+// The bias gradients of one BLSTM layer: db [ndir][n] (the backward recurrence's in-kernel sums) added into the 2 ndir gradient buffers
+// bias_ih / bias_hh of every direction (torch.nn.LSTM keeps two bias vectors per direction; both get the same gradient) - ONE launch
+// instead of 2 ndir `add_` launches on the weight-gradient queue.
+struct BiasGradArgs {
+    const float* db;
+    float* out[4];          // [direction][ih | hh]
+    int ndir, n;
+};
+
+__global__ void bias_grad_add_kernel(const BiasGradArgs A) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int d = blockIdx.y;
+    if (i >= A.n) return;
+    const float g = A.db[(size_t)d * A.n + i];
+    A.out[2 * d][i] += g;
+    A.out[2 * d + 1][i] += g;
+}
+
+}  // namespace ptmi
+
+extern "C" int ptmi_lstm_bias_grad_add(const float* db, int32_t ndir, int32_t n, float* const* bias_ih_grad, float* const* bias_hh_grad,
+                                       ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!db || !bias_ih_grad || !bias_hh_grad || (ndir != 1 && ndir != 2) || n < 1, PTMI_E_INVALID);
+    ptmi::BiasGradArgs A{db, {nullptr, nullptr, nullptr, nullptr}, ndir, n};
+    for (int d = 0; d < ndir; ++d) {
+        PTMI_RETURN_IF(!bias_ih_grad[d] || !bias_hh_grad[d], PTMI_E_INVALID);
+        A.out[2 * d] = bias_ih_grad[d];
+        A.out[2 * d + 1] = bias_hh_grad[d];
+    }
+    hipLaunchKernelGGL(ptmi::bias_grad_add_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)ndir), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), A);
+    return ptmi::launch_status();
+}
+
+namespace ptmi {
+
 }  // namespace ptmi
 
 using namespace ptmi;

@@ -246,6 +246,18 @@ def lstm_recurrence_backward_planes(gates, c, c0, dhy, w_hh_t, dg, dg_t, scratch
     return True
 
 
+@_register('lstm_bias_grad_add_(Tensor db, Tensor(a!)[] bias_ih_grad, Tensor(b!)[] bias_hh_grad) -> ()')
+def lstm_bias_grad_add_(db, bias_ih_grad, bias_hh_grad):
+    """``bias_ih_grad[d] += db[d]; bias_hh_grad[d] += db[d]`` for every direction in one launch (``ptmi_lstm_bias_grad_add``)."""
+    ndir = len(bias_ih_grad)
+    n = bias_ih_grad[0].numel()
+    assert db.numel() == ndir * n and db.dtype == torch.float32 and db.is_contiguous()
+    assert all(t.is_contiguous() and t.numel() == n and t.dtype == torch.float32 for t in list(bias_ih_grad) + list(bias_hh_grad))
+    ih = (ctypes.c_void_p * ndir)(*[t.data_ptr() for t in bias_ih_grad])
+    hh = (ctypes.c_void_p * ndir)(*[t.data_ptr() for t in bias_hh_grad])
+    _lib.check(_lib.load().ptmi_lstm_bias_grad_add(db.data_ptr(), ndir, n, ih, hh, _lib.stream(db.device)), 'ptmi_lstm_bias_grad_add')
+
+
 # ------------------------------------------------------------------------------------------------ LSTM parameter forms
 @_register('lstm_weight_prep(Tensor[] w_ih, Tensor[] w_hh, Tensor[] b_ih, Tensor[] b_hh, int KP) -> '
            '(Tensor, Tensor, Tensor, Tensor, Tensor)')

@@ -916,10 +916,14 @@ class _LstmLayerFn(torch.autograd.Function):
                 main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
             wgrad_rows(dg, todo, amax_dg, both_queues=both, dg_t=dg_t)
             with torch.cuda.stream(side):
-                for d, (_, _, p_bih, p_bhh) in enumerate(params):
-                    db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
-                    p_bih.grad.add_(db_d)
-                    p_bhh.grad.add_(db_d)
+                if db_kernel is not None and all(ps[2].grad.is_contiguous() and ps[3].grad.is_contiguous() for ps in params):
+                    # the kernel's bias sums into all 2 ndir bias gradients: one launch (was one small `add_` per bias vector)
+                    torch.ops.ptmi.lstm_bias_grad_add_(db_kernel, [ps[2].grad for ps in params], [ps[3].grad for ps in params])
+                else:
+                    for d, (_, _, p_bih, p_bhh) in enumerate(params):
+                        db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
+                        p_bih.grad.add_(db_d)
+                        p_bhh.grad.add_(db_d)
             if use_side:
                 done = torch.cuda.Event()
                 done.record(side)
