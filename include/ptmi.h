@@ -475,6 +475,16 @@ int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_
 int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
                      int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products,
                      float* workspace, ptmi_stream_t stream);
+/* A dense layer with the ReLU behind it in one call (torch.nn.Linear + torch.nn.ReLU, pit/model.py:98-104, tcl/dc.py:38-40):
+ * c = max(a b^T + bias, 0) as ptmi_gemm_planes computes the product (no accumulation), and the float bits of max c into *amax_out (may be
+ * NULL; zeroed by the call unless amax_zeroed says the caller has done that) - the operand scale ptmi_pack_planes_n takes when c is the next layer's input, so that neither the activation
+ * nor ptmi_absmax is a pass of its own.  ptmi_relu_backward_absmax is the matching backward step: out = g where y > 0 (y = the ReLU's
+ * output c), else 0, and the float bits of max |out| into *amax_out - what torch's threshold_backward and ptmi_absmax did in two passes. */
+int ptmi_gemm_planes_relu(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
+                          int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t split_k, int32_t products, float* workspace,
+                          uint32_t* amax_out, int32_t amax_zeroed, ptmi_stream_t stream);
+int ptmi_relu_backward_absmax(const float* g, const float* y, float* out, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_y,
+                              int64_t ld_out, uint32_t* amax_out, int32_t amax_zeroed, ptmi_stream_t stream);
 /* The bf16 flavour of the three calls above: the planes hold bf16 (hi, lo) halves, no operand scale (fp32's exponent range).
  * It exists for the LSTM input gradient dx = dgates W_ih (torch.nn.LSTM backward inside pit/model.py:60-66): the persistent
  * backward recurrence hands its gate gradients on as exactly such planes (its scratch, ptmi_lstm_handoff_cols), so the

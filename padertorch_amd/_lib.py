@@ -106,6 +106,8 @@ SIGNATURES = {
     'ptmi_gemm_planes_workspace_elems': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_pack_planes_n': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P, _P]),
     'ptmi_gemm_planes': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+    'ptmi_gemm_planes_relu': (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P]),
+    'ptmi_relu_backward_absmax': (c_int, [_P, _P, _P, c_int64, c_int64, c_int64, c_int64, c_int64, _P, c_int32, _P]),
     'ptmi_pack_planes_t_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_pack_planes_n_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_pack_planes_into': (c_int, [_P, c_int64, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, c_int64, c_int64, _P]),

@@ -130,13 +130,25 @@ class PermutationInvariantTrainingModel(base.Model):
 
         h_data = self.dropout_linear(h.data)
         # BLSTM outputs lie in (-1, 1) (x 2 at most under dropout): no operand scaling pass for the split GEMM
-        h_data = ops.linear.linear(self.linear1, h_data, ops.gemm.UNIT_RANGE)
-        h_data = self.relu(h_data)
-        h_data = ops.linear.linear(self.linear2, h_data)
-        h_data = self.output_activation(h_data)
+        h_data = self._dense(h_data)
 
         mask = PackedSequence(h_data.view(-1, self.K, self.F), h.batch_sizes)  # 'tb (k f) -> tb k f'
         return ops.unpack_sequence(mask)
+
+    def _dense(self, h):
+        """linear1 -> relu -> linear2 -> output activation on BLSTM output rows (``pit/model.py:98-104``).  A plain ``torch.nn.ReLU``
+        behind a layer is computed in that layer's GEMM epilogue (``ops.linear.linear(..., activation='relu')``), which also leaves the
+        next operand's scale behind; any other activation module is applied as it is."""
+        a1 = 'relu' if type(self.relu) is torch.nn.ReLU else None
+        a2 = 'relu' if type(self.output_activation) is torch.nn.ReLU else None
+        # BLSTM outputs lie in (-1, 1) (x 2 at most under dropout): no operand scaling pass for the split GEMM
+        h = ops.linear.linear(self.linear1, h, ops.gemm.UNIT_RANGE, activation=a1)
+        if a1 is None:
+            h = self.relu(h)
+        h = ops.linear.linear(self.linear2, h, activation=a2)
+        if a2 is None:
+            h = self.output_activation(h)
+        return h
 
     def _forward_row_slots(self, Y_abs):
         """``forward`` for a ragged batch on the row-slot layout (``row_slots``): the same network, rows = [T, slots] with the
@@ -151,9 +163,7 @@ class PermutationInvariantTrainingModel(base.Model):
         x = ops.sequence.log1p(self.dropout_input(layout.scatter_rows(padded)))   # log1p(0) = 0: idle rows stay zero
         T, S = layout.T, layout.slots
         h = ops.packed_lstm(self.blstm, PackedSequence(x, torch.full((T,), S, dtype=torch.int64)), meta=layout.meta).data
-        h = self.dropout_linear(h)
-        h = self.relu(ops.linear.linear(self.linear1, h, ops.gemm.UNIT_RANGE))
-        h = self.output_activation(ops.linear.linear(self.linear2, h))
+        h = self._dense(self.dropout_linear(h))
         masks = layout.gather_rows(h.view(-1, self.K, self.F), padded.shape[1])   # 'tb (k f) -> tb k f', back to one example per row
         return PaddedList(masks, lengths, True, lengths_dev)
 

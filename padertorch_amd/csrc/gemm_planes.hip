@@ -61,12 +61,31 @@ struct PlanesArgs {
     // as ONE launch into the two parameters' gradient buffers (m_split a multiple of 16; null: one output)
     float* C2 = nullptr;
     int m_split = 0;
+    // fused epilogue of a dense layer with a ReLU behind it (pit/model.py:98-104): C = max(A B^T + bias, 0), and the float bits of max C
+    // into *amax_out (zeroed by the host call, atomicMax: non-negative floats order like their bits) - the operand scale of the NEXT
+    // GEMM, so that neither the activation nor the maximum is a pass of its own
+    int relu = 0;
+    unsigned* amax_out = nullptr;
 };
+
+// ONE atomicMax per workgroup: the largest of its lanes' non-negative values (inf / nan: the largest finite float, as ptmi_absmax).
+// Atomics on one word are served one after the other (~12 ns each, ptmi_absmax): one per wavefront of a 2048-workgroup launch measured
+// +90 us per launch.  `red`: one word per wavefront; every thread of the workgroup calls this, once.
+__device__ __forceinline__ void block_amax(unsigned* out, unsigned m, unsigned* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < (blockDim.x >> 6); ++w) m = max(m, red[w]);
+        if (m != 0u) atomicMax(out, m >= 0x7f800000u ? 0x7f7fffffu : m);
+    }
+}
 
 // BF16: the planes hold bf16 halves (fp32's exponent range: no operand scale) - the backward recurrence's hand-off copy of the
 // gate gradients, whose range is not known before they are computed, and weights packed to match (csrc/lstm_split.hip)
 // ONE: only the hi planes are multiplied (one product per element: plain 16-bit operands - the reduced-precision "bf16 mode")
-template <bool BF16, bool ONE>
+template <bool BF16, bool ONE, bool RELU = false>
 __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G) {
 #if __HIP_DEVICE_COMPILE__          // (the host pass cannot parse the LDS-DMA builtin; it only needs the stub)
     constexpr int PIECES = 32;      // plane tiles per stage: (8 row tiles + 8 column tiles) x 2 planes
@@ -167,6 +186,8 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
             }
         }
     }
+    const bool fuse = RELU && !slab;          // (RELU: an instantiation of its own - the plain kernels compile as they always did)
+    unsigned mx = 0u;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = tm * PBM + wm * 64 + i * 16 + r;
@@ -177,7 +198,14 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
         for (int j = 0; j < 4; ++j) {
             const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
             float* o = rowp + n;
-            const f4 v = acc[i][j] * inv + bv[j];
+            f4 v = acc[i][j] * inv + bv[j];
+            if (RELU && fuse) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = fmaxf(v[e], 0.f);
+                    if (n + e < G.N) mx = max(mx, __float_as_uint(v[e]));
+                }
+            }
             if (vec && n + 3 < G.N) {
                 f4* o4 = reinterpret_cast<f4*>(o);
                 *o4 = add ? *o4 + v : v;
@@ -186,6 +214,12 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
                 for (int e = 0; e < 4; ++e)
                     if (n + e < G.N) o[e] = add ? o[e] + v[e] : v[e];
             }
+        }
+    }
+    if constexpr (RELU) {
+        if (!slab && G.amax_out) {          // (workgroup-uniform)
+            __shared__ unsigned red[4];
+            block_amax(G.amax_out, mx, red);
         }
     }
 #endif
@@ -210,9 +244,11 @@ struct BigArgs {
     float* slabs = nullptr;
     float* C2 = nullptr;        // two-part output, as in PlanesArgs
     int m_split = 0;
+    int relu = 0;               // as in PlanesArgs (not with split K: planes_reduce_kernel applies it then)
+    unsigned* amax_out = nullptr;
 };
 
-template <bool BF16, int MT, int NT, bool ONE>
+template <bool BF16, int MT, int NT, bool ONE, bool RELU = false>
 __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int WM = 2, WN = 4, RA = WM * MT, RB = WN * NT, PIECES = 2 * (RA + RB);
@@ -275,6 +311,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
     for (int i = 0; i < PW; ++i) issue(i, tm, tn, tz * KBS, 0);
     int st = 0;
     constexpr int PPI = (PW + MT - 1) / MT;             // pieces issued per row-tile iteration
+    unsigned relu_max = 0u;                             // (G.relu: the largest output of all this workgroup's tiles, one atomic at the end)
     while (true) {
         const int nidx = idx + per;
         const bool has_next_tile = nidx < cnt;
@@ -370,7 +407,30 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                 const int m = mrow + i * 16;
                 return (G.C2 != nullptr && m >= G.m_split ? G.C2 + (long long)(m - G.m_split) * G.ldc : G.C + (long long)m * G.ldc) + n0;
             };
-            if (full && !G.accumulate) {
+            if (RELU) {             // dense layer + ReLU (no accumulation): the activation and the next operand's scale, here
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const bool ok = mrow + i * 16 < G.M;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        f4 v = acc[i][j] * inv + bv[j];
+                        acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[e] = fmaxf(v[e], 0.f);
+                            if (ok && n0 + j * 16 + e < G.N) relu_max = max(relu_max, __float_as_uint(v[e]));
+                        }
+                        float* o = rowp(i) + j * 16;
+                        if (full) {
+                            if (ok) *reinterpret_cast<f4*>(o) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (ok && n0 + j * 16 + e < G.N) o[e] = v[e];
+                        }
+                    }
+                }
+            } else if (full && !G.accumulate) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -418,6 +478,12 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
         tz = ntz;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RELU) {
+        if (G.amax_out && G.splits == 1) {
+            __shared__ unsigned red[8];
+            block_amax(G.amax_out, relu_max, red);
+        }
+    }
 #endif
 }
 
@@ -631,16 +697,74 @@ __device__ __forceinline__ void split_chunk(const float (&v)[8], uint4* hi_out, 
 // split K, second pass: C (+)= sum over the slabs in slab order (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restrict__ ws, int splits, float* __restrict__ C, long long ldc,
                                                             const float* __restrict__ bias, int M, int N, int accumulate,
-                                                            float* __restrict__ C2 = nullptr, int m_split = 0) {
+                                                            float* __restrict__ C2 = nullptr, int m_split = 0, int relu = 0,
+                                                            unsigned* __restrict__ amax_out = nullptr) {
     const long long total = (long long)M * N;
+    unsigned mx = 0u;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int r = (int)(i / N), c = (int)(i - (long long)r * N);
         float sum = 0.f;
         for (int z = 0; z < splits; ++z) sum += ws[(long long)z * total + i];
         if (bias) sum += bias[c];
+        if (relu) {
+            sum = fmaxf(sum, 0.f);
+            mx = max(mx, __float_as_uint(sum));
+        }
         float* o = (C2 != nullptr && r >= m_split) ? C2 + (long long)(r - m_split) * ldc + c : C + (long long)r * ldc + c;
         *o = accumulate ? *o + sum : sum;
     }
+    if (relu && amax_out) {
+        __shared__ unsigned red[4];
+        block_amax(amax_out, mx, red);
+    }
+}
+
+// dx of a ReLU and the operand scale of what multiplies it next, one pass: out = g where y > 0 (y: the ReLU's OUTPUT), else 0; float bits
+// of max |out| into *amax_out (zeroed by the host call)
+__global__ __launch_bounds__(256) void relu_backward_absmax_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
+                                                                   long long rows, long long cols, long long ld_g, long long ld_y, long long ld_o,
+                                                                   unsigned* __restrict__ amax_out) {
+    unsigned mx = 0u;
+    const long long n = rows * cols;
+    if (ld_g == cols && ld_y == cols && ld_o == cols && (cols & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const long long n4 = n >> 2, stride = (long long)gridDim.x * 256;
+        const f4* g4 = reinterpret_cast<const f4*>(g);
+        const f4* y4 = reinterpret_cast<const f4*>(y);
+        f4* o4 = reinterpret_cast<f4*>(out);
+        long long i = blockIdx.x * 256ll + threadIdx.x;
+        for (; i + stride < n4; i += 2 * stride) {          // two independent 16-byte pairs per lane and iteration
+            const f4 ga = g4[i], ya = y4[i], gb = g4[i + stride], yb = y4[i + stride];
+            f4 va, vb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                va[q] = ya[q] > 0.f ? ga[q] : 0.f;
+                vb[q] = yb[q] > 0.f ? gb[q] : 0.f;
+                mx = max(mx, max(__float_as_uint(va[q]) & 0x7fffffffu, __float_as_uint(vb[q]) & 0x7fffffffu));
+            }
+            o4[i] = va;
+            o4[i + stride] = vb;
+        }
+        for (; i < n4; i += stride) {
+            const f4 ga = g4[i], ya = y4[i];
+            f4 va;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                va[q] = ya[q] > 0.f ? ga[q] : 0.f;
+                mx = max(mx, __float_as_uint(va[q]) & 0x7fffffffu);
+            }
+            o4[i] = va;
+        }
+    } else {
+        for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const long long r = i / cols, c = i - r * cols;
+            const float v = y[r * ld_y + c] > 0.f ? g[r * ld_g + c] : 0.f;
+            out[r * ld_o + c] = v;
+            mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
+        }
+    }
+    __shared__ unsigned red[4];
+    block_amax(amax_out, mx, red);
 }
 
 // Source x[k][c] (row stride ld; the operand's ROWS are the columns c, its reduction axis the rows k) -> planes.
@@ -876,14 +1000,14 @@ static int cu_count() {
     return cus;
 }
 
-template <bool BF16, int MT, int NT, bool ONE>
+template <bool BF16, int MT, int NT, bool ONE, bool RELU = false>
 static void launch_big_inst(const BigArgs& G0, hipStream_t st) {
     BigArgs G = G0;
     G.tiles_m = (G.M + 32 * MT - 1) / (32 * MT);
     G.tiles_n = (G.N + 64 * NT - 1) / (64 * NT);
     const int T = G.tiles_m * G.tiles_n * G.splits;
     const int grid = std::min((T + 7) / 8 * 8, cu_count() / 8 * 8);
-    hipLaunchKernelGGL((gemm_planes_big_kernel<BF16, MT, NT, ONE>), dim3((unsigned)grid), dim3(512), 0, st, G);
+    hipLaunchKernelGGL((gemm_planes_big_kernel<BF16, MT, NT, ONE, RELU>), dim3((unsigned)grid), dim3(512), 0, st, G);
 }
 
 // Picks the tile - and, for calls that allow split K, the number of k ranges - by a cost model fitted to scripts/mb/gemm_big.hip's
@@ -931,7 +1055,8 @@ static BigPick pick_big(int32_t m, int32_t n, int KB, int max_splits) {
 // splits > 1: `splits` k ranges of `per` k blocks, partial products into `slabs` (the caller runs planes_reduce_kernel behind the launch)
 static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
                        const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int KB, int32_t accumulate, hipStream_t st,
-                       int splits = 1, int per = 0, float* slabs = nullptr, float* c2 = nullptr, int m_split = 0) {
+                       int splits = 1, int per = 0, float* slabs = nullptr, float* c2 = nullptr, int m_split = 0, int relu = 0,
+                       unsigned* amax_out = nullptr) {
     const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
     if (pick < 0 || a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) return false;      // piece offsets are formed in 32-bit signed arithmetic
     BigArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, amax_a, amax_b, bias, m, n, KB, (long long)ldc,
@@ -941,9 +1066,12 @@ static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const u
     G.slabs = slabs;
     G.C2 = c2;
     G.m_split = m_split;
+    G.relu = splits > 1 ? 0 : relu;
+    G.amax_out = amax_out;
 #define PTMI_BIG_CASE(I, MT_, NT_)                                    \
     case I:                                                           \
-        if (bf16 && one) launch_big_inst<true, MT_, NT_, true>(G, st);        \
+        if (G.relu) launch_big_inst<false, MT_, NT_, false, true>(G, st);     \
+        else if (bf16 && one) launch_big_inst<true, MT_, NT_, true>(G, st);   \
         else if (bf16) launch_big_inst<true, MT_, NT_, false>(G, st);         \
         else if (one) launch_big_inst<false, MT_, NT_, true>(G, st);          \
         else launch_big_inst<false, MT_, NT_, false>(G, st);                  \
@@ -961,8 +1089,10 @@ static bool launch_big(int pick, bool bf16, bool one, const uint16_t* a, const u
 
 static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b,
                             const float* bias, float* c, int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate,
-                            int32_t split_k, float* workspace, ptmi_stream_t stream, float* c2 = nullptr, int32_t m_split = 0) {
+                            int32_t split_k, float* workspace, ptmi_stream_t stream, float* c2 = nullptr, int32_t m_split = 0, int relu = 0,
+                            unsigned* amax_out = nullptr) {
     PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || k < 1 || ldc < n, PTMI_E_INVALID);
+    PTMI_RETURN_IF(relu && (accumulate || c2 || bf16 || one), PTMI_E_INVALID);
     PTMI_RETURN_IF(c2 && (m_split < 16 || m_split >= m || m_split % 16 != 0), PTMI_E_INVALID);
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
     const int KB = (k + 31) / 32;
@@ -988,22 +1118,26 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
         per = (KB + splits - 1) / splits;
     }
     if (pk.tile >= 0 && launch_big(pk.tile, bf16, one, a, amax_a, b, amax_b, splits > 1 ? nullptr : bias, c, ldc, m, n, KB,
-                                   splits > 1 ? 0 : accumulate, st, splits, per, workspace, c2, m_split)) {
+                                   splits > 1 ? 0 : accumulate, st, splits, per, workspace, c2, m_split, relu, amax_out)) {
         int rc = launch_status();
         if (rc != PTMI_OK || splits == 1) return rc;
         const long long total = (long long)m * n;
-        const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+        const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, relu ? 1024 : 4096);      // (relu: one atomic per workgroup)
         hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
-                           accumulate ? 1 : 0, c2, m_split);
+                           accumulate ? 1 : 0, c2, m_split, relu, amax_out);
         return launch_status();
     }
     PlanesArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, amax_a, amax_b, bias, m, n, KB,
                  (long long)ldc, accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
     G.C2 = c2;
     G.m_split = m_split;
+    G.relu = splits > 1 ? 0 : relu;
+    G.amax_out = amax_out;
     const int tiles = G.tiles_m * G.tiles_n;
     const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
-    if (bf16 && one)
+    if (G.relu)
+        hipLaunchKernelGGL((gemm_planes_kernel<false, false, true>), grid, dim3(256), 0, st, G);
+    else if (bf16 && one)
         hipLaunchKernelGGL((gemm_planes_kernel<true, true>), grid, dim3(256), 0, st, G);
     else if (bf16)
         hipLaunchKernelGGL((gemm_planes_kernel<true, false>), grid, dim3(256), 0, st, G);
@@ -1014,13 +1148,41 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
     int rc = launch_status();
     if (rc != PTMI_OK || splits == 1) return rc;
     const long long total = (long long)m * n;
-    const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
+    const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, relu ? 1024 : 4096);
     hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, bias, m, n,
-                       accumulate ? 1 : 0, c2, m_split);
+                       accumulate ? 1 : 0, c2, m_split, relu, amax_out);
     return launch_status();
 }
 
 extern "C" {
+
+int ptmi_gemm_planes_relu(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
+                          int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t split_k, int32_t products, float* workspace,
+                          uint32_t* amax_out, int32_t amax_zeroed, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(products != 3 && products != 1, PTMI_E_INVALID);
+    if (amax_out && !amax_zeroed) {
+        hipError_t e = zero_words_async(amax_out, 1, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return (int)e;
+    }
+    return gemm_planes_impl(false, products == 1, a, amax_a, b, amax_b, bias, c, ldc, m, n, k, 0, split_k, workspace, stream, nullptr, 0, 1,
+                            amax_out);
+}
+
+int ptmi_relu_backward_absmax(const float* g, const float* y, float* out, int64_t rows, int64_t cols, int64_t ld_g, int64_t ld_y,
+                              int64_t ld_out, uint32_t* amax_out, int32_t amax_zeroed, ptmi_stream_t stream) {
+    PTMI_RETURN_IF(!g || !y || !out || !amax_out || rows < 0 || cols < 0 || ld_g < cols || ld_y < cols || ld_out < cols, PTMI_E_INVALID);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!amax_zeroed) {
+        hipError_t e = zero_words_async(amax_out, 1, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (rows * cols == 0) return PTMI_OK;
+    const long long work = (rows * cols + 4095) / 4096;
+    const unsigned grid = (unsigned)std::min<long long>(std::max<long long>(work, 1), 1024);          // (one atomic per workgroup)
+    hipLaunchKernelGGL(relu_backward_absmax_kernel, dim3(grid), dim3(256), 0, st, g, y, out, (long long)rows, (long long)cols, (long long)ld_g,
+                       (long long)ld_y, (long long)ld_out, amax_out);
+    return launch_status();
+}
 
 int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* b, const uint32_t* amax_b, const float* bias, float* c,
                      int64_t ldc, int32_t m, int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products,

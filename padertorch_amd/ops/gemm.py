@@ -88,6 +88,25 @@ def invalidate():
     _lstm._STACKED.clear()
 
 
+class _Words(threading.local):
+    """Zeroed device words handed out one by one (views into blocks of 64: ONE fill launch per 64 words; a block lives as long as a view
+    of it does) - the targets of the epilogues that leave an operand maximum behind (``gemm_planes_relu_``, ``relu_backward_absmax``)."""
+    def __init__(self):
+        self.blocks = {}
+
+
+_WORDS = _Words()
+
+
+def zero_word(device):
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ent = _WORDS.blocks.get(key)
+    if ent is None or ent[1] >= 64:
+        ent = _WORDS.blocks[key] = [torch.zeros(64, dtype=torch.int32, device=device), 0]
+    ent[1] += 1
+    return ent[0][ent[1] - 1:ent[1]]
+
+
 def absmax(x):
     """Device word (int32 tensor [1]) holding the float bits of ``max |x|`` of a 2-D fp32 tensor with one unit stride."""
     assert x.dim() == 2 and x.dtype == torch.float32

@@ -336,6 +336,30 @@ def gemm_planes_(out, a, amax_a, b, amax_b, bias, M, N, K, accumulate, split_k):
                           _products(), _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes')
 
 
+@_register('gemm_planes_relu_(Tensor(a!) out, Tensor a, Tensor? amax_a, Tensor b, Tensor? amax_b, Tensor? bias, int M, int N, int K, '
+           'int split_k, Tensor(b!) amax_out) -> ()')
+def gemm_planes_relu_(out, a, amax_a, b, amax_b, bias, M, N, K, split_k, amax_out):
+    """``out = relu(A B^T + bias)`` and the float bits of ``max out`` into the ZEROED word ``amax_out`` (``ptmi_gemm_planes_relu``)."""
+    lib = _lib.load()
+    nws = int(lib.ptmi_gemm_planes_workspace_elems(M, N, K, split_k))
+    ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
+    _lib.check(_lib.timed(f'gemm_planes:{M}x{N}x{K}:{split_k}', lib.ptmi_gemm_planes_relu, a.data_ptr(), _lib.ptr(amax_a), b.data_ptr(),
+                          _lib.ptr(amax_b), _lib.ptr(bias), out.data_ptr(), max(out.stride(0), N), M, N, K, split_k, _products(),
+                          _lib.ptr(ws), amax_out.data_ptr(), 1, _lib.stream(out.device)), 'ptmi_gemm_planes_relu')
+
+
+@_register('relu_backward_absmax(Tensor g, Tensor y, Tensor(a!) amax_out) -> Tensor')
+def relu_backward_absmax(g, y, amax_out):
+    """``g`` where ``y > 0`` (``y``: the ReLU's output) else 0, and the float bits of its ``max |.|`` into the ZEROED word ``amax_out``."""
+    lib = _lib.load()
+    assert g.dim() == 2 and g.shape == y.shape and g.stride(1) == 1 and y.stride(1) == 1
+    out = torch.empty((g.shape[0], g.shape[1]), dtype=torch.float32, device=g.device)
+    _lib.check(_lib.timed(f'relu_backward_absmax:{g.shape[0]}x{g.shape[1]}', lib.ptmi_relu_backward_absmax, g.data_ptr(), y.data_ptr(),
+                          out.data_ptr(), g.shape[0], g.shape[1], _ld(g), _ld(y), _ld(out), amax_out.data_ptr(), 1, _lib.stream(g.device)),
+               'ptmi_relu_backward_absmax')
+    return out
+
+
 def _ld(x):
     """Row stride of a 2-D source with unit inner stride (a single row has none to speak of)."""
     return x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])

@@ -17,38 +17,60 @@ from . import lstm as _lstm
 __all__ = ['linear']
 
 
+#: attribute of the output of a fused Linear + ReLU: (tensor version, device word with the float bits of its maximum) - the operand scale
+#: the next ``linear`` takes instead of measuring it (the record travels WITH the tensor, like ``ops.lstm.HANDOFF_ATTR``)
+AMAX_ATTR = '_ptmi_amax'
+
+#: ``linear(..., activation='relu')``: the ReLU in the GEMM's epilogue (False: a torch op behind the layer, as before round 4 - A/B switch)
+FUSE_RELU = True
+
+
 class _LinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, module, amax_x):
+    def forward(ctx, x, weight, bias, module, amax_x, relu=False):
+        # relu (planes path only, see linear()): y = max(x W^T + b, 0) out of the GEMM's epilogue, which also leaves max y behind
+        # (second output, not differentiable); the backward pass masks the incoming gradient and takes ITS maximum in one pass
         amax_w = _gemm.weight_absmax(module.weight)
         amax_x = amax_x if amax_x is not None else _gemm.absmax(x)
-        ctx.save_for_backward(x, weight)
         ctx.module = module
         ctx.amax = (amax_x, amax_w)
         ctx.has_bias = bias is not None
+        ctx.relu = bool(relu)
         if _gemm.planes_enabled() and x.stride(1) == 1:
             # both operands as fp16 planes (the weight's cached per optimizer step): csrc/gemm_planes.hip
             y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
+            amax_y = _gemm.zero_word(x.device) if relu else None
             lh = _lstm.handoff_planes_of(x) if _lstm.INPUT_FROM_HANDOFF else None
             if lh is not None and x.is_contiguous() and x.shape[1] == lh[1] * lh[2]:
                 # x is the BLSTM output whose recurrence has left it as fp16 planes of 2^10 h: operand A as it lies
                 (scratch, cols), ndir, H = lh
-                wpl = _gemm.weight_planes_h(module.weight, ndir, H, cols)
-                kh = ndir * cols
-                torch.ops.ptmi.gemm_planes_(y, scratch, _gemm.scale_word(x.device), wpl[0], wpl[1], bias, x.shape[0], weight.shape[0], kh,
-                                            False, _gemm.auto_split_k(x.shape[0], weight.shape[0], kh))
-                return y
-            return _gemm.mm_planes_(y, _gemm.pack_n(x, amax_x), _gemm.weight_planes(module.weight), x.shape[0], weight.shape[0],
-                                    x.shape[1], bias=bias)
+                a, b, K = (scratch, _gemm.scale_word(x.device)), _gemm.weight_planes_h(module.weight, ndir, H, cols), ndir * cols
+            else:
+                a, b, K = _gemm.pack_n(x, amax_x), _gemm.weight_planes(module.weight), x.shape[1]
+            split = _gemm.auto_split_k(x.shape[0], weight.shape[0], K)
+            if relu:
+                torch.ops.ptmi.gemm_planes_relu_(y, a[0], a[1], b[0], b[1], bias, x.shape[0], weight.shape[0], K, split, amax_y)
+                ctx.save_for_backward(x, weight, y)
+                ctx.mark_non_differentiable(amax_y)
+                return y, amax_y
+            ctx.save_for_backward(x, weight)
+            torch.ops.ptmi.gemm_planes_(y, a[0], a[1], b[0], b[1], bias, x.shape[0], weight.shape[0], K, False, split)
+            return y
+        assert not relu
+        ctx.save_for_backward(x, weight)
         return _gemm.mm(x, weight.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
 
     @staticmethod
-    def backward(ctx, g):
-        x, weight = ctx.saved_tensors
+    def backward(ctx, g, _g_amax=None):
+        x, weight = ctx.saved_tensors[:2]
         mod = ctx.module
         amax_x, amax_w = ctx.amax
-        g = g.contiguous()
-        amax_g = _gemm.absmax(g)
+        if ctx.relu:
+            amax_g = _gemm.zero_word(g.device)
+            g = torch.ops.ptmi.relu_backward_absmax(g if g.stride(1) == 1 else g.contiguous(), ctx.saved_tensors[2], amax_g)
+        else:
+            g = g.contiguous()
+            amax_g = _gemm.absmax(g)
         planes = _gemm.planes_enabled() and x.stride(1) == 1
         if not ctx.needs_input_grad[0]:
             dx = None
@@ -63,7 +85,7 @@ class _LinearFn(torch.autograd.Function):
         if not in_place:
             dw = _gemm.mm(g.t(), x, amax_x=amax_g, amax_y=amax_x) if ctx.needs_input_grad[1] else None
             db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-            return dx, dw, db, None, None
+            return dx, dw, db, None, None, None
         main = torch.cuda.current_stream(x.device)
         side = _lstm._wgrad_stream(x.device) if oc.wgrad_side_stream else main
         if side is not main:
@@ -84,21 +106,33 @@ class _LinearFn(torch.autograd.Function):
                 t.record_stream(side)
         if oc.grad_ready_hook is not None:
             oc.grad_ready_hook([mod.weight] + ([mod.bias] if ctx.has_bias else []))
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def linear(module: torch.nn.Linear, x, x_range=None):
+def linear(module: torch.nn.Linear, x, x_range=None, activation=None):
     """``module(x)`` for a 2-D ``x``.  ``x_range=ops.gemm.UNIT_RANGE`` when ``x`` is known to lie in a range fp16
-    covers without scaling (e.g. LSTM outputs); by default its maximum is measured."""
+    covers without scaling (e.g. LSTM outputs); by default its maximum is measured - or taken from the record a fused
+    Linear + ReLU has left on ``x``.  ``activation='relu'``: ``relu(module(x))`` (``torch.nn.Linear`` followed by ``torch.nn.ReLU``,
+    ``pit/model.py:98-104``) with the activation in the GEMM's epilogue."""
+    assert activation in (None, 'relu'), activation
     if x.dim() == 2 and _gemm.usable(x, module.weight):
         oc = _context.effective(module)
         if (oc.grad_use_hook is not None and torch.is_grad_enabled() and oc.defer_wgrad and module.weight.requires_grad
                 and module.weight.grad is not None and (module.bias is None or module.bias.grad is not None)):
             oc.grad_use_hook([module.weight] + ([module.bias] if module.bias is not None else []))
-        return _LinearFn.apply(x, module.weight, module.bias, module, x_range)
+        if x_range is None:
+            rec = getattr(x, AMAX_ATTR, None)
+            if rec is not None and rec[0] == x._version:
+                x_range = rec[1]
+        if activation == 'relu' and FUSE_RELU and _gemm.PRODUCTS != 1 and _gemm.planes_enabled() and x.stride(1) == 1:
+            y, amax_y = _LinearFn.apply(x, module.weight, module.bias, module, x_range, True)
+            setattr(y, AMAX_ATTR, (y._version, amax_y))
+            return y
+        y = _LinearFn.apply(x, module.weight, module.bias, module, x_range)
+        return torch.relu(y) if activation == 'relu' else y
     if x.is_cuda:
         from .. import _lib
         _lib.leaving_native_path(f'a Linear({module.in_features}, {module.out_features}) layer',
                                  'ops.gemm.ENABLED = False (library-GEMM A/B mode)' if not _gemm.ENABLED else
                                  f'input of rank {x.dim()} / dtype {x.dtype} (2-D fp32 only)')
-    return module(x)
+    return torch.relu(module(x)) if activation == 'relu' else module(x)

@@ -463,3 +463,45 @@ def test_planes_tn_weight_gradient_form_vs_fp64(M, N, R, split, acc):
     again = c0.clone()
     torch.ops.ptmi.gemm_planes_tn_bf16_(again[:, :N], pa, 0, cbt_a, 2, 2, pb, 0, cbt_b, 1, 1, M, N, rows_eff, acc, split)
     assert torch.equal(again, cbuf)
+
+
+@pytest.mark.parametrize('tile', [-1, 0, 3, 5])
+@pytest.mark.parametrize('M,I,O', [(8096, 1200, 1200), (8096, 1200, 514), (300, 70, 257), (17, 33, 5), (1000, 64, 1282)])
+def test_linear_with_the_relu_in_the_epilogue(tile, M, I, O):
+    """``ops.linear.linear(..., activation='relu')``: values, the maximum it leaves behind, and all gradients against the unfused form
+    (bit for bit: the same products, the activation applied to the same fp32 value) and fp64; every tile, split K included."""
+    import ctypes
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import linear as L
+    lib = _lib.load()
+    dev = _dev()
+    torch.manual_seed(M + I + O)
+    lin = torch.nn.Linear(I, O).to(dev)
+    x = (torch.randn(M, I, device=dev) * 3).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    gy = torch.randn(M, O, device=dev)
+    assert lib.ptmi_gemm_planes_select_tile(tile) == 0
+    try:
+        y = L.linear(lin, x, activation='relu')
+        rec = getattr(y, L.AMAX_ATTR)
+        assert rec[0] == y._version
+        amax = rec[1].view(torch.float32)
+        assert float(amax) == float(y.max())
+        (y * gy).sum().backward()
+        gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+        lin.weight.grad = lin.bias.grad = None
+        y2 = torch.relu(L.linear(lin, x2))
+        (y2 * gy).sum().backward()
+    finally:
+        lib.ptmi_gemm_planes_select_tile(-1)
+    assert torch.equal(y, y2)
+    assert torch.equal(x.grad, x2.grad)
+    assert torch.equal(gw, lin.weight.grad) and torch.equal(gb, lin.bias.grad)
+    ref = torch.relu(x.detach().double() @ lin.weight.detach().double().t() + lin.bias.detach().double())
+    mag = x.detach().double().abs() @ lin.weight.detach().double().abs().t() + lin.bias.detach().double().abs()
+    assert float(((y.double() - ref).abs() / mag).max()) < 4e-7
+    # a second fused layer takes the first one's maximum as its operand scale: same result as measuring it
+    lin_b = torch.nn.Linear(O, 33).to(dev)
+    z = L.linear(lin_b, y.detach().clone() if False else y)
+    z2 = L.linear(lin_b, y2.detach())
+    assert torch.equal(z.detach(), z2)
