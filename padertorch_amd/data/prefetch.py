@@ -33,15 +33,29 @@ class DevicePrefetcher:
     Host tensors should be pinned (``tensor.pin_memory()``) for the copy to be asynchronous.
     """
 
-    def __init__(self, iterable, device, to_device=None):
+    def __init__(self, iterable, device, to_device=None, release='record_stream'):
+        """``release``: how the copy stream's memory pool learns that the consumer is done with an example.
+        ``'record_stream'`` (default): every tensor of an example is marked as used on the consumer's stream (the caching allocator
+        then records one event per tensor on THAT stream when the tensor is freed - a few microseconds of queue time each).
+        ``'mark'``: no marks; instead the copy stream waits, in front of every example it prepares, for everything the consumer's stream
+        has been handed so far.  Valid when every use of an example is enqueued on the consumer's stream - or synchronised into it - before
+        the next example is asked for (``Trainer.train`` with one micro-step per optimizer step: ``optimizer_step`` waits for the
+        weight-gradient stream).  It also orders ``to_device`` work that writes buffers of its own (``ops.pit_features``' planes) behind
+        their last reader."""
+        assert release in ('record_stream', 'mark'), release
         self.iterable = iterable
         self.device = torch.device(device)
         self.to_device = to_device or example_to_device
+        self.release = release
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
 
     def _issue(self, example):
         if self._stream is None:
             return self.to_device(example, self.device), None
+        if self.release == 'mark':
+            mark = torch.cuda.Event()
+            mark.record(torch.cuda.current_stream(self.device))
+            self._stream.wait_event(mark)
         with torch.cuda.stream(self._stream):
             moved = self.to_device(example, self.device)
             done = torch.cuda.Event()
@@ -63,8 +77,9 @@ class DevicePrefetcher:
             if done is not None:
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(done)
-                for t in _tensors(moved):
-                    t.record_stream(cur)          # allocated on the copy stream's pool, used (and freed) on the consumer's
+                if self.release == 'record_stream':
+                    for t in _tensors(moved):
+                        t.record_stream(cur)      # allocated on the copy stream's pool, used (and freed) on the consumer's
             yield moved
 
     def __len__(self):

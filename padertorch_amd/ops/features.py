@@ -134,11 +134,16 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
             # (one buffer per shape AND stream: a call on another stream - a prefetching copy stream, a second host thread - must not
             #  overwrite planes that a GEMM queued on this stream has not read yet)
             key = (dev.type, dev.index, meta.rows, F, torch.cuda.current_stream(dev).cuda_stream)
-            entry = _PLANES.get(key)
-            if entry is None:
+            # TWO buffers in turn: a call retires the planes of the call before the previous one, so the features of the NEXT batch can be
+            # made (data.DevicePrefetcher with a model's example_to_device) while this batch's first projection has yet to read its planes
+            ring = _PLANES.get(key)
+            if ring is None:
                 if len(_PLANES) > 8:
                     _PLANES.clear()
-                entry = _PLANES[key] = [torch.zeros(int(lib.ptmi_planes_elems(meta.rows, F)), dtype=torch.float16, device=dev), 0]
+                ring = _PLANES[key] = [[[torch.zeros(int(lib.ptmi_planes_elems(meta.rows, F)), dtype=torch.float16, device=dev), 0]
+                                        for _ in range(2)], 0]
+            ring[1] ^= 1
+            entry = ring[0][ring[1]]
             entry[1] += 1
         Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features_packed(
             y, s, ns_dev, tb['window'], tb['twiddle'], geom, T, lp, None if entry is None else entry[0],

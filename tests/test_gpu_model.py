@@ -478,3 +478,41 @@ def test_config4_size_step_on_the_rccl_path_next_to_a_cu_occupying_kernel(tmp_pa
         assert float((model.linear2.weight.detach() - before).abs().max()) > 0.
     finally:
         dist.destroy_process_group()
+
+
+def test_features_one_batch_ahead_on_the_prefetch_stream():
+    """``DevicePrefetcher(..., to_device=<transfer + feature kernel>, release='mark')``: the features of batch n + 1 are made on the
+    prefetch stream while batch n trains; the planes batch n's first projection reads are still its own, and three optimizer steps give
+    bit for bit the parameters of the serial loop."""
+    import padertorch_amd as pt
+    from padertorch_amd.data import DevicePrefetcher
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    host = [dict(y=(0.1 * torch.randn(16, 16000, generator=g)).pin_memory(), s=(0.1 * torch.randn(16, 2, 16000, generator=g)).pin_memory())
+            for _ in range(3)]
+    results = []
+    for ahead in (False, True):
+        torch.manual_seed(1)
+        model = PermutationInvariantTrainingModel(recurrent_layers=2, units=600)
+        trainer = pt.Trainer(model, f'/tmp/ptmi_ahead_{int(ahead)}', pt.optimizer.Adam(gradient_clipping=1.),
+                             loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.))
+        trainer.to(dev)
+        trainer.optimizer.use_flat_grads()
+
+        def make(ex, d):
+            return pt.ops.pit_features(ex['y'].to(d, non_blocking=True), ex['s'].to(d, non_blocking=True))
+        batches = DevicePrefetcher(host, dev, to_device=make, release='mark') if ahead else (make(ex, dev) for ex in host)
+        losses = []
+        for feats in batches:
+            assert feats['Y_abs'].packed_log1p.planes() is not None          # not retired by the batch made ahead
+            loss, _, _, _ = trainer.train_step(model, feats, dev)
+            loss.backward()
+            trainer.optimizer_step()
+            losses.append(loss.detach())
+        torch.cuda.synchronize()
+        pt.ops.lstm.check_errors()
+        results.append((torch.stack(losses).cpu(), [p.detach().cpu().clone() for p in model.parameters()]))
+    assert torch.equal(results[0][0], results[1][0])
+    for a, b in zip(results[0][1], results[1][1]):
+        assert torch.equal(a, b)

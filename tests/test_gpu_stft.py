@@ -242,7 +242,8 @@ def test_pit_features_write_the_packed_log_magnitude_input(lens):
     """SURVEY row a9 (``pit/model.py:91-94``, ``ops/sequence/pointwise.py:37``): the feature kernel itself writes the first BLSTM
     layer's input - log1p(Y_abs) in PackedSequence order, fp32 and as fp16 (hi, lo) planes with the fixed scale 2^9 - equal to what
     pack_sequence + log1p (+ the pack pass) make of its Y_abs: rows bit-exact positions, values to an ulp of log1p, planes =
-    hi + lo of 2^9 x within fp16's 22 bits, padding zero; a second call of the same shape retires the first call's planes."""
+    hi + lo of 2^9 x within fp16's 22 bits, padding zero; two buffers per shape in turn - the NEXT call of the same shape (the following
+    batch's features, made ahead of time by a prefetcher) leaves the planes alone, the one after it retires them."""
     from torch.nn.utils.rnn import pack_sequence
     from padertorch_amd.ops import pit_features
     from padertorch_amd.ops import gemm as G
@@ -275,7 +276,12 @@ def test_pit_features_write_the_packed_log_magnitude_input(lens):
     G.mm_planes_(yb, G.pack_n(pk.data, word), wp, rows, 48, F, split_k=1)
     assert torch.equal(ya, yb)
     f2 = pit_features(ys, ss)
-    assert pk.planes() is None and f2['Y_abs'].packed_log1p.planes() is not None
+    assert pk.planes() is planes and f2['Y_abs'].packed_log1p.planes() is not None
+    assert f2['Y_abs'].packed_log1p.planes().data_ptr() != planes.data_ptr()
+    torch.ops.ptmi.gemm_planes_(ya, planes, word, wp[0], wp[1], None, rows, 48, F, False, 1)      # still the first call's values
+    assert torch.equal(ya, yb)
+    f3 = pit_features(ys, ss)
+    assert pk.planes() is None and f2['Y_abs'].packed_log1p.planes() is not None and f3['Y_abs'].packed_log1p.planes() is not None
 
 
 def test_models_take_the_packed_log_magnitude_when_the_list_is_untouched():
