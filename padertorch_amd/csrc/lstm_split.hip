@@ -652,13 +652,16 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             }
         }
         if (act) {
-            gp[0] = ig;
-            gp[H] = fg;
-            gp[2 * H] = gg;
-            gp[3 * H] = og;
+            // saved activations / row-major outputs: nobody in this launch reads them again - stored with the non-temporal hint, so that
+            // they do not displace the operand panels the co-running weight-gradient GEMMs share through the L2s (with the matching
+            // loads in the backward kernel: 7.16 -> 7.12 ms per step, profiles/r4_ab_step.txt)
+            __builtin_nontemporal_store(ig, gp);
+            __builtin_nontemporal_store(fg, gp + H);
+            __builtin_nontemporal_store(gg, gp + 2 * H);
+            __builtin_nontemporal_store(og, gp + 3 * H);
             const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
-            A.c[o] = c_reg;
-            A.hy[o] = h;
+            __builtin_nontemporal_store(c_reg, A.c + o);
+            __builtin_nontemporal_store(h, A.hy + o);
         }
     }
 }
@@ -808,12 +811,12 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const int bb = min(b, nb - 1), jj = min(j, H - 1);
             const long long ohc = (row0 + bb) * ld_h + dir * H + jj;
             const long long ogc = (row0 + bb) * ld_g + (long long)dir * G + jj;
-            dh = A.dhy[ohc];
-            ig = A.gates[ogc];
-            fg = A.gates[ogc + H];
-            gg = A.gates[ogc + 2 * H];
-            og = A.gates[ogc + 3 * H];
-            cn = A.c[ohc];
+            dh = __builtin_nontemporal_load(A.dhy + ohc);
+            ig = __builtin_nontemporal_load(A.gates + ogc);
+            fg = __builtin_nontemporal_load(A.gates + ogc + H);
+            gg = __builtin_nontemporal_load(A.gates + ogc + 2 * H);
+            og = __builtin_nontemporal_load(A.gates + ogc + 3 * H);
+            cn = __builtin_nontemporal_load(A.c + ohc);
             cprev = A.c[(prow0 + min(bb, max(npv - 1, 0))) * ld_h + dir * H + jj];
         } else {        // never used: "defined" without an instruction (a zero store here is hoisted in front of the branch,
                         // where it brings the wait back)
