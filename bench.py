@@ -90,6 +90,9 @@ def parse_args(argv=None):
                     help="SURVEY 8d's training distribution: example lengths ~ U[3 s, 6 s] (sorted, zero-padded waveforms) instead of "
                          'the fixed 4 s of the headline; a reported mode (no roofline entry)')
     ap.add_argument('--no-overlap-allreduce', action='store_true', help='one all-reduce of the flat buffer in optimizer_step')
+    ap.add_argument('--row-slots', action='store_true',
+                    help='with --ragged: 2 x batch examples end to end in `batch` row slots (model.row_slots), the timed step itself '
+                         '(the default line reports the same as value_ragged_row_slots)')
     return ap.parse_args(argv)
 
 
@@ -454,6 +457,11 @@ def main():
         import random
         rnd = random.Random(1234)                         # the same lengths on every rank: equal work per rank (weak scaling)
         lengths = sorted((rnd.randint(3 * cfg['fs'], 6 * cfg['fs']) for _ in range(cfg['batch'])), reverse=True)
+        if args.row_slots:
+            assert cfg['model'] == 'pit' and cfg['batch'] <= 64, 'row slots: PIT model, <= 64 slots'
+            rnd = random.Random(4321)
+            lengths = sorted((rnd.randint(3 * cfg['fs'], 6 * cfg['fs']) for _ in range(2 * cfg['batch'])), reverse=True)
+            model.row_slots = cfg['batch']
         n = lengths[0]
     frames_per_micro = sum(frames_of(nb) for nb in lengths) if lengths else cfg['batch'] * frames_of(n)
     from padertorch_amd import _lib
@@ -487,7 +495,7 @@ def main():
             assert float(got.min()) == float(got.max()) == expect, (float(got.min()), float(got.max()), expect)
             trainer._flat.flat.zero_()
     else:
-        data = synthetic_batch(1000 + rank, cfg['batch'], K, n, device, lengths)
+        data = synthetic_batch(1000 + rank, len(lengths) if lengths else cfg['batch'], K, n, device, lengths)
         variant['data'] = data
         timers = []
 
@@ -772,7 +780,7 @@ def main():
             'dtype': 'fp16/bf16 operands, f32 accumulate (reduced precision)' if args.bf16 else 'f32',
             'data': 'synthetic',
             'config': {
-                'workload': f'{cfg["label"]}, {cfg["batch"]} x {"3-6 s (ragged, U[3 s, 6 s])" if args.ragged else str(SECONDS) + " s"} {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
+                'workload': f'{cfg["label"]}, {(2 if args.row_slots else 1) * cfg["batch"]} x {("3-6 s (ragged, U[3 s, 6 s]" + (", end to end in " + str(cfg["batch"]) + " row slots)" if args.row_slots else ")")) if args.ragged else str(SECONDS) + " s"} {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
                             f'micro-step ({frames_per_micro} frames), {micro} micro-step(s) per optimizer step, STFT '
                             f'{SIZE}/{SHIFT} on device, full optimizer step (Adam, clip 1)',
                 'global_batch': cfg['batch'] * world * micro,

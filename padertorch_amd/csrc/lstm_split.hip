@@ -768,6 +768,18 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     long long row_f = s0 + 1 < A.T ? offs_at(tindex(s0 + 1)) : 0;
     const bool carries = tid < 16 * MR && b < A.max_batch && j < H && A.dc_carry != nullptr;
     if (s0 > 0 && carries) dc_state = A.dc_carry[((size_t)dir * A.max_batch + b) * H + j];
+    // row-slot batches: the mask words of this step's time index (alive rows, rows at a sequence boundary in this direction's sense)
+    // and of the previously processed one
+    const int msel = dir == 0 ? 1 : 2;
+    u64 mk_a = 0ull, mk_b = 0ull, pv_a = 0ull, pv_b = 0ull;
+    if (masked) {
+        mk_a = A.masks[3 * tindex(s0)];
+        mk_b = A.masks[3 * tindex(s0) + msel];
+        if (s0 > 0) {
+            pv_a = A.masks[3 * tindex(s0 - 1)];
+            pv_b = A.masks[3 * tindex(s0 - 1) + msel];
+        }
+    }
     for (int s = s0; s < s1; ++s) {
         const int t = tindex(s);
         const int nb = nb_c;
@@ -789,12 +801,20 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         // masks of this step: rows alive; rows whose NEXT processed... whose previously processed step (time index tn) belongs to the
         // same sequence (its gate gradients reach this step through W_hh; the cell-state gradient carries over); rows whose cell
         // state c_{t-1} (forward sense of this direction) exists
+        // (the mask words arrive one iteration ahead - mk_a / mk_b below - and the previously processed index's are kept: loaded at
+        //  the loop head they put a scalar-load round trip into every step of the chain: 4.8 instead of 3.9 us per step)
         u64 amask = ~0ull, smask = ~0ull, cmask = ~0ull;
         if (masked) {
-            amask = A.masks[3 * t];
+            const u64 cur_a = mk_a, cur_b = mk_b;
+            const int t2m = tindex(min(s + 1, A.T - 1));          // clamped, unconditional
+            mk_a = A.masks[3 * t2m];
+            mk_b = A.masks[3 * t2m + msel];
+            amask = cur_a;
             const bool tn_ok = tn >= 0 && tn < A.T;
-            smask = tn_ok ? A.masks[3 * tn] & ~A.masks[3 * tn + (dir == 0 ? 1 : 2)] : 0ull;
-            cmask = amask & ~A.masks[3 * t + (dir == 0 ? 1 : 2)];
+            smask = tn_ok ? pv_a & ~pv_b : 0ull;
+            cmask = cur_a & ~cur_b;
+            pv_a = cur_a;
+            pv_b = cur_b;
         }
         auto has_succ = [&](int row) { return row < nnext && bit(smask, row); };
         const bool has_rec = masked ? ((smask >> m0) & ((1ull << MR) - 1ull)) != 0ull && nnext > m0 : nnext > m0;
