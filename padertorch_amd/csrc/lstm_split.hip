@@ -59,6 +59,19 @@ __device__ __forceinline__ bool has_fill(unsigned m) { return (m & 0xffffu) == 0
 // ticks at once; every 64th step every wavefront that has not failed since the last one takes 1 tick off (all at the same
 // step: with free-running per-wavefront probing some wavefront of the chain is always just trying a shorter wait, and the
 // whole chain pays its failed attempt).
+// A word of a read-only, launch-constant table (row-slot masks; the PackedSequence batch sizes / row offsets) through the SCALAR cache: the address is wave-uniform, but the
+// compiler cannot prove that none of the kernel's stores aliases the table and issues a vector load - whose use then waits with
+// s_waitcnt vmcnt(0) for every outstanding vector-memory operation, i.e. for the previous step's write-through hand-off stores (a store
+// round trip at the head of every step of the chain).  The tables' entries used to come through `uniform ? A.max_batch : A.bs[t]`, which the
+// compiler turns into ONE load from a selected address - kernel-argument segment or table - i.e. a FLAT load, and with a FLAT load
+// outstanding it can no longer count vector-memory returns: every wait of the operand passes becomes vmcnt(0).
+template <class T>
+__device__ __forceinline__ T ld_const(const T* p, int idx) {
+    typedef const __attribute__((address_space(4))) T* cptr;
+    return reinterpret_cast<cptr>(reinterpret_cast<unsigned long long>(p))[idx];
+}
+__device__ __forceinline__ unsigned long long ld_const64(const unsigned long long* p, int idx) { return ld_const(p, idx); }
+
 struct DafHold {
     unsigned hold, failed;
     unsigned long long ref;
@@ -450,12 +463,12 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     // fall into 64 different banks (pitch NC + 1: SQ_LDS_BANK_CONFLICT 48 % of the LDS cycles)
     __shared__ float red[2][NW][MR][NC + RED_PAD];
     const bool uniform = A.uniform != 0;
-    auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
-    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
+    auto bs_at = [&](int t) { return uniform ? A.max_batch : ld_const(A.bs, t); };
+    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)ld_const(A.offs, t); };
     // row-slot batches: per-step row masks instead of the prefix rules "b < bs[t]" / "b < bs[t -+ 1]" (LstmPersistArgs::masks)
     const bool masked = A.masks != nullptr;
     typedef unsigned long long u64;
-    auto alive_at = [&](int t) -> u64 { return masked ? A.masks[3 * t] : ~0ull; };
+    auto alive_at = [&](int t) -> u64 { return masked ? ld_const64(A.masks, 3 * t) : ~0ull; };
     auto bit = [](u64 m, int i) { return ((m >> (i & 63)) & 1ull) != 0ull; };
     const int nblk = A.KP32 >> 5;
     const int base = nblk / NW, extra = nblk - base * NW;
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
         const int nprev = (tp >= 0 && tp < A.T) ? min(bs_at(tp), nb) : 0;
         // rows of this step that continue a sequence (their hidden / cell state of the previous step counts)
         const u64 amask = alive_at(t);
-        const u64 pmask = masked ? ((tp >= 0 && tp < A.T) ? amask & ~A.masks[3 * t + (dir == 0 ? 1 : 2)] : 0ull) : ~0ull;
+        const u64 pmask = masked ? ((tp >= 0 && tp < A.T) ? amask & ~ld_const64(A.masks, 3 * t + (dir == 0 ? 1 : 2)) : 0ull) : ~0ull;
         auto has_pred = [&](int row) { return row < nprev && bit(pmask, row); };
         const bool has_rec = masked ? ((pmask >> m0) & ((1ull << MR) - 1ull)) != 0ull : nprev > m0;
         const bool act = tid < MR * JT && b < nb && bit(amask, b) && j0 + u < H;
@@ -679,7 +692,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
 // stores one 16-byte chunk.  With the planes, the hand-off copy (the LSTM input gradient's operand) and the in-kernel bias sums,
 // nobody reads the row-major fp32 gate gradients any more: A.dg may be null, and the 155 MB store + two transposing pack
 // passes per layer of the B = 32 step go away.
-template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false, bool TP = false>
+template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false, bool TP = false, bool MSK = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
     static_assert(!TP || DAF, "transposed planes: data-as-flag instantiations only (equal lengths, or row slots with their masks)");
     int bx, by, dir;
@@ -711,12 +724,15 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             }
         }
     };
-    const bool uniform = UNI || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
-    auto bs_at = [&](int t) { if (UNI) return A.max_batch; return uniform ? A.max_batch : A.bs[t]; };
-    auto offs_at = [&](int t) { if (UNI) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
+    // MSK: the row-slot instantiation (host checked: masks present, rows = [T, slots]) - the grid's bookkeeping is arithmetic at compile
+    // time like UNI's, only the masks are data
+    static_assert(!(UNI && MSK), "UNI: no masks");
+    const bool uniform = UNI || MSK || A.uniform != 0;        // equal lengths: bookkeeping by arithmetic (see the forward kernel)
+    auto bs_at = [&](int t) { if (UNI || MSK) return A.max_batch; return uniform ? A.max_batch : ld_const(A.bs, t); };
+    auto offs_at = [&](int t) { if (UNI || MSK) return (long long)t * A.max_batch; return uniform ? (long long)t * A.max_batch : (long long)ld_const(A.offs, t); };
     // row-slot batches (LstmPersistBwdArgs::masks; not in the UNI instantiations): per-step row masks instead of the prefix rules
     typedef unsigned long long u64;
-    const bool masked = !UNI && A.masks != nullptr;
+    const bool masked = MSK || (!UNI && A.masks != nullptr);
     auto bit = [](u64 m, int i) { return ((m >> (i & 63)) & 1ull) != 0ull; };
 
     const int nblk = A.G32 >> 5;
@@ -773,11 +789,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const int msel = dir == 0 ? 1 : 2;
     u64 mk_a = 0ull, mk_b = 0ull, pv_a = 0ull, pv_b = 0ull;
     if (masked) {
-        mk_a = A.masks[3 * tindex(s0)];
-        mk_b = A.masks[3 * tindex(s0) + msel];
+        mk_a = ld_const64(A.masks, 3 * tindex(s0));
+        mk_b = ld_const64(A.masks, 3 * tindex(s0) + msel);
         if (s0 > 0) {
-            pv_a = A.masks[3 * tindex(s0 - 1)];
-            pv_b = A.masks[3 * tindex(s0 - 1) + msel];
+            pv_a = ld_const64(A.masks, 3 * tindex(s0 - 1));
+            pv_b = ld_const64(A.masks, 3 * tindex(s0 - 1) + msel);
         }
     }
     for (int s = s0; s < s1; ++s) {
@@ -807,8 +823,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         if (masked) {
             const u64 cur_a = mk_a, cur_b = mk_b;
             const int t2m = tindex(min(s + 1, A.T - 1));          // clamped, unconditional
-            mk_a = A.masks[3 * t2m];
-            mk_b = A.masks[3 * t2m + msel];
+            mk_a = ld_const64(A.masks, 3 * t2m);
+            mk_b = ld_const64(A.masks, 3 * t2m + msel);
             amask = cur_a;
             const bool tn_ok = tn >= 0 && tn < A.T;
             smask = tn_ok ? pv_a & ~pv_b : 0ull;
@@ -843,8 +859,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             asm volatile("" : "=v"(dh), "=v"(ig), "=v"(fg), "=v"(gg), "=v"(og), "=v"(cn), "=v"(cprev));
         }
         const bool has_prev_c = b < npv && bit(cmask, b);
-        float c0v = 0.f;
-        if (A.c0 && act && !has_prev_c) c0v = A.c0[((long long)dir * A.max_batch + b) * H + j];
+        // (the initial cell state of a sequence that starts here is loaded where it is used, behind the barrier: as `c0v = 0; if (...) c0v =
+        //  A.c0[...]` at this point, the zero-initialisation of a register that a load of the previous iteration may still own made the
+        //  compiler wait HERE with s_waitcnt vmcnt(0) - for the cold loads just issued and for the previous step's stores, in front of the
+        //  hold and the operand requests of every step)
         if (!DAF && has_rec) {
             if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
             __syncthreads();
@@ -1008,7 +1026,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             dc += dh * og * (1.f - tc * tc);
             const float d_i = dc * gg;
             const float d_g = dc * ig;
-            const float d_f = dc * (has_prev_c ? cprev : c0v);
+            float cpv = cprev;
+            if (!has_prev_c) cpv = A.c0 ? A.c0[((long long)dir * A.max_batch + b) * H + j] : 0.f;     // a sequence's first step only
+            const float d_f = dc * cpv;
             dc_state = dc * fg;
             gi = d_i * ig * (1.f - ig);
             gf = d_f * fg * (1.f - fg);
@@ -1142,7 +1162,14 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {
     // equal-length batches: an instantiation without the PackedSequence tables (no loads at the loop head)
     const bool uni = A.uniform != 0 && !A.masks;         // (row-slot batches: the instantiation that reads the per-step masks)
-    if (A.dgtp && A.masks) {          // row slots + dgates^T planes
+    if (A.dgtp && A.masks && A.uniform) {          // row slots (rows = [T, slots]) + dgates^T planes
+        if (mtl == 2)
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, false, true, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        else
+            hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 1, 3, 16, false, true, true, true>), dim3(nwg), dim3(512), 0, st, A);
+        return launch_status();
+    }
+    if (A.dgtp && A.masks) {
         if (mtl == 2)
             hipLaunchKernelGGL((lstm_bwd_split_kernel<8, 10, 2, 3, 16, false, true, true>), dim3(nwg), dim3(512), 0, st, A);
         else

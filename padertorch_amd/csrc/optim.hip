@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void norm_fold_kernel(const double* __restrict
     if (threadIdx.x == 0) norm[0] = (float)sqrt(red[0]);
 }
 
+typedef __attribute__((address_space(1))) float gfloat;
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f32x4v gf32x4;
+
 struct AdamConsts {
     float clip, step_size, bc2_sqrt;
     bool skip;
@@ -127,19 +131,26 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
         }
         const bool full = i0 + 4 <= A.n;
         if (full && i0 + 4 <= seg_off[lo + 1]) {
-            float* pp = reinterpret_cast<float*>(A.segs[3 * lo]) + (i0 - seg_off[lo]);
+            // the parameter's address comes out of the segment table as an integer: as a generic pointer its accesses are FLAT
+            // instructions, behind which the compiler cannot count vector-memory returns (every wait becomes vmcnt(0) lgkmcnt(0)) -
+            // parameters live in device memory: global address space
+            gfloat* pp = reinterpret_cast<gfloat*>(static_cast<unsigned long long>(A.segs[3 * lo])) + (i0 - seg_off[lo]);
             float4 g = *reinterpret_cast<float4*>(A.grad + i0);
             if (!C.skip) {
                 float4 m = *reinterpret_cast<float4*>(A.m + i0), v = *reinterpret_cast<float4*>(A.v + i0);
                 const bool al = (reinterpret_cast<unsigned long long>(pp) & 15) == 0;
                 float4 p;
-                if (al) p = *reinterpret_cast<float4*>(pp);
-                else p = float4{pp[0], pp[1], pp[2], pp[3]};
+                if (al) {
+                    const f32x4v q = *reinterpret_cast<gf32x4*>(pp);
+                    p = float4{q[0], q[1], q[2], q[3]};
+                } else {
+                    p = float4{pp[0], pp[1], pp[2], pp[3]};
+                }
                 adam_one(p.x, g.x, m.x, v.x, A, C);
                 adam_one(p.y, g.y, m.y, v.y, A, C);
                 adam_one(p.z, g.z, m.z, v.z, A, C);
                 adam_one(p.w, g.w, m.w, v.w, A, C);
-                if (al) *reinterpret_cast<float4*>(pp) = p;
+                if (al) *reinterpret_cast<gf32x4*>(pp) = f32x4v{p.x, p.y, p.z, p.w};
                 else { pp[0] = p.x; pp[1] = p.y; pp[2] = p.z; pp[3] = p.w; }
                 *reinterpret_cast<float4*>(A.m + i0) = m;
                 *reinterpret_cast<float4*>(A.v + i0) = v;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
                 const long long i = i0 + e;
                 while (i >= seg_off[s + 1]) ++s;
                 if (!C.skip) {
-                    float* pp = reinterpret_cast<float*>(A.segs[3 * s]) + (i - seg_off[s]);
+                    gfloat* pp = reinterpret_cast<gfloat*>(static_cast<unsigned long long>(A.segs[3 * s])) + (i - seg_off[s]);
                     float p = *pp, g = A.grad[i], m = A.m[i], v = A.v[i];
                     adam_one(p, g, m, v, A, C);
                     *pp = p;

@@ -11,6 +11,8 @@ n_ex = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 rnd = random.Random(4321)
 lens = sorted((rnd.randint(190, 378) for _ in range(n_ex)), reverse=True)
+if len(sys.argv) > 3:          # equal lengths: the masked kernels without a sequence boundary inside the grid
+    lens = [int(sys.argv[3])] * n_ex
 layout = ops.sequence.SlotLayout.cached(tuple(lens), S, dev)
 T, H = layout.T, 600
 lstm = torch.nn.LSTM(257, H, 1, bidirectional=True).to(dev)
