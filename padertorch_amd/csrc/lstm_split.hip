@@ -504,6 +504,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     bool alive = true;
     float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
     float c_reg = 0.f;
+    // initial cell state of this thread's element (the same row and unit at every step; zero without hx)
+    const float c0_own = (A.c0 && tid < MR * JT && b < A.max_batch && j0 + u < H) ? A.c0[((long long)dir * A.max_batch + b) * H + j0 + u] : 0.f;
     {
         const int t0 = dir == 0 ? 0 : A.T - 1;
         if (tid < MR * JT && b < bs_at(t0) && bit(alive_at(t0), b) && j0 + u < H) {
@@ -540,10 +542,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
         auto has_pred = [&](int row) { return row < nprev && bit(pmask, row); };
         const bool has_rec = masked ? ((pmask >> m0) & ((1ull << MR) - 1ull)) != 0ull : nprev > m0;
         const bool act = tid < MR * JT && b < nb && bit(amask, b) && j0 + u < H;
-        float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
-        float cprev = 0.f;
+        // (this step's input pre-activations are in pre_n: requested behind the previous step's reduction, below.  The initial cell
+        //  state of this thread's element is c0_own, loaded once in front of the loop: as a conditional load into a register at this
+        //  point it made the compiler wait with s_waitcnt vmcnt(0) - for the owners' stores of the previous step - in front of the hold.)
+        float pre[4];
         float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
-        if (act && !has_pred(b) && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
         const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
         const bool more = s + 1 < A.T;
         const int nb1 = more ? bs_at(t1) : 0;
@@ -557,11 +560,12 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             }
         };
         if (!has_rec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = pre_n[q];
             prefetch();
             fill_some(s + 1 == A.T);
         }
         if (has_rec) {
-            if (act && has_pred(b)) cprev = c_reg;
             constexpr int NF = MTL * CB * 2;                 // fragments: (row tile mt, k block i, plane p)
             const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
                 A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
@@ -596,7 +600,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            prefetch();
             f32x4 acc[MTL][NT];
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
@@ -623,6 +626,8 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             fill_some(s + 1 == A.T);
             __syncthreads();
             dd.mark();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pre[q] = pre_n[q];
             if (tid < MR * JT) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -633,6 +638,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                     pre[q] += sum * inv;
                 }
             }
+            // the NEXT step's input pre-activations, into the registers this step's have just left: a whole step until they are used
+            // (requested in front of the MFMAs, into registers of their own, the compiler copied them over behind the reduction with
+            //  s_waitcnt vmcnt(0) - cold lines of about a microsecond - in front of the activations and the hand-off store)
+            prefetch();
         }
         float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
         if (act) {
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             fg = sigmoidf_(pre[1]);
             gg = tanhf_(pre[2]);
             og = sigmoidf_(pre[3]);
-            c_reg = fg * cprev + ig * gg;
+            c_reg = fg * ((has_rec && has_pred(b)) ? c_reg : c0_own) + ig * gg;        // (a sequence's first step: its initial cell state)
             h = og * tanhf_(c_reg);
         }
         {
@@ -782,6 +791,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     long long row_c = offs_at(tindex(s0));
     int nb_f = s0 + 1 < A.T ? bs_at(tindex(s0 + 1)) : 0;        // the time index processed next
     long long row_f = s0 + 1 < A.T ? offs_at(tindex(s0 + 1)) : 0;
+    const float c0_own = (A.c0 && tid < 16 * MR && b < A.max_batch && j < H) ? A.c0[((long long)dir * A.max_batch + b) * H + j] : 0.f;
     const bool carries = tid < 16 * MR && b < A.max_batch && j < H && A.dc_carry != nullptr;
     if (s0 > 0 && carries) dc_state = A.dc_carry[((size_t)dir * A.max_batch + b) * H + j];
     // row-slot batches: the mask words of this step's time index (alive rows, rows at a sequence boundary in this direction's sense)
@@ -859,7 +869,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             asm volatile("" : "=v"(dh), "=v"(ig), "=v"(fg), "=v"(gg), "=v"(og), "=v"(cn), "=v"(cprev));
         }
         const bool has_prev_c = b < npv && bit(cmask, b);
-        // (the initial cell state of a sequence that starts here is loaded where it is used, behind the barrier: as `c0v = 0; if (...) c0v =
+        // (the initial cell state of this thread's element is c0_own, loaded once in front of the loop: as `c0v = 0; if (...) c0v =
         //  A.c0[...]` at this point, the zero-initialisation of a register that a load of the previous iteration may still own made the
         //  compiler wait HERE with s_waitcnt vmcnt(0) - for the cold loads just issued and for the previous step's stores, in front of the
         //  hold and the operand requests of every step)
@@ -1026,9 +1036,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             dc += dh * og * (1.f - tc * tc);
             const float d_i = dc * gg;
             const float d_g = dc * ig;
-            float cpv = cprev;
-            if (!has_prev_c) cpv = A.c0 ? A.c0[((long long)dir * A.max_batch + b) * H + j] : 0.f;     // a sequence's first step only
-            const float d_f = dc * cpv;
+            const float d_f = dc * (has_prev_c ? cprev : c0_own);                      // (a sequence's first step: its initial cell state)
             dc_state = dc * fg;
             gi = d_i * ig * (1.f - ig);
             gf = d_f * fg * (1.f - fg);
