@@ -792,6 +792,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     int nb_f = s0 + 1 < A.T ? bs_at(tindex(s0 + 1)) : 0;        // the time index processed next
     long long row_f = s0 + 1 < A.T ? offs_at(tindex(s0 + 1)) : 0;
     const float c0_own = (A.c0 && tid < 16 * MR && b < A.max_batch && j < H) ? A.c0[((long long)dir * A.max_batch + b) * H + j] : 0.f;
+    // ... and the gradient w.r.t. its FINAL cell state (a conditional load behind the barrier made the wait for the saved activations a
+    // vmcnt(0): it then also waited for the plane chunk the thread had just stored)
+    const float dcn_own = (A.dcn && tid < 16 * MR && b < A.max_batch && j < H) ? A.dcn[((size_t)dir * A.max_batch + b) * H + j] : 0.f;
     const bool carries = tid < 16 * MR && b < A.max_batch && j < H && A.dc_carry != nullptr;
     if (s0 > 0 && carries) dc_state = A.dc_carry[((size_t)dir * A.max_batch + b) * H + j];
     // row-slot batches: the mask words of this step's time index (alive rows, rows at a sequence boundary in this direction's sense)
@@ -1013,15 +1016,18 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             __syncthreads();
             dd.mark();
             if (tid < 16 * MR && has_succ(b)) {
+                float part[NW];              // all partial sums requested, then added in order (one LDS round trip, not NW / 2 dependent ones)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) part[w] = red[s & 1][w][bl_][jl];
+                __builtin_amdgcn_sched_barrier(0);
                 float sum = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) sum += red[s & 1][w][bl_][jl];
+                for (int w = 0; w < NW; ++w) sum += part[w];
                 dh += sum;
             }
-            if (TP && t_pend >= 0) {        // the previous step's chunks (parked in front of this barrier)
-                flush_tp((s - 1) & 1, t_pend);
-                t_pend = -1;
-            }
+            // (the previous step's plane chunks - parked in front of this barrier - are stored behind this step's hand-off stores,
+            //  below: stored here, the chunk was the youngest vector-memory operation when the gate arithmetic waits for the saved
+            //  activations, and the wait became a vmcnt(0) that included the store's round trip)
         }
         if (TP && !has_rec && t_pend >= 0) {       // a step without the chain's barrier (row slots: no row of the tile continues a sequence)
             __syncthreads();
@@ -1029,8 +1035,9 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             t_pend = -1;
         }
         float gi = 0.f, gf = 0.f, gc = 0.f, go = 0.f;
+        int t_flush = -1;
         if (act) {
-            float dc = has_succ(b) ? dc_state : (A.dcn ? A.dcn[((size_t)dir * A.max_batch + b) * H + j] : 0.f);
+            float dc = has_succ(b) ? dc_state : dcn_own;         // (a sequence's last step: the gradient of its final cell state)
             const float tc = tanhf_(cn);
             const float d_o = dh * tc;
             dc += dh * og * (1.f - tc * tc);
@@ -1065,6 +1072,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                     tbuf[s & 1][1][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)lo;
                 }
             }
+            t_flush = (TP && DAF && has_rec) ? t_pend : -1;      // the previous step's chunks: behind the hand-off stores
             if (TP) t_pend = t;          // (every thread: the flush in a step without the chain's barrier brings its own barrier)
             if (act || (masked && tid < 16 * MR && b < nb && j < H)) {       // (row slots: zeros for an idle slot step, see the forward kernel)
                 unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
@@ -1075,6 +1083,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                     __hip_atomic_store(tq + handoff_index(g * H + je, plane, bl_ & 15) / 2, ws_[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (TP && t_flush >= 0) flush_tp((s - 1) & 1, t_flush);
         if (A.G32 != G && n0 + 16 >= H && n0 < H) {       // owner of the last unit tile: zero the padding columns 4H .. G32-1
             const int pw2 = (A.G32 - G) >> 1;
             for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
