@@ -172,7 +172,9 @@ __device__ __forceinline__ unsigned pair_word(float v, int lane, int* plane) {
     split1<BF16>(v, &hi, &lo);
     const bool odd = lane & 1;
     const unsigned send = odd ? hi : lo;                               // what the neighbour stores
-    const unsigned recv = (unsigned)__shfl_xor((int)send, 1);
+    // lane ^ 1 through the data-parallel primitive (quad_perm [1, 0, 3, 2]: one VALU operation; __shfl_xor goes through the LDS crossbar,
+    // ds_bpermute_b32 + s_waitcnt lgkmcnt(0), in front of the hand-off store of every step)
+    const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xF, 0xF, true);
     *plane = odd ? 1 : 0;
     return odd ? (recv | (lo << 16)) : (hi | (recv << 16));
 }
@@ -504,6 +506,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
     bool alive = true;
     float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
     float c_reg = 0.f;
+    // hand-off store of this thread's element, in 32-bit words: lanes 2i / 2i+1 store the (hi, lo) pair words of columns c, c + 1
+    const long long hs_step = (long long)A.nt16 * A.ndir * (long long)tile_elems;         // (tile_elems: fp32 = 32-bit words per block)
+    const long long hs_thr = ((long long)(tile16 + (bl_ >> 4)) * A.ndir + dir) * (long long)tile_elems +
+                             handoff_index((j0 + u) & ~1, lane & 1, bl_ & 15) / 2;
     // initial cell state of this thread's element (the same row and unit at every step; zero without hx)
     const float c0_own = (A.c0 && tid < MR * JT && b < A.max_batch && j0 + u < H) ? A.c0[((long long)dir * A.max_batch + b) * H + j0 + u] : 0.f;
     {
@@ -527,7 +533,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             fill_pos = stop;
         }
     };
-    DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : 100u, 0u, 0ull};      // (PTMI_LSTM_DBG bits 16-23: initial hold / 4)
+    // first-request hold of a launch, in ticks of the 100 MHz clock (PTMI_LSTM_DBG bits 16-23: / 4); one 16-row tile per workgroup: 92 (in
+    // the training step, one box: adaptive from 100 / 92 / 88: 6.82 / 6.77 / 6.75 ms, fixed 92: 6.73; two tiles (B = 64): 100 - 22.05 against
+    // 22.15 from 92, 22.6 fixed 92)
+    DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : (MTL == 1 ? 92u : 100u), 0u, 0ull};
     const bool adapt = !(A.dbg & (1 << 24));
     dd.mark();
     for (int s = 0; s < A.T; ++s) {
@@ -661,9 +670,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             // (row-slot batches: an idle slot step writes ZEROS - nobody in this launch waits for them, but the planes then are a
             //  valid operand of the GEMMs that follow, like those of an equal-length batch)
             if (act || (masked && tid < MR * JT && b < nb && j0 + u < H)) {
-                const int ce = (j0 + u) & ~1;
-                unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
-                __hip_atomic_store(tq + handoff_index(ce, plane, bl_ & 15) / 2, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (the thread's slot inside a (time, tile, direction) block is a constant - hs_thr -, the block's offset wave-uniform:
+                //  one vector add in front of the store instead of three 64-bit multiplications)
+                unsigned* dst = reinterpret_cast<unsigned*>(A.hyt) + ((long long)t * hs_step + hs_thr);
+                __hip_atomic_store(dst, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (j0 < H && j0 + JT >= H) {                     // owner of the last unit: the padding columns H .. KP32-1 (every step: they carry the pattern too)
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const int b = m0 + bl_, j = n0 + jl;
     const size_t tile_elems = (size_t)A.G32 * 16;          // floats per (time, 16-row tile, direction)
     bool alive = true;
-    DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : 100u, 0u, 0ull};
+    DafHold dd{(A.dbg >> 16) & 0xff ? (unsigned)((A.dbg >> 16) & 0xff) * 4u : (MTL == 1 ? 92u : 100u), 0u, 0ull};      // (see the forward kernel)
     const bool adapt = !(A.dbg & (1 << 24));
     dd.mark();
     float dc_state = 0.f;
@@ -794,6 +804,12 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     long long row_c = offs_at(tindex(s0));
     int nb_f = s0 + 1 < A.T ? bs_at(tindex(s0 + 1)) : 0;        // the time index processed next
     long long row_f = s0 + 1 < A.T ? offs_at(tindex(s0 + 1)) : 0;
+    // hand-off stores of this thread's element (32-bit words: lanes 2i / 2i+1 store the (hi, lo) pair words of columns c, c + 1 of each gate)
+    const long long hs_step = (long long)A.nt16 * A.ndir * (long long)tile_elems;         // (tile_elems: fp32 = 32-bit words per block)
+    const long long hs_thr = ((long long)(tile16 + (bl_ >> 4)) * A.ndir + dir) * (long long)tile_elems;
+    int hs_gate[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) hs_gate[g] = handoff_index(g * H + (j & ~1), lane & 1, bl_ & 15) / 2;
     const float c0_own = (A.c0 && tid < 16 * MR && b < A.max_batch && j < H) ? A.c0[((long long)dir * A.max_batch + b) * H + j] : 0.f;
     // ... and the gradient w.r.t. its FINAL cell state (a conditional load behind the barrier made the wait for the saved activations a
     // vmcnt(0): it then also waited for the plane chunk the thread had just stored)
@@ -1065,25 +1081,26 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const unsigned w1 = pair_word<true>(gf, lane, &plane);
             const unsigned w2 = pair_word<true>(gc, lane, &plane);
             const unsigned w3 = pair_word<true>(go, lane, &plane);
-            if (TP && tid < 16 * MR) {       // every row of the tile (rows past the batch / units past H carry zeros; flush_tp skips them)
-                const float gv[4] = {gi, gf, gc, go};
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    unsigned hi, lo;
-                    split1<true>(gv[g], &hi, &lo);
-                    tbuf[s & 1][0][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)hi;
-                    tbuf[s & 1][1][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)lo;
-                }
-            }
             t_flush = (TP && DAF && has_rec) ? t_pend : -1;      // the previous step's chunks: behind the hand-off stores
             if (TP) t_pend = t;          // (every thread: the flush in a step without the chain's barrier brings its own barrier)
             if (act || (masked && tid < 16 * MR && b < nb && j < H)) {       // (row slots: zeros for an idle slot step, see the forward kernel)
-                unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
-                const int je = j & ~1;
+                // (block offset wave-uniform, the thread's four slots constants: see the forward kernel)
+                unsigned* tq = reinterpret_cast<unsigned*>(A.dgt) + ((long long)t * hs_step + hs_thr);
                 const unsigned ws_[4] = {w0, w1, w2, w3};
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    __hip_atomic_store(tq + handoff_index(g * H + je, plane, bl_ & 15) / 2, ws_[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(tq + hs_gate[g], ws_[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (TP && tid < 16 * MR) {       // this step's halves parked for the planes of dgates^T - behind the hand-off stores, which the chain waits
+                                         // for (every row of the tile: rows past the batch / units past H carry zeros; flush_tp skips them)
+            const float gv[4] = {gi, gf, gc, go};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned hi, lo;
+                split1<true>(gv[g], &hi, &lo);
+                tbuf[s & 1][0][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)hi;
+                tbuf[s & 1][1][bl_ >> 3][g * 16 + jl][bl_ & 7] = (unsigned short)lo;
             }
         }
         if (TP && t_flush >= 0) flush_tp((s - 1) & 1, t_flush);
