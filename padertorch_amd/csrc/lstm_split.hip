@@ -632,9 +632,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[s & 1][wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
-            fill_some(s + 1 == A.T);
             __syncthreads();
             dd.mark();
+            fill_some(s + 1 == A.T);          // (behind the barrier: the wavefronts without elements have nothing else to do there, and in front
+                                              //  of it the whole workgroup waited for their stores to be issued)
 #pragma unroll
             for (int q = 0; q < 4; ++q) pre[q] = pre_n[q];
             if (tid < MR * JT) {
