@@ -380,8 +380,11 @@ def auto_split_k(M, N, K):
 
 
 #: weight-gradient GEMMs that run BESIDE a persistent recurrence: up to this many reduction rows on the 128 x 128 kernel, whose
-#: workgroups share a CU with the recurrence's (``co_resident_split_k``); longer ones on big tiles on the CUs the recurrence leaves free
-CO_RESIDENT_MAX_K = 16384
+#: workgroups share a CU with the recurrence's (``co_resident_split_k``); longer ones on big tiles on the CUs the recurrence leaves free.
+#: 0 since the end of round 4 (every such GEMM on the big tiles): with the recurrences' step time down to 2.3 / 3.6 us the
+#: weight-gradient queue, not the recurrence, ends the backward phase, and workgroups that share CUs with a recurrence slow it by more than
+#: they gain (B = 32, 8 kHz: 6.645 -> 6.60 ms per step; until then 16384: 7.15 against 7.18; ``profiles/r4_ab_step.txt``)
+CO_RESIDENT_MAX_K = 0
 
 
 def co_resident_split_k(M, N, K):
