@@ -52,27 +52,18 @@ __global__ __launch_bounds__(256) void lstm_weight_prep_kernel(const PrepArgs A)
     int blk = blockIdx.x;
     if (blk < A.blocks_ih) {
         // job 1: rows of w_ih_cat, 4096 elements per workgroup (row-major over [ndir * G][Ipad])
-        // (row / column of the thread's first element by ONE division, then carried along: a 64-bit division per element made this
-        //  streaming copy VALU-bound - 31 us alone for 35 MB)
         const long long total = (long long)A.ndir * A.G * A.Ipad;
         float m = 0.f;
-        long long idx = (long long)blk * 4096 + tid;
-        long long row = idx / A.Ipad;
-        int col = (int)(idx - row * A.Ipad);
-        const int dstep = 256 / A.Ipad, cstep = 256 - dstep * A.Ipad;        // 256 elements further: dstep rows and cstep columns (+ a carry)
-        for (int e = 0; e < 16; ++e, idx += 256) {
+        for (int e = 0; e < 16; ++e) {
+            const long long idx = (long long)blk * 4096 + e * 256 + tid;
             if (idx < total) {
-                const int d = row >= A.G ? 1 : 0;
+                const long long row = idx / A.Ipad;
+                const int col = (int)(idx - row * A.Ipad);
+                const int d = (int)(row / A.G);
                 const long long g = row - (long long)d * A.G;
                 const float v = col < A.I ? A.w_ih[d][g * A.I + col] : 0.f;
                 A.w_ih_cat[idx] = v;
                 m = fmaxf(m, fabsf(v));
-            }
-            row += dstep;
-            col += cstep;
-            if (col >= A.Ipad) {
-                col -= A.Ipad;
-                ++row;
             }
         }
         publish_max(A.amax, m, red);
