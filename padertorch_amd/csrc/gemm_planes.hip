@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_planes_kernel(const PlanesArgs G)
             if (RELU && fuse) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    v[e] = fmaxf(v[e], 0.f);
+                    v[e] = v[e] < 0.f ? 0.f : v[e];           // (not fmaxf: a NaN stays a NaN, like torch.relu - ADVICE r4)
                     if (n + e < G.N) mx = max(mx, __float_as_uint(v[e]));
                 }
             }
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
                         acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            v[e] = fmaxf(v[e], 0.f);
+                            v[e] = v[e] < 0.f ? 0.f : v[e];           // (a NaN stays a NaN, like torch.relu)
                             if (ok && n0 + j * 16 + e < G.N) relu_max = max(relu_max, __float_as_uint(v[e]));
                         }
                         float* o = rowp(i) + j * 16;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restr
         for (int z = 0; z < splits; ++z) sum += ws[(long long)z * total + i];
         if (bias) sum += bias[c];
         if (relu) {
-            sum = fmaxf(sum, 0.f);
+            sum = sum < 0.f ? 0.f : sum;           // (a NaN stays a NaN, like torch.relu)
             mx = max(mx, __float_as_uint(sum));
         }
         float* o = (C2 != nullptr && r >= m_split) ? C2 + (long long)(r - m_split) * ldc + c : C + (long long)r * ldc + c;
@@ -719,7 +719,8 @@ __global__ __launch_bounds__(256) void planes_reduce_kernel(const float* __restr
     }
 }
 
-// dx of a ReLU and the operand scale of what multiplies it next, one pass: out = g where y > 0 (y: the ReLU's OUTPUT), else 0; float bits
+// dx of a ReLU and the operand scale of what multiplies it next, one pass: out = 0 where y <= 0 (y: the ReLU's OUTPUT), else g - torch's
+// threshold_backward, which lets the gradient through where y is NaN; float bits
 // of max |out| into *amax_out (zeroed by the host call)
 __global__ __launch_bounds__(256) void relu_backward_absmax_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out,
                                                                    long long rows, long long cols, long long ld_g, long long ld_y, long long ld_o,
@@ -738,8 +739,8 @@ __global__ __launch_bounds__(256) void relu_backward_absmax_kernel(const float* 
             f4 va, vb;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                va[q] = ya[q] > 0.f ? ga[q] : 0.f;
-                vb[q] = yb[q] > 0.f ? gb[q] : 0.f;
+                va[q] = ya[q] <= 0.f ? 0.f : ga[q];
+                vb[q] = yb[q] <= 0.f ? 0.f : gb[q];
                 mx = max(mx, max(__float_as_uint(va[q]) & 0x7fffffffu, __float_as_uint(vb[q]) & 0x7fffffffu));
             }
             o4[i] = va;
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(256) void relu_backward_absmax_kernel(const float* 
             f4 va;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                va[q] = ya[q] > 0.f ? ga[q] : 0.f;
+                va[q] = ya[q] <= 0.f ? 0.f : ga[q];
                 mx = max(mx, __float_as_uint(va[q]) & 0x7fffffffu);
             }
             o4[i] = va;
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(256) void relu_backward_absmax_kernel(const float* 
     } else {
         for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
             const long long r = i / cols, c = i - r * cols;
-            const float v = y[r * ld_y + c] > 0.f ? g[r * ld_g + c] : 0.f;
+            const float v = y[r * ld_y + c] <= 0.f ? 0.f : g[r * ld_g + c];
             out[r * ld_o + c] = v;
             mx = max(mx, __float_as_uint(v) & 0x7fffffffu);
         }

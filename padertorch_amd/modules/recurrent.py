@@ -10,7 +10,8 @@ does differentiate w.r.t. an initial state handed to it.
 import torch
 from torch.nn.utils.rnn import PackedSequence
 
-from ..ops.lstm import packed_lstm
+from .._lib import leaving_native_path
+from ..ops.lstm import packed_lstm, unsupported_reason
 
 
 class StatefulLSTM(torch.nn.Module):
@@ -41,7 +42,19 @@ class StatefulLSTM(torch.nn.Module):
 
     def forward(self, x):
         if isinstance(x, PackedSequence):           # torch.nn.LSTM takes either form (contrib/jensheit's MaskEstimator packs)
-            out, states = packed_lstm(self.lstm, x, hx=self.states, return_state=True)
+            why = unsupported_reason(self.lstm, x.data)
+            if why is not None:
+                # the host (Trainer.test_run / inference on the CPU, as the reference allows) or an LSTM the kernels do not cover:
+                # torch's own LSTM, said out loud on a GPU
+                if x.data.is_cuda:
+                    leaving_native_path(f'StatefulLSTM({self.lstm.input_size}, {self.hidden_size})', why)
+                out, states = self.lstm(x, self.states)
+            elif self.save_states or self.states is not None:
+                out, states = packed_lstm(self.lstm, x, hx=self.states, return_state=True)
+            else:
+                # no state comes in, none is kept: the plain path (hand-off planes for the next layer, dgates^T planes for the weight
+                # gradients, no state-gradient work - ADVICE r4)
+                return packed_lstm(self.lstm, x)
             self.states = tuple(s.detach() for s in states)
             if not self.save_states:
                 del self.states

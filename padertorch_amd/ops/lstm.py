@@ -218,8 +218,15 @@ def _wgrad_stream(device):
     current, i.e. it finds the forward pass' side stream.)"""
     device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
+    # (keyed by the raw handle: torch hands out stream wrappers afresh on every call, so there is no object to hold weakly.  torch's
+    #  streams come from a fixed pool per device and are never destroyed - a handle seen again IS the same queue -, so the table is
+    #  bounded by the pool; an external stream that was destroyed and whose handle came back would find its predecessor's side stream,
+    #  which is a valid side stream for it too.)
     key = (device.type, index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _WGRAD_STREAMS:
+        if len(_WGRAD_STREAMS) >= 64:
+            sync_deferred()                     # nothing may be pending on a side stream that is let go
+            _WGRAD_STREAMS.clear()
         _WGRAD_STREAMS[key] = torch.cuda.Stream(device=device)
     return _WGRAD_STREAMS[key]
 

@@ -83,6 +83,7 @@ class SlotLayout:
         self.rows_dev = _lib.host_to_device(self.rows_host, torch.int64, self.device)
         self.occupancy = float(sum(lengths)) / float(T * S)
         self._meta = None
+        self._ex_rows = {}           # padded_time -> device index (scatter and gather of a step ask for the same one)
 
     @staticmethod
     def cached(lengths, slots, device):
@@ -98,8 +99,11 @@ class SlotLayout:
 
     def _example_rows(self, padded_time):
         """Index of frame t of example b in a flattened batch-major ``[B, padded_time]`` tensor, examples one after the other."""
-        idx = np.concatenate([b * padded_time + np.arange(n, dtype=np.int64) for b, n in enumerate(self.lengths)])
-        return _lib.host_to_device(idx, torch.int64, self.device)
+        hit = self._ex_rows.get(int(padded_time))
+        if hit is None:
+            idx = np.concatenate([b * padded_time + np.arange(n, dtype=np.int64) for b, n in enumerate(self.lengths)])
+            hit = self._ex_rows[int(padded_time)] = _lib.host_to_device(idx, torch.int64, self.device)
+        return hit
 
     def scatter_rows(self, padded):
         """Batch-major zero-padded ``[B, T_max, ...]`` -> grid rows ``[T * slots, ...]`` (idle rows zero); differentiable."""

@@ -680,12 +680,17 @@ class Trainer:
             self._buckets = None
             return []
         self._buckets = buckets = GradBuckets(self.model, self._flat)
-        side = _lstm._wgrad_stream(self._flat.flat.device) if self._flat.flat.is_cuda else None
+        dev = self._flat.flat.device
+
+        def side():
+            # the weight-gradient stream of the stream that is current WHEN a gradient becomes ready (the backward pass runs under the
+            # forward pass' stream): looked up then, not captured here - train() may be entered under another stream context
+            return _lstm._wgrad_stream(dev) if dev.type == 'cuda' else None
 
         def on_grad(p):
-            buckets.ready((p,), side)
+            buckets.ready((p,), side())
 
-        self.op_context.grad_ready_hook = lambda params: buckets.ready(params, side)
+        self.op_context.grad_ready_hook = lambda params: buckets.ready(params, side())
         self.op_context.grad_use_hook = buckets.expect
         return [p.register_post_accumulate_grad_hook(on_grad) for p in self._flat.params]
 

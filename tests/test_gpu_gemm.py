@@ -505,3 +505,44 @@ def test_linear_with_the_relu_in_the_epilogue(tile, M, I, O):
     z = L.linear(lin_b, y.detach().clone() if False else y)
     z2 = L.linear(lin_b, y2.detach())
     assert torch.equal(z.detach(), z2)
+
+
+@pytest.mark.parametrize('tile', [-1, 0, 5])
+@pytest.mark.parametrize('M,I,O', [(8096, 1200, 1200), (300, 70, 257), (17, 33, 5)])
+def test_fused_relu_propagates_nan_like_torch_relu(tile, M, I, O):
+    """A NaN in the input (or the weights) of a fused Linear + ReLU comes out as NaN in exactly the entries where ``torch.relu(module(x))``
+    has one - ``fmaxf(NaN, 0)`` would have turned it into 0, zero masks and a finite loss the Trainer's non-finite check never sees
+    (reference check: ``padertorch/train/trainer.py:622-636``) -, in every tile's epilogue and in the slab reduction; the
+    backward mask lets the gradient through where the output is NaN, like ``threshold_backward``."""
+    from padertorch_amd import _lib
+    from padertorch_amd.ops import linear as L
+    lib = _lib.load()
+    dev = _dev()
+    torch.manual_seed(M + I + O)
+    lin = torch.nn.Linear(I, O).to(dev)
+    x = torch.randn(M, I, device=dev)
+    x[3, 1] = float('nan')
+    x[M - 1, I - 1] = float('nan')
+    x = x.requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    gy = torch.randn(M, O, device=dev)
+    assert lib.ptmi_gemm_planes_select_tile(tile) == 0
+    try:
+        y = L.linear(lin, x, activation='relu')
+        (y * gy).sum().backward()
+        gx = x.grad.clone()
+        lin.weight.grad = lin.bias.grad = None
+        y2 = torch.relu(L.linear(lin, x2))
+        (y2 * gy).sum().backward()
+    finally:
+        lib.ptmi_gemm_planes_select_tile(-1)
+    nan = torch.isnan(y2)
+    assert bool(nan[3].all()) and bool(nan[M - 1].all()) and int(nan.sum()) == 2 * O      # the NaN rows, nothing else
+    assert torch.equal(torch.isnan(y), nan)
+    assert torch.equal(y[~nan], y2[~nan])
+    # rows without a NaN: gradients bit for bit; NaN rows: NaN gradients in both forms (g passes the mask, g W carries the NaN on)
+    ok = torch.ones(M, dtype=torch.bool, device=dev)
+    ok[3] = ok[M - 1] = False
+    assert torch.equal(gx[ok], x2.grad[ok])
+    assert torch.equal(torch.isnan(gx), torch.isnan(x2.grad))
+    assert not bool(torch.isfinite(y.sum()))          # what the loss, and with it the Trainer's check, gets to see

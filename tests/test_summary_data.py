@@ -124,3 +124,28 @@ def test_row_slot_batches_groups_and_sorts():
     assert got[0]['tag'] == [1, 0, 2]
     raw = list(row_slot_batches(exs, row_slots=4, fill=1.0, key=lambda e: -e['tag'], collate=False))
     assert [[e['tag'] for e in b] for b in raw] == [[0, 1, 2, 3], [4, 5, 6]]
+
+
+def test_device_prefetcher_release_mode_follows_what_to_device_does():
+    """A ``to_device`` that computes (features on the copy stream) gets ``release='mark'`` by default and is refused with an explicit
+    ``'record_stream'``: marks do not reach what such a function allocates or the buffers it writes; the plain mover keeps
+    ``'record_stream'``.  The tensors a ``PaddedList`` carries beside its entries are found."""
+    import pytest
+    import torch
+    from padertorch_amd.data import DevicePrefetcher, example_to_device
+    from padertorch_amd.data.prefetch import _tensors
+    from padertorch_amd.ops.sequence.pack_module import PaddedList
+    assert DevicePrefetcher([], 'cpu').release == 'record_stream'
+    assert DevicePrefetcher([], 'cpu', to_device=example_to_device).release == 'record_stream'
+    custom = lambda ex, dev: example_to_device(ex, dev)      # noqa: E731
+    assert DevicePrefetcher([], 'cpu', to_device=custom).release == 'mark'
+    with pytest.raises(ValueError, match='mark'):
+        DevicePrefetcher([], 'cpu', to_device=custom, release='record_stream')
+    pad = torch.zeros(2, 5, 3)
+    pl = PaddedList(pad, [5, 4], True, torch.tensor([5, 4], dtype=torch.int32))
+
+    class Rec:
+        data = torch.ones(9, 3)
+    pl.packed_log1p = Rec()
+    found = list(_tensors(dict(Y_abs=pl, n=[5, 4])))
+    assert any(t is pad for t in found) and any(t is pl.lengths_dev for t in found) and any(t is Rec.data for t in found)
