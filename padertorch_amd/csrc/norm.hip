@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void unit_norm_fwd_kernel(const float* __restr
     float r[W];
 #pragma unroll
     for (int q = 0; q < W; ++q) {
-        r[q] = 1.f / fmaxf(sqrtf(ss[q]), eps);
+        const float nq = sqrtf(ss[q]);
+        r[q] = 1.f / (nq < eps ? eps : nq);          // clamp_min like torch.nn.functional.normalize: a NaN norm stays NaN (fmaxf would return eps)
         inv[n * F + f0 + q] = r[q];
     }
 #pragma unroll

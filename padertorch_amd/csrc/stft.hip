@@ -588,8 +588,11 @@ __global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdA
 __device__ __forceinline__ void mag_phasor(cpx X, float& mag, cpx& ph) {
     const float p = X.x * X.x + X.y * X.y;
     const float r = __builtin_amdgcn_rsqf(p);            // 1/|X|; inf at 0, selected away below
-    mag = p > 0.f ? p * r : 0.f;
-    ph = p > 0.f ? cpx{X.x * r, X.y * r} : cpx{1.f, 0.f};
+    // (the select tests for ZERO, not for "positive": a NaN bin - a NaN sample in the frame - stays NaN in the magnitude and in the
+    //  phasor like np.abs / np.angle of the reference's features (pit/data.py:67-75), so that the loss and with it the Trainer's
+    //  non-finite check see it; `p > 0 ? ... : 0` had turned it into magnitude 0 / phase 0)
+    mag = p == 0.f ? 0.f : p * r;
+    ph = p == 0.f ? cpx{1.f, 0.f} : cpx{X.x * r, X.y * r};
 }
 
 template <class PL>

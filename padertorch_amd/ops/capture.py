@@ -1,0 +1,56 @@
+"""What the ops need to know while an optimizer step is CAPTURED into a hipGraph (``train.graphed.GraphedStep``).
+
+The eager step's host side orders itself with state that lives ACROSS steps: parameter-derived operand forms cached per
+``Parameter._version``, the preparation stream waiting for the PREVIOUS step's optimizer event, weight-gradient events of the last
+step, words of zeroed buffers handed out one by one.  Inside a capture every dependency has to be an edge of the graph: a stream
+may only wait for events recorded in the same capture, every value a replay reads must be (re)made by a node of the graph, and a
+buffer a replay accumulates into has to be zeroed by the graph itself.  :func:`capture_mode` empties those caches on the way in (so
+that the forms are rebuilt INSIDE the capture, on streams that fork from and join the capturing stream) and on the way out (their
+entries hold captured events and tensors of the graph's memory pool: nothing an eager step may wait for or overwrite).
+"""
+import contextlib
+
+import torch
+
+__all__ = ['ACTIVE', 'capture_mode', 'zero_word', 'reset_step_caches']
+
+#: True while a step is being captured (host thread of the capture AND autograd's worker threads read it)
+ACTIVE = False
+
+_zero_blocks = []       # [[block of zeroed int32 words (allocated and zero-filled INSIDE the capture), words handed out]]
+
+
+def zero_word(device, block_words=64):
+    """A zeroed int32 word for an accumulating epilogue (``ops.gemm.zero_word`` / ``ops.library._zero_word``) during a capture: from
+    blocks that are allocated - and therefore zero-filled - by nodes of the graph, so that every replay starts from zero.  (The
+    eager pools hand out words of blocks that were filled once, when they were allocated; a replay would accumulate into the last
+    replay's maximum.)"""
+    if not _zero_blocks or _zero_blocks[-1][1] >= _zero_blocks[-1][0].numel() or _zero_blocks[-1][0].device != device:
+        _zero_blocks.append([torch.zeros(block_words, dtype=torch.int32, device=device), 0])
+    ent = _zero_blocks[-1]
+    ent[1] += 1
+    return ent[0][ent[1] - 1:ent[1]]
+
+
+def reset_step_caches():
+    """Forget everything the ops have cached from earlier steps that orders work (events) or stands for parameter values (forms)."""
+    from . import gemm as _gemm, lstm as _lstm
+    _gemm.invalidate()              # operand scales / planes / stacked LSTM forms / the optimizer's update event / learned prefetches
+    _gemm._WAITED.clear()
+    _lstm._WGRAD_DONE.clear()
+
+
+@contextlib.contextmanager
+def capture_mode():
+    """Everything between ``__enter__`` and ``__exit__`` runs with :data:`ACTIVE` set and starts (and leaves) with empty step caches."""
+    global ACTIVE
+    assert not ACTIVE, 'nested capture'
+    reset_step_caches()
+    del _zero_blocks[:]
+    ACTIVE = True
+    try:
+        yield
+    finally:
+        ACTIVE = False
+        reset_step_caches()
+        # (the zero blocks stay alive with the graph: its nodes write them)

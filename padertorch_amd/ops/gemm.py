@@ -99,6 +99,9 @@ _WORDS = _Words()
 
 
 def zero_word(device):
+    from . import capture as _capture
+    if _capture.ACTIVE:                 # a captured step: words the graph itself zeroes at every replay
+        return _capture.zero_word(device)
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ent = _WORDS.blocks.get(key)
     if ent is None or ent[1] >= 64:

@@ -180,6 +180,9 @@ _ZERO_WORDS = {}
 def _zero_word(device):
     """One int32 word that is zero on the current stream: words of a buffer zeroed ONCE (a fill launch per 256 words instead of a
     zeroing launch in front of every reduction: five per training step); a buffer per stream, each word handed out once."""
+    from . import capture as _capture
+    if _capture.ACTIVE:                 # a captured step: words the graph itself zeroes at every replay
+        return _capture.zero_word(device, 256)
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     pool = _ZERO_WORDS.get(key)
     if pool is None or pool[1] >= pool[0].numel():

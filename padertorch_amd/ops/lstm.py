@@ -206,6 +206,19 @@ DG_PLANES_FROM_KERNEL = True
 #: both directions' dW_ih of a BLSTM layer as one GEMM launch with a two-part output (with DG_PLANES_FROM_KERNEL)
 FUSE_DW_IH = True
 _WGRAD_DONE = {}
+#: captured steps (ops.capture): a layer's weight-gradient launches are ENQUEUED behind the next lower layer's recurrence launch (they
+#: still wait for the event recorded where they used to be enqueued).  The hipGraph executor lays a captured step out by following a
+#: node's FIRST-captured successor on the same queue: with the side-stream chain captured first, the next recurrence ended up behind
+#: that chain on one queue (rocprofv3 timeline of the replay: 0.43 ms of weight-gradient GEMMs in front of the first layer's backward
+#: recurrence instead of beside it); with the recurrence captured first the chain gets a queue of its own.
+_PENDING_WGRAD = []
+
+
+def flush_pending_wgrad():
+    while _PENDING_WGRAD:
+        _PENDING_WGRAD.pop(0)()
+
+
 # (Measured in round 2 and not kept - DESIGN.md sections 3.9 / 4 have the numbers -: the pattern fill ahead of time on a side stream,
 # the weight gradients' forward-data operand planes packed during the forward pass, a layer's weight gradients started behind its
 # recurrence instead of behind its input-gradient GEMM, the backward recurrence cut into several launches.)
@@ -289,13 +302,18 @@ def warm_side_stream(device, nbytes=1 << 30):
 
 def sync_deferred(device=None):
     """Make the current stream wait for every deferred weight-gradient accumulation."""
+    flush_pending_wgrad()
     want = None
     if device is not None:
         device = torch.device(device)
         want = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    for (typ, idx, _main), side in list(_WGRAD_STREAMS.items()):
+    from . import capture as _capture
+    for (typ, idx, main_handle), side in list(_WGRAD_STREAMS.items()):
         if want is None or want == (typ, idx):
-            torch.cuda.current_stream(torch.device(typ, idx)).wait_stream(side)
+            cur = torch.cuda.current_stream(torch.device(typ, idx))
+            if _capture.ACTIVE and main_handle != cur.cuda_stream:
+                continue            # a captured step joins ITS side stream; a wait for a stream outside the capture is no edge of the graph
+            cur.wait_stream(side)
 
 
 #: ONE word per device that every persistent launch whose bounded spin runs out increments (``ptmi_lstm_set_error_sink``):
@@ -876,6 +894,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
                 if lib.ptmi_lstm_split_enabled():
                     amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
+        flush_pending_wgrad()          # (captured steps: the layer above's weight gradients, behind this layer's recurrence launch)
         amax_dg = None
         if gm is not None:
             amax_x, amax_w = gm
@@ -917,38 +936,58 @@ class _LstmLayerFn(torch.autograd.Function):
                 else:
                     xplanes[todo[0]] = _gemm.pack_t(x, gm[0])
                     dgplanes[(0, todo[0])] = _gemm.pack_t(operands[0][0][0], amax_dg)
-            if use_side:
-                side.wait_stream(main)
-            else:
-                main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
-            wgrad_rows(dg, todo, amax_dg, both_queues=both, dg_t=dg_t)
-            with torch.cuda.stream(side):
-                if db_kernel is not None and all(ps[2].grad.is_contiguous() and ps[3].grad.is_contiguous() for ps in params):
-                    # the kernel's bias sums into all 2 ndir bias gradients: one launch (was one small `add_` per bias vector)
-                    torch.ops.ptmi.lstm_bias_grad_add_(db_kernel, [ps[2].grad for ps in params], [ps[3].grad for ps in params])
+            from . import capture as _capture
+            # captured steps: enqueue behind the next lower layer's recurrence launch (_PENDING_WGRAD); the side stream waits for the
+            # event of THIS point, as it would have
+            later = bool(_capture.ACTIVE and use_side and not both and ctx.needs_input_grad[0])
+            here = None
+            if later:
+                here = torch.cuda.Event()
+                here.record(main)
+            ext_ = ctx.ext
+
+            def accumulate():
+                if use_side:
+                    if later:
+                        side.wait_event(here)
+                    else:
+                        side.wait_stream(main)
                 else:
-                    for d, (_, _, p_bih, p_bhh) in enumerate(params):
-                        db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
-                        p_bih.grad.add_(db_d)
-                        p_bhh.grad.add_(db_d)
-            if use_side:
-                done = torch.cuda.Event()
-                done.record(side)
-                for ps in params:
-                    for p in ps[:2]:
-                        _WGRAD_DONE[id(p)] = done
-            if both:
-                main.wait_event(done)                          # the main queue is now behind both
-                for t in (dgplanes[(0, todo[0])][:1] if dg_t is None else (xplanes[todo[0]],)):
-                    t.record_stream(side)
+                    main.wait_stream(_wgrad_stream(x.device))      # earlier accumulations into the same .grad views
+                wgrad_rows(dg, todo, amax_dg, both_queues=both, dg_t=dg_t)
+                with torch.cuda.stream(side):
+                    if db_kernel is not None and all(ps[2].grad.is_contiguous() and ps[3].grad.is_contiguous() for ps in params):
+                        # the kernel's bias sums into all 2 ndir bias gradients: one launch (was one small `add_` per bias vector)
+                        torch.ops.ptmi.lstm_bias_grad_add_(db_kernel, [ps[2].grad for ps in params], [ps[3].grad for ps in params])
+                    else:
+                        for d, (_, _, p_bih, p_bhh) in enumerate(params):
+                            db_d = operands[0][d][0].sum(0) if db_kernel is None else db_kernel[d * G:(d + 1) * G]
+                            p_bih.grad.add_(db_d)
+                            p_bhh.grad.add_(db_d)
+                done = None
+                if use_side:
+                    done = torch.cuda.Event()
+                    done.record(side)
+                    for ps in params:
+                        for p in ps[:2]:
+                            _WGRAD_DONE[id(p)] = done
+                if both:
+                    main.wait_event(done)                          # the main queue is now behind both
+                    for t in (dgplanes[(0, todo[0])][:1] if dg_t is None else (xplanes[todo[0]],)):
+                        t.record_stream(side)
+                    if oc.grad_ready_hook is not None:
+                        side.wait_stream(main)                     # whoever orders itself after `side` sees every gradient
+                if use_side:
+                    for t in (x, hy) + tuple(v for v in (dg, dg_t, h0, ext_, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
+                            + tuple(h_prev for _, h_prev in operands[0]):
+                        t.record_stream(side)           # keep the operands alive until the side stream is done
                 if oc.grad_ready_hook is not None:
-                    side.wait_stream(main)                     # whoever orders itself after `side` sees every gradient
-            if use_side:
-                for t in (x, hy) + tuple(v for v in (dg, dg_t, h0, ctx.ext, db_kernel, amax_dg) if v is not None and torch.is_tensor(v)) \
-                        + tuple(h_prev for _, h_prev in operands[0]):
-                    t.record_stream(side)           # keep the operands alive until the side stream is done
-            if oc.grad_ready_hook is not None:
-                oc.grad_ready_hook([p for ps in params for p in ps])
+                    oc.grad_ready_hook([p for ps in params for p in ps])
+
+            if later:
+                _PENDING_WGRAD.append(accumulate)
+            else:
+                accumulate()
             gh0 = gc0 = None
             if state_grad:
                 gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
@@ -1061,7 +1100,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
                  or (oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for p in flat_params)))):
         # after an optimizer step: the operand forms of ALL layers on a side stream, next to whatever the main stream is
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
-        pre = _prep_stream(data.device)
+        pre = forked = _prep_stream(data.device)
         updated = _gemm.update_event(flat_params)
         if updated is not None:
             pre.wait_event(updated)       # behind the optimizer kernel, i.e. next to the step's front-end, not behind it
@@ -1076,6 +1115,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # the first layer's forms are needed at once: on the main queue itself (a cross-queue wait in front of the first
         # projection was measured to cost the main queue 110-260 us; the later layers' forms are long done when their
         # projection is reached, and a wait for a finished event costs nothing)
+    else:
+        forked = None
     prev_handoff = None
     for layer in range(lstm.num_layers):
         params = all_params[layer]
@@ -1119,6 +1160,11 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         if lstm.dropout > 0 and training and layer + 1 < lstm.num_layers:
             h = torch.nn.functional.dropout(h, lstm.dropout, True)
             prev_handoff = None               # the next layer's input is no longer this layer's output
+    from . import capture as _capture
+    if _capture.ACTIVE and forked is not None:
+        # a captured step: the preparation stream has forked from the capturing stream (above) and must join it again, whether or not
+        # a layer has waited for its forms (by now they are long done: the wait is free)
+        torch.cuda.current_stream(data.device).wait_stream(forked)
     if not (torch.is_grad_enabled() and h.requires_grad):
         # inference: nobody will run Trainer.clip_grad (which reads the watchdog words of the persistent kernels during
         # training) - check them here, so that results of a timed-out launch are never returned silently

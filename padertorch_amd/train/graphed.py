@@ -1,0 +1,240 @@
+"""One optimizer step of a :class:`~padertorch_amd.train.trainer.Trainer` as ONE hipGraph.
+
+The eager step (reference ``padertorch/train/trainer.py:357-393,512-565``: ``train_step`` -> ``backward`` -> ``optimizer_step``) is
+~120 launches that the host enqueues in ~4 ms of python; the GPU needs ~6.5 ms for them.  That only hides while the host may run
+AHEAD of the GPU, i.e. while nobody looks at a result of the step - but the reference raises a non-finite loss / gradient norm in the
+iteration it occurs (``trainer.py:622-636``, ``:740-780``), which needs one host synchronisation per step, after which the GPU waits
+for the host at the head of every step (``deferred_checks='step'``: 7.3 instead of 6.8 ms at BASELINE configs[1]).
+
+:class:`GraphedStep` captures the whole step - every micro-step's forward, review, backward, then the clip + Adam + zeroing kernel and
+the staged scalars' copies - once per input shape (``torch.cuda.CUDAGraph`` = hipGraph) and replays it: one ``hipGraphLaunch`` per
+optimizer step, no python between the kernels.  The loss / gradient-norm / watchdog checks then cost what a synchronisation costs and
+raise in the iteration they belong to (``checks='step'``), or one step late without any synchronisation (``checks='deferred'``); the
+update itself is gated on the device either way (``csrc/optim.hip``), so a non-finite step leaves the parameters untouched like the
+reference's raise in front of ``optimizer.step()``.
+
+What a capture needs from the ops is in ``ops.capture``.  Limits: fixed input shapes (a PackedSequence length pattern is part of the
+launch arguments - ragged batches of changing patterns stay on the eager path), one process group of one rank inside the graph (the
+data-parallel exchange stays outside: ``split_for_allreduce``), a constant learning rate (it is a kernel argument).
+"""
+import numpy as np
+import torch
+
+from ..ops import capture as _capture
+
+__all__ = ['GraphedStep']
+
+
+class _StaticStage:
+    """Pinned host words for the staged scalars of a captured step: the copy nodes of the graph write the same addresses at every replay."""
+
+    def __init__(self, words=1024):
+        self.f32 = torch.empty(words, dtype=torch.float32, pin_memory=True).fill_(float('nan'))
+        self.i32 = torch.empty(words, dtype=torch.int32, pin_memory=True).fill_(torch.iinfo(torch.int32).min)
+        self.used = {torch.float32: 0, torch.int32: 0}
+        self.jobs = []          # [(what, host tensor(s), context, device value(s))] in the order the step staged them
+
+    def blank(self, shape, dtype):
+        assert dtype in self.used, f'staged scalars are fp32 / int32 (got {dtype})'
+        n = int(np.prod(shape)) if len(shape) else 1
+        buf = self.f32 if dtype == torch.float32 else self.i32
+        start = self.used[dtype]
+        assert start + n <= buf.numel(), 'too many staged scalars for a captured step'
+        self.used[dtype] = start + n
+        return buf[start:start + n].view(shape)
+
+    def poison(self):
+        self.f32.fill_(float('nan'))
+        self.i32.fill_(torch.iinfo(torch.int32).min)
+
+
+class GraphedStep:
+    """``step = GraphedStep(trainer, example_batches)``; ``step(example_batches)`` runs one optimizer step.
+
+    ``examples``: the list of ``virtual_minibatch_size`` device-resident examples of one optimizer step (what ``Trainer.train`` would
+    hand to ``train_step`` one by one); their tensors become the graph's static inputs: ``step(new_examples)`` copies new data of the
+    same shapes into them (``None`` / the same objects: run on what they hold).
+    ``prepare``: optional function ``example -> model input`` captured in front of ``train_step`` (the feature front-end when it is part
+    of the step, ``ops.pit_features``).
+    ``checks``: ``'step'`` (default: one host synchronisation behind the replay; errors raise in the iteration they belong to, as in
+    the reference) or ``'deferred'`` (no synchronisation: the previous step's values are inspected after this step is enqueued).
+    """
+
+    def __init__(self, trainer, examples, prepare=None, checks='step', warmup=2):
+        assert checks in ('step', 'deferred'), checks
+        self.trainer = trainer
+        self.prepare = prepare
+        self.checks = checks
+        self.examples = list(examples)
+        self.device = trainer._flat.flat.device
+        assert self.device.type == 'cuda', 'GraphedStep captures a hipGraph: the model has to live on an MI355X'
+        self._inputs = [self._tensors(e) for e in self.examples]
+        self._stage = None
+        self._graph = None
+        self._steps = 0
+        self._late = None           # checks='deferred': (event, host snapshot) of the step before
+        self._eager(warmup)         # every lazily made table / stream / kernel attribute exists before the capture starts
+        self._capture()
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _tensors(example):
+        out = []
+
+        def walk(x):
+            if torch.is_tensor(x):
+                out.append(x)
+            elif isinstance(x, dict):
+                for v in x.values():
+                    walk(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    walk(v)
+        walk(example)
+        return out
+
+    def _one_step(self):
+        """What ``Trainer.train`` does between two iterations, on the static examples (``trainer.py:357-393``)."""
+        tr = self.trainer
+        for i, example in enumerate(self.examples):
+            if tr._buckets is not None:
+                tr._buckets.active = i + 1 == len(self.examples)
+            batch = self.prepare(example) if self.prepare is not None else example
+            loss, _, _, review = tr.train_step(tr.model, batch, self.device)
+            tr.train_summary.update(review)
+            loss.backward()
+            del loss, review, batch
+        return tr.optimizer_step()
+
+    def _eager(self, n):
+        tr = self.trainer
+        keep = tr.deferred_checks
+        tr.deferred_checks = True
+        try:
+            for _ in range(n):
+                self._one_step()
+            tr._check_pending(flush=True)
+        finally:
+            tr.deferred_checks = keep
+        torch.cuda.synchronize(self.device)
+
+    def _capture(self):
+        tr = self.trainer
+        assert tr.world_size == 1 or tr._buckets is None, 'the data-parallel exchange is not captured: use split_for_allreduce'
+        keep = tr.deferred_checks
+        tr._check_pending(flush=True)
+        tr.deferred_checks = True               # no host synchronisation inside the capture; this class does the checks
+        self._stage = tr._graph_stage = _StaticStage()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with _capture.capture_mode():
+                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                    self._one_step()
+        finally:
+            tr._graph_stage = None
+            tr.deferred_checks = keep
+        tr.train_summary.reset()                # (the capture's review entries point at the static words: not a step that ran)
+        self._graph = graph
+        # checks='deferred': two pinned snapshots of the staged scalars, filled in turn behind the replays
+        def like(host):
+            return [torch.empty_like(h).pin_memory() for h in host] if isinstance(host, list) else torch.empty_like(host).pin_memory()
+        self._snapshots = [[like(host) for _, host, _, _ in self._stage.jobs] for _ in range(2)]
+        # the capture itself executed nothing: parameters, moments, step counts and gradients are what the warm-up left
+
+    # ------------------------------------------------------------------ the step
+    def load(self, examples):
+        """Copy new example data (same structure and shapes) into the graph's static inputs, on the current stream."""
+        assert len(examples) == len(self.examples), (len(examples), len(self.examples))
+        for example, static in zip(examples, self._inputs):
+            new = self._tensors(example)
+            assert len(new) == len(static), 'example structure differs from the captured one'
+            for src, dst in zip(new, static):
+                if src is not dst:
+                    assert src.shape == dst.shape and src.dtype == dst.dtype, (src.shape, dst.shape, src.dtype, dst.dtype)
+                    dst.copy_(src, non_blocking=True)
+
+    def __call__(self, examples=None):
+        tr = self.trainer
+        if examples is not None and examples is not self.examples:
+            self.load(examples)
+        self._graph.replay()
+        tr._opt_step += 1
+        self._steps += 1
+        if self.checks == 'step':
+            # ONE synchronisation per optimizer step, behind everything the step consists of; the graph's own copy nodes have left
+            # the step's scalars in the static pinned words
+            torch.cuda.current_stream(self.device).synchronize()
+            self._inspect([(what, host, context) for what, host, context, _ in self._stage.jobs])
+            self._record_summary()
+        else:
+            # no synchronisation: this step's scalars are copied (eagerly, behind the replay) into one of two pinned snapshots - the
+            # static words belong to whichever replay ran last - and the PREVIOUS step's snapshot is inspected now that this step is queued
+            snap = self._snapshots[self._steps & 1]
+            for (_, _, _, vals), host in zip(self._stage.jobs, snap):
+                for h, v in (zip(host, vals) if isinstance(host, list) else ((host, vals),)):
+                    h.copy_(v, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            late, self._late = self._late, (ev, snap)
+            if late is not None:
+                self._inspect_late(late)
+        return self._summary()
+
+    def _inspect_late(self, late):
+        ev, snap = late
+        ev.synchronize()
+        self._inspect([(what, host, context) for (what, _, context, _), host in zip(self._stage.jobs, snap)])
+
+    def finish(self):
+        """Wait for the last step and run its checks (``checks='deferred'``; a no-op otherwise)."""
+        late, self._late = self._late, None
+        if late is not None:
+            self._inspect_late(late)
+
+    def _record_summary(self):
+        """The step's scalars into the Trainer's running summary as python floats (the review of the capture holds the static words)."""
+        scalars = {}
+        for what, host, context, _ in self._stage.jobs:
+            if what == 'loss':
+                for key, value in context.get('scalars', {}).items():
+                    scalars[key] = float(value) if torch.is_tensor(value) else value
+            elif what == 'grad_norm':
+                scalars['grad_norm'] = float(host[0][0])
+        self.trainer.train_summary.update({'scalars': scalars})
+
+    def _summary(self):
+        out = {'scalars': {}, 'histograms': {}}
+        for what, host, _, _ in self._stage.jobs:
+            if what == 'grad_norm':
+                out['scalars']['grad_norm'] = host[0][0]
+                out['histograms']['grad_norm_'] = host[0]
+        return out
+
+    def _inspect(self, jobs):
+        tr = self.trainer
+        from ..ops import lstm as _lstm
+        for what, host, context in jobs:
+            if what == 'loss':
+                value = float(host[-1])
+                if not np.isfinite(value):
+                    path = tr.log_error_state({'state_dict': tr.state_dict(), 'review': context})
+                    raise RuntimeError(f'The loss ({value}) is not finite.\n'
+                                       f'See error states (model, example, model_out and review) in {path}.')
+            elif what == 'grad_norm':
+                norm, timeouts = float(host[0][0]), int(host[1][0])
+                if _lstm.errors_since_last_report(self.device, timeouts):
+                    _lstm.raise_timeout(self.device)
+                if not np.isfinite(norm):
+                    path = tr.log_error_state({'state_dict': tr.state_dict(), 'optimizer_summary': context})
+                    raise RuntimeError(f'The grad_norm ({norm}) is not finite.\n'
+                                       f'See error states (model, example, model_out and review) in {path}.')
+
+    def scalars(self):
+        """The staged values of the last replay as python numbers (valid behind a synchronisation: ``checks='step'`` or ``finish``)."""
+        out = {}
+        for what, host, context, _ in self._stage.jobs:
+            if what == 'loss':
+                out['loss'] = float(host[-1])
+            elif what == 'grad_norm':
+                out['grad_norm'] = float(host[0][0])
+        return out

@@ -201,6 +201,7 @@ class Trainer:
         self._buckets = None
         self._pending = []           # [(what, event, host tensor, context, optimizer step)]
         self._stage_queue = []       # staged scalars whose copies are not enqueued yet (_flush_stage)
+        self._graph_stage = None     # train.graphed: the static pinned words of a step that is being captured
         self._opt_step = 0
         self._loss_acc = None        # device scalar: sum of the losses of the current optimizer step (non-finite -> skip)
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
@@ -607,6 +608,8 @@ class Trainer:
         their copy has run they read NaN (floating point) / the type's minimum (integers), never stale memory, and the
         queue is bounded - code that calls ``train_step`` without ever reaching ``optimizer_step`` has its oldest entries flushed."""
         def blank(shape, dtype):
+            if self._graph_stage is not None:       # a captured step (train.graphed): fixed addresses, no allocation inside the capture
+                return self._graph_stage.blank(tuple(shape), dtype)
             h = torch.empty(shape, dtype=dtype, pin_memory=True)
             return h.fill_(float('nan')) if dtype.is_floating_point else h.fill_(torch.iinfo(dtype).min)
         if len(self._stage_queue) >= 64:
@@ -620,6 +623,8 @@ class Trainer:
                 self._loss_acc = vals[-1] if self._loss_acc is None else self._loss_acc + vals[-1]
             host = blank(vals.shape, torch.float32)
         self._stage_queue.append((what, vals, host, context, self._opt_step))
+        if self._graph_stage is not None:
+            self._graph_stage.jobs.append((what, host, context, vals))
         return host
 
     def _flush_stage(self):
@@ -630,6 +635,8 @@ class Trainer:
         for _, vals, host, _, _ in jobs:
             for h, v in (zip(host, vals) if isinstance(host, list) else ((host, vals),)):
                 h.copy_(v, non_blocking=True)
+        if self._graph_stage is not None:
+            return                          # (captured copy nodes: whoever replays the graph synchronises and inspects)
         event = torch.cuda.Event()
         event.record()
         for what, _, host, context, opt_step in jobs:

@@ -139,6 +139,21 @@ def test_unit_norm_vs_oracle_and_torch(shape):
 
 
 @pytest.mark.gpu
+def test_unit_norm_keeps_nan_like_torch():
+    """``F.normalize`` clamps the norm with ``clamp_min`` (a NaN norm stays NaN): a NaN entry makes its whole (n, :, f) vector NaN, the
+    others are untouched - ``fmaxf(norm, eps)`` would have divided the vector's finite entries by ``eps`` instead."""
+    import torch
+    from padertorch_amd import ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 20, 33)).astype(np.float32)
+    x[2, 7, 5] = np.nan
+    yd = ops.unit_norm(torch.tensor(x, device='cuda:0')).cpu().numpy()
+    yt = torch.nn.functional.normalize(torch.tensor(x), dim=-2).numpy()
+    assert np.array_equal(np.isnan(yd), np.isnan(yt)) and np.isnan(yt[2, :, 5]).all() and int(np.isnan(yt).sum()) == 20
+    np.testing.assert_allclose(yd[~np.isnan(yt)], yt[~np.isnan(yt)], rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
 def test_unit_norm_full_size_properties():
     """C5 embedding size (8 x 503 rows x 20 x 257): unit norms, idempotence, scale invariance, and a
     gradient orthogonal to the output (d/dx of a function of x / |x| has no radial component)."""

@@ -336,3 +336,33 @@ def test_edited_feature_list_is_not_served_from_the_packed_log_magnitude():
                 assert torch.equal(a, b), edit.__name__          # the same generic path on the same values: bit-identical
         stale, got, want = run(lambda lst: None)
         assert not stale
+
+
+def test_pit_features_keep_a_nan_sample_like_the_reference():
+    """A NaN sample in the mixture (or a source) makes exactly the frames that cover it NaN in |Y| (|X|), in the cosine of the phase
+    difference and in the packed log-magnitude input - the oracle's pattern (``np.abs`` / ``np.angle``, reference ``pit/data.py:67-75``),
+    so that the loss and with it ``Trainer``'s non-finite check (``trainer.py:622-636``) see it.  (Until round 5 the magnitude /
+    phasor select tested ``|X|^2 > 0`` and turned a NaN bin into magnitude 0, phase 0: a finite loss on corrupt data.)"""
+    from padertorch_amd.ops import pit_features
+    rng = np.random.RandomState(3)
+    exs = [features_np.synthetic_mixture(rng, n) for n in (4000, 3500)]
+    exs[0][1][1000] = np.nan            # mixture of example 0
+    exs[1][0][1, 2000] = np.nan         # source 1 of example 1
+    ref = [features_np.pre_batch_transform(s, y) for s, y in exs]
+    f = pit_features([torch.from_numpy(y).to(DEV) for _, y in exs], [torch.from_numpy(s).to(DEV) for s, _ in exs])
+    for b, r in enumerate(ref):
+        for key in ('Y_abs', 'X_abs', 'cos_phase_difference'):
+            got = f[key][b].cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(r[key])), (b, key, int(np.isnan(got).sum()), int(np.isnan(r[key]).sum()))
+            ok = ~np.isnan(r[key])
+            if key != 'cos_phase_difference':
+                np.testing.assert_allclose(got[ok], r[key][ok], atol=2e-5)
+    assert np.isnan(ref[0]['Y_abs']).any() and np.isnan(ref[1]['X_abs']).any() and not np.isnan(ref[1]['Y_abs']).any()
+    packed = f['Y_abs'].packed_log1p
+    assert packed is not None and bool(torch.isnan(packed.data).any())
+    # frame t of example b is packed row offs[t] + b: the NaN rows of the packed input are the NaN frames of example 0
+    bs = packed.batch_sizes.numpy()
+    offs = np.concatenate([[0], np.cumsum(bs)])[:-1]
+    nan_rows = set(np.nonzero(torch.isnan(packed.data).any(1).cpu().numpy())[0].tolist())
+    want_rows = {int(offs[t]) for t in np.nonzero(np.isnan(ref[0]['Y_abs']).any(1))[0]}
+    assert nan_rows == want_rows
