@@ -25,8 +25,11 @@ The JSON line also carries
   value_ragged    the same step on SURVEY 8d's training distribution (example lengths ~ U[3 s, 6 s]) in frames/s, ms_per_step_ragged;
   cpu_baseline    the oracle's torch-CPU port of the reference step (oracle/torch_ref.py) timed on this box's host
                   cores on a bounded sample (rank 0, N = 1 only), at 1 thread, 16 threads and all cores;
-  ms_per_step_sync_checks   the same step with the reference's two host syncs per step (loss / grad-norm checks
-                  in the step they belong to; the default defers them by one step, see Trainer.deferred_checks);
+  value / ms_per_step   N = 1: the CAPTURED step (train.graphed.GraphedStep: every launch of the optimizer step in one hipGraph, replayed)
+                  with the loss / gradient-norm / watchdog checks at the end of the SAME step - one host synchronisation per step, errors
+                  raise in the iteration they belong to like the reference's (trainer.py:622-636, :740-780);
+  ms_per_step_eager_deferred / _end_of_step_checks / _sync_checks   the eager step of rounds 1-4 with the checks one step late (the host
+                  runs ahead), at the end of the same step, and with the reference's two mid-step syncs;
   ms_per_step_h2d the same step with the waveform batch starting in (pinned) host memory;
   rccl            (N > 1) world size, bucket layout and the time of a blocking all-reduce of the flat gradient buffer.
 ``--dry`` (no GPU needed; used by the CPU test suite): the same launcher, process group (gloo), gradient buckets
@@ -84,6 +87,10 @@ def parse_args(argv=None):
     ap.add_argument('--sync-checks', action='store_true',
                     help='loss / grad-norm finiteness checks in the step they belong to (two host syncs per step, '
                          'the reference behaviour) instead of Trainer(deferred_checks=True)')
+    ap.add_argument('--eager', action='store_true',
+                    help='time the eager step with deferred checks (rounds 1-4) instead of the captured step (train.graphed.GraphedStep: one '
+                         'hipGraph per optimizer step, loss / grad-norm checks at the end of the SAME step); N > 1, --ragged and --sync-checks '
+                         'are eager anyway')
     ap.add_argument('--no-overlap', action='store_true',
                     help='LSTM weight gradients through autograd on the main stream (ops.lstm.DEFER_WGRAD off)')
     ap.add_argument('--ragged', action='store_true',
@@ -616,10 +623,33 @@ def main():
         schedule['used'] = 'overlap' if (args.dry and 'overlap' in ok) else min(ok, key=ok.get)      # (dry: stub timings mean nothing)
         set_overlap(schedule['used'] == 'overlap')
 
+    use_graph = bool(world == 1 and not args.dry and not args.eager and not args.ragged and not args.sync_checks)
+    graph_state = {}
+
     def measure():
         for _ in range(args.warmup):
             step(False)
-        return timed_loop(args.steps, timed=True)
+        if not use_graph:
+            return timed_loop(args.steps, timed=True)
+        # N = 1: the optimizer step as ONE captured hipGraph, checks at the end of the same step (reference semantics)
+        from padertorch_amd.train.graphed import GraphedStep
+        trainer._check_pending(flush=True)
+        graphed = graph_state['step'] = GraphedStep(trainer, [data] * micro, prepare=features, warmup=0)
+        for _ in range(3):
+            graphed()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graphed()
+        sync()
+        elapsed_graph = time.perf_counter() - t0
+        # per-kernel HIP events cannot be recorded inside a replay: the same launches are bracketed in an eager pass of the same step
+        # behind the timed region (rocprofv3's summary of this command sees the replays' kernels themselves: profiles/)
+        ev_steps = max(TIMER_EVERY, min(args.steps, 10 * TIMER_EVERY))
+        for _ in range(2):
+            step(False)
+        graph_state['eager_deferred_ms'] = timed_loop(ev_steps, timed=True) / ev_steps * 1e3
+        return elapsed_graph
 
     try:
         elapsed = measure()
@@ -648,6 +678,10 @@ def main():
     trace('timed steps done')
     if not args.dry and not args.no_extras:
         nx = max(5, min(args.steps, 50))
+        if use_graph:
+            graphed = graph_state['step']
+            extras['ms_per_step_eager_deferred'] = graph_state['eager_deferred_ms']
+            trace('captured-step variants done')
         if not args.sync_checks:
             # the reference's semantics: loss and gradient norm cross to the host in the step they belong to
             opt = trainer.optimizer.optimizer
@@ -668,6 +702,20 @@ def main():
             step(False, host)
         extras['ms_per_step_h2d'] = timed_loop(nx, source=host) / nx * 1e3
         extras['h2d_bytes_per_step'] = int((host['y'].numel() + host['s'].numel()) * 4 * micro)
+        if use_graph:
+            # the captured step fed from pinned host memory: the waveforms cross PCIe into the graph's static inputs at the head of the step
+            graphed = graph_state['step']
+            hosts = [host] * micro
+            for _ in range(3):
+                graphed(hosts)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(nx):
+                graphed(hosts)
+            sync()
+            extras['ms_per_step_graph_h2d'] = (time.perf_counter() - t0) / nx * 1e3
+            graphed([data] * micro)          # (back on the resident batch)
+            sync()
         # the same with the NEXT batch's transfer issued under the current step (padertorch_amd.data.DevicePrefetcher: what a
         # data pipeline in front of Trainer.train does)
         if micro == 1:
@@ -686,6 +734,24 @@ def main():
                 return time.perf_counter() - t0
             prefetched_loop(3)
             extras['ms_per_step_h2d_prefetched'] = prefetched_loop(nx) / nx * 1e3
+            if use_graph:
+                graphed = graph_state['step']
+
+                def prefetched_graph_loop(n):
+                    sync()
+                    t0 = time.perf_counter()
+                    # (the batch crosses PCIe one step ahead on the copy stream; its 12 MB reach the graph's static inputs device to
+                    #  device BEHIND the running step's replay and in front of that step's synchronisation: `then_load`)
+                    batches = iter(DevicePrefetcher((host for _ in range(n + 1)), device))
+                    graphed.load([next(batches)])
+                    for nxt in batches:
+                        graphed(None, then_load=[nxt])
+                    sync()
+                    return time.perf_counter() - t0
+                prefetched_graph_loop(3)
+                extras['ms_per_step_graph_h2d_prefetched'] = prefetched_graph_loop(nx) / nx * 1e3
+                graphed([data] * micro)
+                sync()
         trace('host-to-device variants done')
         if not args.ragged and micro == 1:
             # SURVEY 8d's training distribution: lengths ~ U[3 s, 6 s] (the same draw as --ragged), zero-padded waveforms, the
@@ -792,7 +858,11 @@ def main():
                           'csrc/gemm_planes.hip: fp32 in / out, 3 16-bit MFMA products per product (fp32-equivalent accuracy); projections, '
                           'linears and weight gradients on operands pre-split into fp16 planes, LSTM input gradients on the bf16 planes the '
                           'backward recurrence hands on'),
-                'host_checks': 'same step (2 syncs)' if args.sync_checks else 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)',
+                'host_checks': ('same step (2 syncs)' if args.sync_checks else
+                                'end of the SAME optimizer step (one host synchronisation per step behind the captured step; errors raise in the '
+                                'iteration they belong to, optimizer update gated on the device): train.graphed.GraphedStep' if use_graph else
+                                'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)'),
+                'step_driver': 'one hipGraph per optimizer step (train.graphed.GraphedStep), replayed' if use_graph else 'eager launches (python)',
                 'optimizer': 'csrc/optim.hip: reproducible 2-norm + fused clip / Adam / zero_grad over the flat bucket',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',
             },
@@ -807,6 +877,9 @@ def main():
             kernels, family = ([], None) if args.ragged else kernel_report(
                 timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro, 1 if args.bf16 else 3, overhead)
             out['kernel_event_steps'] = counted[1]
+            out['kernel_event_source'] = ('HIP events around the same launches in an eager pass of the same step behind the timed region (a graph '
+                                          'replay takes no event records between its nodes); rocprofv3 --kernel-trace of this command times the '
+                                          "replays' kernels themselves (profiles/r5_kernel_trace_bench.txt)") if use_graph else 'HIP events inside the timed steps'
             out['event_bracket_overhead_us'] = overhead * 1e3
             # `roofline`: the ONE kernel with the most GPU time per step - what leads rocprofv3's summary of this command
             # (profiles/r4_kernel_trace_bench.txt); `roofline_family`: all planes GEMM launches together (round 3's headline entry)
@@ -822,7 +895,9 @@ def main():
         # inside the step: that figure, with the next batch's transfer issued one step ahead (data.DevicePrefetcher), is
         # value_to_device_inclusive; ms_per_step_h2d is the same without the prefetch (blocking copies at the head of the step)
         out['ms_per_step_resident'] = out['ms_per_step']
-        if 'ms_per_step_h2d_prefetched' in extras:
+        if 'ms_per_step_graph_h2d_prefetched' in extras:
+            out['value_to_device_inclusive'] = frames_per_step * world / (extras['ms_per_step_graph_h2d_prefetched'] * 1e-3)
+        elif 'ms_per_step_h2d_prefetched' in extras:
             out['value_to_device_inclusive'] = frames_per_step * world / (extras['ms_per_step_h2d_prefetched'] * 1e-3)
         if rccl is not None:
             out['rccl'] = rccl

@@ -9,9 +9,8 @@ for the host at the head of every step (``deferred_checks='step'``: 7.3 instead 
 :class:`GraphedStep` captures the whole step - every micro-step's forward, review, backward, then the clip + Adam + zeroing kernel and
 the staged scalars' copies - once per input shape (``torch.cuda.CUDAGraph`` = hipGraph) and replays it: one ``hipGraphLaunch`` per
 optimizer step, no python between the kernels.  The loss / gradient-norm / watchdog checks then cost what a synchronisation costs and
-raise in the iteration they belong to (``checks='step'``), or one step late without any synchronisation (``checks='deferred'``); the
-update itself is gated on the device either way (``csrc/optim.hip``), so a non-finite step leaves the parameters untouched like the
-reference's raise in front of ``optimizer.step()``.
+raise in the iteration they belong to; the update itself is gated on the device (``csrc/optim.hip``), so a non-finite step leaves the
+parameters untouched like the reference's raise in front of ``optimizer.step()``.
 
 What a capture needs from the ops is in ``ops.capture``.  Limits: fixed input shapes (a PackedSequence length pattern is part of the
 launch arguments - ragged batches of changing patterns stay on the eager path), one process group of one rank inside the graph (the
@@ -22,7 +21,43 @@ import torch
 
 from ..ops import capture as _capture
 
-__all__ = ['GraphedStep']
+__all__ = ['GraphedStep', 'signature']
+
+
+def signature(examples):
+    """What a captured step bakes in of its examples: structure, tensor shapes / dtypes / devices, and every python value (lengths,
+    frame counts: they become launch arguments).  Two lists of examples with equal signatures can share one graph; ``None`` when
+    an example holds a leaf this function does not know (the step then stays eager)."""
+    import numpy as np
+    from ..ops.sequence.pack_module import PaddedList
+    parts = []
+
+    def walk(x):
+        if torch.is_tensor(x):
+            parts.append(('T', tuple(x.shape), str(x.dtype), str(x.device), tuple(x.stride())))
+        elif isinstance(x, PaddedList):
+            if not x.intact():
+                raise TypeError('edited PaddedList')
+            parts.append(('PL', tuple(x.padded.shape), str(x.padded.dtype), str(x.padded.device), tuple(x.lengths), bool(x.batch_first)))
+        elif isinstance(x, dict):
+            parts.append(('D', tuple(x.keys())))
+            for v in x.values():
+                walk(v)
+        elif isinstance(x, (list, tuple)):
+            parts.append(('L', type(x).__name__, len(x)))
+            for v in x:
+                walk(v)
+        elif x is None or isinstance(x, (bool, int, float, str)):
+            parts.append(('V', x))
+        elif isinstance(x, np.generic):
+            parts.append(('V', x.item()))
+        else:
+            raise TypeError(type(x).__name__)
+    try:
+        walk(list(examples))
+    except TypeError:
+        return None
+    return tuple(parts)
 
 
 class _StaticStage:
@@ -56,34 +91,39 @@ class GraphedStep:
     same shapes into them (``None`` / the same objects: run on what they hold).
     ``prepare``: optional function ``example -> model input`` captured in front of ``train_step`` (the feature front-end when it is part
     of the step, ``ops.pit_features``).
-    ``checks``: ``'step'`` (default: one host synchronisation behind the replay; errors raise in the iteration they belong to, as in
-    the reference) or ``'deferred'`` (no synchronisation: the previous step's values are inspected after this step is enqueued).
+    The checks run at the end of every call, behind ONE host synchronisation: errors raise in the iteration they belong to, as in the
+    reference.  (A mode that inspects them one step late, like the eager ``deferred_checks=True``, was built and measured: 6.591 against
+    6.596 ms per step at BASELINE configs[1] - with no python between the launches there is nothing left for the host to run ahead
+    with - and removed.)
     """
 
-    def __init__(self, trainer, examples, prepare=None, checks='step', warmup=2):
-        assert checks in ('step', 'deferred'), checks
+    def __init__(self, trainer, examples, prepare=None, warmup=2):
         self.trainer = trainer
         self.prepare = prepare
-        self.checks = checks
         self.examples = list(examples)
         self.device = trainer._flat.flat.device
         assert self.device.type == 'cuda', 'GraphedStep captures a hipGraph: the model has to live on an MI355X'
+        for e in self.examples:
+            self._strip_records(e)
         self._inputs = [self._tensors(e) for e in self.examples]
         self._stage = None
         self._graph = None
         self._steps = 0
-        self._late = None           # checks='deferred': (event, host snapshot) of the step before
         self._eager(warmup)         # every lazily made table / stream / kernel attribute exists before the capture starts
         self._capture()
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def _tensors(example):
+        """The device tensors of an example in a fixed order: the graph's static inputs (a ``PaddedList`` counts as its ONE padded buffer)."""
+        from ..ops.sequence.pack_module import PaddedList
         out = []
 
         def walk(x):
             if torch.is_tensor(x):
                 out.append(x)
+            elif isinstance(x, PaddedList) and x.intact():
+                out.append(x.padded)
             elif isinstance(x, dict):
                 for v in x.values():
                     walk(v)
@@ -92,6 +132,25 @@ class GraphedStep:
                     walk(v)
         walk(example)
         return out
+
+    @staticmethod
+    def _strip_records(example):
+        """Records that hang on an example's containers and name tensors OUTSIDE the static inputs - the packed log-magnitude a feature
+        front-end attaches to ``Y_abs`` (``ops.features.PackedLog1p``: its rows and planes would be those of the captured batch at
+        every replay) - are dropped: the model then packs inside the graph."""
+        from ..ops.sequence.pack_module import PaddedList
+
+        def walk(x):
+            if isinstance(x, PaddedList):
+                if getattr(x, 'packed_log1p', None) is not None:
+                    x.packed_log1p = None
+            elif isinstance(x, dict):
+                for v in x.values():
+                    walk(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    walk(v)
+        walk(example)
 
     def _one_step(self):
         """What ``Trainer.train`` does between two iterations, on the static examples (``trainer.py:357-393``)."""
@@ -126,6 +185,8 @@ class GraphedStep:
         tr.deferred_checks = True               # no host synchronisation inside the capture; this class does the checks
         self._stage = tr._graph_stage = _StaticStage()
         graph = torch.cuda.CUDAGraph()
+        running_summary = tr.train_summary
+        tr.train_summary = type(running_summary)()      # (the capture's review entries point at the static words: not a step that ran)
         try:
             with _capture.capture_mode():
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
@@ -133,12 +194,8 @@ class GraphedStep:
         finally:
             tr._graph_stage = None
             tr.deferred_checks = keep
-        tr.train_summary.reset()                # (the capture's review entries point at the static words: not a step that ran)
+            tr.train_summary = running_summary
         self._graph = graph
-        # checks='deferred': two pinned snapshots of the staged scalars, filled in turn behind the replays
-        def like(host):
-            return [torch.empty_like(h).pin_memory() for h in host] if isinstance(host, list) else torch.empty_like(host).pin_memory()
-        self._snapshots = [[like(host) for _, host, _, _ in self._stage.jobs] for _ in range(2)]
         # the capture itself executed nothing: parameters, moments, step counts and gradients are what the warm-up left
 
     # ------------------------------------------------------------------ the step
@@ -153,54 +210,48 @@ class GraphedStep:
                     assert src.shape == dst.shape and src.dtype == dst.dtype, (src.shape, dst.shape, src.dtype, dst.dtype)
                     dst.copy_(src, non_blocking=True)
 
-    def __call__(self, examples=None):
+    def __call__(self, examples=None, then_load=None):
+        """One optimizer step on ``examples`` (``None``: on what the static inputs hold).  ``then_load``: the NEXT step's examples,
+        copied into the static inputs right behind this replay and in front of this step's synchronisation - a loop that knows its
+        next batch (``data.DevicePrefetcher`` has it on the device already) then starts every step with the replay itself."""
         tr = self.trainer
         if examples is not None and examples is not self.examples:
             self.load(examples)
         self._graph.replay()
+        if then_load is not None:
+            self.load(then_load)
         tr._opt_step += 1
         self._steps += 1
-        if self.checks == 'step':
-            # ONE synchronisation per optimizer step, behind everything the step consists of; the graph's own copy nodes have left
-            # the step's scalars in the static pinned words
-            torch.cuda.current_stream(self.device).synchronize()
-            self._inspect([(what, host, context) for what, host, context, _ in self._stage.jobs])
-            self._record_summary()
-        else:
-            # no synchronisation: this step's scalars are copied (eagerly, behind the replay) into one of two pinned snapshots - the
-            # static words belong to whichever replay ran last - and the PREVIOUS step's snapshot is inspected now that this step is queued
-            snap = self._snapshots[self._steps & 1]
-            for (_, _, _, vals), host in zip(self._stage.jobs, snap):
-                for h, v in (zip(host, vals) if isinstance(host, list) else ((host, vals),)):
-                    h.copy_(v, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            late, self._late = self._late, (ev, snap)
-            if late is not None:
-                self._inspect_late(late)
+        # ONE synchronisation per optimizer step, behind everything the step consists of; the graph's own copy nodes have left the
+        # step's scalars in the static pinned words
+        torch.cuda.current_stream(self.device).synchronize()
+        jobs = [(what, host, context) for what, host, context, _ in self._stage.jobs]
+        self._inspect(jobs)
+        self._record_summary(jobs)
         return self._summary()
 
-    def _inspect_late(self, late):
-        ev, snap = late
-        ev.synchronize()
-        self._inspect([(what, host, context) for (what, _, context, _), host in zip(self._stage.jobs, snap)])
-
-    def finish(self):
-        """Wait for the last step and run its checks (``checks='deferred'``; a no-op otherwise)."""
-        late, self._late = self._late, None
-        if late is not None:
-            self._inspect_late(late)
-
-    def _record_summary(self):
-        """The step's scalars into the Trainer's running summary as python floats (the review of the capture holds the static words)."""
-        scalars = {}
-        for what, host, context, _ in self._stage.jobs:
+    def _record_summary(self, jobs):
+        """The step's scalars into the Trainer's running summary as python floats.  The review of the capture names its scalars by
+        views into the static words, in staging order: the i-th staged value of a job is the i-th host word of that job."""
+        for (what, host, context), (_, static_host, _, _) in zip(jobs, self._stage.jobs):
+            scalars = {}
             if what == 'loss':
+                # which key of the review reads which static word: compare storage offsets
+                base = static_host.data_ptr()
                 for key, value in context.get('scalars', {}).items():
-                    scalars[key] = float(value) if torch.is_tensor(value) else value
+                    if torch.is_tensor(value) and value.numel() == 1 and value.is_pinned():
+                        i = (value.data_ptr() - base) // value.element_size()
+                        if 0 <= i < static_host.numel():
+                            scalars[key] = float(host.reshape(-1)[i])
+                            continue
+                    if not torch.is_tensor(value):
+                        scalars[key] = value
             elif what == 'grad_norm':
                 scalars['grad_norm'] = float(host[0][0])
-        self.trainer.train_summary.update({'scalars': scalars})
+                for key, value in context.get('scalars', {}).items():
+                    if not torch.is_tensor(value):
+                        scalars[key] = value
+            self.trainer.train_summary.update({'scalars': scalars})
 
     def _summary(self):
         out = {'scalars': {}, 'histograms': {}}

@@ -165,6 +165,7 @@ class Trainer:
             overlap_wgrad=True,
             deferred_checks=False,
             overlap_allreduce=True,
+            graph_steps=False,
     ):
         if not isinstance(model, torch.nn.Module):
             raise TypeError('Expect that the model is a subclass from padertorch.Module.\n'
@@ -194,6 +195,16 @@ class Trainer:
         #: micro-step of the optimizer step are complete, under the rest of the backward pass (False: one all-reduce
         #: of the whole flat buffer in optimizer_step)
         self.overlap_allreduce = overlap_allreduce
+        #: True (one process, GPU): an optimizer step whose examples have been seen before - same structure, shapes, lengths - runs as ONE
+        #: captured hipGraph (``train.graphed.GraphedStep``): no python between its ~120 launches, the loss / gradient-norm / watchdog
+        #: checks at the end of the SAME step at the cost of one synchronisation (whatever ``deferred_checks`` says: a replayed step
+        #: raises in its own iteration); the first step of every new shape runs eagerly, the second one captures.  Ragged data with
+        #: ever-new length patterns stays eager.
+        self.graph_steps = graph_steps
+        #: optional ``example -> model input`` captured inside the graph in front of ``train_step`` (a feature front-end on the device)
+        self.graph_prepare = None
+        self._graphs = {}            # signature -> GraphedStep (at most two: a graph owns the memory of a whole step)
+        self._graph_seen = {}
         #: this Trainer's switches / hooks of the in-place weight-gradient path, attached to every module of its model
         #: (ops.context): nothing process-global is set or reset around train()
         from ..ops import context as _context
@@ -290,6 +301,21 @@ class Trainer:
                     self._pre_step()            # hooks run between the epochs (trainer.py:348-353)
                     train_iterable = iter(train_dataset)
                 optimize = True
+                if self.graph_steps and W == 1 and not self._dp_active() and self._flat.flat.is_cuda:
+                    t0 = time.perf_counter()
+                    whole = list(itertools.islice(train_iterable, self.virtual_minibatch_size))
+                    self._time('time_per_data_loading', t0)
+                    if len(whole) == self.virtual_minibatch_size:
+                        if new_epoch:
+                            new_epoch = False
+                        else:
+                            self._pre_step()
+                        t0 = time.perf_counter()
+                        self._graph_or_eager_step(whole, device)
+                        self._time('time_per_optimize', t0)
+                        self.iteration += 1
+                        continue
+                    train_iterable = iter(whole)        # the epoch ends inside this group: the plain loop takes what is left
                 for minibatch_index in range(self.virtual_minibatch_size // W):
                     if self._buckets is not None:
                         self._buckets.active = minibatch_index + 1 == self.virtual_minibatch_size // W
@@ -341,7 +367,35 @@ class Trainer:
             try:
                 self._check_pending(flush=True)
             finally:
+                self._graphs, self._graph_seen = {}, {}
                 self._close()
+
+    def _graph_or_eager_step(self, group, device):
+        """One optimizer step on the ``virtual_minibatch_size`` examples ``group`` (``graph_steps``): replayed from the graph of their
+        signature, captured at the second sighting of a signature, eager before that and for examples no graph can take."""
+        from .graphed import GraphedStep, signature
+        examples = [self.model.example_to_device(e, device) for e in group]
+        sig = signature(examples)
+        graphed = self._graphs.get(sig) if sig is not None else None
+        if graphed is None and sig is not None and self._graph_seen.get(sig, 0) >= 1:
+            if len(self._graphs) >= 2:                  # a graph keeps a whole step's memory: the oldest one goes
+                self._graphs.pop(next(iter(self._graphs)))
+            graphed = self._graphs[sig] = GraphedStep(self, examples, prepare=self.graph_prepare, warmup=0)
+        if graphed is not None:
+            return graphed(examples)
+        if sig is not None:
+            if len(self._graph_seen) > 64:
+                self._graph_seen.clear()
+            self._graph_seen[sig] = self._graph_seen.get(sig, 0) + 1
+        for example in examples:
+            batch = self.graph_prepare(example) if self.graph_prepare is not None else example
+            loss, _, _, review = self.train_step(self.model, batch, device)
+            self.train_summary.update(review)
+            loss.backward(retain_graph=False)
+            del loss, review, batch
+        summary = self.optimizer_step()
+        self.train_summary.update(summary)
+        return summary
 
     # ------------------------------------------------------------------ hooks (fixed set)
     def _pre_step(self):

@@ -79,9 +79,9 @@ def main():
 
     out = {'config': args.config}
     if args.replay_only:
-        step = GraphedStep(trainer, datas, prepare=features, checks='deferred')
-        ms = timed(step, args.replay_only, step.finish)
-        print(json.dumps({'config': args.config, 'graph_deferred_ms': ms}), flush=True)
+        step = GraphedStep(trainer, datas, prepare=features)
+        ms = timed(step, args.replay_only)
+        print(json.dumps({'config': args.config, 'graph_step_checks_ms': ms}), flush=True)
         return
     if args.eager_only:
         for _ in range(3):
@@ -129,7 +129,7 @@ def main():
     want_p = [p.detach().clone() for p in trainer._flat.params]
 
     t0 = time.perf_counter()
-    step = GraphedStep(trainer, datas, prepare=features, checks='step')
+    step = GraphedStep(trainer, datas, prepare=features)
     out['capture_s'] = time.perf_counter() - t0
     restore()
     got = []
@@ -148,11 +148,6 @@ def main():
     for _ in range(5):
         step()
     out['graph_step_checks_ms'] = timed(step, args.steps)
-    step.checks = 'deferred'
-    for _ in range(3):
-        step()
-    out['graph_deferred_ms'] = timed(step, args.steps, step.finish)
-    step.checks = 'step'
     # with fresh data copied into the static inputs every step (what a training loop does)
     fresh = [dict(y=d['y'].clone(), s=d['s'].clone(), num_samples=d['num_samples']) for d in datas]
     out['graph_step_checks_with_input_copy_ms'] = timed(lambda: step(fresh), args.steps)
