@@ -400,7 +400,7 @@ int ptmi_norm_elementwise(int32_t backward, const float* x, const float* gy, con
 
 /* ---- Unit-norm embeddings ------------------------------------------------------------------------
  * Replaces torch.nn.functional.normalize(h, dim=-2) of padertorch/contrib/tcl/dc.py:70 (and its autograd
- * backward) on the [N, E, F] embedding (F contiguous, E <= 32):
+ * backward) on the [N, E, F] embedding (F contiguous; E <= 32: register-tiled, one HBM pass; wider: the E values read twice):
  *   forward : y = x / max(||x[n, :, f]||_2, eps);  inv_norm [N, F] = 1 / max(norm, eps) is kept for
  *   backward: dx = inv_norm (gy - y <gy, y>_E)   (inv_norm gy where the norm was clamped to eps).
  * One HBM pass each. */

@@ -43,7 +43,7 @@ class DeepClusteringModel(base.Model):
     def _embed_rows(self, rows):
         """Packed BLSTM outputs ``[tb, 2 units]`` -> unit-norm embeddings ``[tb, E, F]`` (Hershey 2016, p. 2)."""
         e = ops.linear.linear(self.linear, rows, ops.gemm.UNIT_RANGE).view(-1, self.E, self.F)     # 'tb (e f) -> tb e f'
-        if e.is_cuda and e.dtype == torch.float32 and self.E <= 32:
+        if e.is_cuda and e.dtype == torch.float32:
             return ops.unit_norm(e)                    # one HIP pass forward, one backward (csrc/norm.hip)
         return torch.nn.functional.normalize(e, dim=-2)
 
@@ -99,7 +99,8 @@ class DeepClusteringModel(base.Model):
         """Mean deep-clustering loss of the batch (reference ``dc.py:73-84``: per-example loop over
         re-laid-out copies).  A :class:`PaddedList` output is consumed in place by ONE fused HIP
         pass; anything else follows the reference loop through ``deep_clustering_loss``."""
-        if isinstance(model_out, PaddedList) and model_out.intact():
+        wide = len(model_out) > 0 and model_out[0].shape[1] + batch['target_mask'][0].shape[1] > 32       # E + K > 32: the per-example loop below
+        if isinstance(model_out, PaddedList) and model_out.intact() and not wide:
             tm, _, _ = as_padded(batch['target_mask'])
             loss, _ = ops.losses.dc_loss_batched(
                 model_out.padded, tm, model_out.lengths_dev,

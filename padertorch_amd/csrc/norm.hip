@@ -503,6 +503,42 @@ __global__ __launch_bounds__(256) void unit_norm_bwd_kernel(const float* __restr
     }
 }
 
+// E > 32 (no register tile of the whole vector): the same arithmetic in the same order with the E strided values read twice - once for
+// the sum of squares (the dot product), once for the scaled store; one column per thread.  The second read comes from the caches.
+__global__ __launch_bounds__(256) void unit_norm_fwd_wide_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv,
+                                                                 long long N, int E, int F, float eps) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * F) return;
+    const long long n = gid / F;
+    const int f = (int)(gid - n * F);
+    const float* xp = x + n * (long long)E * F + f;
+    float* yp = y + n * (long long)E * F + f;
+    float ss = 0.f;
+    for (int e = 0; e < E; ++e) {
+        const float v = xp[(long long)e * F];
+        ss += v * v;
+    }
+    const float nq = sqrtf(ss);
+    const float r = 1.f / (nq < eps ? eps : nq);
+    inv[n * F + f] = r;
+    for (int e = 0; e < E; ++e) yp[(long long)e * F] = xp[(long long)e * F] * r;
+}
+
+__global__ __launch_bounds__(256) void unit_norm_bwd_wide_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                 const float* __restrict__ inv, float* __restrict__ dx, long long N, int E,
+                                                                 int F, float eps) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= N * F) return;
+    const long long n = gid / F;
+    const int f = (int)(gid - n * F);
+    const long long base = n * (long long)E * F + f;
+    const float r = inv[n * F + f];
+    float dot = 0.f;
+    for (int e = 0; e < E; ++e) dot += g[base + (long long)e * F] * y[base + (long long)e * F];
+    if (r * eps >= 1.f) dot = 0.f;
+    for (int e = 0; e < E; ++e) dx[base + (long long)e * F] = r * (g[base + (long long)e * F] - y[base + (long long)e * F] * dot);
+}
+
 }  // namespace ptmi
 
 extern "C" {
@@ -512,7 +548,13 @@ int ptmi_unit_norm_forward(const float* x, float* y, float* inv_norm, int64_t N,
     PTMI_RETURN_IF(N < 0 || E < 1 || F < 1 || !(eps > 0.f), PTMI_E_INVALID);
     if (N == 0) return PTMI_OK;
     PTMI_RETURN_IF(!x || !y || !inv_norm, PTMI_E_INVALID);
-    PTMI_RETURN_IF(E > 32, PTMI_E_UNSUPPORTED);
+    if (E > 32) {
+        const long long wb = (N * F + 255) / 256;
+        PTMI_RETURN_IF(wb > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+        hipLaunchKernelGGL(ptmi::unit_norm_fwd_wide_kernel, dim3((unsigned)wb), dim3(256), 0, static_cast<hipStream_t>(stream), x, y, inv_norm,
+                           (long long)N, E, F, eps);
+        return ptmi::launch_status();
+    }
     const int W = (F & 3) == 0 ? 4 : 1;
     const long long blocks = (N * (F / W) + 255) / 256;
     PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
@@ -533,7 +575,13 @@ int ptmi_unit_norm_backward(const float* gy, const float* y, const float* inv_no
     PTMI_RETURN_IF(N < 0 || E < 1 || F < 1 || !(eps > 0.f), PTMI_E_INVALID);
     if (N == 0) return PTMI_OK;
     PTMI_RETURN_IF(!gy || !y || !inv_norm || !dx, PTMI_E_INVALID);
-    PTMI_RETURN_IF(E > 32, PTMI_E_UNSUPPORTED);
+    if (E > 32) {
+        const long long wb = (N * F + 255) / 256;
+        PTMI_RETURN_IF(wb > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+        hipLaunchKernelGGL(ptmi::unit_norm_bwd_wide_kernel, dim3((unsigned)wb), dim3(256), 0, static_cast<hipStream_t>(stream), gy, y, inv_norm,
+                           dx, (long long)N, E, F, eps);
+        return ptmi::launch_status();
+    }
     const int W = (F & 3) == 0 ? 4 : 1;
     const long long blocks = (N * (F / W) + 255) / 256;
     PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);

@@ -51,6 +51,32 @@ class _DcFn(torch.autograd.Function):
         return dx, None, None, None
 
 
+class _DcWideFn(torch.autograd.Function):
+    """The loss for E + K > 32 columns (wider than the one 32 x 32 matrix-core tile of ``csrc/dc_loss.hip``): the reference's three
+    products ``X'X``, ``X'T``, ``T'T`` (``source_separation.py:26-30``) and the two of the gradient ``4 / N^2 (X (X'X) - T (T'X))`` on
+    the split-fp16 planes GEMM (``ops.gemm.mm`` -> ``csrc/gemm_planes.hip``: fp32 in / out, fp32-equivalent products) - no BLAS
+    library, no reduced precision; the squared Frobenius norms are summed in fp64 like the Gram kernel's partials."""
+
+    @staticmethod
+    def forward(ctx, x, t):
+        from .. import gemm as _gemm
+        N = x.shape[0]
+        gxx = _gemm.mm(x.t(), x)
+        gxt = _gemm.mm(x.t(), t)
+        gtt = _gemm.mm(t.t(), t)
+        ctx.save_for_backward(x, t, gxx, gxt)
+        total = gxx.double().pow(2).sum() - 2. * gxt.double().pow(2).sum() + gtt.double().pow(2).sum()
+        return (total / float(N) ** 2).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import gemm as _gemm
+        x, t, gxx, gxt = ctx.saved_tensors
+        N = x.shape[0]
+        dx = _gemm.mm(x, gxx) - _gemm.mm(t, gxt.t())
+        return dx * (g.to(torch.float32) * (4. / float(N) ** 2)), None
+
+
 def deep_clustering_loss(x, t):
     """Deep clustering loss as in Hershey 2016 (``source_separation.py:13-31``).
 
@@ -64,14 +90,17 @@ def deep_clustering_loss(x, t):
     N, E = x.shape
     K = t.shape[1]
     assert t.shape[0] == N, (x.shape, t.shape)
-    if E + K > 32 or x.dtype != torch.float32:
-        # wider than one 32x32 matrix-core tile: the reference's three products on the device BLAS
-        _lib.leaving_native_path('deep_clustering_loss', f'E + K = {E + K} > 32 columns' if E + K > 32 else f'dtype {x.dtype} (fp32 only)')
+    if x.dtype != torch.float32:
+        _lib.leaving_native_path('deep_clustering_loss', f'dtype {x.dtype} (fp32 only)')
         t = t.to(x.dtype)
         return (torch.sum((x.t() @ x) ** 2) - 2 * torch.sum((x.t() @ t) ** 2)
                 + torch.sum((t.t() @ t) ** 2)) / N ** 2
     x = x.contiguous()
     t = t.to(torch.float32).contiguous()
+    if E + K > 32:          # wider than the Gram kernel's one matrix-core tile: the products on the planes GEMM (still hand-written HIP)
+        if N == 0:
+            return x.sum() * float('nan')                  # 0 / 0 like the reference
+        return _DcWideFn.apply(x, t)
     geom = (1, N, E, K, 1, (0, E, 1, 0), (0, K, 1, 0))
     return _DcFn.apply(x, t, None, geom)[0]
 

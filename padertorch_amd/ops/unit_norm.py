@@ -25,8 +25,9 @@ class _UnitNormFn(torch.autograd.Function):
 
 
 def unit_norm(x, eps=1e-12):
-    """``F.normalize(x, p=2, dim=-2, eps=eps)`` for a float32 CUDA tensor ``[N, E, F]`` with ``E <= 32``."""
+    """``F.normalize(x, p=2, dim=-2, eps=eps)`` for a float32 CUDA tensor ``[N, E, F]`` (any E: register-tiled kernels up to 32,
+    a two-read kernel beyond)."""
     _lib.require_gpu(x)
-    if x.dim() != 3 or x.dtype != torch.float32 or x.shape[1] > 32:
-        raise NotImplementedError('unit_norm: float32 [N, E, F] with E <= 32')
+    if x.dim() != 3 or x.dtype != torch.float32:
+        raise NotImplementedError('unit_norm: float32 [N, E, F]')
     return _UnitNormFn.apply(x, float(eps))

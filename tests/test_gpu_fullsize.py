@@ -10,8 +10,9 @@ the same weights and the same input features:
   * configs[4] shape:    deep clustering, 2 x BLSTM-600, E = 20, K = 3, B = 34, T = 503, a ragged tail (shorter examples).
 
 A hand-off race in the persistent recurrence (a stale tile, a missed flag) would show up here as a wrong mask; tolerances:
-masks / embeddings atol 1e-5, losses 1e-4 (BASELINE.json north_star), gradients 2e-4 of each parameter's largest
-gradient entry (fp32 accumulation order differs between the CPU's and the GPU's reductions over 8096 - 20120 rows).
+masks / embeddings atol 1e-5, losses 1e-4 (BASELINE.json north_star) against the fp32 oracle; gradients against the SAME oracle
+step in fp64: within 2e-4 of each parameter's largest gradient entry and within twice the fp32 CPU oracle's own distance from fp64
+(``_grad_check``).
 """
 import numpy as np
 import pytest
@@ -29,14 +30,45 @@ def _waveforms(B, K, n, lens, seed):
     return s
 
 
-def _grad_check(model, ref, tol=2e-4):
+#: the relative gate's floor, as a fraction of a parameter's largest gradient entry: where the CPU's fp32 gradient happens to be exact to
+#: far below the split products' own rounding (2^-17 per product pair), "twice the CPU's error" would be a gate on luck
+RATIO_FLOOR = 5e-5
+
+
+def _double_oracle(ref, run):
+    """The same oracle step in fp64 (``run(model64, to64)`` does forward, review and backward): what both fp32 gradients - the HIP
+    path's and the CPU oracle's - are measured against."""
+    import copy
+    ref64 = copy.deepcopy(ref).double()
+    for p in ref64.parameters():
+        p.grad = None
+    run(ref64, lambda t: t.detach().cpu().double())
+    return ref64
+
+
+def _grad_check(model, ref, ref64=None, tol=2e-4):
+    """Every parameter gradient of the HIP step against the fp64 oracle: within ``tol`` of the gradient's largest entry, AND within
+    twice the error the fp32 CPU oracle itself has against fp64 (plus RATIO_FLOOR): the two error sources - the CPU's summation
+    order over 8 k - 28 k rows and the HIP path's own arithmetic - are told apart instead of sharing one widened gate."""
     worst = {}
-    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-        g, r = p.grad.detach().cpu().double(), q.grad.double()
+    truth = ref64 if ref64 is not None else ref
+    report = []
+    for (n, p), (_, q), (_, q64) in zip(model.named_parameters(), ref.named_parameters(), truth.named_parameters()):
+        g, r32, r = p.grad.detach().cpu().double(), q.grad.double(), q64.grad.double()
         scale = float(r.abs().max())
         err = float((g - r).abs().max())
+        err_cpu = float((r32 - r).abs().max())
         worst[n] = err / max(scale, 1e-30)
+        report.append((n, err / max(scale, 1e-30), err_cpu / max(scale, 1e-30)))
         assert err <= tol * scale + 1e-9, (n, err, scale)
+        if ref64 is not None:
+            assert err <= 2. * err_cpu + RATIO_FLOOR * scale + 1e-9, (n, err, err_cpu, scale)
+    import os
+    if os.environ.get('PTMI_GRAD_REPORT'):
+        with open(os.environ['PTMI_GRAD_REPORT'], 'a') as f:
+            for n, e, c in report:
+                f.write(f'{n} hip {e:.3e} cpu32 {c:.3e}\n')
+            f.write('--\n')
     return worst
 
 
@@ -80,7 +112,11 @@ def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, i
     assert worst_mask < 1e-5, worst_mask
     for k in ('pit_mse_loss', 'pit_ips_loss'):
         assert abs(float(losses[k]) - float(rlosses[k])) < 1e-4, (k, float(losses[k]), float(rlosses[k]))
-    return worst_mask, _grad_check(model, ref, grad_tol)
+
+    def run64(m64, to64):
+        b64 = {k: [to64(t) for t in feats[k]] for k in ('Y_abs', 'X_abs', 'cos_phase_difference')}
+        m64.review(b64, m64(b64))['losses']['pit_ips_loss'].backward()
+    return worst_mask, _grad_check(model, ref, _double_oracle(ref, run64), grad_tol)
 
 
 def test_pit_step_config2_size_vs_oracle():
@@ -121,10 +157,9 @@ def test_pit_step_on_row_slots_vs_oracle(B, slots, units, layers, in_place):
     layout = SlotLayout(frames, slots)
     per_slot = np.bincount(layout.slot, minlength=slots)
     assert per_slot.max() >= 2 and layout.T == max(np.bincount(layout.slot, weights=frames, minlength=slots)), (per_slot, layout.T)
-    # (B = 100: linear1.weight's gradient differs from the oracle's by 3.3e-4 of its largest entry with OR WITHOUT slots - the same
-    #  6.896e-7 in both, fp32 summation order over 28 k rows against a 2e-3 gradient - so this case is held to 5e-4)
-    _pit_case(B, 8000, lens=lens, seed=B, n=n, row_slots=slots, grad_tol=5e-4 if B == 100 else 2e-4, in_place=in_place, units=units,
-              recurrent_layers=layers, K=2 + B % 2)
+    # (B = 100: linear1.weight's gradient differed from the fp32 CPU oracle's by 3.3e-4 of its largest entry with OR WITHOUT slots -
+    #  the CPU's fp32 summation order over 28 k rows; against the fp64 oracle every case holds the one gate)
+    _pit_case(B, 8000, lens=lens, seed=B, n=n, row_slots=slots, in_place=in_place, units=units, recurrent_layers=layers, K=2 + B % 2)
 
 
 def test_row_slot_masks_equal_the_packed_sequence_path():
@@ -193,7 +228,11 @@ def _dc_case(B, K, n, lens, seed, padded_target=False, row_slots=None, **model_k
     worst = max(float((m.detach().cpu() - r.detach()).abs().max()) for m, r in zip(emb, remb))
     assert worst < 1e-5, worst
     assert abs(float(loss) - float(rloss)) < 1e-4 * max(1., abs(float(rloss))), (float(loss), float(rloss))
-    _grad_check(model, ref)
+
+    def run64(m64, to64):
+        b64 = dict(Y_abs=[to64(t) for t in feats['Y_abs']], target_mask=[to64(t) for t in target])
+        m64.review(b64, m64(b64))['losses']['dc_loss'].backward()
+    _grad_check(model, ref, _double_oracle(ref, run64))
 
 
 @pytest.mark.parametrize('B,slots,transform', [(36, 16, 'log1p'), (9, 4, 'identity')])

@@ -230,6 +230,52 @@ def test_dc_loss_vs_reference(g1, g5):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g5['grad'], atol=1e-6)
 
 
+@pytest.mark.parametrize('N,E,K', [(5000, 40, 3), (257 * 60, 31, 2), (300, 64, 5), (17, 33, 1)])
+def test_dc_loss_wider_than_one_matrix_core_tile_vs_oracle(N, E, K):
+    """E + K > 32 (the reference has no such limit, ``source_separation.py:13-31``): the three products and the gradient on the planes
+    GEMM - value against the fp64 oracle, gradient against torch autograd of the reference formula in fp64; and a DeepClusteringModel
+    with such an embedding width reviews through it (strict: nothing leaves the hand-written path)."""
+    from oracle import losses_np
+    from padertorch_amd.ops import deep_clustering_loss
+    rng = np.random.RandomState(N + E)
+    x = rng.standard_normal((N, E)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    t = np.eye(K, dtype=np.float32)[rng.randint(0, K, N)]
+    xd = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    loss = deep_clustering_loss(xd, torch.from_numpy(t).to(DEV))
+    want = losses_np.deep_clustering_loss(x, t)
+    np.testing.assert_allclose(loss.item(), want, rtol=2e-6, atol=1e-7)
+    loss.backward()
+    x64 = torch.from_numpy(x).double().requires_grad_(True)
+    t64 = torch.from_numpy(t).double()
+    ref = (torch.sum((x64.t() @ x64) ** 2) - 2 * torch.sum((x64.t() @ t64) ** 2) + torch.sum((t64.t() @ t64) ** 2)) / N ** 2
+    ref.backward()
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), x64.grad.numpy(), rtol=0, atol=2e-6 * float(x64.grad.abs().max()))
+
+
+def test_dc_model_with_a_wide_embedding_reviews_on_the_hip_path():
+    from oracle import torch_ref
+    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
+    torch.manual_seed(0)
+    kw = dict(F=33, recurrent_layers=1, units=16, E=36)
+    model = DeepClusteringModel(**kw)
+    ref = torch_ref.DCModelRef(**kw)
+    ref.load_state_dict(model.state_dict())
+    model.to(DEV).train()
+    lens = [40, 31, 12]
+    Y = [torch.rand(n, 33) for n in lens]
+    tm = [torch.nn.functional.one_hot(torch.randint(0, 3, (n, 33)), 3).permute(0, 2, 1).float() for n in lens]
+    batch = dict(Y_abs=[y.to(DEV) for y in Y], target_mask=[m.to(DEV) for m in tm])
+    loss = model.review(batch, model(batch))['losses']['dc_loss']
+    rb = dict(Y_abs=Y, target_mask=tm)
+    rloss = ref.review(rb, ref(rb))['losses']['dc_loss']
+    assert abs(float(loss) - float(rloss)) < 1e-5, (float(loss), float(rloss))
+    loss.backward()
+    rloss.backward()
+    for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), atol=2e-4 * float(q.grad.abs().max()) + 1e-9, err_msg=n)
+
+
 def test_dc_loss_batched_full_size_vs_oracle():
     """Config-5 shape (K=3, E=20, F=257): fused batched kernel on the model's (T,B,E,F) layout vs the
     fp64 oracle per example, value and gradient; ragged lengths."""

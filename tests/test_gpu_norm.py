@@ -113,7 +113,7 @@ def test_full_size_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('shape', [(37, 20, 257), (5, 4, 9), (3, 8, 64), (2, 32, 12), (1, 1, 1), (0, 20, 257)])
+@pytest.mark.parametrize('shape', [(37, 20, 257), (5, 4, 9), (3, 8, 64), (2, 32, 12), (1, 1, 1), (0, 20, 257), (9, 36, 33), (4, 70, 64)])
 def test_unit_norm_vs_oracle_and_torch(shape):
     """ops.unit_norm (ptmi_unit_norm_forward / _backward) == F.normalize(dim=-2) of dc.py:70: forward and
     input gradient against the numpy oracle and torch on the CPU, incl. zero vectors (eps clamp), F not a
