@@ -133,7 +133,16 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
         if _gemm.planes_enabled():
             # (one buffer per shape AND stream: a call on another stream - a prefetching copy stream, a second host thread - must not
             #  overwrite planes that a GEMM queued on this stream has not read yet)
+            from . import capture as _capture
             key = (dev.type, dev.index, meta.rows, F, torch.cuda.current_stream(dev).cuda_stream)
+            if _capture.ACTIVE:
+                # a captured step runs on the capture's own stream: a ring made here would be allocated - and zero-filled - by the graph,
+                # i.e. twice 8 MB of fills at every replay.  The ring of this shape that the warm-up steps made (any stream) serves: the
+                # replays are ordered on one stream, nobody else touches it while the graph lives.
+                for k in _PLANES:
+                    if k[:4] == key[:4]:
+                        key = k
+                        break
             # TWO buffers in turn: a call retires the planes of the call before the previous one, so the features of the NEXT batch can be
             # made (data.DevicePrefetcher with a model's example_to_device) while this batch's first projection has yet to read its planes
             ring = _PLANES.get(key)
