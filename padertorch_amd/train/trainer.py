@@ -471,7 +471,7 @@ class Trainer:
         With W > 1 the flat gradient bucket is summed over all ranks first (one collective)."""
         from ..ops import lstm as _lstm
         _lstm.sync_deferred()          # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
-        if self._dp_active():
+        if self._dp_active() and not getattr(self, '_skip_allreduce', False):      # (_skip_allreduce: bench.py's local-step measurement)
             t0 = time.perf_counter()
             if self._buckets is not None:
                 self._buckets.finish()             # buckets not yet issued + wait for all of them

@@ -32,6 +32,11 @@ def test_self_launch_two_ranks_bucketed_allreduce():
     # PIT model: three BLSTM layers and two linears -> five layer buckets covering all 23 480 914 parameters
     assert len(r['buckets']) == 5 and sum(r['buckets']) == 23480914 and r['flat_gradient_bytes'] == 4 * 23480914
     assert out['value'] > 0 and out['unit'] == 'frames/s'
+    # what the first real SCALE record is read against: every bucket's own all-reduce, and the efficiency fields (the dry run has no
+    # step without exchange to relate them to)
+    assert len(r['bucket_all_reduce_ms']) == 5 and all(t > 0 for t in r['bucket_all_reduce_ms'])
+    assert set(r['scaling']) == {'ms_per_step_without_exchange', 'measured_efficiency', 'predicted_efficiency_unoverlapped',
+                                 'predicted_efficiency_fully_overlapped'}
 
 
 def test_recurrence_timeout_falls_back_to_the_unoverlapped_schedule():
