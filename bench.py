@@ -212,15 +212,15 @@ def event_bracket_overhead_ms(device, n=200):
     two tools quote one number (the raw bracket stays in the entry as ``avg_launch_ms_events``)."""
     import torch
     from padertorch_amd import _lib
-    lib = _lib.load()
+    hooks = _lib.test_hooks()          # (the empty launch lives in the test-hook library, not in libptmi.so)
     st = _lib.stream(device)
     for _ in range(20):
-        lib.ptmi_debug_occupy(1, 64, 0, 0, st)
+        hooks.ptmi_test_occupy(1, 64, 0, 0, st)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in ev:
         a.record()
-        lib.ptmi_debug_occupy(1, 64, 0, 0, st)
+        hooks.ptmi_test_occupy(1, 64, 0, 0, st)
         b.record()
     torch.cuda.synchronize()
     v = sorted(a.elapsed_time(b) for a, b in ev)
@@ -301,24 +301,21 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
     gemm, packs = {}, {}
     family = dict(flop=0., ms=0., launches=0)
     for n, v in by_name.items():
-        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:', 'gemm_planes_tn:')):          # gemm_planes[_bf16|_tn]:MxNxK:split
+        if n.startswith(('gemm_planes:', 'gemm_planes_bf16:')):          # gemm_planes[_bf16]:MxNxK:split
             parts = n.split(':')
             M, N, Kd = (int(x) for x in parts[1].split('x'))
             bf16 = n.startswith('gemm_planes_bf16')
-            if n.startswith('gemm_planes_tn'):
-                key = ('gemm_planes_tn_kernel<bf16>', 3, 'weight gradients on row-major planes (LDS transpose reads)')
+            split = int(parts[2]) if len(parts) > 2 and parts[2].lstrip('-').isdigit() else 1
+            plan = int(lib.ptmi_gemm_planes_plan(M, N, Kd, split))
+            tile, ranges = plan // 100, plan % 100
+            dt = 'bf16' if bf16 else 'fp16'
+            one = ', one product' if products_mode == 1 else ''
+            if tile == 5:
+                key = (f'gemm_planes_kernel<{dt}{one}> (128 x 128, slab split K' + (', co-resident with a recurrence' if split < 0 else '') + ')',
+                       products_mode, 'weight gradients beside a backward recurrence')
             else:
-                split = int(parts[2]) if len(parts) > 2 and parts[2].lstrip('-').isdigit() else 1
-                plan = int(lib.ptmi_gemm_planes_plan(M, N, Kd, split))
-                tile, ranges = plan // 100, plan % 100
-                dt = 'bf16' if bf16 else 'fp16'
-                one = ', one product' if products_mode == 1 else ''
-                if tile == 5:
-                    key = (f'gemm_planes_kernel<{dt}{one}> (128 x 128, slab split K' + (', co-resident with a recurrence' if split < 0 else '') + ')',
-                           products_mode, 'weight gradients beside a backward recurrence')
-                else:
-                    key = (f'gemm_planes_big_kernel<{dt}, {TILE_NAMES[tile]}{one}>' + (' split K + planes_reduce_kernel' if ranges > 1 else ''),
-                           products_mode, 'persistent big-tile kernel')
+                key = (f'gemm_planes_big_kernel<{dt}, {TILE_NAMES[tile]}{one}>' + (' split K + planes_reduce_kernel' if ranges > 1 else ''),
+                       products_mode, 'persistent big-tile kernel')
             e = gemm.setdefault(key, dict(flop=0., ms=0., launches=0, shapes=set()))
             e['flop'] += 2.0 * M * N * Kd * len(v)
             e['ms'] += float(np.sum(v)) - overhead_ms * len(v)

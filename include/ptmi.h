@@ -24,11 +24,6 @@ extern "C" {
 typedef void* ptmi_stream_t; /* hipStream_t */
 
 const char* ptmi_version(void);
-/* DEBUG / TEST ONLY (not part of the hot path's contract; ptmi_gemm_planes_select_tile below is the other such entry: a process-wide,
- * not thread-safe override for sweeps and tests).  `workgroups` workgroups of `threads` threads with `lds_bytes` of LDS each stay resident for `ticks_100mhz`
- * ticks of the 100 MHz clock - a stand-in for a communication kernel holding CUs next to the persistent recurrence kernels
- * (the RCCL all-reduce of padertorch/train/trainer.py:396-442's data-parallel branch runs beside them). */
-int ptmi_debug_occupy(int32_t workgroups, int32_t threads, int32_t lds_bytes, int64_t ticks_100mhz, ptmi_stream_t stream);
 const char* ptmi_error_string(int code);
 
 /* ---------------------------------------------------------------------------------------------
@@ -507,26 +502,10 @@ int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bia
 int ptmi_gemm_planes_bf16_two(const uint16_t* a, const uint16_t* b, float* c, float* c2, int32_t m_split, int64_t ldc, int32_t m,
                               int32_t n, int32_t k, int32_t accumulate, int32_t split_k, int32_t products, float* workspace,
                               ptmi_stream_t stream);
-/* The weight-gradient form on the SAME planes: C[m, n] (+)= sum over rows r of A[r, m] B[r, n], both operands bf16 planes of
- * matrices whose rows are r (ptmi_pack_planes_n_bf16 of the layer input / output; the backward recurrence's hand-off planes of the
- * gate gradients): the reduction runs over the planes' ROW tiles, the MFMA fragments are read with the LDS transpose read, and no
- * transposing pack pass exists (torch.nn.LSTM backward inside pit/model.py:60-66: dW_ih = dgates^T x, dW_hh = dgates^T h_prev).
- *   a / b               planes; a tile of 16 rows x 32 columns lies at ((row_tile * col_blocks + col_block) * 2 + plane) * 1 KB
- *   x_col_blocks        32-column blocks per row tile in memory (e.g. both directions' gate columns in the hand-off planes)
- *   x_col_block0        first block of this operand's m (n) columns;  x_row_tile0: first row tile (a shifted view: h_prev)
- *   rows                rows to reduce over (the last row tile may be partial: rows behind it must read as finite values)
- *   split_k > 1: that many row ranges, summed in order by a second kernel (ptmi_gemm_planes_tn_workspace_elems floats).
- * Measured in the training step: alone it replaces a 70 us pack pass per direction at 10-15 % more GEMM time,
- * next to the backward recurrence it loses that again (7.68 vs 7.57 ms per step for all layers, 7.54 vs 7.56 for the last layer
- * only), so ops.lstm keeps the packed route; the entry point stays for callers whose operands already lie in row-major planes. */
-int64_t ptmi_gemm_planes_tn_workspace_elems(int32_t m, int32_t n, int64_t rows, int32_t split_k);
-int ptmi_gemm_planes_tn_bf16(const uint16_t* a, int32_t a_col_blocks, int32_t a_col_block0, int64_t a_row_tile0, const uint16_t* b,
-                             int32_t b_col_blocks, int32_t b_col_block0, int64_t b_row_tile0, float* c, int64_t ldc, int32_t m, int32_t n,
-                             int64_t rows, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream);
 /* Calls without split K run on a persistent big-tile kernel (8 wavefronts, workgroup tile picked per problem by a cost model:
  * 0 = 256 x 320, 1 = 256 x 256, 2 = 256 x 192, 3 = 128 x 320, 4 = 128 x 256) or on the 128 x 128 kernel (5) that also carries
- * every split-K call.  ptmi_gemm_planes_select_tile pins that choice for the process (tests, A/B timing); -1 = the cost model. */
-int ptmi_gemm_planes_select_tile(int32_t tile);     /* DEBUG / TEST ONLY: process-wide, not thread-safe */
+ * every co-resident split-K call; ptmi_gemm_planes_plan reports the choice.  (Tests and sweeps pin a tile through the environment
+ * variable PTMI_GEMM_TILE, read at every call; there is no entry point for it.) */
 /* What a ptmi_gemm_planes[_bf16] call of this shape runs as: 100 * tile + k ranges (tile as above; measurement / labelling only). */
 int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k);
 

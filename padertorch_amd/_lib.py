@@ -112,11 +112,6 @@ SIGNATURES = {
     'ptmi_pack_planes_n_bf16': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_pack_planes_into': (c_int, [_P, c_int64, c_int64, c_int64, c_int32, c_int32, _P, _P, c_int64, c_int64, c_int64, _P]),
     'ptmi_gemm_planes_bf16': (c_int, [_P, _P, _P, _P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-    'ptmi_gemm_planes_tn_workspace_elems': (c_int64, [c_int32, c_int32, c_int64, c_int32]),
-    'ptmi_gemm_planes_tn_bf16': (c_int, [_P, c_int32, c_int32, c_int64, _P, c_int32, c_int32, c_int64, _P, c_int64, c_int32, c_int32,
-                                         c_int64, c_int32, c_int32, _P, _P]),
-    'ptmi_gemm_planes_select_tile': (c_int, [c_int32]),
-    'ptmi_debug_occupy': (c_int, [c_int32, c_int32, c_int32, c_int64, _P]),
     'ptmi_gemm_planes_bf16_two': (c_int, [_P, _P, _P, _P, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
     'ptmi_gemm_planes_plan': (c_int32, [c_int32, c_int32, c_int32, c_int32]),
     'ptmi_comm_rccl_version': (c_int32, []),
@@ -150,6 +145,35 @@ def load():
             fn.argtypes = args
         _lib = lib
     return _lib
+
+
+_hooks = None
+
+
+def test_hooks():
+    """``libptmi_testhooks.so`` (``csrc/testhooks``: ``ptmi_test_occupy``) - kernels only tests and measurement brackets launch; not part
+    of the hot path's library."""
+    global _hooks
+    if _hooks is None:
+        path = _PKG / 'libptmi_testhooks.so'
+        if not path.exists():
+            raise ImportError(f'{path} is missing: python -m padertorch_amd.build')
+        lib = ctypes.CDLL(str(path))
+        lib.ptmi_test_occupy.restype = c_int
+        lib.ptmi_test_occupy.argtypes = [c_int32, c_int32, c_int32, c_int64, _P]
+        _hooks = lib
+    return _hooks
+
+
+def select_gemm_tile(tile):
+    """Pin the planes GEMM's workgroup tile for the calls that follow (0..5; -1 / None: the cost model) - the ``PTMI_GEMM_TILE`` variable
+    ``csrc/gemm_planes.hip`` reads at every call: tests and sweeps only."""
+    if tile is None or tile < 0:
+        os.environ.pop('PTMI_GEMM_TILE', None)
+    else:
+        assert 0 <= tile <= 5, tile
+        os.environ['PTMI_GEMM_TILE'] = str(int(tile))
+    return 0
 
 
 def check(rc, what=''):

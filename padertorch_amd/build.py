@@ -15,6 +15,9 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / 'csrc'
 LIB = PKG / 'libptmi.so'
+#: test hooks (csrc/testhooks/*.hip: kernels only tests and bench.py's measurement brackets launch) - a library of their own, so that
+#: libptmi.so exports exactly the hot path's C ABI (include/ptmi.h)
+HOOKS = PKG / 'libptmi_testhooks.so'
 ARCH = 'gfx950'
 
 
@@ -36,6 +39,7 @@ def hipcc_path():
 
 def build(force=False, verbose=False):
     if not force and not _stale():
+        build_hooks()
         return LIB
     objdir = PKG / 'csrc' / '_obj'
     objdir.mkdir(exist_ok=True)
@@ -69,7 +73,21 @@ def build(force=False, verbose=False):
         print(' '.join(cmd))
     subprocess.run(cmd, check=True)
     os.replace(tmp, LIB)
+    build_hooks(force=True, verbose=verbose)
     return LIB
+
+
+def build_hooks(force=False, verbose=False):
+    srcs = sorted((CSRC / 'testhooks').glob('*.hip'))
+    if not force and HOOKS.exists() and all(p.stat().st_mtime <= HOOKS.stat().st_mtime for p in srcs):
+        return HOOKS
+    tmp = HOOKS.with_suffix('.so.tmp')
+    cmd = [hipcc_path(), '-O3', '-std=c++17', '-shared', '-fPIC', f'--offload-arch={ARCH}', *map(str, srcs), '-o', str(tmp)]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, check=True)
+    os.replace(tmp, HOOKS)
+    return HOOKS
 
 
 if __name__ == '__main__':

@@ -487,148 +487,6 @@ __global__ __launch_bounds__(512, 2) void gemm_planes_big_kernel(const BigArgs G
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------------------------- weight-gradient form
-// C[m, n] (+)= sum over rows r of A[r, m] B[r, n] for operands given as planes whose ROWS are the reduction index r and whose
-// 32-wide "k" blocks run along m resp. n - the layout the recurrences hand their rows on in (row tile, column block, plane) and
-// ptmi_pack_planes_n_bf16 writes: dW = dgates^T x with NO transposing pack pass.  The 1 KB plane tiles (16 rows x 32 columns,
-// chunk (column group g, row r) = 8 columns of one row) land in LDS by LDS-DMA as they lie - with one twist, chunk (g, r) at slot
-// 16 g + (r ^ 4 (g & 1)) - and the MFMA fragments (8 consecutive r per lane for one column) come out of ds_read_b64_tr_b16: a
-// 16-lane group reads a [4 rows][16 columns] block, lane i supplying the 8 bytes of row i / 4, columns 4 (i % 4) .., and
-// receives column i of the block (scripts/mb/tr_probe.hip prints the mapping); two reads make the 8 k values of a lane, and the
-// twist makes the 32 lanes of a read hit 16 different 16-byte bank slots.  Tile 128 x 128, 32 rows per k step, otherwise the
-// structure of gemm_planes_kernel (two 32 KB stages, one barrier per k step, slab split K).
-struct TnArgs {
-    const uint4* A;             // planes of the [rows, M] operand
-    const uint4* B;             // planes of the [rows, N] operand
-    float* C;
-    float* workspace;           // split K: [splits][M][N]
-    int M, N, RT;               // RT = 16-row tiles to reduce over
-    int a_cbt, a_cb0, a_rt0;    // A: column blocks per row tile in memory, first column block of the operand, first row tile
-    int b_cbt, b_cb0, b_rt0;
-    long long ldc;
-    int accumulate;
-    int ks_per_split;           // k steps (32 rows) per K range
-    int tiles_m, tiles_n;
-};
-
-typedef short s4 __attribute__((ext_vector_type(4)));
-
-template <bool BF16>
-__global__ __launch_bounds__(256, 2) void gemm_planes_tn_kernel(const TnArgs G) {
-#if __HIP_DEVICE_COMPILE__
-    constexpr int PIECES = 32;      // per stage: A [row tile 0 | 1][column block 0..3][plane], then B likewise
-    __shared__ uint4 lds[2 * PIECES * FR];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int T = G.tiles_m * G.tiles_n;
-    const int q8 = T / 8, r8 = T % 8, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    if (idx >= (xcd < r8 ? q8 + 1 : q8)) return;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
-    const int tm = tile / G.tiles_n, tn = tile - tm * G.tiles_n;
-    const int KS = (G.RT + 1) / 2;
-    const int ks0 = blockIdx.z * G.ks_per_split, ks1 = min(KS, ks0 + G.ks_per_split);
-    const int wm = wave >> 1, wn = wave & 1;
-    // LDS-DMA: lane l of a piece fetches the source chunk that belongs at slot l
-    const int sg = lane >> 4, perm = 16 * sg + ((lane & 15) ^ (4 * (sg & 1)));
-    const int cbn_a = (G.M + 31) / 32, cbn_b = (G.N + 31) / 32;
-    const uint4* gbase[8];
-    int rtl[8];
-    long long rstride[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = wave * 8 + i;
-        const bool isa = f < 16;
-        const int rt_local = (f >> 3) & 1, cb_local = (f >> 1) & 3, p = f & 1;
-        const int cb = isa ? G.a_cb0 + min(tm * 4 + cb_local, cbn_a - 1) : G.b_cb0 + min(tn * 4 + cb_local, cbn_b - 1);
-        const int cbt = isa ? G.a_cbt : G.b_cbt;
-        gbase[i] = (isa ? G.A : G.B) + ((long long)(isa ? G.a_rt0 : G.b_rt0) * cbt + cb) * 2 * FR + p * FR + perm;
-        rtl[i] = rt_local;
-        rstride[i] = (long long)cbt * 2 * FR;
-    }
-    auto stage_load = [&](int ks, int st) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int rt = min(2 * ks + rtl[i], G.RT - 1);          // (an odd last tile: fetched twice, its second use multiplied by zero)
-            __builtin_amdgcn_global_load_lds(gbase[i] + rt * rstride[i], &lds[(st * PIECES + wave * 8 + i) * FR], 16, 0, 0);
-        }
-    };
-    // fragment reads: lane (q = k group, i = column of the 16-column MFMA tile)
-    const int q = lane >> 4, il = lane & 15;
-    const int g0 = (il & 3) >> 1;                                   // column group of this lane's 4 columns inside a 16-column half block
-    const int off0 = (16 * g0 + 8 * (q & 1) + 4 * (0 ^ (g0 & 1)) + (il >> 2)) * 16 + 8 * (il & 1) + (q >> 1) * 8 * 1024;
-    const int off1 = (16 * g0 + 8 * (q & 1) + 4 * (1 ^ (g0 & 1)) + (il >> 2)) * 16 + 8 * (il & 1) + (q >> 1) * 8 * 1024;
-    const char* const lbase = reinterpret_cast<const char*>(lds);
-    const int baseA0 = off0 + wm * 4 * 1024, baseA1 = off1 + wm * 4 * 1024;                       // column blocks 2 wm, 2 wm + 1
-    const int baseB0 = off0 + 16 * 1024 + wn * 4 * 1024, baseB1 = off1 + 16 * 1024 + wn * 4 * 1024;
-    auto frag = [&](int base0, int base1, int st, int i, int p) -> h8 {
-        const int o = st * 32 * 1024 + ((i >> 1) * 2 + p) * 1024 + (i & 1) * 512;
-        const s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lbase + base0 + o));
-        const s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)(lbase + base1 + o));
-        typedef short s8 __attribute__((ext_vector_type(8)));
-        const s8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        return __builtin_bit_cast(h8, v);
-    };
-    f4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
-    if (ks0 < ks1) stage_load(ks0, 0);
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const int st = (ks - ks0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ks + 1 < ks1) stage_load(ks + 1, st ^ 1);
-        const bool dead = 2 * ks + (q >> 1) >= G.RT;               // this lane's rows lie behind the last row tile
-        h8 bh[4], bl[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bh[j] = frag(baseB0, baseB1, st, j, 0);
-            bl[j] = frag(baseB0, baseB1, st, j, 1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            h8 ah = frag(baseA0, baseA1, st, i, 0), al = frag(baseA0, baseA1, st, i, 1);
-            if (dead) {
-                ah = h8{0, 0, 0, 0, 0, 0, 0, 0};
-                al = ah;
-            }
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = BF16 ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b8, p == 0 ? bl[j] : bh[j]),
-                                                                               __builtin_bit_cast(b8, p == 1 ? al : ah), acc[i][j], 0, 0, 0)
-                                     : __builtin_amdgcn_mfma_f32_16x16x32_f16(p == 0 ? bl[j] : bh[j], p == 1 ? al : ah, acc[i][j], 0, 0, 0);
-        }
-    }
-    const bool slab = gridDim.z > 1;
-    float* const Cz = slab ? G.workspace + (long long)blockIdx.z * G.M * G.N : G.C;
-    const long long ldc = slab ? G.N : G.ldc;
-    const bool vec = (ldc & 3) == 0 && (reinterpret_cast<unsigned long long>(Cz) & 15) == 0;
-    const bool add = G.accumulate && !slab;
-    const int r = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = tm * PBM + wm * 64 + i * 16 + r;
-        if (m >= G.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = tn * PBN + wn * 64 + j * 16 + g * 4;
-            float* o = Cz + (long long)m * ldc + n;
-            const f4 v = acc[i][j];
-            if (vec && n + 3 < G.N) {
-                f4* o4 = reinterpret_cast<f4*>(o);
-                *o4 = add ? *o4 + v : v;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n + e < G.N) o[e] = add ? o[e] + v[e] : v[e];
-            }
-        }
-    }
-#endif
-}
-
 // max |x| as float bits (non-negative floats order like unsigned integers): one atomicMax per workgroup
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long rows, long long cols, long long ld,
                                                      unsigned* __restrict__ out) {
@@ -987,7 +845,14 @@ int64_t ptmi_gemm_planes_workspace_elems(int32_t m, int32_t n, int32_t k, int32_
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------------- big-tile dispatch
-static int g_tile_override = -1;        // ptmi_gemm_planes_select_tile
+// PTMI_GEMM_TILE=0..5 pins the workgroup tile of every call (5 = the 128 x 128 kernel) for the sweeps of scripts/ and the tile tests; read at
+// every call (the tests change it between calls), unset / -1: the cost model.  Not an entry point of the library.
+static int tile_override() {
+    const char* v = getenv("PTMI_GEMM_TILE");
+    if (!v || !*v) return -1;
+    const int t = atoi(v);
+    return (t >= 0 && t <= 5) ? t : -1;
+}
 
 static int cu_count() {
     static int cus = 0;
@@ -1028,6 +893,7 @@ static BigPick pick_big(int32_t m, int32_t n, int KB, int max_splits) {
     BigPick best{-1, 1};
     double best_cost = 1e300;
     const int smax = std::max(1, std::min(max_splits, KB / 4));
+    const int g_tile_override = tile_override();
     for (int i = -1; i < 5; ++i) {
         if (g_tile_override >= 0 && g_tile_override != (i < 0 ? 5 : i)) continue;
         const double area = i < 0 ? 128.0 * 128 : 32.0 * cands[i].mt * 64.0 * cands[i].nt;
@@ -1098,7 +964,7 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
     const int KB = (k + 31) / 32;
     // split_k = the most k ranges the caller's workspace holds; how many are used (and on which tile) is the cost model's choice - a
-    // function of the shape alone, so a call is reproducible bit for bit.  A pinned tile (ptmi_gemm_planes_select_tile: tests, sweeps)
+    // function of the shape alone, so a call is reproducible bit for bit.  A pinned tile (PTMI_GEMM_TILE: tests, sweeps)
     // takes split_k as it is.
     // split_k < 0: exactly -split_k ranges on the 128 x 128 kernel - its workgroups (4 wavefronts, 64 KB of LDS) fit on a CU NEXT TO a
     // persistent recurrence workgroup, a big tile needs a whole CU and only gets the ~100 the recurrence leaves free: what a caller
@@ -1111,6 +977,7 @@ static int gemm_planes_impl(bool bf16, bool one, const uint16_t* a, const uint32
     PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const bool big_split = !(getenv("PTMI_GEMM_BIG_SPLIT") && atoi(getenv("PTMI_GEMM_BIG_SPLIT")) == 0);
+    const int g_tile_override = tile_override();
     BigPick pk = pick_big(m, n, KB, ((big_split && !co_resident) || g_tile_override >= 0) ? splits : 1);
     if (g_tile_override >= 0) pk.splits = splits;
     else if (co_resident || (!big_split && splits > 1)) pk = BigPick{-1, splits};    // 128 x 128 (slabs) as asked for
@@ -1192,42 +1059,6 @@ int ptmi_gemm_planes(const uint16_t* a, const uint32_t* amax_a, const uint16_t* 
     return gemm_planes_impl(false, products == 1, a, amax_a, b, amax_b, bias, c, ldc, m, n, k, accumulate, split_k, workspace, stream);
 }
 
-int64_t ptmi_gemm_planes_tn_workspace_elems(int32_t m, int32_t n, int64_t rows, int32_t split_k) {
-    const int KS = (int)(((rows + 15) / 16 + 1) / 2);
-    const int splits = std::max(1, std::min<int>(split_k, KS));
-    return splits > 1 ? (int64_t)splits * m * n : 0;
-}
-
-int ptmi_gemm_planes_tn_bf16(const uint16_t* a, int32_t a_col_blocks, int32_t a_col_block0, int64_t a_row_tile0, const uint16_t* b,
-                             int32_t b_col_blocks, int32_t b_col_block0, int64_t b_row_tile0, float* c, int64_t ldc, int32_t m, int32_t n,
-                             int64_t rows, int32_t accumulate, int32_t split_k, float* workspace, ptmi_stream_t stream) {
-    PTMI_RETURN_IF(!a || !b || !c || m < 1 || n < 1 || rows < 1 || ldc < n, PTMI_E_INVALID);
-    PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) != 0, PTMI_E_INVALID);
-    PTMI_RETURN_IF(a_col_block0 < 0 || b_col_block0 < 0 || a_row_tile0 < 0 || b_row_tile0 < 0, PTMI_E_INVALID);
-    PTMI_RETURN_IF(a_col_blocks < a_col_block0 + (m + 31) / 32 || b_col_blocks < b_col_block0 + (n + 31) / 32, PTMI_E_INVALID);
-    const long long RT = (rows + 15) / 16;
-    PTMI_RETURN_IF(RT > 0x3fffffff || a_row_tile0 > 0x3fffffff || b_row_tile0 > 0x3fffffff, PTMI_E_UNSUPPORTED);
-    const int KS = (int)((RT + 1) / 2);
-    int splits = std::max(1, std::min<int>(split_k, KS));
-    const int per = (KS + splits - 1) / splits;
-    splits = (KS + per - 1) / per;
-    PTMI_RETURN_IF(splits > 1 && !workspace, PTMI_E_INVALID);
-    TnArgs G{reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), c, workspace, m, n, (int)RT,
-             a_col_blocks, a_col_block0, (int)a_row_tile0, b_col_blocks, b_col_block0, (int)b_row_tile0, (long long)ldc,
-             accumulate ? 1 : 0, per, (m + PBM - 1) / PBM, (n + PBN - 1) / PBN};
-    const int tiles = G.tiles_m * G.tiles_n;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((tiles + 7) / 8 * 8), 1u, (unsigned)splits);
-    hipLaunchKernelGGL(gemm_planes_tn_kernel<true>, grid, dim3(256), 0, st, G);
-    int rc = launch_status();
-    if (rc != PTMI_OK || splits == 1) return rc;
-    const long long total = (long long)m * n;
-    const unsigned rgrid = (unsigned)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(planes_reduce_kernel, dim3(rgrid), dim3(256), 0, st, workspace, splits, c, (long long)ldc, (const float*)nullptr, m, n,
-                       accumulate ? 1 : 0);
-    return launch_status();
-}
-
 int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k) {
     // the choice gemm_planes_impl makes for this call: 100 * tile + k ranges (tile 0..4: the big-tile instantiations, 5: 128 x 128)
     if (m < 1 || n < 1 || k < 1) return -1;
@@ -1238,18 +1069,13 @@ int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k) 
     const int per0 = (KB + splits - 1) / splits;
     splits = (KB + per0 - 1) / per0;
     static const bool big_split = !(getenv("PTMI_GEMM_BIG_SPLIT") && atoi(getenv("PTMI_GEMM_BIG_SPLIT")) == 0);
+    const int g_tile_override = tile_override();
     BigPick pk = pick_big(m, n, KB, ((big_split && !co_resident) || g_tile_override >= 0) ? splits : 1);
     if (g_tile_override >= 0) pk.splits = splits;
     else if (co_resident || (!big_split && splits > 1)) pk = BigPick{-1, splits};
     const long long a_bytes = (long long)((m + 15) / 16) * KB * 2048, b_bytes = (long long)((n + 15) / 16) * KB * 2048;
     if (a_bytes >= (1ll << 31) || b_bytes >= (1ll << 31)) pk.tile = -1;
     return (pk.tile < 0 ? 5 : pk.tile) * 100 + pk.splits;
-}
-
-int ptmi_gemm_planes_select_tile(int32_t tile) {
-    PTMI_RETURN_IF(tile < -1 || tile > 5, PTMI_E_INVALID);
-    g_tile_override = tile;
-    return PTMI_OK;
 }
 
 int ptmi_gemm_planes_bf16(const uint16_t* a, const uint16_t* b, const float* bias, float* c, int64_t ldc, int32_t m, int32_t n,

@@ -429,22 +429,6 @@ def gemm_planes_bf16_two_(out, out2, a, a_offset, b, M, N, K, accumulate, split_
                           _products(), _lib.ptr(ws), _lib.stream(out.device)), 'ptmi_gemm_planes_bf16_two')
 
 
-@_register('gemm_planes_tn_bf16_(Tensor(a!) out, Tensor a, int a_offset, int a_col_blocks, int a_col_block0, int a_row_tile0, '
-           'Tensor b, int b_offset, int b_col_blocks, int b_col_block0, int b_row_tile0, int M, int N, int rows, bool accumulate, '
-           'int split_k) -> ()')
-def gemm_planes_tn_bf16_(out, a, a_offset, a_col_blocks, a_col_block0, a_row_tile0, b, b_offset, b_col_blocks, b_col_block0,
-                         b_row_tile0, M, N, rows, accumulate, split_k):
-    """``out [M, N] (+)= A^T B`` over ``rows`` rows for bf16 planes of ``A [rows, ...]`` / ``B [rows, ...]`` (``ptmi_gemm_planes_tn_bf16``):
-    ``a`` / ``b`` any tensors whose storage holds the planes from byte ``x_offset`` on (e.g. the backward recurrence's scratch)."""
-    lib = _lib.load()
-    nws = int(lib.ptmi_gemm_planes_tn_workspace_elems(M, N, rows, split_k))
-    ws = torch.empty(nws, dtype=torch.float32, device=out.device) if nws else None
-    _lib.check(_lib.timed(f'gemm_planes_tn:{M}x{N}x{rows}', lib.ptmi_gemm_planes_tn_bf16, a.data_ptr() + a_offset, a_col_blocks,
-                          a_col_block0, a_row_tile0, b.data_ptr() + b_offset, b_col_blocks, b_col_block0, b_row_tile0, out.data_ptr(),
-                          max(out.stride(0), N), M, N, rows, int(accumulate), split_k, _lib.ptr(ws), _lib.stream(out.device)),
-               'ptmi_gemm_planes_tn_bf16')
-
-
 # ------------------------------------------------------------------------------------------------ unit norm
 @_register('unit_norm_forward(Tensor x, float eps) -> (Tensor, Tensor)')
 def unit_norm_forward(x, eps):

@@ -690,7 +690,7 @@ class _LstmLayerFn(torch.autograd.Function):
         state_grad = False
         carry = None
         gm, params = ctx.gemm, ctx.params
-        has_grads = params is not None and all(p.grad is not None for ps in params for p in ps)
+        has_grads = params is not None and all(p.is_leaf and p.grad is not None for ps in params for p in ps)
         if ctx.forms is not None and not has_grads:
             raise RuntimeError('packed_lstm: the forward pass ran on the cached stacked weights (in-place weight gradients), '
                                'but a parameter of the layer has no .grad buffer any more')
@@ -1037,15 +1037,12 @@ def _recurrent_operands(meta, dg, hy, ext, h0, ndir, H):
 
 
 def unsupported_reason(lstm, data):
-    """Why :func:`packed_lstm` cannot evaluate ``lstm`` on ``data`` (``None``: it can)."""
-    if not isinstance(lstm, torch.nn.LSTM):
+    """Why :func:`packed_lstm` cannot evaluate ``lstm`` on ``data`` (``None``: it can).  Any ``hidden_size`` and ``bias=False`` are
+    covered (round 5: :class:`_PaddedLstm`); ``proj_size`` and non-fp32 modules are not."""
+    if not isinstance(lstm, (torch.nn.LSTM, _PaddedLstm)):
         return f'{type(lstm).__name__} is not a torch.nn.LSTM'
-    if lstm.hidden_size % 4 != 0:
-        return f'hidden_size {lstm.hidden_size} is not a multiple of 4'
     if lstm.proj_size != 0:
         return 'proj_size != 0'
-    if not lstm.bias:
-        return 'bias=False'
     if not data.is_cuda:
         return 'the input is not on the GPU'
     if data.dtype != torch.float32:
@@ -1055,6 +1052,60 @@ def unsupported_reason(lstm, data):
 
 def supported(lstm, data):
     return unsupported_reason(lstm, data) is None
+
+
+class _PaddedLstm:
+    """A ``torch.nn.LSTM`` whose ``hidden_size`` is not a multiple of 4 (the kernels' unit granularity: 16-byte weight rows), or that has
+    no biases, as the LSTM the kernels DO run: every gate block of every parameter zero-padded from H to H4 = 4 ceil(H / 4) units (the
+    reference constructs ``torch.nn.LSTM(F, units)`` for any ``units``, ``pit/model.py:60-66``).  A padded unit's pre-activations are 0 at
+    every step - i = f = o = 1/2, g = 0, so c = h = 0 for ever - and its columns of ``W_hh`` / of the next layer's ``W_ih`` are zero:
+    the real units compute what they compute in the unpadded LSTM, bit for bit in exact arithmetic.  The padded tensors are functions of
+    the module's parameters (``F.pad``): gradients reach the parameters through autograd, the padding's gradients are dropped there."""
+    proj_size = 0
+    bias = True
+
+    def __init__(self, lstm):
+        H, ndir = lstm.hidden_size, 2 if lstm.bidirectional else 1
+        H4 = (H + 3) // 4 * 4
+        self.real_hidden, self.hidden_size = H, H4
+        self.num_layers, self.bidirectional, self.dropout, self.training = lstm.num_layers, lstm.bidirectional, lstm.dropout, lstm.training
+        ctx = lstm.__dict__.get(_context._ATTR)
+        if ctx is not None:
+            self.__dict__[_context._ATTR] = ctx
+        pad = torch.nn.functional.pad
+
+        def gate_rows(w):                     # [4 H, ...] -> [4 H4, ...]: every gate block padded
+            w4 = w.reshape(4, H, *w.shape[1:])
+            return pad(w4, (0, 0) * (w4.dim() - 2) + (0, H4 - H)).reshape(4 * H4, *w.shape[1:])
+        for layer in range(lstm.num_layers):
+            for sfx in (['', '_reverse'] if lstm.bidirectional else ['']):
+                w_ih = getattr(lstm, f'weight_ih_l{layer}{sfx}')
+                w_hh = getattr(lstm, f'weight_hh_l{layer}{sfx}')
+                if layer > 0:                 # the input is the padded output of the layer below: [.., ndir, H4]
+                    w_ih = pad(w_ih.reshape(4 * H, ndir, H), (0, H4 - H)).reshape(4 * H, ndir * H4)
+                setattr(self, f'weight_ih_l{layer}{sfx}', gate_rows(w_ih))
+                setattr(self, f'weight_hh_l{layer}{sfx}', gate_rows(pad(w_hh, (0, H4 - H))))
+                for name in ('bias_ih', 'bias_hh'):
+                    b = getattr(lstm, f'{name}_l{layer}{sfx}') if lstm.bias else w_hh.new_zeros(4 * H)
+                    setattr(self, f'{name}_l{layer}{sfx}', gate_rows(b))
+
+
+def _packed_lstm_padded(lstm, packed, training, hx, return_state, meta):
+    """:func:`packed_lstm` for a module :class:`_PaddedLstm` covers: run the padded LSTM, slice the real units out."""
+    shadow = _PaddedLstm(lstm)
+    H, H4 = shadow.real_hidden, shadow.hidden_size
+    ndir = 2 if lstm.bidirectional else 1
+    if hx is not None:
+        hx = tuple(torch.nn.functional.pad(t, (0, H4 - H)) for t in hx)
+    out = packed_lstm(shadow, packed, training=lstm.training if training is None else training, hx=hx, return_state=return_state, meta=meta)
+    states = None
+    if isinstance(out, tuple):
+        out, states = out
+        states = tuple(t[..., :H] for t in states)
+    rows = out.data.shape[0]
+    data = out.data.view(rows, ndir, H4)[:, :, :H].reshape(rows, ndir * H)
+    out = PackedSequence(data, out.batch_sizes)
+    return out if states is None else (out, states)
 
 
 def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=None, return_state=False, input_planes=None, meta=None):
@@ -1071,8 +1122,10 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     data = packed.data
     _lib.require_gpu(data)
     if not supported(lstm, data):
-        raise NotImplementedError(
-            'packed_lstm needs an fp32 torch.nn.LSTM with bias, proj_size=0 and hidden_size % 4 == 0')
+        raise NotImplementedError('packed_lstm needs an fp32 torch.nn.LSTM with proj_size=0: ' + str(unsupported_reason(lstm, data)))
+    if isinstance(lstm, torch.nn.LSTM) and (lstm.hidden_size % 4 != 0 or not lstm.bias):
+        # (a producer's fp16 planes of the input - ops.pit_features - are not used on this path: the padded first layer packs its input)
+        return _packed_lstm_padded(lstm, packed, training, hx, return_state, meta)
     assert packed.sorted_indices is None, 'sequences must be sorted by length (enforce_sorted=True)'
     training = lstm.training if training is None else training
     oc = _context.effective(lstm)
@@ -1097,7 +1150,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
     if (CACHE_STACKED_WEIGHTS and data.is_cuda and any(_stacked_stale(ps_) for ps_ in all_params)
             and all(p.is_cuda and p.dtype == torch.float32 for p in flat_params)
             and (not (torch.is_grad_enabled() and any(p.requires_grad for p in flat_params))
-                 or (oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for p in flat_params)))):
+                 or (oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.is_leaf and p.grad is not None for p in flat_params)))):
         # after an optimizer step: the operand forms of ALL layers on a side stream, next to whatever the main stream is
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
         pre = forked = _prep_stream(data.device)
@@ -1123,7 +1176,7 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
         # runs on the cached stacked / padded / transposed forms of its parameters
         graph = torch.is_grad_enabled() and any(p.requires_grad for ps in params for p in ps)
-        in_place = oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.grad is not None for ps in params for p in ps)
+        in_place = oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.is_leaf and p.grad is not None for ps in params for p in ps)
         forms = anchor = None
         if CACHE_STACKED_WEIGHTS and data.is_cuda and (not graph or in_place):
             forms = _stacked_weights(params, (H + 15) // 16 * 16)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The planes GEMM (csrc/gemm_planes.hip) vs the library fp32 GEMM at the shapes of the PIT step (B = 32, T = 253: 8096 rows;
 `python scripts/bench_gemm.py 32192` for the 16 kHz batch of 64): the persistent big-tile kernel with the tile the cost model
-picks, every tile pinned (ptmi_gemm_planes_select_tile), the 128 x 128 kernel (with split K for the weight-gradient shapes), the
+picks, every tile pinned (PTMI_GEMM_TILE / _lib.select_gemm_tile), the 128 x 128 kernel (with split K for the weight-gradient shapes), the
 one-product (reduced precision) mode, the pack passes.  One JSON line per shape -> profiles/r3_gemm_microbench.jsonl."""
 import json
 import sys
@@ -67,23 +67,15 @@ for name, M, N, K, form in [
     rec['planes_max_err_over_mag'] = float(((out.double() - ref).abs() / (a.double().abs() @ b.double().abs())).max())
     if sk == 1:
         for tile, label in TILES.items():
-            _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+            _lib.select_gemm_tile(tile)
             try:
                 t = timeit(lambda: gemm.mm_planes_(out, A, Bp, M, N, K, split_k=1))
             finally:
-                _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+                _lib.select_gemm_tile(-1)
             rec[f'tile_{label}_us'] = t
     else:
         for s in (1, 2, 4, 8):
             rec[f'k128_split{s}_us'] = timeit(lambda: gemm.mm_planes_(out, A, Bp, M, N, K, split_k=s))
-        # the weight-gradient form on row-major bf16 planes (LDS transpose reads, no transposing pack)
-        ta = torch.ops.ptmi.pack_planes_bf16(dg.contiguous(), False)
-        tb = torch.ops.ptmi.pack_planes_bf16(xx, False)
-        for s in (1, 2, 4, 8):
-            rec[f'tn_split{s}_us'] = timeit(lambda: torch.ops.ptmi.gemm_planes_tn_bf16_(out, ta, 0, (M + 31) // 32, 0, 0, tb, 0, (N + 31) // 32, 0, 0,
-                                                                                     M, N, K, False, s))
-        rec['tn_max_err_over_mag'] = float(((out.double() - ref).abs() / (a.double().abs() @ b.double().abs())).max())
-        rec['pack_n_bf16_a_us'] = timeit(lambda: torch.ops.ptmi.pack_planes_bf16(dg.contiguous(), False))
     gemm.PRODUCTS = 1
     try:
         t = timeit(lambda: gemm.mm_planes_(out, A, Bp, M, N, K))

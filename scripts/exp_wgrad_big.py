@@ -48,12 +48,12 @@ for name, M, N in [('dW_ih', 2400, 1200), ('dW_hh', 2400, 600), ('dW_ih l0', 240
         for S in (1, 2, 3, 4, 6, 8, 12):
             if tile == 5 and S > 8:
                 continue
-            _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+            _lib.select_gemm_tile(tile)
             try:
                 t = timeit(lambda: torch.ops.ptmi.gemm_planes_bf16_(out, A, 0, B, None, M, N, R, False, S))
                 err = float(((out.double() - ref).abs() / mag).max())
             finally:
-                _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+                _lib.select_gemm_tile(-1)
             row.append(f'S{S}: {t:6.1f} us {flop / t / 1e6 / PEAK:.2f}' + ('' if err < 4e-6 else f' ERR {err:.1e}'))
         print(f'{label:8s} ' + ' | '.join(row))
     t = timeit(lambda: torch.ops.ptmi.pack_planes_bf16(dg, True))

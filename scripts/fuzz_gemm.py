@@ -48,11 +48,11 @@ for it in range(n):
     out = base.clone()[:, :N]
     want = x.double() @ y.double() + (bias.double() if bias is not None else 0) + (out.double() if acc else 0)
     mag = x.double().abs() @ y.double().abs() + (bias.double().abs() if bias is not None else 0) + (out.double().abs() if acc else 0)
-    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    _lib.select_gemm_tile(tile)
     try:
         got = G.mm(x, y, bias=bias, out=out, accumulate=acc, split_k=split)
     finally:
-        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+        _lib.select_gemm_tile(-1)
     err = float(((got.double() - want).abs() / mag.clamp_min(1e-30)).max())
     tol = 6e-7 if G.PRODUCTS == 3 else 3e-3      # (hi + lo halves carry 22 bits of each operand: up to ~2 x 2^-22 per product)
     worst = max(worst, err / tol)

@@ -289,7 +289,7 @@ def test_bf16_planes_gemm_vs_fp64(M, N, K, split):
 @pytest.mark.parametrize('M,N,K,acc,bias', [(1000, 700, 257, False, True), (530, 1282, 96, True, False), (257, 321, 1200, True, True),
                                             (16, 4, 64, False, False)])
 def test_planes_big_tiles_vs_fp64(tile, M, N, K, acc, bias):
-    """Every workgroup tile of the persistent big-tile kernel (ptmi_gemm_planes_select_tile; 5 = the 128 x 128 kernel): rows /
+    """Every workgroup tile of the persistent big-tile kernel (PTMI_GEMM_TILE through _lib.select_gemm_tile; 5 = the 128 x 128 kernel): rows /
     columns that end inside a tile, inside an MFMA tile and inside a 4-column store group, several tiles per workgroup
     (more tiles than CUs at 128-wide tiles is not reachable at test sizes - the flat tile loop is exercised through tiles > grid / 8
     per XCD range), bias, accumulation into a strided C; bit-identical between two calls."""
@@ -306,7 +306,7 @@ def test_planes_big_tiles_vs_fp64(tile, M, N, K, acc, bias):
     want = x.double() @ w.double().t() + (b.double() if bias else 0) + (c.double() if acc else 0)
     mag = x.double().abs() @ w.double().abs().t() + (b.double().abs() if bias else 0) + (c.double().abs() if acc else 0)
     pa, pb = G.pack_n(x), G.pack_n(w)
-    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    _lib.select_gemm_tile(tile)
     try:
         G.mm_planes_(c, pa, pb, M, N, K, accumulate=acc, split_k=1, bias=b)
         torch.cuda.synchronize()
@@ -316,7 +316,7 @@ def test_planes_big_tiles_vs_fp64(tile, M, N, K, acc, bias):
         G.mm_planes_(again[:, :N], pa, pb, M, N, K, accumulate=acc, split_k=1, bias=b)
         assert torch.equal(again, cbuf)
     finally:
-        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+        _lib.select_gemm_tile(-1)
 
 
 @pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, -1])
@@ -347,7 +347,7 @@ def test_planes_big_tiles_with_split_k_vs_fp64(tile, M, N, K, split, acc, bias, 
                                              M, N, K, acc, split)
         else:
             G.mm_planes_(out, G.pack_t(a), G.pack_t(x), M, N, K, accumulate=acc, split_k=split, bias=b)
-    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    _lib.select_gemm_tile(tile)
     try:
         run(c)
         torch.cuda.synchronize()
@@ -357,7 +357,7 @@ def test_planes_big_tiles_with_split_k_vs_fp64(tile, M, N, K, split, acc, bias, 
         run(again[:, :N])
         assert torch.equal(again, cbuf)
     finally:
-        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+        _lib.select_gemm_tile(-1)
 
 
 @pytest.mark.parametrize('tile', [-1, 0, 3, 5])
@@ -379,7 +379,7 @@ def test_planes_gemm_with_a_two_part_output_vs_fp64(tile, M, split_at, N, K, spl
     want = a.double().t() @ x.double()
     mag = a.double().abs().t() @ x.double().abs()
     before = torch.cat([c1, c2]).double() if acc else 0
-    _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+    _lib.select_gemm_tile(tile)
     try:
         torch.ops.ptmi.gemm_planes_bf16_two_(c1, c2, pa, 0, px, M, N, K, acc, split)
         torch.cuda.synchronize()
@@ -394,7 +394,7 @@ def test_planes_gemm_with_a_two_part_output_vs_fp64(tile, M, split_at, N, K, spl
             torch.ops.ptmi.gemm_planes_bf16_(r2, pa, half, px, None, M - split_at, N, K, acc, split)
             assert float((torch.cat([r1, r2]) - torch.cat([c1, c2])).abs().max()) <= 1e-6 * float(torch.cat([c1, c2]).abs().max())
     finally:
-        _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+        _lib.select_gemm_tile(-1)
 
 
 def test_planes_big_tile_many_tiles_per_workgroup():
@@ -412,59 +412,17 @@ def test_planes_big_tile_many_tiles_per_workgroup():
     mag = x.double().abs() @ w.double().abs().t()
     pa, pb = G.pack_n(x), G.pack_n(w)
     for tile in (4, 0):
-        _lib.check(lib.ptmi_gemm_planes_select_tile(tile), 'select_tile')
+        _lib.select_gemm_tile(tile)
         try:
             y = torch.full((M, N), float('nan'), device='cuda')
             G.mm_planes_(y, pa, pb, M, N, K, split_k=1)
             assert float(((y.double() - want).abs() / mag).max()) < 4e-7
         finally:
-            _lib.check(lib.ptmi_gemm_planes_select_tile(-1), 'select_tile')
+            _lib.select_gemm_tile(-1)
 
 
 @pytest.mark.parametrize('M,N,R,split,acc', [(2400, 1200, 8096, 2, True), (2400, 600, 8096, 4, False), (2400, 257, 8096, 8, True),
                                              (100, 70, 50, 1, False), (129, 130, 16 * 7, 2, True), (33, 4, 3000, 3, False)])
-def test_planes_tn_weight_gradient_form_vs_fp64(M, N, R, split, acc):
-    """ptmi_gemm_planes_tn_bf16: C = A^T B over the rows of two row-major operands packed by pack_planes_n (bf16) - the MFMA
-    fragments come out of the LDS transpose read, no transposing pack pass: against fp64 (bf16 halves: 16 mantissa bits per
-    operand), odd row-tile counts, partial last tiles, split K, accumulation into a strided C, and the addressing of operands
-    that are parts of wider planes (a column-block offset = one direction of the hand-off planes; a row-tile offset = h_prev)."""
-    import padertorch_amd.ops  # noqa: F401  (registers torch.ops.ptmi.*)
-    torch.manual_seed(M + N + R)
-    wide_a = torch.randn(R + 64, M + 96, device='cuda') * torch.logspace(-3, 1, M + 96, device='cuda')
-    wide_b = torch.randn(R + 64, N + 64, device='cuda') * 0.1
-    if R % 16:                                     # rows behind a partial last tile must read as finite values: they do (packed zeros)
-        pass
-    a, b = wide_a[32:32 + R, 64:64 + M], wide_b[16:16 + R, 32:32 + N]
-    # planes of the WIDE matrices; the operands are addressed inside them by (column block, row tile) offsets
-    pa = torch.ops.ptmi.pack_planes_bf16(wide_a.contiguous(), False)
-    pb = torch.ops.ptmi.pack_planes_bf16(wide_b.contiguous(), False)
-    cbt_a, cbt_b = (M + 96 + 31) // 32, (N + 64 + 31) // 32
-    cbuf = torch.randn(M, N + 3, device='cuda')
-    c0 = cbuf.clone()
-    c = cbuf[:, :N]
-    # operand = rows 32.. / 16.. of the wide matrix (row tiles 2 / 1), columns from block 2 / 1 on; columns past M (N) inside the
-    # planes belong to the wide matrix (not zero): they only reach output columns that are not stored
-    want = a.double().t() @ b.double() + (c.double() if acc else 0)
-    mag = a.double().abs().t() @ b.double().abs() + (c.double().abs() if acc else 0)
-    rows_eff = R
-    torch.ops.ptmi.gemm_planes_tn_bf16_(c, pa, 0, cbt_a, 2, 2, pb, 0, cbt_b, 1, 1, M, N, rows_eff, acc, split)
-    torch.cuda.synchronize()
-    if R % 16 == 0:
-        err = float(((c.double() - want).abs() / mag).max())
-        assert err < 1.2e-5, err
-    else:
-        # a partial last row tile multiplies the wide matrices' next rows too: compare with that sum
-        Rp = (R + 15) // 16 * 16
-        a2, b2 = wide_a[32:32 + Rp, 64:64 + M], wide_b[16:16 + Rp, 32:32 + N]
-        want2 = a2.double().t() @ b2.double() + (c0[:, :N].double() if acc else 0)
-        mag2 = a2.double().abs().t() @ b2.double().abs() + (c0[:, :N].double().abs() if acc else 0)
-        assert float(((c.double() - want2).abs() / mag2).max()) < 1.2e-5
-    assert torch.equal(cbuf[:, N:], c0[:, N:])
-    again = c0.clone()
-    torch.ops.ptmi.gemm_planes_tn_bf16_(again[:, :N], pa, 0, cbt_a, 2, 2, pb, 0, cbt_b, 1, 1, M, N, rows_eff, acc, split)
-    assert torch.equal(again, cbuf)
-
-
 @pytest.mark.parametrize('tile', [-1, 0, 3, 5])
 @pytest.mark.parametrize('M,I,O', [(8096, 1200, 1200), (8096, 1200, 514), (300, 70, 257), (17, 33, 5), (1000, 64, 1282)])
 def test_linear_with_the_relu_in_the_epilogue(tile, M, I, O):
@@ -480,7 +438,7 @@ def test_linear_with_the_relu_in_the_epilogue(tile, M, I, O):
     x = (torch.randn(M, I, device=dev) * 3).requires_grad_(True)
     x2 = x.detach().clone().requires_grad_(True)
     gy = torch.randn(M, O, device=dev)
-    assert lib.ptmi_gemm_planes_select_tile(tile) == 0
+    assert _lib.select_gemm_tile(tile) == 0
     try:
         y = L.linear(lin, x, activation='relu')
         rec = getattr(y, L.AMAX_ATTR)
@@ -493,7 +451,7 @@ def test_linear_with_the_relu_in_the_epilogue(tile, M, I, O):
         y2 = torch.relu(L.linear(lin, x2))
         (y2 * gy).sum().backward()
     finally:
-        lib.ptmi_gemm_planes_select_tile(-1)
+        _lib.select_gemm_tile(-1)
     assert torch.equal(y, y2)
     assert torch.equal(x.grad, x2.grad)
     assert torch.equal(gw, lin.weight.grad) and torch.equal(gb, lin.bias.grad)
@@ -526,7 +484,7 @@ def test_fused_relu_propagates_nan_like_torch_relu(tile, M, I, O):
     x = x.requires_grad_(True)
     x2 = x.detach().clone().requires_grad_(True)
     gy = torch.randn(M, O, device=dev)
-    assert lib.ptmi_gemm_planes_select_tile(tile) == 0
+    assert _lib.select_gemm_tile(tile) == 0
     try:
         y = L.linear(lin, x, activation='relu')
         (y * gy).sum().backward()
@@ -535,7 +493,7 @@ def test_fused_relu_propagates_nan_like_torch_relu(tile, M, I, O):
         y2 = torch.relu(L.linear(lin, x2))
         (y2 * gy).sum().backward()
     finally:
-        lib.ptmi_gemm_planes_select_tile(-1)
+        _lib.select_gemm_tile(-1)
     nan = torch.isnan(y2)
     assert bool(nan[3].all()) and bool(nan[M - 1].all()) and int(nan.sum()) == 2 * O      # the NaN rows, nothing else
     assert torch.equal(torch.isnan(y), nan)

@@ -472,7 +472,7 @@ def test_gradients_wrt_the_initial_state(lens):
 def test_recurrences_next_to_a_cu_occupying_kernel(wgs, threads, lds, monkeypatch):
     """the persistent recurrence kernels need all their workgroups co-resident; a communication kernel on
     another queue (RCCL's channels during the bucketed all-reduce of the data-parallel Trainer, trainer.py:396-442) holds CUs
-    meanwhile.  Stand-in: ptmi_debug_occupy keeps `wgs` workgroups resident for ~1.5 ms, launched back to back on a third
+    meanwhile.  Stand-in: ptmi_test_occupy (libptmi_testhooks.so) keeps `wgs` workgroups resident for ~1.5 ms, launched back to back on a third
     stream while a BLSTM layer of the BASELINE size runs forward and backward on the main stream: no timed-out wait, and
     bit-identical results to the undisturbed run (the hand-off protocol does not depend on timing)."""
     from padertorch_amd import _lib
@@ -492,7 +492,7 @@ def test_recurrences_next_to_a_cu_occupying_kernel(wgs, threads, lds, monkeypatc
         if disturb:
             with torch.cuda.stream(side):
                 for _ in range(12):          # ~18 ms of occupancy: covers the forward and the backward recurrence
-                    _lib.check(lib.ptmi_debug_occupy(wgs, threads, lds, 150000, _lib.stream(torch.device(DEV))), 'occupy')
+                    _lib.check(_lib.test_hooks().ptmi_test_occupy(wgs, threads, lds, 150000, _lib.stream(torch.device(DEV))), 'occupy')
         y = packed_lstm(lstm, pack_sequence(xd))
         (y.data * g).sum().backward()
         torch.cuda.synchronize()
@@ -559,3 +559,78 @@ def test_backward_recurrence_hands_the_weight_gradient_operand_on(B, T, H, ndir)
     nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, B)) + 8
     db = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
     torch.testing.assert_close(db, dg_ref.sum(0), rtol=2e-5, atol=2e-5 * float(dg_ref.abs().sum(0).max()))
+
+
+@pytest.mark.parametrize('I,H,layers,bidir,bias,lens', [
+    (9, 6, 2, True, True, [6, 5, 3]),
+    (33, 10, 3, True, True, [17] * 5),
+    (20, 601, 1, True, True, [12, 12, 7]),
+    (7, 5, 2, False, True, [11, 11, 4, 1]),
+    (12, 24, 2, True, False, [9, 8, 8, 2]),                # bias=False
+    (12, 7, 1, True, False, [9, 8]),
+])
+def test_any_hidden_size_and_no_bias_vs_torch_cpu(I, H, layers, bidir, bias, lens, monkeypatch):
+    """``hidden_size % 4 != 0`` and ``bias=False`` (the reference builds ``torch.nn.LSTM(F, units)`` for any ``units``,
+    ``pit/model.py:60-66``): the kernels run the zero-padded LSTM (``ops.lstm._PaddedLstm``), outputs, states and every gradient equal
+    torch's LSTM on the CPU - strict mode: nothing goes to MIOpen."""
+    from padertorch_amd.ops import packed_lstm, lstm as L
+    monkeypatch.setattr(L, 'CHECK_PERSISTENT_ERRORS', True)
+    torch.manual_seed(I + H)
+    ref = torch.nn.LSTM(I, H, layers, bidirectional=bidir, bias=bias)
+    dut = torch.nn.LSTM(I, H, layers, bidirectional=bidir, bias=bias)
+    dut.load_state_dict(ref.state_dict())
+    dut = dut.to(DEV)
+    assert L.unsupported_reason(dut, torch.zeros(1, I, device=DEV)) is None
+    xs = [torch.randn(l, I) for l in lens]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    xd = [x.clone().to(DEV).requires_grad_(True) for x in xs]
+    yr, (hr, cr) = ref(pack_sequence(xr))
+    yd, (hd, cd) = packed_lstm(dut, pack_sequence(xd), return_state=True)
+    np.testing.assert_allclose(yd.data.detach().cpu().numpy(), yr.data.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(hd.detach().cpu().numpy(), hr.detach().numpy(), atol=2e-6)
+    np.testing.assert_allclose(cd.detach().cpu().numpy(), cr.detach().numpy(), atol=4e-6)
+    g = torch.randn(yr.data.shape)
+    (yr.data * g).sum().backward()
+    (yd.data * g.to(DEV)).sum().backward()
+    for a, b in zip(xd, xr):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), atol=2e-5, rtol=1e-4)
+    for (n, pd), pr in zip(dut.named_parameters(), ref.parameters()):
+        scale = max(1., pr.grad.abs().max().item())
+        np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.numpy(), atol=3e-5 * scale, err_msg=n)
+    # the plain call (no states), without a graph
+    with torch.no_grad():
+        y2 = packed_lstm(dut, pack_sequence([x.to(DEV) for x in xs]))
+    np.testing.assert_allclose(y2.data.cpu().numpy(), yr.data.detach().numpy(), atol=2e-6)
+
+
+def test_pit_model_with_an_odd_number_of_units_trains_on_the_hip_path(tmp_path):
+    """``PermutationInvariantTrainingModel(units=50)``: three Trainer steps (in-place side-stream machinery around a padded BLSTM)
+    against the oracle's."""
+    import padertorch_amd as pt
+    from oracle import features_np, torch_ref
+    from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
+    rng = np.random.RandomState(0)
+    exs = [features_np.synthetic_mixture(rng, n) for n in (4000, 3300, 2100)]
+    torch.manual_seed(0)
+    kw = dict(F=257, recurrent_layers=2, units=50, K=2)
+    model = PermutationInvariantTrainingModel(**kw)
+    ref = torch_ref.PITModelRef(**kw)
+    ref.load_state_dict(model.state_dict())
+    lw = dict(pit_ips_loss=1., pit_mse_loss=0.)
+    t = pt.Trainer(model, tmp_path, pt.optimizer.Adam(gradient_clipping=1.), loss_weights=lw)
+    t.to(torch.device(DEV))
+    t._flat = t.optimizer.use_flat_grads()
+    t.op_context.defer_wgrad = True
+    model.train()
+    f = [features_np.pre_batch_transform(s, y) for s, y in exs]
+    batch = {k: [torch.from_numpy(e[k]) for e in f] for k in ['Y_abs', 'X_abs', 'cos_phase_difference']}
+    opt = torch.optim.Adam(ref.parameters())
+    for _ in range(3):
+        loss, _, _, _ = t.train_step(model, {k: [v.to(DEV) for v in vs] for k, vs in batch.items()}, DEV)
+        loss.backward()
+        t.optimizer_step()
+        ref_losses, _ = torch_ref.train_step(ref, opt, [batch], lw, 1.)
+        assert abs(float(loss) - ref_losses[0]) < 1e-4, (float(loss), ref_losses[0])
+    torch.cuda.synchronize()
+    for (k, v), vr in zip(model.state_dict().items(), ref.state_dict().values()):
+        np.testing.assert_allclose(v.cpu().numpy(), vr.numpy(), atol=3e-4, err_msg=k)

@@ -501,7 +501,7 @@ def test_config4_size_step_on_the_rccl_path_next_to_a_cu_occupying_kernel(tmp_pa
             for step in range(2):
                 with torch.cuda.stream(occupy):
                     for _ in range(80):          # ~120 ms of occupancy: covers the optimizer step's four micro-steps
-                        _lib.check(lib.ptmi_debug_occupy(256, 256, 0, 150000, _lib.stream(torch.device(DEV))), 'occupy')
+                        _lib.check(_lib.test_hooks().ptmi_test_occupy(256, 256, 0, 150000, _lib.stream(torch.device(DEV))), 'occupy')
                 for m in range(4):
                     buckets.active = m == 3
                     feats = pt.ops.pit_features(y, s_)
