@@ -421,8 +421,6 @@ def test_planes_big_tile_many_tiles_per_workgroup():
             _lib.select_gemm_tile(-1)
 
 
-@pytest.mark.parametrize('M,N,R,split,acc', [(2400, 1200, 8096, 2, True), (2400, 600, 8096, 4, False), (2400, 257, 8096, 8, True),
-                                             (100, 70, 50, 1, False), (129, 130, 16 * 7, 2, True), (33, 4, 3000, 3, False)])
 @pytest.mark.parametrize('tile', [-1, 0, 3, 5])
 @pytest.mark.parametrize('M,I,O', [(8096, 1200, 1200), (8096, 1200, 514), (300, 70, 257), (17, 33, 5), (1000, 64, 1282)])
 def test_linear_with_the_relu_in_the_epilogue(tile, M, I, O):
