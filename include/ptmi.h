@@ -331,19 +331,6 @@ int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_
  * and the caller passes prefilled = 1 to the backward launch.  Otherwise the pointer is ignored. */
 int ptmi_lstm_forward_fills(int32_t T, int32_t ndir, int32_t max_batch, int32_t H);
 
-/* Plans: the two time loops over FIXED buffers captured once as hipGraphs and replayed with one
- * host call each (same buffers / bookkeeping arguments as ptmi_lstm_forward / ptmi_lstm_backward;
- * dhy, w_hh_t, dgates, dc_state may be NULL for an inference-only plan).  The caller owns the
- * buffers and must keep them alive and at the same addresses for the lifetime of the plan. */
-typedef struct ptmi_lstm_plan ptmi_lstm_plan;
-int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float* c, const float* w_hh_pad,
-                          const float* dhy, const float* w_hh_t, float* dgates, float* dc_state,
-                          const int32_t* batch_sizes, const int64_t* offsets, int32_t T, int32_t max_batch,
-                          int32_t H, int32_t KP, int32_t ndir);
-int ptmi_lstm_plan_forward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
-int ptmi_lstm_plan_backward(ptmi_lstm_plan* plan, ptmi_stream_t stream);
-void ptmi_lstm_plan_destroy(ptmi_lstm_plan* plan);
-
 /* ---- (log-)mel features ----------------------------------------------------------------------------
  * Replaces MelTransform.forward (padertorch/contrib/je/modules/features.py:297-330: spectrogram @
  * fbanks, log(x + eps)) and, fused with the STFT, the extractor front-end features.py:171-176

@@ -94,11 +94,6 @@ SIGNATURES = {
     'ptmi_lstm_backward_persistent_planes': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int64, c_int32,
                                                      c_int32, c_int32, c_int32, c_int32, _P]),
     'ptmi_lstm_scratch_prefill': (c_int, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
-    'ptmi_lstm_plan_create': (c_int, [POINTER(c_void_p), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32,
-                                      c_int32, c_int32, c_int32]),
-    'ptmi_lstm_plan_forward': (c_int, [c_void_p, _P]),
-    'ptmi_lstm_plan_backward': (c_int, [c_void_p, _P]),
-    'ptmi_lstm_plan_destroy': (None, [c_void_p]),
     'ptmi_absmax': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_absmax_accumulate': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'ptmi_planes_elems': (c_int64, [c_int64, c_int64]),

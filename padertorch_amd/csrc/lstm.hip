@@ -308,434 +308,9 @@ __global__ __launch_bounds__(NW * 64) void lstm_bwd_step_kernel(const LstmBwdArg
     }
 }
 
-// ================================================================================================
-// Persistent forward recurrence: ONE launch per layer.  Every workgroup keeps its slice of W_hh in
-// registers for all T steps (the step-per-launch variant re-streams W_hh, 11.7 MB at H = 600, from
-// Infinity Cache on every step because L2 is invalidated at each kernel boundary) and the steps
-// are chained inside the launch:
-//   producer  h_t / c_t stores are write-through (sc1), drained (s_waitcnt vmcnt(0)) by every
-//             wavefront, then ONE lane adds 1 to the step's arrival counter (8 shards per
-//             direction and step, relaxed agent-scope atomics);
-//   consumer  wavefront 0 polls the 8 shards of step s-1 of ITS direction (relaxed loads +
-//             s_sleep), the workgroup barrier releases the other wavefronts, h_{t-1} / c_{t-1}
-//             are read with sc1 loads (never served from this CU's L1).
-// All rows of hy / c are written exactly once and never read before their producer's counter was
-// observed, so no stale copy can exist in any cache.  The two directions use separate counters and
-// drift freely.  Every workgroup must be resident (checked on the host against 256 CUs x 2);
-// every spin is bounded and reports through an error word instead of hanging.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// MTL = 16-row M tiles per workgroup.  Row tiles are independent recurrences: each has its own
-// arrival counters, so with MTL = 1 a batch of 32 runs as TWO interleaved chains of 16 rows whose
-// workgroups share CUs, and one chain's hand-off latency hides behind the other chain's MFMAs.
-// OCC = workgroups per CU the register budget allows (2: up to 448 co-resident workgroups; 1: up to
-// 256, twice the registers, no spills).
-// PHASES: instrumented variant (a template parameter the library no longer instantiates; it produced the phase tables of
-// DESIGN.md 3.3): lane 0 of workgroup 0 sums the 100 MHz clock over the
-// phases of a step and leaves the sums in the first words of the scratch.
-template <int JT, int NW, int CH, int MTL, int OCC, bool PHASES = false>
-__global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_persistent_kernel(const LstmPersistArgs A) {
-    constexpr int NC = 4 * JT;
-    constexpr int NT = NC / 16;
-    constexpr int MR = 16 * MTL;                  // rows per workgroup
-    const int dir = blockIdx.y;
-    const int j0 = blockIdx.x * JT;
-    const int m0 = (A.tile0 + blockIdx.z) * MR;
-    const int H = A.H, G = 4 * H;
-    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[NW][MR][NC + 1];
-
-    // resident slice of W_hh: CH 16-wide K blocks of NT x 16 gate columns per wavefront
-    const int nblk = A.KP >> 4;
-    const int per = (nblk + NW - 1) / NW;         // <= CH (host checked)
-    const int kb0 = wave * per;
-    const int kb1 = min(nblk, kb0 + per);
-    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));          // wavefront-uniform
-    const int ilast = __builtin_amdgcn_readfirstlane(max(kb1 - kb0 - 1, 0));
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bq[CH][NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int cidx = nt * 16 + r;
-        const int gate = cidx / JT, uu = cidx - gate * JT;
-        const bool bv = j0 + uu < H;
-        const float* bp = A.w + ((long long)dir * G + gate * H + (bv ? j0 + uu : 0)) * A.KP + 4 * g4;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            bq[i][nt] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
-    }
-    const size_t tile_elems = (size_t)A.KP * 16;         // one 16-row tile of the tile-major h copy
-    const int tile16 = (A.tile0 + blockIdx.z) * MTL;     // first 16-row tile of this workgroup
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + blockIdx.z) * kSlots;   // this chain's slots
-    unsigned* const err = A.flags + A.err_off;
-    const int bl = tid / JT, u = tid - bl * JT;
-    const int b = m0 + bl;
-    bool alive = true;                           // false once a wait has run out: no further spinning
-    float pre_n[4] = {0.f, 0.f, 0.f, 0.f};       // input pre-activations of the step about to run
-    float c_reg = 0.f;                           // cell state of (b, u) after the previous step
-    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
-    auto mark = [&](int kk) {
-        if (PHASES && tid == 0) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            ph[kk] += now - ph_last;
-            ph_last = now;
-        }
-    };
-    if (PHASES && tid == 0) ph_last = __builtin_amdgcn_s_memrealtime();
-    {
-        const int t0 = dir == 0 ? 0 : A.T - 1;
-        if (tid < MR * JT && b < A.bs[t0] && j0 + u < H) {
-            const float* np = A.gx + (A.offs[t0] + b) * ld_g + (long long)dir * G + j0 + u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
-        }
-    }
-
-    for (int s = 0; s < A.T; ++s) {
-        const int t = dir == 0 ? s : A.T - 1 - s;
-        const int nb = A.bs[t];
-        const long long row0 = A.offs[t];
-        const int tp = dir == 0 ? t - 1 : t + 1;
-        const int nprev = (tp >= 0 && tp < A.T) ? min(A.bs[tp], nb) : 0;      // rows that have a previous step
-        const bool has_rec = nprev > m0;                 // workgroup-uniform
-        const bool act = tid < MR * JT && b < nb && j0 + u < H;
-        float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
-        float cprev = 0.f;
-        float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
-        if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];   // first step of sequence b
-        // next step's input pre-activations come from HBM; they are requested AFTER this step's operand
-        // loads (loads retire in order) so that their latency sits under the MFMAs, not in the chain
-        const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
-        const bool more = s + 1 < A.T;
-        const int nb1 = more ? A.bs[t1] : 0;
-        const long long row1 = more ? A.offs[t1] : 0;
-        auto prefetch = [&]() {
-            if (tid < MR * JT && b < nb1 && j0 + u < H && !(A.dbg & 256)) {
-                const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
-            }
-        };
-        if (!has_rec) prefetch();
-        if (has_rec) {
-            mark(0);
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
-            mark(1);
-            __syncthreads();
-            mark(2);
-            if (act && b < nprev) cprev = c_reg;          // this thread wrote c_{t-1}(b, u) itself
-            // h_{t-1} comes from the TILE-MAJOR copy (see the backward kernel): one load = one 16 x 16 tile =
-            // 1 KB of consecutive bytes.  Rows past the batch: out-of-range offset (the buffer returns 0);
-            // K blocks past this wavefront's slice re-read its last valid tile (x zero weights); the
-            // padding columns H..KP-1 of the last tile are written as zeros by the producer.
-            // fragments = K blocks of the first row tile, then of the second (MTL = 2); CH of them in flight, each
-            // re-requested as soon as its MFMAs have consumed it (see the backward kernel)
-            constexpr int NF = MTL * CH;
-            const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-                A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP * 64, 0x00020000);
-            const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-                A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP * 64, 0x00020000);
-            const unsigned vin = (unsigned)(kfirst * 1024 + r * 64 + g4 * 16);
-            const unsigned vb0 = (m0 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
-            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
-            auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
-                return __builtin_bit_cast(f32x4, f < CH ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, min(f, ilast) * 1024, 16 /* sc1 */)
-                                                        : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, min(f - CH, ilast) * 1024, 16));
-            };
-            constexpr int CA = PTMI_FWD_CA < CH ? PTMI_FWD_CA : CH;      // fragments in flight
-            f32x4 a[CA];
-#pragma unroll
-            for (int i = 0; i < CA; ++i) a[i] = fragment(i);
-            prefetch();
-            mark(3);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[MTL][NT];
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
-            if (!(A.dbg & 64)) {
-#pragma unroll
-                for (int p0 = 0; p0 < NF; p0 += CA) {
-#pragma unroll
-                    for (int i = 0; i < CA; ++i) {
-                        if (p0 + i < NF) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[(p0 + i) / CH][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[(p0 + i) % CH][nt][q], acc[(p0 + i) / CH][nt], 0, 0, 0);
-                            }
-                            if (p0 + i + CA < NF) a[i] = fragment(p0 + i + CA);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
-            mark(4);
-            __syncthreads();
-            mark(5);
-            if (tid < MR * JT) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int cidx = q * JT + u;
-                    float sum = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) sum += red[w][bl][cidx];
-                    pre[q] += sum;
-                }
-            }
-        }
-        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
-        if (act) {
-            ig = sigmoidf_(pre[0]);
-            fg = sigmoidf_(pre[1]);
-            gg = tanhf_(pre[2]);
-            og = sigmoidf_(pre[3]);
-            c_reg = fg * cprev + ig * gg;
-            h = og * tanhf_(c_reg);
-            // tile-major, written through: what this chain's workgroups read in the next step.  It is the
-            // only store the arrival below has to wait for; the row-major results follow after it.
-            float* tq = A.hyt + (((size_t)t * A.nt16 + tile16 + (bl >> 4)) * A.ndir + dir) * tile_elems;
-            __hip_atomic_store(tq + ((j0 + u) >> 4) * 256 + (bl & 15) * 16 + ((j0 + u) & 15), h, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (j0 < H && j0 + JT >= H && tid < MR * (A.KP - H)) {      // owner of the last unit: zero padding columns
-            const int pw = A.KP - H, rl = tid / pw, col = H + tid - rl * pw;
-            if (m0 + rl < nb) {
-                float* tq = A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems;
-                __hip_atomic_store(tq + (col >> 4) * 256 + (rl & 15) * 16 + (col & 15), 0.f, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // publish step s: every wavefront drains its stores, then one lane arrives
-        mark(6);
-        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        mark(7);
-        __syncthreads();
-        mark(8);
-        if (tid == 0)
-            __hip_atomic_store(myflags + blockIdx.x, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (act) {                                        // nobody in this launch reads these
-            gp[0] = ig;
-            gp[H] = fg;
-            gp[2 * H] = gg;
-            gp[3 * H] = og;
-            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
-            A.c[o] = c_reg;                               // saved for the backward pass only
-            A.hy[o] = h;                                  // row-major: the layer output
-        }
-        mark(9);
-    }
-    if (PHASES && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(A.hyt);
-        for (int kk = 0; kk < 10; ++kk) out[kk] = ph[kk];
-    }
-}
-
-// Persistent backward-through-time: the mirror of lstm_fwd_persistent_kernel.  Workgroup tile =
-// 16 (or 2 x 16) batch rows x 16 hidden units; its slice of W_hh^T (16 rows x 4H) stays in the registers
-// of its 8 (wide layers: 16) wavefronts for all T steps; dgates are published write-through in the
-// tile-major hand-off copy and chained by one slot per producer workgroup; the cell-state gradient and
-// the bias-gradient sums of element (b, j) live in registers of the one thread that owns it.
-template <int NW, int CH, int MTL = 1>
-__global__ __launch_bounds__(NW * 64, NW == 16 ? 4 : 2) void lstm_bwd_persistent_kernel(const LstmPersistBwdArgs A) {
-    int bx, by, dir;
-    if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
-    const int n0 = bx * 16;
-    constexpr int MR = 16 * MTL;                   // rows per workgroup
-    const int m0 = (A.tile0 + by) * MR;
-    const int tile16 = (A.tile0 + by) * MTL;       // first 16-row tile (index into the tile-major copy)
-    const int H = A.H, G = 4 * H;
-    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[NW][MR][17];
-
-    const int nblk = G >> 4;
-    const int per = (nblk + NW - 1) / NW;          // <= CH (host checked)
-    const int kb0 = wave * per;
-    const int kb1 = min(nblk, kb0 + per);
-    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));          // wavefront-uniform
-    const int ilast = __builtin_amdgcn_readfirstlane(max(kb1 - kb0 - 1, 0));
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 bq[CH];
-    {
-        const bool bv = n0 + r < H;
-        const float* bp = A.wt + ((long long)dir * H + (bv ? n0 + r : 0)) * G + 4 * g4;
-#pragma unroll
-        for (int i = 0; i < CH; ++i)
-            bq[i] = (bv && kb0 + i < kb1) ? *reinterpret_cast<const f32x4*>(bp + (kb0 + i) * 16) : zero;
-    }
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * kSlots;   // this row tile's chain
-    unsigned* const err = A.flags + A.err_off;
-    const int bl = (tid >> 4) & (MR - 1), jl = tid & 15;
-    const int b = m0 + bl, j = n0 + jl;
-    bool alive = true;         // false once a wait has run out: no further spinning
-    float dc_state = 0.f;      // d loss / d c of (b, j) flowing to the next (earlier) step
-    float sb0 = 0.f, sb1 = 0.f, sb2 = 0.f, sb3 = 0.f;      // bias gradient: this thread's dgates summed over time
-
-    for (int s = 0; s < A.T; ++s) {
-        const int t = dir == 0 ? A.T - 1 - s : s;
-        const int nb = A.bs[t];
-        const long long row0 = A.offs[t];
-        const int tn = dir == 0 ? t + 1 : t - 1;     // processed in iteration s - 1
-        const int tp = dir == 0 ? t - 1 : t + 1;     // forward-sense predecessor (c_{t-1})
-        const int nnext = (tn >= 0 && tn < A.T) ? min(A.bs[tn], nb) : 0;
-        int npv = 0;
-        long long prow0 = 0;
-        if (tp >= 0 && tp < A.T) {
-            npv = min(A.bs[tp], nb);
-            prow0 = A.offs[tp];
-        }
-        const bool has_rec = nnext > m0;
-        const bool act = tid < 16 * MR && b < nb && j < H;
-        float dh = 0.f, ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cprev = 0.f;
-        const long long oh = (row0 + b) * ld_h + dir * H + j;
-        const long long og_ = (row0 + b) * ld_g + (long long)dir * G + j;
-        if (act) {
-            dh = A.dhy[oh];
-            ig = A.gates[og_];
-            fg = A.gates[og_ + H];
-            gg = A.gates[og_ + 2 * H];
-            og = A.gates[og_ + 3 * H];
-            cn = A.c[oh];
-            if (b < npv) cprev = A.c[(prow0 + b) * ld_h + dir * H + j];
-            else if (A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j];
-        }
-        if (has_rec) {
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
-            __syncthreads();
-            // The operand comes from the TILE-MAJOR copy: one load instruction of a wavefront = one 16 x 16
-            // tile = 1 KB of consecutive bytes (8 full cache lines; from the row-major dgates it would be
-            // 16 half lines, measured 1.9 us per step slower at batch 32).  All CH loads go out back to
-            // back and are consumed in order; rows past the batch get an out-of-range offset (the buffer
-            // returns 0), K blocks past the end of this wavefront's slice re-read its last valid tile
-            // (finite data x zero weights).
-            const size_t tile_stride = (size_t)A.ndir * G * 16;     // to the workgroup's second 16-row tile (MTL = 2)
-            const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * (size_t)G * 16;
-            const unsigned vin = (unsigned)(kfirst * 1024 + r * 64 + g4 * 16);
-            const bool av = m0 + r < nnext && !(A.dbg & 128);
-            const __amdgpu_buffer_rsrc_t dg_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, G * 64, 0x00020000);
-            const unsigned vbase = av ? vin : 0x80000000u;
-            // HALF (8-wavefront, one row tile): the K slice goes through the registers in passes of PTMI_BWD_CA
-            // fragments, each re-requested as soon as its MFMAs have consumed it (a scheduler barrier per pass
-            // keeps the order): 5 instead of 19 loads in front of the first MFMA, 50 VGPRs less per lane.
-            // us per step at B = 32 / 16 / 1: all 19 up front 5.37 / 5.15 / 4.69, passes of 10: 5.10 / 4.84 / 4.45,
-            // 7: 5.06 / 4.76 / 4.66, 5: 4.93 / 4.62 / 4.62, 4: 4.91 / 4.68 / 4.80, 3: 4.92 / 4.70 / 5.31.
-            constexpr bool HALF = NW == 8 && CH > 10;
-            constexpr int NF = MTL * CH;                   // fragments: K blocks of the first row tile, then of the second
-            constexpr int CA = HALF ? PTMI_BWD_CA : CH;
-            // second row tile (MTL = 2): its own 16 x 16 tiles; rows past the batch are out of range (zeros)
-            const __amdgpu_buffer_rsrc_t dg_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(tbase + (MTL > 1 ? tile_stride : 0)), 0, G * 64, 0x00020000);
-            const unsigned vbase1 = (MTL > 1 && m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
-            auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
-                return __builtin_bit_cast(f32x4, f < CH ? __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc, vbase, min(f, ilast) * 1024, 16 /* sc1 */)
-                                                        : __builtin_amdgcn_raw_buffer_load_b128(dg_rsrc1, vbase1, min(f - CH, ilast) * 1024, 16));
-            };
-            f32x4 a[CA];
-#pragma unroll
-            for (int i = 0; i < CA; ++i) a[i] = fragment(i);
-            __builtin_amdgcn_sched_barrier(0);      // or the scheduler re-serialises load / wait / 4 MFMAs to save registers
-            f32x4 acc[MTL];
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt) acc[mt] = zero;
-            if (HALF) {
-#pragma unroll
-                for (int p0 = 0; p0 < NF; p0 += CA) {
-#pragma unroll
-                    for (int i = 0; i < CA; ++i) {
-                        if (p0 + i < NF) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-                                acc[(p0 + i) / CH] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[(p0 + i) % CH][q], acc[(p0 + i) / CH], 0, 0, 0);
-                            if (p0 + i + CA < NF) a[i] = fragment(p0 + i + CA);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                static_assert(MTL == 1 || HALF, "two row tiles only in the 8-wavefront kernel");
-                if (!(A.dbg & 64)) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][q], bq[i][q], acc[0], 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][r] = acc[mt][q];
-            __syncthreads();
-            if (tid < 16 * MR && b < nnext) {
-                float sum = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sum += red[w][bl][jl];
-                dh += sum;
-            }
-        }
-        if (act) {
-            float dc = b < nnext ? dc_state : 0.f;     // rows without a successor step start from 0
-            const float tc = tanhf_(cn);
-            const float d_o = dh * tc;
-            dc += dh * og * (1.f - tc * tc);
-            const float d_i = dc * gg;
-            const float d_g = dc * ig;
-            const float d_f = dc * cprev;
-            dc_state = dc * fg;
-            const float gi = d_i * ig * (1.f - ig), gf = d_f * fg * (1.f - fg), gc = d_g * (1.f - gg * gg),
-                        go = d_o * og * (1.f - og);
-            sb0 += gi;
-            sb1 += gf;
-            sb2 += gc;
-            sb3 += go;
-            float* dgp = A.dg + og_;                  // row-major: what the weight / input gradient GEMMs read
-            dgp[0] = gi;
-            dgp[H] = gf;
-            dgp[2 * H] = gc;
-            dgp[3 * H] = go;
-            // tile-major, written through: what the other workgroups of this chain read in the next step
-            float* tp = A.dgt + (((size_t)t * A.nt16 + tile16 + (bl >> 4)) * A.ndir + dir) * (size_t)G * 16 + (bl & 15) * 16;
-            const int c0_ = j, c1_ = H + j, c2_ = 2 * H + j, c3_ = 3 * H + j;
-            __hip_atomic_store(tp + (c0_ >> 4) * 256 + (c0_ & 15), gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(tp + (c1_ >> 4) * 256 + (c1_ & 15), gf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(tp + (c2_ >> 4) * 256 + (c2_ & 15), gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(tp + (c3_ >> 4) * 256 + (c3_ & 15), go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // bias gradient = sum of dgates over all rows: fold this workgroup's rows, one atomic per (gate, unit)
-    float* const fold = &red[0][0][0];              // >= 4 * MR * 16 floats (NW >= 4)
-    __syncthreads();
-    if (tid < 16 * MR) {
-        fold[(0 * MR + bl) * 16 + jl] = sb0;
-        fold[(1 * MR + bl) * 16 + jl] = sb1;
-        fold[(2 * MR + bl) * 16 + jl] = sb2;
-        fold[(3 * MR + bl) * 16 + jl] = sb3;
-    }
-    __syncthreads();
-    if (tid < 64 && n0 + jl < H) {
-        const int g = tid >> 4;
-        float sum = 0.f;
-#pragma unroll
-        for (int rr = 0; rr < MR; ++rr) sum += fold[(g * MR + rr) * 16 + jl];
-        atomicAdd(A.dbias + (size_t)dir * G + g * H + n0 + jl, sum);
-    }
-}
+// (Rounds 1-4 kept a persistent EXACT-fp32 pair of kernels here - lstm_fwd_persistent_kernel / lstm_bwd_persistent_kernel, the flag
+//  protocol on v_mfma_f32_16x16x4_f32 - reachable only through PTMI_LSTM_F32=1 once the split kernels of lstm_split.hip covered every
+//  resident configuration.  Removed in round 5: PTMI_LSTM_F32=1 now selects the step-per-launch kernels above, which are exact fp32 too.)
 
 static void neighbour(const int32_t* bs, const int64_t* offs, int T, int t, int tn, int* n, long long* row) {
     *n = 0;
@@ -808,37 +383,6 @@ static int cu_count() {
         cached[dev] = n;
     }
     return cached[dev];
-}
-
-// A plan = the forward and backward time loops over FIXED buffers, captured once as hipGraphs.
-// Replaying a graph costs one host call and the per-kernel dispatch overhead inside a graph is
-// lower than 2 x T eager launches (measured 7.2 vs 9.4 us per forward step at B = 32, H = 600).
-struct ptmi_lstm_plan {
-    hipGraphExec_t fwd = nullptr;
-    hipGraphExec_t bwd = nullptr;
-};
-
-template <class F>
-static int capture_graph(hipGraphExec_t* exec, F&& enqueue) {
-    hipStream_t cs = nullptr;
-    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
-    if (e != hipSuccess) return (int)e;
-    e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) {
-        (void)hipStreamDestroy(cs);
-        return (int)e;
-    }
-    int rc = enqueue(cs);
-    hipGraph_t graph = nullptr;
-    e = hipStreamEndCapture(cs, &graph);
-    if (rc == PTMI_OK && e != hipSuccess) rc = (int)e;
-    if (rc == PTMI_OK) {
-        e = hipGraphInstantiate(exec, graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) rc = (int)e;
-    }
-    if (graph) (void)hipGraphDestroy(graph);
-    (void)hipStreamDestroy(cs);
-    return rc;
 }
 
 // Per-device word that counts timed-out persistent launches (set once by the host binding; see ptmi_lstm_set_error_sink).
@@ -995,12 +539,11 @@ int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const 
     PTMI_RETURN_IF(step_masks && (rows != (int64_t)T * max_batch || max_batch > 64 || c0), PTMI_E_UNSUPPORTED);
     PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2) || rows < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
-    constexpr int NW = 8, CH = 5;
-    // the resident W slice must fit CH K-blocks per wavefront; all workgroups must be co-resident
-    // (512-thread workgroups at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2)
+    constexpr int NW = 8;
+    // the resident W slice must fit 3 k blocks of 32 per wavefront; all workgroups must be co-resident
     const int KP32 = (H + 31) / 32 * 32;
     const bool split = ptmi_lstm_split_enabled() && (KP32 / 32 + NW - 1) / NW <= 3;      // split kernels: <= 3 k blocks of 32 per wavefront
-    PTMI_RETURN_IF(!split && (KP / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
+    PTMI_RETURN_IF(!split, PTMI_E_UNSUPPORTED);                     // the caller falls back to the step-per-launch kernels
     // 16-row workgroups (two interleaved chains per 32 rows) while all of them stay co-resident
     // (512 threads at <= 128 VGPRs: 2 per CU; keep a margin below 256 x 2), else 32-row workgroups
     const int jx8 = (H + 7) / 8;
@@ -1026,6 +569,7 @@ int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const 
     float* const hyt = reinterpret_cast<float*>(flags);
     flags += lstm_tile_elems(T, ndir, max_batch, KP32);
     const bool daf = split && fwd_uses_daf(max_batch, H, ndir);
+    PTMI_RETURN_IF(!daf, PTMI_E_UNSUPPORTED);          // no data-as-flag instantiation for this tile shape: the step-per-launch kernels
     PTMI_RETURN_IF(step_masks && !daf, PTMI_E_UNSUPPORTED);          // the data-as-flag kernels carry the row masks
     if (daf && !prefilled) {        // every 16-bit value of the planes = 0xFFFF (no value can be), the counters behind them zero: one launch
         int fe = daf_prefill_and_zero(hyt, (size_t)lstm_tile_elems(T, ndir, max_batch, KP32), flags, (size_t)ptmi_lstm_flags_elems(T, ndir, max_batch), st);
@@ -1050,37 +594,16 @@ int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const 
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
         const int nt = std::min(per_launch, ntiles - t0);
-        const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt), block(NW * 64);
+        const dim3 grid((unsigned)jx, (unsigned)ndir, (unsigned)nt);
         const bool one_per_cu = (long long)jx * ndir * nt <= cus;
-        if (split) {
-            // one workgroup per CU: the workgroups of a chain (direction x row tile) on 8 / chains neighbouring XCDs, as in the
-            // backward kernel (a chain's hand-off rows and slots then live in the L2s of those XCDs only)
-            const int chains = ndir * nt;
-            A.span = (one_per_cu && chains <= 8 && 8 % chains == 0 && (jx + 8 / chains - 1) / (8 / chains) * 8 <= cus) ? 8 / chains : 0;
-            A.nx = jx;
-            A.nt = nt;
-            const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
-            int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st, daf);
-            if (rc) return rc;
-            continue;
-        }
-        if (jt == 12 && small)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 1, 1>), grid, block, 0, st, A);
-        else if (wide && small)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 1, 1>), grid, block, 0, st, A);
-        else if (jt == 12)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<12, NW, CH, 2, 1>), grid, block, 0, st, A);
-        else if (wide)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<16, NW, CH, 2, 1>), grid, block, 0, st, A);
-        else if (small && one_per_cu)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 1>), grid, block, 0, st, A);
-        else if (small)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 1, 2>), grid, block, 0, st, A);
-        else if (one_per_cu)
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 1>), grid, block, 0, st, A);
-        else
-            hipLaunchKernelGGL((lstm_fwd_persistent_kernel<8, NW, CH, 2, 2>), grid, block, 0, st, A);
-        int rc = launch_status();
+        // one workgroup per CU: the workgroups of a chain (direction x row tile) on 8 / chains neighbouring XCDs, as in the
+        // backward kernel (a chain's hand-off rows and slots then live in the L2s of those XCDs only)
+        const int chains = ndir * nt;
+        A.span = (one_per_cu && chains <= 8 && 8 % chains == 0 && (jx + 8 / chains - 1) / (8 / chains) * 8 <= cus) ? 8 / chains : 0;
+        A.nx = jx;
+        A.nt = nt;
+        const dim3 grid1(A.span ? (unsigned)((jx + A.span - 1) / A.span * 8) : 0u);
+        int rc = launch_fwd_split(A, jt, small, one_per_cu, A.span ? grid1 : grid, st, daf);
         if (rc) return rc;
     }
     return PTMI_OK;
@@ -1165,11 +688,9 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
     const bool whole = s_begin == 0 && s_end == T;
     PTMI_RETURN_IF(!whole && !dc_carry, PTMI_E_INVALID);
     PTMI_RETURN_IF(H % 4 != 0, PTMI_E_UNSUPPORTED);
-    constexpr int NW = 16, CH = 10;
     const int G32 = (4 * H + 31) / 32 * 32;
     const bool split = ptmi_lstm_split_enabled() && (G32 / 32 + 7) / 8 <= 10;           // split kernel: <= 10 k blocks of 32 per wavefront
-    PTMI_RETURN_IF(!split && (4 * H / 16 + NW - 1) / NW > CH, PTMI_E_UNSUPPORTED);
-    PTMI_RETURN_IF(!split && !whole, PTMI_E_UNSUPPORTED);          // step ranges: split kernels only
+    PTMI_RETURN_IF(!split, PTMI_E_UNSUPPORTED);                     // the caller falls back to the step-per-launch kernels
     const int resident = cu_count() - 16;     // one workgroup per CU, with a margin
     // One workgroup per CU must be resident (at most 240 per launch).  Row tiles are independent recurrences,
     // so a batch whose tiles do not fit at once runs as several launches over groups of tiles; before that,
@@ -1177,8 +698,7 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
     // H = 600; 7.5 us per step instead of 2 x 5.0).
     const int nx = (H + 15) / 16, nt16 = (max_batch + 15) / 16;
     PTMI_RETURN_IF((long long)nx * ndir > resident || nx > kSlots, PTMI_E_UNSUPPORTED);
-    const bool fits8 = split || (4 * H / 16 + 7) / 8 <= 19;
-    int mtl = (nt16 > resident / (nx * ndir) && fits8) ? 2 : 1;
+    int mtl = nt16 > resident / (nx * ndir) ? 2 : 1;
     const int ntiles = (nt16 + mtl - 1) / mtl;
     const int per_launch = std::min(ntiles, resident / (nx * ndir));
     const long long dg_bytes = rows * ndir * 4 * H * 4;
@@ -1241,67 +761,8 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
         A.nt = nt;
         A.span = (chains <= 8 && 8 % chains == 0) ? 8 / chains : 0;
         const unsigned nwg = A.span ? (unsigned)((nx + A.span - 1) / A.span * 8) : (unsigned)(nx * chains);
-        if (split) {
-            int rc = launch_bwd_split(A, mtl, nwg, st);
-            if (rc) return rc;
-            continue;
-        }
-        if (mtl == 2)
-            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19, 2>), dim3(nwg), dim3(512), 0, st, A);
-        else if (fits8)    // 8 wavefronts x 19 K blocks; 16 x 10 (128 VGPRs per lane, spills) only for wider layers
-            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<8, 19>), dim3(nwg), dim3(512), 0, st, A);
-        else
-            hipLaunchKernelGGL((lstm_bwd_persistent_kernel<NW, CH>), dim3(nwg), dim3(NW * 64), 0, st, A);
-        int rc = launch_status();
+        int rc = launch_bwd_split(A, mtl, nwg, st);
         if (rc) return rc;
     }
     return PTMI_OK;
 }
-
-extern "C" {
-
-int ptmi_lstm_plan_create(ptmi_lstm_plan** plan, float* gates, float* hy, float* c, const float* w_hh_pad,
-                          const float* dhy, const float* w_hh_t, float* dgates, float* dc_state,
-                          const int32_t* batch_sizes, const int64_t* offsets, int32_t T, int32_t max_batch,
-                          int32_t H, int32_t KP, int32_t ndir) {
-    PTMI_RETURN_IF(!plan || !gates || !hy || !c || !w_hh_pad || !batch_sizes || !offsets, PTMI_E_INVALID);
-    PTMI_RETURN_IF(T < 1 || max_batch < 1 || H < 1 || (ndir != 1 && ndir != 2), PTMI_E_INVALID);
-    PTMI_RETURN_IF(H % 4 != 0 || KP % 16 != 0 || KP < H, PTMI_E_UNSUPPORTED);
-    ptmi_lstm_plan* p = new ptmi_lstm_plan();
-    int rc = capture_graph(&p->fwd, [&](hipStream_t cs) {
-        return enqueue_forward(gates, hy, c, nullptr, w_hh_pad, batch_sizes, offsets, T, max_batch, H, KP, ndir, cs);
-    });
-    if (rc == PTMI_OK && dhy && w_hh_t && dgates && dc_state) {
-        rc = capture_graph(&p->bwd, [&](hipStream_t cs) {
-            return enqueue_backward(gates, c, nullptr, dhy, w_hh_t, dgates, dc_state, batch_sizes, offsets, T, max_batch,
-                                    H, ndir, cs);
-        });
-    }
-    if (rc != PTMI_OK) {
-        ptmi_lstm_plan_destroy(p);
-        return rc;
-    }
-    *plan = p;
-    return PTMI_OK;
-}
-
-int ptmi_lstm_plan_forward(ptmi_lstm_plan* plan, ptmi_stream_t stream) {
-    PTMI_RETURN_IF(!plan || !plan->fwd, PTMI_E_INVALID);
-    hipError_t e = hipGraphLaunch(plan->fwd, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? PTMI_OK : (int)e;
-}
-
-int ptmi_lstm_plan_backward(ptmi_lstm_plan* plan, ptmi_stream_t stream) {
-    PTMI_RETURN_IF(!plan || !plan->bwd, PTMI_E_INVALID);
-    hipError_t e = hipGraphLaunch(plan->bwd, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? PTMI_OK : (int)e;
-}
-
-void ptmi_lstm_plan_destroy(ptmi_lstm_plan* plan) {
-    if (!plan) return;
-    if (plan->fwd) (void)hipGraphExecDestroy(plan->fwd);
-    if (plan->bwd) (void)hipGraphExecDestroy(plan->bwd);
-    delete plan;
-}
-
-}  // extern "C"

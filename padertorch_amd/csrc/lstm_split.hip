@@ -180,262 +180,6 @@ __device__ __forceinline__ unsigned pair_word(float v, int lane, int* plane) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Forward.  Template parameters as lstm_fwd_persistent_kernel; CB = 32-wide k blocks per wavefront (K = KP32 split
-// evenly over the NW wavefronts).
-template <int JT, int NW, int CB, int MTL, int OCC, bool PHASES = false, int CP = 16>
-__global__ __launch_bounds__(NW * 64, 2 * OCC) void lstm_fwd_split_kernel(const LstmPersistArgs A) {
-    constexpr int NC = 4 * JT;
-    constexpr int NT = NC / 16;
-    constexpr int MR = 16 * MTL;
-    constexpr int ACTW = (MR * JT + 63) / 64;        // wavefronts that own elements (and store); the others only multiply
-    constexpr bool WARM = ACTW < NW;                 // the last wavefront touches the input pre-activations two steps ahead
-    int bx = blockIdx.x, bz = blockIdx.z, dir = blockIdx.y;
-    if (A.span > 0 && !chain_tile(A.nx, A.nt, A.span, &bx, &bz, &dir, A.ndir * A.nt)) return;
-    const int j0 = bx * JT;
-    const int m0 = (A.tile0 + bz) * MR;
-    const int H = A.H, G = 4 * H;
-    const long long ld_g = (long long)A.ndir * G, ld_h = (long long)A.ndir * H;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
-    const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[NW][MR][NC + 1];
-    // batch size / first packed row of a time index: arithmetic for a batch of equal lengths (no scalar loads in front of
-    // every step's poll), the PackedSequence tables otherwise
-    const bool uniform = A.uniform != 0;
-    auto bs_at = [&](int t) { return uniform ? A.max_batch : A.bs[t]; };
-    auto offs_at = [&](int t) { return uniform ? (long long)t * A.max_batch : (long long)A.offs[t]; };
-
-    // this wavefront's k blocks (32 wide): an even split of the KP32 / 32 blocks
-    const int nblk = A.KP32 >> 5;
-    const int base = nblk / NW, extra = nblk - base * NW;
-    const int kb0 = __builtin_amdgcn_readfirstlane(wave * base + min(wave, extra));
-    const int nbw = __builtin_amdgcn_readfirstlane(base + (wave < extra ? 1 : 0));        // <= CB (host checked)
-    const int kfirst = __builtin_amdgcn_readfirstlane(min(kb0, nblk - 1));
-    const int ilast = __builtin_amdgcn_readfirstlane(max(nbw - 1, 0));
-    const float ws = pow2_scale(A.w_amax);
-    const float inv = 1.f / (ws * kHScale);
-    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // resident slice of W_hh as fp16 halves: lane (gate column r of tile nt, k group g4) holds k = 32 (kb0 + i) + 8 g4 ..
-    uint4 bh[CB][NT], bl[CB][NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int cidx = nt * 16 + r;
-        const int gate = cidx / JT, uu = cidx - gate * JT;
-        const bool bv = j0 + uu < H;
-        const float* bp = A.w + ((long long)dir * G + gate * H + (bv ? j0 + uu : 0)) * A.KP;
-#pragma unroll
-        for (int i = 0; i < CB; ++i) {
-            const int k = (kb0 + i) * 32 + g4 * 8;
-            const bool in = bv && i < nbw;
-            const f32x4 w0 = (in && k + 4 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 4 <= A.KP ? k : 0)) : zero;
-            const f32x4 w1 = (in && k + 8 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 8 <= A.KP ? k + 4 : 0)) : zero;
-            const float v[8] = {w0[0] * ws, w0[1] * ws, w0[2] * ws, w0[3] * ws, w1[0] * ws, w1[1] * ws, w1[2] * ws, w1[3] * ws};
-            split8<false>(v, &bh[i][nt], &bl[i][nt]);
-        }
-    }
-    const size_t tile_elems = (size_t)A.KP32 * 16;       // floats per (time, 16-row tile, direction): 2 halves per value
-    const int tile16 = (A.tile0 + bz) * MTL;
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + bz) * kSlots;
-    unsigned* const err = A.flags + A.err_off;
-    const int bl_ = tid / JT, u = tid - bl_ * JT;
-    const int b = m0 + bl_;
-    // PHASES (instrumentation, not instantiated in the library): thread 0 of every workgroup (written out by workgroup (0, 0, 0)) sums the 100 MHz clock per phase of a step (scripts/exp_lstm_phases.py)
-    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ph_last = 0;
-    auto mark = [&](int kk) {
-        if (PHASES && tid == 0) {
-            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-            ph[kk] += now - ph_last;
-            ph_last = now;
-        }
-    };
-    bool alive = true;
-    float pre_n[4] = {0.f, 0.f, 0.f, 0.f};
-    float c_reg = 0.f;
-    constexpr int NWARM = (MR * 8 + 63) / 64;
-    float warm[NWARM];
-#pragma unroll
-    for (int i = 0; i < NWARM; ++i) warm[i] = 0.f;
-    {
-        const int t0 = dir == 0 ? 0 : A.T - 1;
-        if (tid < MR * JT && b < bs_at(t0) && j0 + u < H) {
-            const float* np = A.gx + (offs_at(t0) + b) * ld_g + (long long)dir * G + j0 + u;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
-        }
-    }
-
-    if (PHASES && tid == 0) ph_last = __builtin_amdgcn_s_memrealtime();
-    for (int s = 0; s < A.T; ++s) {
-        mark(11);
-        const int t = dir == 0 ? s : A.T - 1 - s;
-        const int nb = bs_at(t);
-        const long long row0 = offs_at(t);
-        const int tp = dir == 0 ? t - 1 : t + 1;
-        const int nprev = (tp >= 0 && tp < A.T) ? min(bs_at(tp), nb) : 0;
-        const bool has_rec = nprev > m0;
-        const bool act = tid < MR * JT && b < nb && j0 + u < H;
-        float pre[4] = {pre_n[0], pre_n[1], pre_n[2], pre_n[3]};
-        float cprev = 0.f;
-        float* gp = A.gx + (row0 + b) * ld_g + (long long)dir * G + j0 + u;
-        if (act && b >= nprev && A.c0) cprev = A.c0[((long long)dir * A.max_batch + b) * H + j0 + u];
-        const int t1 = dir == 0 ? s + 1 : A.T - 2 - s;
-        const bool more = s + 1 < A.T;
-        const int nb1 = more ? bs_at(t1) : 0;
-        const long long row1 = more ? offs_at(t1) : 0;
-        auto prefetch = [&]() {
-            if (tid < MR * JT && b < nb1 && j0 + u < H && !(A.dbg & 256)) {
-                const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pre_n[q] = np[q * H];
-            }
-        };
-        if (!has_rec) prefetch();
-        if (has_rec) {
-            mark(0);
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
-            mark(1);
-            __syncthreads();
-            mark(2);
-            if (act && b < nprev) cprev = c_reg;
-            // fragments: (row tile mt, k block i, plane p); one 1 KB tile per load instruction
-            constexpr int NF = MTL * CB * 2;
-            const __amdgpu_buffer_rsrc_t h_rsrc0 = __builtin_amdgcn_make_buffer_rsrc(
-                A.hyt + (((size_t)tp * A.nt16 + tile16) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
-            const __amdgpu_buffer_rsrc_t h_rsrc1 = __builtin_amdgcn_make_buffer_rsrc(
-                A.hyt + (((size_t)tp * A.nt16 + tile16 + (MTL > 1 ? 1 : 0)) * A.ndir + dir) * tile_elems, 0, A.KP32 * 64, 0x00020000);
-            const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
-            const unsigned vb0 = (m0 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
-            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nprev && !(A.dbg & 128)) ? vin : 0x80000000u;
-            auto fragment = [&](int f) {                   // f is a compile-time constant after unrolling
-                const int mt = f / (2 * CB), rem = f - mt * 2 * CB, i = rem >> 1, p = rem & 1;
-                return mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, (min(i, ilast) * 2 + p) * 1024, CP /* 16: sc1 */)
-                               : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, (min(i, ilast) * 2 + p) * 1024, CP);
-            };
-            uint4 a[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) a[f] = __builtin_bit_cast(uint4, fragment(f));
-            prefetch();
-            mark(3);
-            __builtin_amdgcn_sched_barrier(0);
-            f32x4 acc[MTL][NT];
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
-            if (!(A.dbg & 64)) {
-#pragma unroll
-                for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                    for (int i = 0; i < CB; ++i) {
-                        const uint4 ah = a[(mt * CB + i) * 2], al = a[(mt * CB + i) * 2 + 1];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(al, bh[i][nt], acc[mt][nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bl[i][nt], acc[mt][nt]);
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bh[i][nt], acc[mt][nt]);
-                    }
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) red[wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
-            if (WARM && wave == NW - 1 && !(A.dbg & 1024)) {
-                // The owners request their input pre-activations one step ahead, behind their operand loads; from HBM those
-                // rows (written by the projection GEMM, long evicted) take longer than the rest of the step, and the step's
-                // write-through drain (vmcnt counts loads and stores alike) waited for them.  This wavefront owns no
-                // element and stores nothing: it touches the first and last word of every (row, gate) segment of the step
-                // AFTER the next one, so that the owners' requests hit this XCD's L2.  The values are never used; the sink
-                // keeps their registers reserved until the loads have come back.
-#pragma unroll
-                for (int i = 0; i < NWARM; ++i) asm volatile("" ::"v"(warm[i]));
-                const int s2 = s + 2;
-                if (s2 < A.T) {
-                    const int t2 = dir == 0 ? s2 : A.T - 1 - s2;
-                    const int nb2 = bs_at(t2);
-                    const float* base2 = A.gx + offs_at(t2) * ld_g + (long long)dir * G;
-                    const int jlast = min(j0 + JT, H) - 1;
-#pragma unroll
-                    for (int i = 0; i < NWARM; ++i) {
-                        const int e = lane + 64 * i, seg = e >> 1, rl = seg >> 2, q = seg & 3;
-                        if (e < MR * 8 && m0 + rl < nb2) warm[i] = base2[(long long)(m0 + rl) * ld_g + q * H + ((e & 1) ? jlast : j0)];
-                    }
-                }
-            }
-            mark(4);
-            __syncthreads();
-            mark(5);
-            if (tid < MR * JT) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int cidx = q * JT + u;
-                    float sum = 0.f;
-#pragma unroll
-                    for (int w = 0; w < NW; ++w) sum += red[w][bl_][cidx];
-                    pre[q] += sum * inv;
-                }
-            }
-        }
-        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
-        if (act) {
-            ig = sigmoidf_(pre[0]);
-            fg = sigmoidf_(pre[1]);
-            gg = tanhf_(pre[2]);
-            og = sigmoidf_(pre[3]);
-            c_reg = fg * cprev + ig * gg;
-            h = og * tanhf_(c_reg);
-        }
-        mark(6);
-        // hand-off copy: the (hi, lo) planes of this step's tile, written through; lanes 2i / 2i+1 trade one half
-        {
-            int plane;
-            const unsigned word = pair_word<false>(h * kHScale, lane, &plane);
-            if (act) {
-                const int ce = (j0 + u) & ~1;
-                unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (bl_ >> 4)) * A.ndir + dir) * tile_elems);
-                __hip_atomic_store(tq + handoff_index(ce, plane, bl_ & 15) / 2, word, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if (j0 < H && j0 + JT >= H) {                     // owner of the last unit: zero the padding columns H .. KP32-1
-            const int pw2 = (A.KP32 - H) >> 1;           // pairs per row and plane
-            for (int e = tid; e < MR * pw2 * 2 && tid < ACTW * 64; e += ACTW * 64) {
-                const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = H + 2 * (rem - plane * pw2);
-                if (m0 + rl < nb) {
-                    unsigned* tq = reinterpret_cast<unsigned*>(A.hyt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
-                    __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        mark(7);
-        if (!(A.dbg & 32) && wave < ACTW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // wavefronts that have stored
-        mark(8);
-        __syncthreads();
-        mark(9);
-        if (tid == 0)
-            __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (act) {                                        // nobody in this launch reads these
-            gp[0] = ig;
-            gp[H] = fg;
-            gp[2 * H] = gg;
-            gp[3 * H] = og;
-            const long long o = (row0 + b) * ld_h + dir * H + j0 + u;
-            A.c[o] = c_reg;
-            A.hy[o] = h;
-        }
-        mark(10);
-    }
-    if (PHASES && tid == 0 && bx == 0 && dir == 0 && bz == 0) {
-        unsigned long long* out = reinterpret_cast<unsigned long long*>(A.hyt);
-        for (int kk = 0; kk < 12; ++kk) out[kk] = ph[kk];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // Forward, data-as-flag hand-off (the default wherever fwd_daf_applies; one workgroup per CU).
 // The protocol above costs every step two store round trips in series (the write-through drain, then the flag) and two
 // load round trips (the poll, then the operands).  Here the scratch planes are pre-filled with a pattern no value can
@@ -717,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
 // passes per layer of the B = 32 step go away.
 template <int NW, int CB, int MTL, int CABW, int CP = 16, bool UNI = false, bool DAF = false, bool TP = false, bool MSK = false>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPersistBwdArgs A) {
-    static_assert(!TP || DAF, "transposed planes: data-as-flag instantiations only (equal lengths, or row slots with their masks)");
+    static_assert(DAF, "the flag-protocol form of this kernel (rounds 1-2) is gone: data-as-flag instantiations only");
     int bx, by, dir;
     if (!chain_tile(A.nx, A.nt, A.span, &bx, &by, &dir)) return;
     const int n0 = bx * 16;
@@ -729,7 +473,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (A.dbg & 512) __builtin_amdgcn_s_setprio(3);      // experiment: issue priority over co-resident GEMM wavefronts
     const int g4 = lane >> 4, r = lane & 15;
-    __shared__ float red[DAF ? 2 : 1][NW][MR][DAF ? 20 : 17];       // DAF: double-buffered by step parity (one barrier per step); pitch 20: conflict-free accumulator writes
+    __shared__ float red[2][NW][MR][20];       // double-buffered by step parity (one barrier per step); pitch 20: conflict-free accumulator writes
     __shared__ unsigned short tbuf[TP ? 2 : 1][2][TP ? MR / 8 : 1][TP ? 64 : 1][8];      // TP: [step parity][plane][8-row group][gate-major column][row]
     int t_pend = -1;                                   // TP: time index whose chunks lie in tbuf[(its step) & 1], not stored yet
     auto flush_tp = [&](int par, int tt) {
@@ -780,7 +524,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             split8<true>(v, &bh[i], &bl[i]);
         }
     }
-    unsigned* const myflags = A.flags + ((size_t)dir * A.ntiles + A.tile0 + by) * kSlots;
     unsigned* const err = A.flags + A.err_off;
     const int bl_ = (tid >> 4) & (MR - 1), jl = tid & 15;
     const int b = m0 + bl_, j = n0 + jl;
@@ -874,7 +617,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         // vmcnt(0): the trailing row-major stores) BEFORE it issues these loads - cold HBM lines that need the whole step
         // to arrive.  Values of threads without an element are never used.
         float dh, ig, fg, gg, og, cn, cprev;
-        const long long oh = (row0 + b) * ld_h + dir * H + j;
         const long long og_ = (row0 + b) * ld_g + (long long)dir * G + j;
         if (__builtin_amdgcn_readfirstlane(wave) < (16 * MR) / 64 && !(A.dbg & 4096)) {        // scalar branch (4096: timing ablation)
             const int bb = min(b, nb - 1), jj = min(j, H - 1);
@@ -896,68 +638,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         //  A.c0[...]` at this point, the zero-initialisation of a register that a load of the previous iteration may still own made the
         //  compiler wait HERE with s_waitcnt vmcnt(0) - for the cold loads just issued and for the previous step's stores, in front of the
         //  hold and the operand requests of every step)
-        if (!DAF && has_rec) {
-            if (wave == 0 && !(A.dbg & 16) && alive) alive = wait_arrivals(myflags, A.expected, (unsigned)s, A.max_polls, err, A.err_sink);
-            __syncthreads();
-            const float* const tbase = A.dgt + (((size_t)tn * A.nt16 + tile16) * A.ndir + dir) * tile_elems;
-            const unsigned vin = (unsigned)(kfirst * 2048 + lane * 16);
-            const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tbase), 0, A.G32 * 64, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(tbase + (MTL > 1 ? (size_t)A.ndir * tile_elems : 0)), 0, A.G32 * 64, 0x00020000);
-            const unsigned vb0 = (m0 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
-            const unsigned vb1 = (MTL > 1 && m0 + 16 + r < nnext && !(A.dbg & 128)) ? vin : 0x80000000u;
-            constexpr int NB = MTL * CB;                    // k blocks of the first row tile, then of the second
-            constexpr int CAB = CABW < NB ? CABW : NB;      // blocks in flight
-            auto fragment = [&](int blk, int p) {           // compile-time constants after unrolling
-                const int mt = blk / CB, i = blk - mt * CB;
-                return __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rs0, vb0, (min(i, ilast) * 2 + p) * 1024, CP /* 16: sc1 */)
-                                                         : __builtin_amdgcn_raw_buffer_load_b128(rs1, vb1, (min(i, ilast) * 2 + p) * 1024, CP));
-            };
-            uint4 ah[CAB], al[CAB];
-#pragma unroll
-            for (int i = 0; i < CAB; ++i) {
-                ah[i] = fragment(i, 0);
-                al[i] = fragment(i, 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // one accumulator per product kind: three consecutive MFMAs never wait for each other's result
-            f32x4 acc3[MTL][3];
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc3[mt][k] = zero;
-#pragma unroll
-            for (int p0 = 0; p0 < NB; p0 += CAB) {
-#pragma unroll
-                for (int i = 0; i < CAB; ++i) {
-                    const int blk = p0 + i;
-                    if (blk < NB) {
-                        if (!(A.dbg & 64)) {
-                            acc3[blk / CB][0] = mma16<true>(al[i], bh[blk % CB], acc3[blk / CB][0]);
-                            acc3[blk / CB][1] = mma16<true>(ah[i], bl[blk % CB], acc3[blk / CB][1]);
-                            acc3[blk / CB][2] = mma16<true>(ah[i], bh[blk % CB], acc3[blk / CB][2]);
-                        }
-                        if (blk + CAB < NB) {
-                            ah[i] = fragment(blk + CAB, 0);
-                            al[i] = fragment(blk + CAB, 1);
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MTL; ++mt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) red[0][wave][mt * 16 + g4 * 4 + q][r] = (acc3[mt][0][q] + acc3[mt][1][q]) + acc3[mt][2][q];
-            __syncthreads();
-            if (tid < 16 * MR && b < nnext) {
-                float sum = 0.f;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) sum += red[0][w][bl_][jl];
-                dh += sum;
-            }
-        }
-        if (DAF && has_rec) {
+        if (has_rec) {
             // data-as-flag: no poll, no barrier in front of the operand loads.  The k blocks of this wavefront go through two
             // register sets in passes of CAB blocks: pass p is checked (and requested again until it is free of the fill
             // pattern), pass p + 1 is requested, pass p is multiplied.
@@ -1082,7 +763,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const unsigned w1 = pair_word<true>(gf, lane, &plane);
             const unsigned w2 = pair_word<true>(gc, lane, &plane);
             const unsigned w3 = pair_word<true>(go, lane, &plane);
-            t_flush = (TP && DAF && has_rec) ? t_pend : -1;      // the previous step's chunks: behind the hand-off stores
+            t_flush = (TP && has_rec) ? t_pend : -1;      // the previous step's chunks: behind the hand-off stores
             if (TP) t_pend = t;          // (every thread: the flush in a step without the chain's barrier brings its own barrier)
             if (act || (masked && tid < 16 * MR && b < nb && j < H)) {       // (row slots: zeros for an idle slot step, see the forward kernel)
                 // (block offset wave-uniform, the thread's four slots constants: see the forward kernel)
@@ -1115,12 +796,6 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-        }
-        if (!DAF) {
-            if (!(A.dbg & 32)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0)
-                __hip_atomic_store(myflags + bx, (unsigned)s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (masked && !act && tid < 16 * MR && b < nb && j < H && A.dg) {       // a slot's idle step: its row exists in the buffers - zeros
             float* dgp = A.dg + og_;
@@ -1171,7 +846,6 @@ bool bwd_daf_applies() { return true; }
 int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_cu, dim3 grid, hipStream_t st, bool daf) {
     constexpr int NW = 8, CB = 3;
     const dim3 block(NW * 64);
-    const bool wide = jt >= 12;
     if (daf) {
         if (jt == 16 && small)
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<16, NW, CB, 1>), grid, block, 0, st, A);
@@ -1183,18 +857,7 @@ int launch_fwd_split(const LstmPersistArgs& A, int jt, bool small, bool one_per_
             hipLaunchKernelGGL((lstm_fwd_daf_kernel<12, NW, CB, 2>), grid, block, 0, st, A);
         return launch_status();
     }
-    // flag-protocol kernels: the tile shapes the data-as-flag kernels do not cover (fwd_daf_applies)
-    if (wide)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<16, NW, CB, 2, 1>), grid, block, 0, st, A);
-    else if (small && one_per_cu)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 1, 1>), grid, block, 0, st, A);
-    else if (small)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 1, 2>), grid, block, 0, st, A);
-    else if (one_per_cu)
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 2, 1>), grid, block, 0, st, A);
-    else
-        hipLaunchKernelGGL((lstm_fwd_split_kernel<8, NW, CB, 2, 2>), grid, block, 0, st, A);
-    return launch_status();
+    return PTMI_E_UNSUPPORTED;        // (a tile shape without a data-as-flag instantiation: the caller has checked fwd_daf_applies)
 }
 
 int launch_bwd_split(const LstmPersistBwdArgs& A, int mtl, unsigned nwg, hipStream_t st) {

@@ -40,7 +40,7 @@ class _LinearFn(torch.autograd.Function):
             # both operands as fp16 planes (the weight's cached per optimizer step): csrc/gemm_planes.hip
             y = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.float32, device=x.device)
             amax_y = _gemm.zero_word(x.device) if relu else None
-            lh = _lstm.handoff_planes_of(x) if _lstm.INPUT_FROM_HANDOFF else None
+            lh = _lstm.handoff_planes_of(x)
             if lh is not None and x.is_contiguous() and x.shape[1] == lh[1] * lh[2]:
                 # x is the BLSTM output whose recurrence has left it as fp16 planes of 2^10 h: operand A as it lies
                 (scratch, cols), ndir, H = lh

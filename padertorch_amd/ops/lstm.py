@@ -84,67 +84,6 @@ def pack_meta(batch_sizes, device):
     return _meta(tuple(int(b) for b in batch_sizes.tolist()), (device.type, device.index))
 
 
-class _Workspace:
-    """Fixed device buffers of one (layer-call, packing pattern) + the hipGraph plan over them."""
-
-    def __init__(self, meta, ndir, H, device):
-        lib = _lib.load()
-        G, KP = 4 * H, (H + 15) // 16 * 16
-        f32 = dict(dtype=torch.float32, device=device)
-        self.gates = torch.empty((meta.rows, ndir * G), **f32)
-        self.hy = torch.empty((meta.rows, ndir * H), **f32)
-        self.c = torch.empty((meta.rows, ndir * H), **f32)
-        self.dhy = torch.empty((meta.rows, ndir * H), **f32)
-        self.dg = torch.empty((meta.rows, ndir * G), **f32)
-        self.dcs = torch.empty((meta.max_batch, ndir, H), **f32)
-        self.w_pad = torch.zeros((ndir, G, KP), **f32)
-        self.w_t = torch.empty((ndir, H, G), **f32)
-        self.busy = False
-        self.generation = 0
-        self.plan = ctypes.c_void_p()
-        _lib.check(lib.ptmi_lstm_plan_create(
-            ctypes.byref(self.plan), self.gates.data_ptr(), self.hy.data_ptr(), self.c.data_ptr(),
-            self.w_pad.data_ptr(), self.dhy.data_ptr(), self.w_t.data_ptr(), self.dg.data_ptr(),
-            self.dcs.data_ptr(), meta.bs_host.ctypes.data, meta.offs_host.ctypes.data, meta.T,
-            meta.max_batch, H, KP, ndir), 'ptmi_lstm_plan_create')
-
-    def __del__(self):
-        try:
-            if getattr(self, 'plan', None):
-                _lib.load().ptmi_lstm_plan_destroy(self.plan)
-                self.plan = None
-        except Exception:       # interpreter shutdown
-            pass
-
-
-class _Lease:
-    """Exclusive use of a workspace from a forward call until its backward (or until dropped)."""
-
-    def __init__(self, ws):
-        self.ws = ws
-        ws.busy = True
-        ws.generation += 1
-        self.generation = ws.generation
-
-    def valid(self):
-        return self.ws is not None and self.ws.generation == self.generation
-
-    def release(self):
-        if self.ws is not None and self.ws.generation == self.generation:
-            self.ws.busy = False
-        self.ws = None
-
-    def __del__(self):
-        self.release()
-
-
-#: key -> [seen count, [workspaces]]; a plan is only built when a packing pattern repeats
-_POOL = {}
-_MAX_WS_PER_KEY = 8
-_MAX_KEYS = 16
-#: replay captured hipGraphs over pooled workspaces (saves host launches; the GPU time per step is
-#: the same as eager launches, so it only pays when the host is the bottleneck)
-USE_GRAPHS = False
 #: run the forward recurrence as ONE persistent launch per layer (W_hh resident in registers)
 PERSISTENT = True
 #: read back the error words of the persistent kernels after every call (host sync; tests only)
@@ -175,14 +114,10 @@ WGRAD_SIDE_STREAM = True
 _WGRAD_STREAMS = {}
 
 
-#: run BLSTM layers on per-parameter-version cached stacked weights where autograd does not need the concatenations
-CACHE_STACKED_WEIGHTS = True
-#: the first layer's weight gradients (the step's tail) on both queues: forward direction on the side stream, reverse on the main one
-TAIL_ON_BOTH_QUEUES = True
-#: the backward scratch's data-as-flag pattern written by the forward recurrence kernel (ptmi_lstm_forward_fills)
-FILL_IN_FORWARD = True
-#: the forward recurrence's hand-off planes as operand A of the next projection / of the dense layer behind the BLSTM (no pack pass)
-INPUT_FROM_HANDOFF = True
+# (Always on since they were measured - rounds 2-4, DESIGN.md sections 3.3 / 3.9 / 4 - and no switches any more: per-version cached stacked
+#  weights; the first layer's weight gradients on both queues (the step's tail); the backward scratch's data-as-flag pattern written by the
+#  forward recurrence kernel; the forward recurrence's hand-off planes as operand A of the next projection / dense layer; the gate gradients
+#  handed to the weight-gradient GEMMs as bf16 planes of dgates^T by the backward kernel; both directions' dW_ih as one launch.)
 #: attribute of a packed_lstm output tensor whose recurrence has left it as hand-off planes: (version, (scratch, cols), ndir, H)
 HANDOFF_ATTR = '_ptmi_handoff_planes'
 
@@ -196,15 +131,8 @@ def handoff_planes_of(x):
     return rec[1:]
 #: LSTM input gradients on the planes GEMM straight from the backward recurrence's hand-off planes (no pack pass)
 DX_FROM_HANDOFF = True
-#: the top layer's backward recurrence in two launches for batches of at least this many packed rows (see _LstmLayerFn.backward)
-SPLIT_TOP_BACKWARD = True
+#: the top layer's backward recurrence runs in two launches for batches of at least this many packed rows (see _LstmLayerFn.backward)
 SPLIT_TOP_BACKWARD_ROWS = 16384
-#: the backward recurrence hands its gate gradients to the weight-gradient GEMMs itself, as bf16 planes of dgates^T
-#: (ptmi_lstm_backward_persistent_planes): no row-major fp32 store, no transposing pack pass per direction (equal-length batches
-#: whose size is a multiple of 16, in-place weight gradients)
-DG_PLANES_FROM_KERNEL = True
-#: both directions' dW_ih of a BLSTM layer as one GEMM launch with a two-part output (with DG_PLANES_FROM_KERNEL)
-FUSE_DW_IH = True
 _WGRAD_DONE = {}
 #: captured steps (ops.capture): a layer's weight-gradient launches are ENQUEUED behind the next lower layer's recurrence launch (they
 #: still wait for the event recorded where they used to be enqueued).  The hipGraph executor lays a captured step out by following a
@@ -371,28 +299,6 @@ def check_errors():
             raise_timeout(device)
 
 
-def _acquire(meta, ndir, H, device):
-    """A free workspace for this packing pattern, or None (-> eager launches)."""
-    if not USE_GRAPHS or meta.T < 8:
-        return None
-    key = (device.type, device.index, meta.key, ndir, H)
-    entry = _POOL.get(key)
-    if entry is None:
-        if len(_POOL) >= _MAX_KEYS:
-            _POOL.pop(next(iter(_POOL)))        # oldest pattern; its workspaces die with their leases
-        _POOL[key] = [1, []]
-        return None                             # first sighting: eager
-    entry[0] += 1
-    for ws in entry[1]:
-        if not ws.busy:
-            return _Lease(ws)
-    if len(entry[1]) >= _MAX_WS_PER_KEY:
-        return None
-    ws = _Workspace(meta, ndir, H, device)
-    entry[1].append(ws)
-    return _Lease(ws)
-
-
 _STACKED = {}
 
 
@@ -461,7 +367,7 @@ def _stacked_weights(params, KP, stream=None):
                 # per direction padded to the planes' width): that layer's scratch then is operand A of this layer's projection
                 planes = planes_h = None
                 ndir_ = len(params)
-                cols_ = int(_lib.load().ptmi_lstm_handoff_cols(H, 0)) if (_gemm.planes_enabled() and INPUT_FROM_HANDOFF) else 0
+                cols_ = int(_lib.load().ptmi_lstm_handoff_cols(H, 0)) if _gemm.planes_enabled() else 0
                 if cols_ and I == ndir_ * H:
                     planes_h = ((_gemm.pack_n_direction_blocks(w_ih_k[:, :I], ndir_, H, cols_, amax[0:1]), amax[0:1]), cols_)
                     if cols_ == H:
@@ -528,131 +434,114 @@ class _LstmLayerFn(torch.autograd.Function):
             h0 = torch.zeros_like(c0) if h0 is None else h0.detach().to(torch.float32).contiguous()
             c0 = torch.zeros_like(h0) if c0 is None else c0.detach().to(torch.float32).contiguous()
             assert h0.shape == c0.shape == (ndir, meta.max_batch, H), (h0.shape, c0.shape, meta.max_batch)
-        lease = None if stateful else _acquire(meta, ndir, H, x.device)
         st = _lib.stream(x.device)
-        if lease is not None:
-            ws = lease.ws
-            torch.addmm(bias, x, w_ih.t(), out=ws.gates)              # [rows, ndir*4H]
-            ws.w_pad[:, :, :H].copy_(w_hh)
-            _lib.check(_lib.timed('lstm_forward', lib.ptmi_lstm_plan_forward, ws.plan, st),
-                       'ptmi_lstm_plan_forward')
-            hy = ws.hy.clone()                                        # outputs never alias the workspace
-            ctx.save_for_backward(x, w_ih, w_hh)
-            ctx.lease = lease
-            ctx.ext = None
-            ctx.gemm = None
-            ctx.scratch_b = (None, False)
-            if not any(ctx.needs_input_grad):     # inference: nothing will come back for the buffers
-                lease.release()
+        # hand-off scratch of this layer's backward pass when one will come: its data-as-flag pattern is written by the forward
+        # recurrence kernel itself (below); the forward scratch is allocated and filled by the op
+        scratch_f = scratch_b = None
+        pre_f = pre_b = False
+        if (PERSISTENT and scratch_b is None and x.is_cuda and any(ctx.needs_input_grad)
+                and lib.ptmi_lstm_forward_fills(meta.T, ndir, meta.max_batch, H)):
+            # the forward recurrence itself writes the pattern into the planes of this layer's backward scratch (an idle
+            # wavefront per workgroup, a slice per time step)
+            scratch_b = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
+                                    device=x.device)
+            pre_b = True
+            fill_b = scratch_b
         else:
-            # hand-off scratch of this layer's backward pass when one will come: its data-as-flag pattern is written by the forward
-            # recurrence kernel itself (below); the forward scratch is allocated and filled by the op
-            scratch_f = scratch_b = None
-            pre_f = pre_b = False
-            if (PERSISTENT and scratch_b is None and x.is_cuda and any(ctx.needs_input_grad) and FILL_IN_FORWARD
-                    and lib.ptmi_lstm_forward_fills(meta.T, ndir, meta.max_batch, H)):
-                # the forward recurrence itself writes the pattern into the planes of this layer's backward scratch (an idle
-                # wavefront per workgroup, a slice per time step)
-                scratch_b = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
-                                        device=x.device)
-                pre_b = True
-                fill_b = scratch_b
+            fill_b = None
+        use_gemm = _gemm.usable(x, w_ih)
+        # operand ranges of the split GEMM: the layer input is taken as it is when it is a hidden state (|h| < 1,
+        # a dropout scale aside), measured otherwise; the stacked weights' maximum is cached per optimizer step
+        hplanes = prev.get('planes') if prev else None
+        xplanes = prev.get('xplanes') if prev else None
+        if not (xplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
+                and forms.get('w_ih_planes') is not None):
+            xplanes = None
+        amax_x = ((_gemm.UNIT_RANGE if x_unit else _gemm.scale_word(x.device, xplanes[1]) if xplanes is not None
+                   else _gemm.absmax(x)) if use_gemm else None)
+        amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
+                  if use_gemm else None)
+        if xplanes is not None:
+            # the producer of x has left it as fp16 planes with a fixed operand scale (the feature kernel: 2^9 log1p|Y|);
+            # the same scale word serves the weight gradient's pack of the fp32 x in the backward pass
+            word = amax_x
+            gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
+            wpl = _w_ih_planes(forms)
+            torch.ops.ptmi.gemm_planes_(gates, xplanes[0], word, wpl[0], wpl[1], bias, meta.rows, ndir * G, x.shape[1], False, 1)
+        elif (hplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
+                and forms.get('w_ih_planes_h') is not None and forms['w_ih_planes_h'][1] == hplanes[1]):
+            # the previous layer's recurrence has left its output as fp16 (hi, lo) planes of 2^10 h in fragment order (its
+            # hand-off copy): operand A of this projection as it lies, no pack pass
+            gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
+            kh = (x.shape[1] // H) * hplanes[1]
+            wpl = forms['w_ih_planes_h'][0]
+            torch.ops.ptmi.gemm_planes_(gates, hplanes[0], _gemm.scale_word(x.device), wpl[0], wpl[1], bias, meta.rows, ndir * G, kh,
+                                        False, _gemm.auto_split_k(meta.rows, ndir * G, kh))
+        elif use_gemm and _gemm.planes_enabled() and forms is not None and forms.get('w_ih_planes') is not None:
+            # both operands as fp16 planes: the input split once here, the stacked weights' planes come with the forms
+            gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
+            _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), _w_ih_planes(forms), meta.rows, ndir * G, x.shape[1], bias=bias)
+        elif use_gemm:
+            # an input width that is not a multiple of 4 (F = 257) would send the projection and its weight gradient
+            # down the kernel's unaligned (scalar-load) path: zero-pad the reduction axis of both operands instead
+            kpad = -x.shape[1] % 4
+            if kpad:
+                x_in = x
+                x = torch.nn.functional.pad(x_in, (0, kpad))
+                w_ih_k = forms['w_ih_kpad'] if forms is not None else torch.nn.functional.pad(w_ih, (0, kpad))
+                gates = _gemm.mm(x, w_ih_k.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
+                x = x[:, :x_in.shape[1]]                  # view with the padded row stride: what the backward pass multiplies
             else:
-                fill_b = None
-            use_gemm = _gemm.usable(x, w_ih)
-            # operand ranges of the split GEMM: the layer input is taken as it is when it is a hidden state (|h| < 1,
-            # a dropout scale aside), measured otherwise; the stacked weights' maximum is cached per optimizer step
-            hplanes = prev.get('planes') if prev else None
-            xplanes = prev.get('xplanes') if prev else None
-            if not (xplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
-                    and forms.get('w_ih_planes') is not None):
-                xplanes = None
-            amax_x = ((_gemm.UNIT_RANGE if x_unit else _gemm.scale_word(x.device, xplanes[1]) if xplanes is not None
-                       else _gemm.absmax(x)) if use_gemm else None)
-            amax_w = ((_gemm.weights_absmax([ps[0] for ps in params]) if params is not None else _gemm.absmax(w_ih))
-                      if use_gemm else None)
-            if xplanes is not None:
-                # the producer of x has left it as fp16 planes with a fixed operand scale (the feature kernel: 2^9 log1p|Y|);
-                # the same scale word serves the weight gradient's pack of the fp32 x in the backward pass
-                word = amax_x
-                gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
-                wpl = _w_ih_planes(forms)
-                torch.ops.ptmi.gemm_planes_(gates, xplanes[0], word, wpl[0], wpl[1], bias, meta.rows, ndir * G, x.shape[1], False, 1)
-            elif (hplanes is not None and use_gemm and _gemm.planes_enabled() and forms is not None
-                    and forms.get('w_ih_planes_h') is not None and forms['w_ih_planes_h'][1] == hplanes[1]):
-                # the previous layer's recurrence has left its output as fp16 (hi, lo) planes of 2^10 h in fragment order (its
-                # hand-off copy): operand A of this projection as it lies, no pack pass
-                gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
-                kh = (x.shape[1] // H) * hplanes[1]
-                wpl = forms['w_ih_planes_h'][0]
-                torch.ops.ptmi.gemm_planes_(gates, hplanes[0], _gemm.scale_word(x.device), wpl[0], wpl[1], bias, meta.rows, ndir * G, kh,
-                                            False, _gemm.auto_split_k(meta.rows, ndir * G, kh))
-            elif use_gemm and _gemm.planes_enabled() and forms is not None and forms.get('w_ih_planes') is not None:
-                # both operands as fp16 planes: the input split once here, the stacked weights' planes come with the forms
-                gates = torch.empty((meta.rows, ndir * G), dtype=torch.float32, device=x.device)
-                _gemm.mm_planes_(gates, _gemm.pack_n(x, amax_x), _w_ih_planes(forms), meta.rows, ndir * G, x.shape[1], bias=bias)
-            elif use_gemm:
-                # an input width that is not a multiple of 4 (F = 257) would send the projection and its weight gradient
-                # down the kernel's unaligned (scalar-load) path: zero-pad the reduction axis of both operands instead
-                kpad = -x.shape[1] % 4
-                if kpad:
-                    x_in = x
-                    x = torch.nn.functional.pad(x_in, (0, kpad))
-                    w_ih_k = forms['w_ih_kpad'] if forms is not None else torch.nn.functional.pad(w_ih, (0, kpad))
-                    gates = _gemm.mm(x, w_ih_k.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
-                    x = x[:, :x_in.shape[1]]                  # view with the padded row stride: what the backward pass multiplies
-                else:
-                    gates = _gemm.mm(x, w_ih.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
-            else:
-                gates = torch.addmm(bias, x, w_ih.t())
-            if stateful:        # h0 W_hh^T enters the pre-activations of each sequence's first processed step
-                gv = gates.view(meta.rows, ndir, G)
-                for d in range(ndir):
-                    gv[:, d].index_add_(0, meta.first_rows[d], h0[d] @ w_hh[d].t())
-            if forms is not None:
-                w_pad = forms['w_pad']
-            else:
-                w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
-            # equal-length batch: bs[0] rows of "state before the first step" (zero or h0) in front of and
-            # behind the output rows, so that the backward pass reads h_{t-1} as a shifted view (no gather)
-            pad = meta.bs0 if meta.equal_lengths else 0
-            masks = getattr(meta, 'masks_dev', None)          # row-slot batch (ops.sequence.SlotLayout): idle rows stay zero
-            assert masks is None or not stateful, 'row-slot batches take no initial states'
-            ext = (torch.zeros if masks is not None else torch.empty)((meta.rows + 2 * pad, ndir * H), dtype=torch.float32, device=x.device)
-            hy = ext[pad:pad + meta.rows]
-            if pad:
-                # (both ends in ONE fill launch: a [2, pad, C] view over the first and the last `pad` rows)
-                C_ = ndir * H
-                torch.as_strided(ext, (2, pad, C_), ((pad + meta.rows) * C_, C_, 1)).zero_()
-                if stateful:
-                    ext[:pad].view(pad, ndir, H)[:, 0] = h0[0]
-                    if ndir > 1:
-                        ext[pad + meta.rows:].view(pad, ndir, H)[:, 1] = h0[1]
-            ctx.ext = ext if pad else None
-            # split-precision recurrence: the scale of W_hh's fp16 halves comes from its maximum (cached per optimizer step)
-            amax_whh = None
-            if PERSISTENT and lib.ptmi_lstm_split_enabled():
-                amax_whh = (_gemm.weights_absmax([ps[1] for ps in params]) if params is not None
-                            else _gemm.absmax(w_pad.view(-1, KP)))
-            if PERSISTENT:
-                _error_sink(x.device)           # the word a timed-out launch reports to (set before the first launch)
-            c, flags = torch.ops.ptmi.lstm_recurrence_forward(
-                gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b, masks)
-            if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
-                pre_b = False
-            # (a row-slot batch's planes are operands as well: its kernels write zeros for the idle slot steps)
-            if handoff is not None and flags is not None and not stateful and (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0:
-                cols_out = int(lib.ptmi_lstm_handoff_cols(H, 0))
-                if cols_out:
-                    handoff['planes'] = (flags, cols_out)
-            ctx.scratch_b = (scratch_b, pre_b)
-            if flags is not None:
-                if CHECK_PERSISTENT_ERRORS:
-                    check_errors()
-            ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
-            ctx.lease = None
-            ctx.gemm = (amax_x, amax_w) if use_gemm else None
+                gates = _gemm.mm(x, w_ih.t(), bias=bias, amax_x=amax_x, amax_y=amax_w)
+        else:
+            gates = torch.addmm(bias, x, w_ih.t())
+        if stateful:        # h0 W_hh^T enters the pre-activations of each sequence's first processed step
+            gv = gates.view(meta.rows, ndir, G)
+            for d in range(ndir):
+                gv[:, d].index_add_(0, meta.first_rows[d], h0[d] @ w_hh[d].t())
+        if forms is not None:
+            w_pad = forms['w_pad']
+        else:
+            w_pad = torch.nn.functional.pad(w_hh, (0, KP - H)).contiguous() if KP != H else w_hh.contiguous()
+        # equal-length batch: bs[0] rows of "state before the first step" (zero or h0) in front of and
+        # behind the output rows, so that the backward pass reads h_{t-1} as a shifted view (no gather)
+        pad = meta.bs0 if meta.equal_lengths else 0
+        masks = getattr(meta, 'masks_dev', None)          # row-slot batch (ops.sequence.SlotLayout): idle rows stay zero
+        assert masks is None or not stateful, 'row-slot batches take no initial states'
+        ext = (torch.zeros if masks is not None else torch.empty)((meta.rows + 2 * pad, ndir * H), dtype=torch.float32, device=x.device)
+        hy = ext[pad:pad + meta.rows]
+        if pad:
+            # (both ends in ONE fill launch: a [2, pad, C] view over the first and the last `pad` rows)
+            C_ = ndir * H
+            torch.as_strided(ext, (2, pad, C_), ((pad + meta.rows) * C_, C_, 1)).zero_()
+            if stateful:
+                ext[:pad].view(pad, ndir, H)[:, 0] = h0[0]
+                if ndir > 1:
+                    ext[pad + meta.rows:].view(pad, ndir, H)[:, 1] = h0[1]
+        ctx.ext = ext if pad else None
+        # split-precision recurrence: the scale of W_hh's fp16 halves comes from its maximum (cached per optimizer step)
+        amax_whh = None
+        if PERSISTENT and lib.ptmi_lstm_split_enabled():
+            amax_whh = (_gemm.weights_absmax([ps[1] for ps in params]) if params is not None
+                        else _gemm.absmax(w_pad.view(-1, KP)))
+        if PERSISTENT:
+            _error_sink(x.device)           # the word a timed-out launch reports to (set before the first launch)
+        c, flags = torch.ops.ptmi.lstm_recurrence_forward(
+            gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
+            meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b, masks)
+        if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
+            pre_b = False
+        # (a row-slot batch's planes are operands as well: its kernels write zeros for the idle slot steps)
+        if handoff is not None and flags is not None and not stateful and (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0:
+            cols_out = int(lib.ptmi_lstm_handoff_cols(H, 0))
+            if cols_out:
+                handoff['planes'] = (flags, cols_out)
+        ctx.scratch_b = (scratch_b, pre_b)
+        if flags is not None:
+            if CHECK_PERSISTENT_ERRORS:
+                check_errors()
+        ctx.save_for_backward(x, w_ih, w_hh, gates, c, hy, h0, c0)
+        ctx.gemm = (amax_x, amax_w) if use_gemm else None
         ctx.meta = meta
         ctx.params = params
         ctx.forms = forms
@@ -664,29 +553,15 @@ class _LstmLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dhy, _dc=None):
-        meta, lease = ctx.meta, ctx.lease
+        meta = ctx.meta
         if dhy is None:             # only the cell states were used
             dhy = torch.zeros((meta.rows, ctx.saved_tensors[2].shape[0] * ctx.saved_tensors[2].shape[2]), dtype=torch.float32,
                               device=ctx.saved_tensors[0].device)
         h0 = c0 = db_kernel = amax_kernel = None
         lib = _lib.load()
         st = _lib.stream(dhy.device)
-        if lease is not None:
-            x, w_ih, w_hh = ctx.saved_tensors
-            if not lease.valid():
-                raise RuntimeError(
-                    'packed_lstm: the workspace of this forward pass has been released or reused (backward '
-                    'twice / retain_graph?). Set padertorch_amd.ops.lstm.USE_GRAPHS = False for that use.')
-            ws = lease.ws
-            ndir, G, H = w_hh.shape
-            ws.dhy.copy_(dhy)
-            ws.w_t.copy_(w_hh.transpose(1, 2))
-            _lib.check(_lib.timed('lstm_backward', lib.ptmi_lstm_plan_backward, ws.plan, st),
-                       'ptmi_lstm_plan_backward')
-            dg, hy = ws.dg, ws.hy
-        else:
-            x, w_ih, w_hh, gates, c, hy, h0, c0 = ctx.saved_tensors
-            ndir, G, H = w_hh.shape
+        x, w_ih, w_hh, gates, c, hy, h0, c0 = ctx.saved_tensors
+        ndir, G, H = w_hh.shape
         state_grad = False
         carry = None
         gm, params = ctx.gemm, ctx.params
@@ -698,7 +573,7 @@ class _LstmLayerFn(torch.autograd.Function):
         # kernels never wait for sibling workgroups - always safe next to a persistent recurrence -, library kernels only
         # when their shape is pinned to a rocBLAS solution
         oc = ctx.oc
-        in_place = (oc.defer_wgrad or ctx.forms is not None) and lease is None and has_grads
+        in_place = (oc.defer_wgrad or ctx.forms is not None) and has_grads
         use_side = in_place and oc.wgrad_side_stream and (
             gm is not None or _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
         main = torch.cuda.current_stream(x.device) if in_place else None
@@ -709,7 +584,7 @@ class _LstmLayerFn(torch.autograd.Function):
 
         def wgrad_rows(dg, ranges, amax_dg, both_queues=False, dg_t=None):
             """dW_ih, dW_hh of every direction d over the rows ranges[d] = (r0, r1) of the packed batch, on `side`
-            (both_queues: all but the forward direction's dW_hh on the main stream - see TAIL_ON_BOTH_QUEUES).
+            (both_queues: all but the forward direction's dW_hh on the main stream - the step's tail, see `both` below).
             dg_t: the kernel's bf16 planes of dgates^T for exactly these row ranges (then `dg` is None)."""
             # the first layer's weight gradients have the chip to themselves (the step's tail): big tiles; every other layer's run
             # beside the next recurrence: short ones on the kernel whose workgroups share CUs with the recurrence's
@@ -717,7 +592,7 @@ class _LstmLayerFn(torch.autograd.Function):
             # both directions' dW_ih = [dgates_f | dgates_r]^T x share the operand x and the kernel's planes of dgates^T lie behind each
             # other: ONE launch with a two-part output (ptmi_gemm_planes_bf16_two) instead of two GEMMs + two slab reductions
             fused_ih = False
-            if (dg_t is not None and FUSE_DW_IH and ndir == 2 and ranges[0] == ranges[1] and ranges[0][1] > ranges[0][0]):
+            if (dg_t is not None and ndir == 2 and ranges[0] == ranges[1] and ranges[0][1] > ranges[0][0]):
                 ga, gb = params[0][0].grad, params[1][0].grad
                 if ga.stride() == gb.stride() and (ga.data_ptr() ^ gb.data_ptr()) & 15 == 0 and ga.is_contiguous():
                     r0, r1 = ranges[0]
@@ -777,123 +652,122 @@ class _LstmLayerFn(torch.autograd.Function):
 
         todo = [(0, meta.rows)] * ndir                  # row ranges whose weight gradients are still to be accumulated
         use_tp, dg_t = False, None
-        if lease is None:
-            dhy = dhy.contiguous()
-            w_t = ctx.forms['w_t'] if ctx.forms is not None else w_hh.transpose(1, 2).contiguous()      # [ndir, H, 4H]
-            if PERSISTENT:
-                _error_sink(dhy.device)
-            dg = flags = None
-            T = meta.T
-            # gradients w.r.t. the initial state: the range entry point leaves the cell-state gradient behind the last step
-            state_grad = h0 is not None and any(ctx.needs_input_grad[5:7])
-            # gradient w.r.t. the FINAL cell state: `_dc` is the gradient of the cell-state tensor this layer returned; packed_lstm
-            # exposes only each sequence's last row of it (c_n), so only those rows can carry a gradient: gathered into [ndir, B, H]
-            # and handed to the kernel, which adds it to the cell-state gradient at each sequence's last step
-            dcn = None
-            if _dc is not None and h0 is not None:
-                dcv = _dc.reshape(meta.rows, ndir, H)
-                dcn = torch.stack([dcv[meta.last_rows[d], d] for d in range(ndir)]).contiguous()
-                state_grad = True                    # (the states entry point of the range launcher)
-            if state_grad and not (PERSISTENT and lib.ptmi_lstm_split_enabled()):
-                raise NotImplementedError('gradients w.r.t. the LSTM states need the persistent split kernels')
-            carry = None
-            # The TOP layer's backward recurrence runs while the weight-gradient queue is still empty; for long batches, where
-            # that queue is the critical one of the backward phase (16 kHz configurations: 11.9 ms of GEMMs and pack passes
-            # beside 9.7 ms of recurrences), it runs as two launches over step ranges and the finished half's weight gradients
-            # start under the second launch (ptmi_lstm_backward_persistent_range).  For every layer, or at B = 32 / T = 253,
-            # the same cut measured neutral to slower (a recurrence next to GEMMs loses what the GEMMs gain): c3 23.97 -> 23.55 ms
-            # with the top layer in two launches, 23.35 / 23.33 in three / four, 23.70 with every layer in two.
-            masks = getattr(meta, 'masks_dev', None)          # row-slot batch
-            chunks = 2 if (SPLIT_TOP_BACKWARD and getattr(ctx, 'top', False) and PERSISTENT and use_side and gm is not None
-                           and _gemm.planes_enabled() and lib.ptmi_lstm_split_enabled() and T >= 128
-                           and meta.rows >= SPLIT_TOP_BACKWARD_ROWS and masks is None) else 1
-            # the gate gradients as bf16 planes of dgates^T straight from the kernel (no row-major fp32 tensor at all when the
-            # input gradient takes the hand-off planes, or is not needed)
-            cols_dx = int(lib.ptmi_lstm_handoff_cols(H, 1)) if DX_FROM_HANDOFF else 0
-            uniform_rows = (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0        # rows = [T, batch]: the planes are operands
-            dx_needs_rows = ctx.needs_input_grad[0] and not (cols_dx and uniform_rows)
-            use_tp = bool(DG_PLANES_FROM_KERNEL and PERSISTENT and in_place and gm is not None and _gemm.planes_enabled()
-                          and not state_grad and not dx_needs_rows
-                          and lib.ptmi_lstm_backward_planes_ok(T, ndir, meta.max_batch, meta.rows, H))
-            if use_tp:
-                flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
-                    int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
-                pre = bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0])
-                cuts = [T * i // chunks for i in range(chunks + 1)]
-                carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device) if chunks > 1 else None
-                B_ = meta.max_batch
+        dhy = dhy.contiguous()
+        w_t = ctx.forms['w_t'] if ctx.forms is not None else w_hh.transpose(1, 2).contiguous()      # [ndir, H, 4H]
+        if PERSISTENT:
+            _error_sink(dhy.device)
+        dg = flags = None
+        T = meta.T
+        # gradients w.r.t. the initial state: the range entry point leaves the cell-state gradient behind the last step
+        state_grad = h0 is not None and any(ctx.needs_input_grad[5:7])
+        # gradient w.r.t. the FINAL cell state: `_dc` is the gradient of the cell-state tensor this layer returned; packed_lstm
+        # exposes only each sequence's last row of it (c_n), so only those rows can carry a gradient: gathered into [ndir, B, H]
+        # and handed to the kernel, which adds it to the cell-state gradient at each sequence's last step
+        dcn = None
+        if _dc is not None and h0 is not None:
+            dcv = _dc.reshape(meta.rows, ndir, H)
+            dcn = torch.stack([dcv[meta.last_rows[d], d] for d in range(ndir)]).contiguous()
+            state_grad = True                    # (the states entry point of the range launcher)
+        if state_grad and not (PERSISTENT and lib.ptmi_lstm_split_enabled()):
+            raise NotImplementedError('gradients w.r.t. the LSTM states need the persistent split kernels')
+        carry = None
+        # The TOP layer's backward recurrence runs while the weight-gradient queue is still empty; for long batches, where
+        # that queue is the critical one of the backward phase (16 kHz configurations: 11.9 ms of GEMMs and pack passes
+        # beside 9.7 ms of recurrences), it runs as two launches over step ranges and the finished half's weight gradients
+        # start under the second launch (ptmi_lstm_backward_persistent_range).  For every layer, or at B = 32 / T = 253,
+        # the same cut measured neutral to slower (a recurrence next to GEMMs loses what the GEMMs gain): c3 23.97 -> 23.55 ms
+        # with the top layer in two launches, 23.35 / 23.33 in three / four, 23.70 with every layer in two.
+        masks = getattr(meta, 'masks_dev', None)          # row-slot batch
+        chunks = 2 if (getattr(ctx, 'top', False) and PERSISTENT and use_side and gm is not None
+                       and _gemm.planes_enabled() and lib.ptmi_lstm_split_enabled() and T >= 128
+                       and meta.rows >= SPLIT_TOP_BACKWARD_ROWS and masks is None) else 1
+        # the gate gradients as bf16 planes of dgates^T straight from the kernel (no row-major fp32 tensor at all when the
+        # input gradient takes the hand-off planes, or is not needed)
+        cols_dx = int(lib.ptmi_lstm_handoff_cols(H, 1)) if DX_FROM_HANDOFF else 0
+        uniform_rows = (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0        # rows = [T, batch]: the planes are operands
+        dx_needs_rows = ctx.needs_input_grad[0] and not (cols_dx and uniform_rows)
+        use_tp = bool(PERSISTENT and in_place and gm is not None and _gemm.planes_enabled()
+                      and not state_grad and not dx_needs_rows
+                      and lib.ptmi_lstm_backward_planes_ok(T, ndir, meta.max_batch, meta.rows, H))
+        if use_tp:
+            flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
+                int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
+            pre = bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0])
+            cuts = [T * i // chunks for i in range(chunks + 1)]
+            carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device) if chunks > 1 else None
+            B_ = meta.max_batch
 
-                def launch_tp(i):
-                    n_rows = (cuts[i + 1] - cuts[i]) * B_
-                    planes = torch.empty(ndir * int(lib.ptmi_planes_elems(G, n_rows)), dtype=torch.bfloat16, device=dhy.device)
-                    ok = torch.ops.ptmi.lstm_recurrence_backward_planes(
-                        gates, c, c0, dhy, w_t, None, planes, flags, carry, meta.bs_dev, meta.offs_dev, T, B_, meta.rows, H, ndir,
-                        cuts[i], cuts[i + 1], pre, masks)
-                    # rows of this range per direction (forward direction: processed from the last time index down)
-                    part = [((T - cuts[i + 1]) * B_, (T - cuts[i]) * B_), (cuts[i] * B_, cuts[i + 1] * B_)][:ndir]
-                    return ok, planes, part
-                ok, dg_t, part_t = launch_tp(0)
-                if ok:
-                    for i in range(1, chunks):
-                        done = torch.cuda.Event()
-                        done.record(main)
-                        side.wait_event(done)
-                        wgrad_rows(None, part_t, None, dg_t=dg_t)        # the finished range, under the next launch
-                        dg_t.record_stream(side)
-                        ok, dg_t, part_t = launch_tp(i)
-                        if not ok:
-                            raise RuntimeError('ptmi_lstm_backward_persistent_planes: a later range was refused')
-                    todo = part_t
-                else:
-                    use_tp, dg_t, flags = False, None, None
+            def launch_tp(i):
+                n_rows = (cuts[i + 1] - cuts[i]) * B_
+                planes = torch.empty(ndir * int(lib.ptmi_planes_elems(G, n_rows)), dtype=torch.bfloat16, device=dhy.device)
+                ok = torch.ops.ptmi.lstm_recurrence_backward_planes(
+                    gates, c, c0, dhy, w_t, None, planes, flags, carry, meta.bs_dev, meta.offs_dev, T, B_, meta.rows, H, ndir,
+                    cuts[i], cuts[i + 1], pre, masks)
+                # rows of this range per direction (forward direction: processed from the last time index down)
+                part = [((T - cuts[i + 1]) * B_, (T - cuts[i]) * B_), (cuts[i] * B_, cuts[i + 1] * B_)][:ndir]
+                return ok, planes, part
+            ok, dg_t, part_t = launch_tp(0)
+            if ok:
+                for i in range(1, chunks):
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    side.wait_event(done)
+                    wgrad_rows(None, part_t, None, dg_t=dg_t)        # the finished range, under the next launch
+                    dg_t.record_stream(side)
+                    ok, dg_t, part_t = launch_tp(i)
+                    if not ok:
+                        raise RuntimeError('ptmi_lstm_backward_persistent_planes: a later range was refused')
+                todo = part_t
             else:
-                dg_t = None
-            if not use_tp and (chunks > 1 or state_grad):
-                dg = torch.empty_like(gates)
-                flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
-                    int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
-                carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device)
-                cuts = [T * i // chunks for i in range(chunks + 1)]
-                nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
-                amax_word = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
-                offs = [int(v) for v in meta.offs_host[:T]] + [meta.rows]
+                use_tp, dg_t, flags = False, None, None
+        else:
+            dg_t = None
+        if not use_tp and (chunks > 1 or state_grad):
+            dg = torch.empty_like(gates)
+            flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
+                int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
+            carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device)
+            cuts = [T * i // chunks for i in range(chunks + 1)]
+            nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
+            amax_word = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
+            offs = [int(v) for v in meta.offs_host[:T]] + [meta.rows]
 
-                def launch(i):
-                    return torch.ops.ptmi.lstm_recurrence_backward_range(
-                        gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
-                        ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]), dcn)
-                if launch(0):
-                    for i in range(1, chunks):
-                        snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
-                        done = torch.cuda.Event()
-                        done.record(main)
-                        side.wait_event(done)
-                        s0, s1 = cuts[i - 1], cuts[i]                # steps finished by the previous launch
-                        part = [(offs[T - s1], offs[T - s0]), (offs[s0], offs[s1])][:ndir]
-                        wgrad_rows(dg, part, snap)
-                        snap.record_stream(side)
-                        if not launch(i):
-                            raise RuntimeError('ptmi_lstm_backward_persistent_range: a later range was refused')
-                    if chunks > 1:
-                        s0 = cuts[chunks - 1]
-                        todo = [(offs[0], offs[T - s0]), (offs[s0], offs[T])][:ndir]
-                else:
-                    dg = flags = None                                # not resident: the one-call path decides
-                    if state_grad:
-                        raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
-                                                  'persistent kernels')
-            if dg is None and not use_tp:
-                dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
-                    gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                    T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1], masks)
-            if flags is not None:
-                if CHECK_PERSISTENT_ERRORS:
-                    check_errors()
-                # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]
-                nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
-                db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
-                if lib.ptmi_lstm_split_enabled():
-                    amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
+            def launch(i):
+                return torch.ops.ptmi.lstm_recurrence_backward_range(
+                    gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
+                    ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]), dcn)
+            if launch(0):
+                for i in range(1, chunks):
+                    snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
+                    done = torch.cuda.Event()
+                    done.record(main)
+                    side.wait_event(done)
+                    s0, s1 = cuts[i - 1], cuts[i]                # steps finished by the previous launch
+                    part = [(offs[T - s1], offs[T - s0]), (offs[s0], offs[s1])][:ndir]
+                    wgrad_rows(dg, part, snap)
+                    snap.record_stream(side)
+                    if not launch(i):
+                        raise RuntimeError('ptmi_lstm_backward_persistent_range: a later range was refused')
+                if chunks > 1:
+                    s0 = cuts[chunks - 1]
+                    todo = [(offs[0], offs[T - s0]), (offs[s0], offs[T])][:ndir]
+            else:
+                dg = flags = None                                # not resident: the one-call path decides
+                if state_grad:
+                    raise NotImplementedError('gradients w.r.t. the initial LSTM state: this configuration cannot run on the '
+                                              'persistent kernels')
+        if dg is None and not use_tp:
+            dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
+                gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
+                T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1], masks)
+        if flags is not None:
+            if CHECK_PERSISTENT_ERRORS:
+                check_errors()
+            # scratch tail: [bias gradient [ndir * 4H] | 8 words, word 0 = max |dgates| | slots | error words]
+            nflags = int(lib.ptmi_lstm_flags_elems(T, ndir, meta.max_batch)) + 8
+            db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
+            if lib.ptmi_lstm_split_enabled():
+                amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
         flush_pending_wgrad()          # (captured steps: the layer above's weight gradients, behind this layer's recurrence launch)
         amax_dg = None
         if gm is not None:
@@ -922,7 +796,7 @@ class _LstmLayerFn(torch.autograd.Function):
             # but the forward direction's dW_hh go to the main queue, so that the side queue is done first and the optimizer does
             # not start behind a cross-queue hand-over (small launches with ~12 us of dispatch gap between dependent kernels of
             # one queue; a wait for an event that has not fired yet costs 30-60 us)
-            both = (TAIL_ON_BOTH_QUEUES and use_side and ndir > 1 and gm is not None and _gemm.planes_enabled()
+            both = (use_side and ndir > 1 and gm is not None and _gemm.planes_enabled()
                     and not ctx.needs_input_grad[0] and todo[0] == (0, meta.rows))
             if both:
                 for p in (params[0][0], params[1][0], params[1][1]):     # earlier side-stream accumulations into the same .grad views
@@ -1000,10 +874,8 @@ class _LstmLayerFn(torch.autograd.Function):
         else:
             dw_ih = dg.t() @ x                                            # [ndir*4H, I]
             dw_hh = torch.stack([a.t() @ b for a, b in _recurrent_operands(meta, dg, hy, ctx.ext, h0, ndir, H)])
-        if lease is not None:
-            lease.release()
         gh0 = gc0 = None
-        if lease is None and state_grad:
+        if state_grad:
             gh0, gc0 = _state_grads(meta, dg, w_hh, carry, ndir, G, ctx.needs_input_grad)
         return (dx, dw_ih, db, dw_hh, None, gh0, gc0) + (None,) * 8
 
@@ -1147,10 +1019,10 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
                          getattr(lstm, f'bias_ih_l{layer}{s}'), getattr(lstm, f'bias_hh_l{layer}{s}')) for s in sfx)
                   for layer in range(lstm.num_layers)]
     flat_params = [p for ps_ in all_params for ps in ps_ for p in ps]
-    if (CACHE_STACKED_WEIGHTS and data.is_cuda and any(_stacked_stale(ps_) for ps_ in all_params)
+    if (data.is_cuda and any(_stacked_stale(ps_) for ps_ in all_params)
             and all(p.is_cuda and p.dtype == torch.float32 for p in flat_params)
             and (not (torch.is_grad_enabled() and any(p.requires_grad for p in flat_params))
-                 or (oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.is_leaf and p.grad is not None for p in flat_params)))):
+                 or (oc.defer_wgrad and all(p.requires_grad and p.is_leaf and p.grad is not None for p in flat_params)))):
         # after an optimizer step: the operand forms of ALL layers on a side stream, next to whatever the main stream is
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
         pre = forked = _prep_stream(data.device)
@@ -1176,9 +1048,9 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # no graph, or weight gradients accumulated in place by the backward pass (the Trainer's flat bucket): the layer
         # runs on the cached stacked / padded / transposed forms of its parameters
         graph = torch.is_grad_enabled() and any(p.requires_grad for ps in params for p in ps)
-        in_place = oc.defer_wgrad and not USE_GRAPHS and all(p.requires_grad and p.is_leaf and p.grad is not None for ps in params for p in ps)
+        in_place = oc.defer_wgrad and all(p.requires_grad and p.is_leaf and p.grad is not None for ps in params for p in ps)
         forms = anchor = None
-        if CACHE_STACKED_WEIGHTS and data.is_cuda and (not graph or in_place):
+        if data.is_cuda and (not graph or in_place):
             forms = _stacked_weights(params, (H + 15) // 16 * 16)
             if forms.get('ready') is not None:
                 torch.cuda.current_stream(data.device).wait_event(forms['ready'])

@@ -41,48 +41,6 @@ def test_packed_lstm_vs_torch_cpu(I, H, layers, bidir, lens, monkeypatch):
         np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.numpy(), atol=3e-5 * scale, err_msg=n)
 
 
-def test_graph_plan_path_matches_eager_and_reference(monkeypatch):
-    """Second and later calls with the same packing pattern replay captured hipGraphs over pooled
-    workspaces: same values/gradients as the eager path, outputs do not alias the workspace, two
-    live forward passes get two workspaces, and a double backward is refused loudly."""
-    from padertorch_amd.ops import lstm as L
-    monkeypatch.setattr(L, 'USE_GRAPHS', True)
-    torch.manual_seed(3)
-    I, H, lens = 33, 40, [17, 17, 12, 9, 9, 2, 1, 1, 1, 1]
-    ref = torch.nn.LSTM(I, H, 2, bidirectional=True)
-    dut = torch.nn.LSTM(I, H, 2, bidirectional=True)
-    dut.load_state_dict(ref.state_dict())
-    dut = dut.to(DEV)
-    xs = [torch.randn(l, I) for l in lens]
-    yr, _ = ref(pack_sequence([x.clone().requires_grad_(True) for x in xs]))
-    L._POOL.clear()
-    outs = []
-    for it in range(3):                      # 1st call eager, later calls graph plans
-        xd = [x.clone().to(DEV).requires_grad_(True) for x in xs]
-        y = L.packed_lstm(dut, pack_sequence(xd))
-        np.testing.assert_allclose(y.data.detach().cpu().numpy(), yr.data.detach().numpy(), atol=2e-6)
-        outs.append((y, xd))
-    key = next(iter(L._POOL))
-    assert L._POOL[key][0] >= 3 and len(L._POOL[key][1]) >= 2     # live forwards -> distinct workspaces
-    first = outs[0][0].data.clone()
-    g = torch.randn(yr.data.shape)
-    (yr.data * g).sum().backward()
-    for y, xd in outs:                       # every pending forward still backpropagates correctly
-        for p in dut.parameters():
-            p.grad = None
-        (y.data * g.to(DEV)).sum().backward(retain_graph=True)
-        for (n, pd), pr in zip(dut.named_parameters(), ref.parameters()):
-            np.testing.assert_allclose(pd.grad.cpu().numpy(), pr.grad.numpy(),
-                                       atol=3e-5 * max(1., pr.grad.abs().max().item()), err_msg=n)
-    assert torch.equal(outs[0][0].data, first)                      # output untouched by later replays
-    with pytest.raises(RuntimeError, match='released or reused'):
-        (outs[2][0].data * g.to(DEV)).sum().backward()
-    with torch.no_grad():                    # inference replays a plan and releases it at once
-        y = L.packed_lstm(dut, pack_sequence([x.to(DEV) for x in xs]))
-    np.testing.assert_allclose(y.data.cpu().numpy(), yr.data.detach().numpy(), atol=2e-6)
-    assert all(not ws.busy for ws in L._POOL[key][1])
-
-
 @pytest.mark.library_path
 def test_model_uses_hip_lstm_and_matches_library_lstm():
     """Same weights, HIP recurrence vs torch.nn.LSTM (MIOpen) inside the PIT model."""
