@@ -971,7 +971,7 @@ def _packed_lstm_padded(lstm, packed, training, hx, return_state, meta):
         hx = tuple(torch.nn.functional.pad(t, (0, H4 - H)) for t in hx)
     out = packed_lstm(shadow, packed, training=lstm.training if training is None else training, hx=hx, return_state=return_state, meta=meta)
     states = None
-    if isinstance(out, tuple):
+    if return_state or hx is not None:          # (a PackedSequence is a tuple itself: ask what was asked for)
         out, states = out
         states = tuple(t[..., :H] for t in states)
     rows = out.data.shape[0]
