@@ -7,7 +7,7 @@ for stmt in "$@"; do
   for rep in 1 2; do
     ms=$(python -c "
 import sys
-sys.argv = ['bench.py', '--steps', '${STEPS:-100}', '--warmup', '10', '--no-cpu-baseline', '--no-extras'] + '${BENCH_ARGS:-}'.split()
+sys.argv = ['bench.py', '--steps', '${STEPS:-100}', '--warmup', '10', '--no-cpu-baseline', '--no-extras', '--eager'] + '${BENCH_ARGS:-}'.split()
 import padertorch_amd.ops.lstm as L, padertorch_amd.ops.gemm as G
 $stmt
 import bench

@@ -9,7 +9,7 @@ from collections import defaultdict
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-sys.argv = ['bench.py', '--steps', '48', '--warmup', '10', '--no-cpu-baseline', '--no-extras'] + sys.argv[1:]
+sys.argv = ['bench.py', '--steps', '48', '--warmup', '10', '--no-cpu-baseline', '--no-extras', '--eager'] + sys.argv[1:]       # (the eager step: a replay takes no event records)
 import torch  # noqa: E402
 
 from padertorch_amd import _lib  # noqa: E402

@@ -3,7 +3,7 @@
 #   bench line, rocprofv3 kernel trace of the same bench command, FETCH_SIZE / WRITE_SIZE PMC passes
 #   (separate runs, kernel-trace only), kernel micro-benchmarks.  Text summaries -> gpurun_out/p/.
 # usage: scripts/refresh_profiles.sh <round-tag>
-tag=${1:-r3}
+tag=${1:-r5}
 repo=$(pwd)
 out=$repo/gpurun_out/p
 mkdir -p $out
@@ -25,26 +25,17 @@ db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
 [ -n "$db" ] && python $repo/scripts/step_timeline.py "$db" --min-us 25 > $out/${tag}_step_timeline.txt 2>&1 </dev/null
 # the other configurations and modes: one JSON line each
 ( for cfg in c3 c4 c5; do timeout 900 python $repo/bench.py --config $cfg --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1; done
-  timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --library-gemms 2>/dev/null | tail -1
-  timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1
-  PTMI_LSTM_F32=1 timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
-# the big-tile GEMM prototype: tile shapes and ablations, on random and on zero-filled operands (DVFS)
-if [ -x $repo/scripts/mb/gemm_big ]; then
-  bash $repo/scripts/mb/run_gemm_big.sh "8096 4800 1216" "8096 1200 4864" "32192 4800 1216" "8192 8192 4096" > /dev/null 2>&1; cp $repo/gpurun_out/mb/gemm_big.txt $out/${tag}_mb_gemm_big.txt
-  ZERO=1 bash $repo/scripts/mb/run_gemm_big.sh "8096 4800 1216" "8192 8192 4096" > /dev/null 2>&1; cp $repo/gpurun_out/mb/gemm_big.txt $out/${tag}_mb_gemm_big_zero.txt
-fi
-# where the step's critical path goes without a profiler attached (HIP events around the phase-marking launches), c2 and c3
+  timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --eager 2>/dev/null | tail -1
+  timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
+# the captured step's schedule: rocprofv3 kernel trace of graph replays (a replay does not depend on the host), c2 and c3
+cd $repo; bash scripts/timeline_graph.sh > /dev/null 2>&1; cp gpurun_out/timeline_graph.txt $out/${tag}_graph_timeline.txt
+bash scripts/timeline_graph.sh --config c3 > /dev/null 2>&1; cp gpurun_out/timeline_graph.txt $out/${tag}_graph_timeline_c3.txt; cd /tmp
+# where the EAGER step's critical path goes without a profiler attached (HIP events around the phase-marking launches)
 timeout 300 python $repo/scripts/phase_events.py 2>/dev/null | grep -E '^#|^[ms] ' > $out/${tag}_phase_events.txt
-timeout 300 python $repo/scripts/phase_events.py --config c3 --steps 24 2>/dev/null | grep -E '^#|^[ms] ' > $out/${tag}_phase_events_c3.txt
-# HIP runtime calls between kernel launches (event-record / stream-wait clusters = marker packets in front of a kernel)
-rm -rf /tmp/kt3; timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace -d /tmp/kt3 -o p -- python $repo/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras > /tmp/kt3.log 2>&1 </dev/null
-db3=$(find /tmp/kt3 -name "*.db" 2>/dev/null | head -1)
-[ -n "$db3" ] && python $repo/scripts/hip_api_between_launches.py "$db3" --min 2 > $out/${tag}_hip_api_between_launches.txt 2>&1 </dev/null
 [ -x $repo/scripts/mb/pack_t ] && { cd $repo/scripts/mb; { ./pack_t 8096 2400 4800; ./pack_t 32192 2400 4800; ./pack_t 32192 1200 1200; } > $out/${tag}_mb_pack_t.txt 2>&1; cd /tmp; }
 # ragged batches (lengths U[3 s, 6 s], bookkeeping rebuilt every step): a reported mode
 ( for a in "" "--config c3" "--config c5"; do timeout 600 python $repo/bench.py $a --ragged --steps 60 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('ragged $a: %.2f ms/step, %d frames/s, %d frames/step' % (d['ms_per_step'], d['value'], d['config']['frames_per_step']))"; done
   timeout 300 python $repo/scripts/phase_events.py --ragged 2>/dev/null | grep -E '^#|^[ms] ' ) > $out/${tag}_ragged.txt
 timeout 600 python $repo/scripts/bf16_delta.py 2>/dev/null | tail -1 > $out/${tag}_bf16_delta.json
 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' > $out/${tag}_lstm_us_per_step.txt
-PTMI_LSTM_F32=1 timeout 300 python $repo/scripts/exp_lstm.py 2>/dev/null | grep 'B=' | sed 's/^/exact-fp32 kernels: /' >> $out/${tag}_lstm_us_per_step.txt
 ls -la $out
