@@ -142,3 +142,26 @@ def test_signature_tells_shapes_lengths_and_unknown_leaves_apart():
     pl = PaddedList(torch.zeros(2, 5, 3, device=DEV), [5, 4])
     assert signature([dict(y=pl)]) != signature([dict(y=PaddedList(torch.zeros(2, 5, 3, device=DEV), [5, 3]))])
     assert signature([dict(x=object())]) is None
+
+
+def test_trainer_graph_prepare_captures_the_feature_front_end(tmp_path):
+    """``Trainer.graph_prepare``: raw waveform examples go through ``Trainer.train(graph_steps=True)``, the feature front-end is part of
+    the captured step; same parameters as the eager loop over features made in the data pipeline."""
+    import padertorch_amd as pt
+    g = torch.Generator().manual_seed(11)
+    waves = []
+    for _ in range(6):
+        s = 0.1 * torch.randn(8, 2, 6000, generator=g)
+        waves.append(dict(y=s.sum(1).to(DEV), s=s.to(DEV)))
+
+    def features(src):
+        return pt.ops.pit_features(src['y'], src['s'])
+    a, b = _pit(units=48), _pit(units=48)
+    ta = _train(a, (features(w) for w in waves), tmp_path / 'a', 6, vmb=1)
+    tb = pt.Trainer(b, tmp_path / 'b', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW, summary_trigger=(1, 'iteration'),
+                    checkpoint_trigger=(1000, 'iteration'), stop_trigger=(6, 'iteration'), graph_steps=True)
+    tb.graph_prepare = features
+    tb.train(waves, device=DEV)
+    assert ta.iteration == tb.iteration == 6 and len(tb._graphs) == 0          # (train() lets its graphs go at the end)
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
