@@ -293,6 +293,9 @@ def raise_timeout(device):
 def check_errors():
     """Raise if a bounded spin of a persistent LSTM kernel ran out since the last report (the recurrence results
     are then invalid).  One 4-byte device-to-host copy per device that has run such a kernel."""
+    from . import capture as _capture
+    if _capture.ACTIVE:         # (a host read: not inside a captured step - GraphedStep stages the word and checks it after the replay)
+        return
     for key, ent in list(_ERR_SINK.items()):
         device = torch.device(key[0], key[1])
         if errors_since_last_report(device, int(ent[0])):

@@ -58,9 +58,13 @@ def one(it, rng, verbose):
 
 
 def run(n, seed, verbose=True):
+    before = L.CHECK_PERSISTENT_ERRORS
     L.CHECK_PERSISTENT_ERRORS = True
-    rng = np.random.default_rng(seed)
-    return max(one(it, rng, verbose) for it in range(n))
+    try:
+        rng = np.random.default_rng(seed)
+        return max(one(it, rng, verbose) for it in range(n))
+    finally:
+        L.CHECK_PERSISTENT_ERRORS = before
 
 
 if __name__ == '__main__':
