@@ -681,6 +681,10 @@ class _LstmLayerFn(torch.autograd.Function):
         # the same cut measured neutral to slower (a recurrence next to GEMMs loses what the GEMMs gain): c3 23.97 -> 23.55 ms
         # with the top layer in two launches, 23.35 / 23.33 in three / four, 23.70 with every layer in two.
         masks = getattr(meta, 'masks_dev', None)          # row-slot batch
+        # (The BOTTOM layer in two launches - its first half's weight gradients under its second launch instead of in the step's tail -
+        #  measured in the captured step, round 5: c2 6.60 -> 6.90 ms, c3 21.4 -> 22.0, c5 18.1 -> 18.5.  The replay's timeline: the side
+        #  queue has no room in that window - the layer above's weight gradients (0.45 ms) run there, and as captured they ended up BEHIND
+        #  the first range's -, two launches take 36 us longer than one, and the last range's GEMMs lose the two-queue tail.)
         chunks = 2 if (getattr(ctx, 'top', False) and PERSISTENT and use_side and gm is not None
                        and _gemm.planes_enabled() and lib.ptmi_lstm_split_enabled() and T >= 128
                        and meta.rows >= SPLIT_TOP_BACKWARD_ROWS and masks is None) else 1
@@ -714,12 +718,15 @@ class _LstmLayerFn(torch.autograd.Function):
                 for i in range(1, chunks):
                     done = torch.cuda.Event()
                     done.record(main)
-                    side.wait_event(done)
-                    wgrad_rows(None, part_t, None, dg_t=dg_t)        # the finished range, under the next launch
-                    dg_t.record_stream(side)
+                    finished, finished_part = dg_t, part_t
+                    # (the next range's launch is enqueued FIRST: a captured step is laid out in capture order, and the recurrence must
+                    #  not end up behind the side queue's GEMMs - _PENDING_WGRAD)
                     ok, dg_t, part_t = launch_tp(i)
                     if not ok:
                         raise RuntimeError('ptmi_lstm_backward_persistent_planes: a later range was refused')
+                    side.wait_event(done)
+                    wgrad_rows(None, finished_part, None, dg_t=finished)        # the finished range, under the next launch
+                    finished.record_stream(side)
                 todo = part_t
             else:
                 use_tp, dg_t, flags = False, None, None
