@@ -17,7 +17,7 @@ __all__ = ['ACTIVE', 'capture_mode', 'zero_word', 'reset_step_caches']
 #: True while a step is being captured (host thread of the capture AND autograd's worker threads read it)
 ACTIVE = False
 
-_zero_blocks = []       # [[block of zeroed int32 words (allocated and zero-filled INSIDE the capture), words handed out]]
+_zero_blocks = []       # [[block of zeroed int32 words (allocated and zero-filled INSIDE the capture), words handed out, stream]]
 
 
 def zero_word(device, block_words=64):
@@ -25,9 +25,12 @@ def zero_word(device, block_words=64):
     blocks that are allocated - and therefore zero-filled - by nodes of the graph, so that every replay starts from zero.  (The
     eager pools hand out words of blocks that were filled once, when they were allocated; a replay would accumulate into the last
     replay's maximum.)"""
-    if not _zero_blocks or _zero_blocks[-1][1] >= _zero_blocks[-1][0].numel() or _zero_blocks[-1][0].device != device:
-        _zero_blocks.append([torch.zeros(block_words, dtype=torch.int32, device=device), 0])
-    ent = _zero_blocks[-1]
+    # (a block belongs to the stream it was zero-filled on: a word handed to another stream's kernel would not be ordered behind the fill)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    ent = next((e for e in reversed(_zero_blocks) if e[2] == stream and e[0].device == device and e[1] < e[0].numel()), None)
+    if ent is None:
+        ent = [torch.zeros(block_words, dtype=torch.int32, device=device), 0, stream]
+        _zero_blocks.append(ent)
     ent[1] += 1
     return ent[0][ent[1] - 1:ent[1]]
 
