@@ -1045,6 +1045,71 @@ __global__ __launch_bounds__(256) void stft_generic_kernel(const FwdArgs A) {
     }
 }
 
+// The fused PIT features for any even size (direct DFT; same outputs as pit_features_kernel incl. the packed log1p rows and planes):
+// one workgroup per (example, frame), the mixture first (unit phasors kept in LDS), then every source.
+__global__ __launch_bounds__(256) void pit_features_generic_kernel(const FwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int F = A.g.size / 2 + 1;
+    cpx* yph = reinterpret_cast<cpx*>(smem);                    // [F]
+    float* xw = reinterpret_cast<float*>(yph + F);              // [L]
+    const long long b = blockIdx.x / A.out_frames;
+    const long long t = blockIdx.x - b * A.out_frames;
+    const long long n_b = A.row_samples ? (long long)A.row_samples[b] : A.num_samples;
+    const bool valid = t < row_frames_of(A.g, n_b);
+    const int nsig = A.s ? A.K + 1 : 1;
+    for (int q = 0; q < nsig; ++q) {
+        const float* xrow = q == 0 ? A.x + b * A.x_row_stride : A.s + (b * A.K + (q - 1)) * A.x_row_stride;
+        __syncthreads();            // (the previous signal's samples have been consumed)
+        for (int j = threadIdx.x; j < A.g.L; j += 256) {
+            const long long xi = t * A.g.shift - A.g.pad_left + j;
+            xw[j] = (xi >= 0 && xi < n_b) ? xrow[xi] * A.window[j] : 0.f;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < F; k += 256) {
+            cpx X{0.f, 0.f};
+            if (valid) {
+                for (int j = 0; j < A.g.L; ++j) {
+                    const cpx w = tw_any(A.twiddle, A.g.size, (long long)k * j);
+                    X.x += xw[j] * w.x;
+                    X.y += xw[j] * w.y;
+                }
+            }
+            float mag;
+            cpx ph;
+            mag_phasor(X, mag, ph);
+            if (q == 0) {
+                A.out[(b * A.out_frames + t) * F + k] = mag;
+                yph[k] = ph;
+                if (A.lp_out && valid) {
+                    const long long prow = (A.lp_offs ? A.lp_offs[t] : t * A.batch) + b;
+                    const float lv = __log2f(1.f + mag) * 0.69314718f;
+                    A.lp_out[prow * F + k] = lv;
+                    if (A.lp_planes) {
+                        const float sv = lv * 512.f;
+                        const _Float16 hi = (_Float16)sv, lo = (_Float16)(sv - (float)hi);
+                        _Float16* o = A.lp_planes + (((prow >> 4) * A.lp_kb + (k >> 5)) * 2) * 512 + (((k >> 3) & 3) * 16 + (prow & 15)) * 8 + (k & 7);
+                        o[0] = hi;
+                        o[512] = lo;
+                    }
+                }
+            } else {
+                const long long o = ((b * A.out_frames + t) * A.K + (q - 1)) * F + k;
+                A.X_abs[o] = mag;
+                const cpx c = yph[k] * ph;          // cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)
+                A.cos_pd[o] = valid ? c.x + c.y : 0.f;
+            }
+        }
+        if (q == 0 && A.lp_out && A.lp_planes && valid) {       // bins F .. 32 lp_kb - 1 of this row: zero (the GEMM reads whole k blocks)
+            const long long prow = (A.lp_offs ? A.lp_offs[t] : t * A.batch) + b;
+            for (int k = F + threadIdx.x; k < A.lp_kb * 32; k += 256) {
+                _Float16* o = A.lp_planes + (((prow >> 4) * A.lp_kb + (k >> 5)) * 2) * 512 + (((k >> 3) & 3) * 16 + (prow & 15)) * 8 + (k & 7);
+                o[0] = (_Float16)0.f;
+                o[512] = (_Float16)0.f;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void istft_generic_kernel(const InvArgs A) {
     const int F = A.g.size / 2 + 1, M = A.g.size / 2;
     const long long per_row = (A.out_samples + 255) / 256;
@@ -1441,7 +1506,17 @@ int ptmi_pit_features_packed(const float* y, const float* s, int64_t batch, int3
     A.lp_planes = reinterpret_cast<_Float16*>(log1p_planes);
     A.lp_offs = reinterpret_cast<const long long*>(packed_offsets);
     A.lp_kb = (g->size / 2 + 1 + 31) / 32;
-    return dispatch_fwd(A, batch, true, static_cast<hipStream_t>(stream));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = dispatch_fwd(A, batch, true, st);
+    if (rc != PTMI_E_UNSUPPORTED) return rc;
+    // any other even size (paderbox.stft takes any: pit/data.py:52-53): direct DFT, one workgroup per frame
+    A.batch = batch;
+    const long long blocks = (long long)batch * out_frames;
+    PTMI_RETURN_IF(blocks > 0x7fffffffLL, PTMI_E_UNSUPPORTED);
+    const size_t smem = sizeof(cpx) * (size_t)(g->size / 2 + 1) + sizeof(float) * (size_t)g->window_length;
+    PTMI_RETURN_IF(smem > kMaxSmem, PTMI_E_UNSUPPORTED);
+    hipLaunchKernelGGL(pit_features_generic_kernel, dim3((unsigned)blocks), dim3(256), smem, st, A);
+    return launch_status();
 }
 
 }  // extern "C"

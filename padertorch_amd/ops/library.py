@@ -107,7 +107,7 @@ def _pit_features(y, s, num_samples, window, twiddle, geom, frames, log1p_packed
                     window.data_ptr(), twiddle.data_ptr(), _geom(geom), frames, Y_abs.data_ptr(), _lib.ptr(X_abs),
                     _lib.ptr(cos_pd), _lib.ptr(log1p_packed), _lib.ptr(log1p_planes), _lib.ptr(packed_offsets), _lib.stream(dev))
     if rc == -2:
-        raise NotImplementedError(f'pit_features needs a power-of-two STFT size in 64..2048 (got {geom[0]})')
+        raise NotImplementedError(f'pit_features: STFT size {geom[0]} / window {geom[2]} beyond what the direct-DFT kernel stages in LDS')
     _lib.check(rc, 'ptmi_pit_features')
     return Y_abs, X_abs, cos_pd
 

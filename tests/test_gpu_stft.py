@@ -237,6 +237,42 @@ def test_pit_features_ragged_batch_vs_oracle():
     assert f['Y_abs'].padded[3, f['num_frames'][3]:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize('size,shift,K', [(400, 160, 2), (100, 25, 3), (6, 2, 1)])
+def test_pit_features_of_any_even_stft_size_vs_oracle(size, shift, K):
+    """``paderbox.stft`` - and with it the reference's ``pre_batch_transform`` (``pit/data.py:52-75``) - takes any STFT size; sizes that
+    are not powers of two in 64..2048 run the direct-DFT feature kernel (``pit_features_generic_kernel``): same outputs, the packed
+    log-magnitude rows and planes included, ragged batch."""
+    from torch.nn.utils.rnn import pack_sequence
+    from padertorch_amd.ops import pit_features, STFT
+    rng = np.random.RandomState(size)
+    lens = [2000, 1711, 1710, 400]
+    exs = [features_np.synthetic_mixture(rng, n, K=K) for n in lens]
+    ref = [features_np.pre_batch_transform(s, y, size, shift) for s, y in exs]
+    f = pit_features([torch.from_numpy(y).to(DEV) for _, y in exs], [torch.from_numpy(s).to(DEV) for s, _ in exs], stft=STFT(size, shift))
+    assert f['num_frames'] == [r['num_frames'] for r in ref]
+    for b, r in enumerate(ref):
+        assert f['Y_abs'][b].shape == r['Y_abs'].shape and f['X_abs'][b].shape == r['X_abs'].shape
+        np.testing.assert_allclose(f['Y_abs'][b].cpu().numpy(), r['Y_abs'], atol=2e-5)
+        np.testing.assert_allclose(f['X_abs'][b].cpu().numpy(), r['X_abs'], atol=2e-5)
+        w = np.minimum(r['Y_abs'][:, None, :], r['X_abs'])
+        err = np.abs(f['cos_phase_difference'][b].cpu().numpy() - r['cos_phase_difference']) * w
+        assert err.max() < 2e-5
+    assert f['Y_abs'].padded[3, f['num_frames'][3]:].abs().max().item() == 0
+    pk = f['Y_abs'].packed_log1p
+    assert pk is not None
+    want = pack_sequence([torch.log1p(a) for a in f['Y_abs']])
+    assert torch.equal(pk.batch_sizes, want.batch_sizes)
+    torch.testing.assert_close(pk.data, want.data, atol=1e-6, rtol=2e-7)
+    planes = pk.planes()
+    if planes is not None:
+        rows, F = want.data.shape
+        KB = (F + 31) // 32
+        p = planes.view((rows + 15) // 16, KB, 2, 4, 16, 8).float()
+        val = (p[:, :, 0] + p[:, :, 1]).permute(0, 3, 1, 2, 4).reshape(-1, KB * 32) / 512.
+        torch.testing.assert_close(val[:rows, :F], pk.data, atol=2e-7, rtol=3e-7)
+        assert float(val[:, F:].abs().max()) == 0.
+
+
 @pytest.mark.parametrize('lens', [[4000, 3500, 3499, 900], [2048] * 32, [3000] * 5])
 def test_pit_features_write_the_packed_log_magnitude_input(lens):
     """SURVEY row a9 (``pit/model.py:91-94``, ``ops/sequence/pointwise.py:37``): the feature kernel itself writes the first BLSTM
