@@ -2,10 +2,10 @@
 
 Same constructor; the parameters live in a ``torch.nn.LSTM`` (same ``state_dict`` keys:
 ``lstm.weight_ih_l0`` ...).  The time loop runs in ``csrc/lstm.hip`` (``ops.lstm.packed_lstm``); ``(h_n, c_n)`` of a call is
-carried into the next one like the reference does.  Documented difference: the carried states are
-constants of the next call (detached) - backpropagation does not reach across calls (the reference
-would need ``retain_graph`` for that; streaming use detaches anyway).  ``ops.lstm.packed_lstm`` itself
-does differentiate w.r.t. an initial state handed to it.
+carried into the next one like the reference does - WITH their graph (``modules/recurrent.py:42-43`` stores what ``torch.nn.LSTM``
+returns): a loss on a later chunk reaches the earlier chunks' inputs and the parameters through the carried states (the persistent
+kernels' state gradients, ``ptmi_lstm_backward_persistent_states``), and - as with the reference - a second ``backward`` through a chunk
+whose graph has been freed raises torch's error: truncated backpropagation is the caller's ``states = tuple(s.detach() ...)``.
 """
 import torch
 from torch.nn.utils.rnn import PackedSequence
@@ -55,7 +55,7 @@ class StatefulLSTM(torch.nn.Module):
                 # no state comes in, none is kept: the plain path (hand-off planes for the next layer, dgates^T planes for the weight
                 # gradients, no state-gradient work - ADVICE r4)
                 return packed_lstm(self.lstm, x)
-            self.states = tuple(s.detach() for s in states)
+            self.states = states
             if not self.save_states:
                 del self.states
             return out
@@ -65,7 +65,7 @@ class StatefulLSTM(torch.nn.Module):
         packed = PackedSequence(xt.reshape(T * B, -1), torch.full((T,), B, dtype=torch.int64))
         if self.save_states or self.states is not None:
             out, states = packed_lstm(self.lstm, packed, hx=self.states, return_state=True)
-            self.states = tuple(s.detach() for s in states)
+            self.states = states
             if not self.save_states:
                 del self.states
         else:

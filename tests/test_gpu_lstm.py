@@ -119,6 +119,39 @@ def test_stateful_lstm_streams_like_the_reference_module():
     assert m2(x.to(DEV)).shape == (3, 30, 40) and m2.states is None
 
 
+def test_stateful_lstm_carries_the_graph_across_calls():
+    """``modules/recurrent.py:42``: the reference stores ``(h_n, c_n)`` as ``torch.nn.LSTM`` returns them - with their graph.  A loss on
+    the second chunk's output then reaches the FIRST chunk's input and the parameters through the carried states: equal to autograd
+    through torch's LSTM on the CPU; backward a second time through the freed first chunk raises, as with the reference."""
+    from padertorch_amd.modules import StatefulLSTM
+    torch.manual_seed(6)
+    for bidir in (False, True):
+        m = StatefulLSTM(9, 24, num_layers=2, bidirectional=bidir, batch_first=True, save_states=True).to(DEV)
+        ref = torch.nn.LSTM(9, 24, 2, batch_first=True, bidirectional=bidir)
+        ref.load_state_dict({k[len('lstm.'):]: v.cpu() for k, v in m.state_dict().items()})
+        x1, x2 = torch.randn(4, 11, 9), torch.randn(4, 7, 9)
+        a1, a2 = x1.clone().requires_grad_(), x2.clone().requires_grad_()
+        y1, st = ref(a1)
+        y2, _ = ref(a2, st)
+        g = torch.randn_like(y2)
+        (y2 * g).sum().backward()
+        b1, b2 = x1.to(DEV).requires_grad_(), x2.to(DEV).requires_grad_()
+        z1 = m(b1)
+        assert m.states[0].requires_grad and m.states[1].requires_grad
+        z2 = m(b2)
+        np.testing.assert_allclose(z2.detach().cpu().numpy(), y2.detach().numpy(), atol=5e-6)
+        (z2 * g.to(DEV)).sum().backward()
+        assert float(a1.grad.abs().max()) > 0
+        np.testing.assert_allclose(b1.grad.cpu().numpy(), a1.grad.numpy(), atol=2e-5 * float(a1.grad.abs().max()) + 1e-7)
+        np.testing.assert_allclose(b2.grad.cpu().numpy(), a2.grad.numpy(), atol=2e-5 * float(a2.grad.abs().max()) + 1e-7)
+        for (k, p), (_, q) in zip(m.lstm.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(p.grad.cpu().numpy(), q.grad.numpy(), atol=2e-5 * float(q.grad.abs().max()) + 1e-7, err_msg=k)
+        z3 = m(torch.randn(4, 3, 9, device=DEV))
+        with pytest.raises(RuntimeError, match='second time|already been freed'):
+            z3.sum().backward()
+        del m.states
+
+
 def test_random_configurations_vs_torch_cpu():
     """scripts/fuzz_lstm.py: 16 random (B, T, H, I, layers, directions, ragged / equal lengths, initial
     state) configurations - outputs, final states, input and parameter gradients against torch.nn.LSTM on
