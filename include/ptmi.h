@@ -89,6 +89,7 @@ int ptmi_istft_forward(const float* spec, int64_t batch, int64_t num_frames, con
  *   row_samples  device int32[batch] or NULL
  *   Y_abs        device [batch, out_frames, F]
  *   X_abs, cos_pd device [batch, out_frames, K, F]    (NULL when s is NULL)
+ * Any even g->size (paderbox.stft takes any): powers of two in 64..2048 run the FFT kernels, every other size the direct-DFT kernel.
  */
 int ptmi_pit_features(const float* y, const float* s, int64_t batch, int32_t K, int64_t row_stride,
                       int64_t num_samples, const int32_t* row_samples, const float* window,
