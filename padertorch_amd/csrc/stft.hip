@@ -598,7 +598,7 @@ __device__ __forceinline__ void mag_phasor(cpx X, float& mag, cpx& ph) {
 template <class PL>
 __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
-    constexpr int NP = M / 2 + 1, YS = WaveLds<PL>::YS;
+    constexpr int YS = WaveLds<PL>::YS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const WaveLds<PL> S(smem, 4);
     const int nsig = A.s ? A.K + 1 : 1;
@@ -675,76 +675,78 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
                 }
                 if (!(A.dbg & 2)) fft_to_lds_wave<PL, false>(a, wbuf + fl * FS, l, S.tw1t);
             }
-            // bin pairs (k, M-k) in batches of UA per lane: all LDS reads of a batch first, so that
-            // their latency is paid once per batch instead of once per pair
             const int fstride = (q == 0) ? F : A.K * F;
             const long long o0 = (q == 0) ? ((long long)b * A.out_frames + tw0) * F
                                           : (((long long)b * A.out_frames + tw0) * A.K + (q - 1)) * F;
             float* __restrict__ mag_out = (q == 0 ? A.out : A.X_abs) + o0;
             float* __restrict__ cp = A.cos_pd + o0;      // q > 0 only
-            constexpr int UA = 3;
-            const int npairs = nfr * NP;
-            if (!(A.dbg & 8))
-            for (int p0 = lane; p0 < npairs; p0 += 64 * UA) {
-                cpx z1[UA], z2[UA], w[UA], yk[UA], ym[UA];
-#pragma unroll
-                for (int u = 0; u < UA; ++u) {
-                    const int p = min(p0 + 64 * u, npairs - 1);
-                    const int f = p / NP, k = p - f * NP;
-                    z1[u] = wbuf[f * FS + (k & (M - 1))];
-                    z2[u] = wbuf[f * FS + ((M - k) & (M - 1))];
-                    w[u] = S.tws[k];
+            {
+                // Bins OWNED per lane (round 5).  The kernel is bound by vector-instruction issue, and more than half of its instructions
+                // were this epilogue's: with a flat (frame, bin pair) index per lane (rounds 2 - 4) every pair paid a division by NP,
+                // 64-bit store addresses and a per-lane validity select; same arithmetic per bin, outputs bit-identical, 6 - 12 % less
+                // time (profiles/r5_graph_head.txt).  A lane owns bin pair (k, M - k), k = kb + (lane mod KPL), of frame
+                // f0 + lane / KPL (KPL = min(64, M / 2): for M >= 128 one frame at a time, f wave-uniform): the twiddle is read once per
+                // k and serves all frames, row bases and the validity are scalar, stores take a scalar base + 32-bit lane offset.
+                // Bin M / 2 (its own partner) is the last pass, one lane per frame.
+                constexpr int HM = M / 2, KPL = HM < 64 ? HM : 64, FG = 64 / KPL;
+                const int fo = FG > 1 ? lane / KPL : 0, kl = FG > 1 ? lane - fo * KPL : lane;
+                auto one_pair = [&](int f, int k, bool two, cpx w) {
+                    const int km = M - k;
+                    const cpx z1 = wbuf[f * FS + (k & (M - 1))], z2 = wbuf[f * FS + (km & (M - 1))];
+                    cpx yk{0.f, 0.f}, ym{0.f, 0.f};
                     if (q > 0) {
-                        yk[u] = yph[f * YS + k];
-                        ym[u] = yph[f * YS + M - k];
+                        yk = yph[f * YS + k];
+                        ym = yph[f * YS + km];
                     }
-                }
-#pragma unroll
-                for (int u = 0; u < UA; ++u) {
-                    const int p = p0 + 64 * u;
-                    const int pc = min(p, npairs - 1);
-                    const int f = pc / NP, k = pc - f * NP, km = M - k;
                     const bool valid = tw0 + f < frames_b;
                     cpx Xk, Xm, pk, pm;
                     float mk, mm;
-                    split_vals(z1[u], z2[u], w[u], Xk, Xm);
+                    split_vals(z1, z2, w, Xk, Xm);
                     if (!valid) Xk = Xm = cpx{0.f, 0.f};
                     mag_phasor(Xk, mk, pk);
                     mag_phasor(Xm, mm, pm);
-                    if (p < npairs && (!(A.dbg & 1) || mk == 123456.f)) {
-                        mag_out[f * fstride + k] = mk;
-                        if (km != k) mag_out[f * fstride + km] = mm;
-                        if (q == 0) {
-                            yph[f * YS + k] = pk;
-                            if (km != k) yph[f * YS + km] = pm;
-                            if (A.lp_out && valid) {
-                                // pit/model.py:91-94: pack_sequence -> log1p, and the fp16 planes the first projection multiplies
-                                const int t = tw0 + f;
-                                const long long prow = (A.lp_offs ? A.lp_offs[t] : (long long)t * A.batch) + b;
-                                // log1p on the hardware log2 (v_log_f32): the kernel is VALU-bound and the library log1pf costs
-                                // ~35 instructions per value; 1 + |Y| rounds with an absolute error <= 6e-8, far inside the tolerance
-                                // the features are compared at (the oracle's log1p: atol 1e-6)
-                                const float lk = __log2f(1.f + mk) * 0.69314718f, lm = __log2f(1.f + mm) * 0.69314718f;
-                                float* lrow = A.lp_out + prow * F;
-                                lrow[k] = lk;
-                                if (km != k) lrow[km] = lm;
-                                if (A.lp_planes) {
-                                    // parked in the spectrum slots this lane has just consumed (k and M - k; slot M is nobody's):
-                                    // the planes are written in 16-byte chunks of 8 bins by the pass behind this loop
-                                    wbuf[f * FS + k].x = lk;
-                                    if (km != k) wbuf[f * FS + km].x = lm;
-                                }
+                    float* mrow = mag_out + f * fstride;
+                    mrow[k] = mk;
+                    if (two) mrow[km] = mm;
+                    if (q == 0) {
+                        yph[f * YS + k] = pk;
+                        if (two) yph[f * YS + km] = pm;
+                        if (A.lp_out && valid) {
+                            // pit/model.py:91-94: pack_sequence -> log1p, and the fp16 planes the first projection multiplies.
+                            // log1p on the hardware log2 (v_log_f32): the library log1pf costs ~35 instructions per value; 1 + |Y| rounds
+                            // with an absolute error <= 6e-8, far inside the tolerance the features are compared at (atol 1e-6).  The
+                            // values are parked in the spectrum slots this lane has just consumed (k and M - k; slot M is nobody's):
+                            // the planes are written in 16-byte chunks of 8 bins by the pass behind this loop
+                            const int t = tw0 + f;
+                            const long long prow = (A.lp_offs ? A.lp_offs[t] : (long long)t * A.batch) + b;
+                            const float lk = __log2f(1.f + mk) * 0.69314718f, lm = __log2f(1.f + mm) * 0.69314718f;
+                            float* lrow = A.lp_out + prow * F;
+                            lrow[k] = lk;
+                            if (two) lrow[km] = lm;
+                            if (A.lp_planes) {
+                                wbuf[f * FS + k].x = lk;
+                                if (two) wbuf[f * FS + km].x = lm;
                             }
-                        } else {
-                            // cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)
-                            const cpx ck = yk[u] * pk, cm = ym[u] * pm;
-                            cp[f * fstride + k] = valid ? ck.x + ck.y : 0.f;
-                            if (km != k) cp[f * fstride + km] = valid ? cm.x + cm.y : 0.f;
                         }
+                    } else {
+                        float* crow = cp + f * fstride;
+                        const cpx ck = yk * pk, cm = ym * pm;
+                        crow[k] = valid ? ck.x + ck.y : 0.f;
+                        if (two) crow[km] = valid ? cm.x + cm.y : 0.f;
+                    }
+                };
+                for (int kb = 0; kb < HM; kb += KPL) {
+                    const int k = kb + kl;
+                    const cpx w = S.tws[k];
+#pragma unroll
+                    for (int f0 = 0; f0 < FPW; f0 += FG) {
+                        const int f = f0 + fo;
+                        if (f < nfr) one_pair(f, k, true, w);
                     }
                 }
+                if (lane < nfr) one_pair(lane, HM, false, S.tws[HM]);
             }
-            if (q == 0 && A.lp_planes && !(A.dbg & 8)) {
+            if (q == 0 && A.lp_planes) {
                 // fp16 (hi, lo) planes of 2^9 log1p|Y| in MFMA-fragment order: chunk (bins 8 c .. 8 c + 7 of one packed row) = one
                 // 16-byte store per plane; bins past F are zero (csrc/gemm_planes.hip reads whole 32-wide blocks)
                 wave_sync();
