@@ -625,8 +625,12 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
     const unsigned stride = gridDim.x * 4;
     auto decode = [&](unsigned item, int q) {
         Task I;
-        I.b = (int)(item / (unsigned)A.nchunks);
-        I.tw0 = (int)(item - (unsigned)I.b * (unsigned)A.nchunks) * FPW;
+        // frame-group major, example minor: neighbouring wavefronts hold the SAME frames of neighbouring examples, whose packed rows
+        // (t * batch + b) and 16-byte plane chunks (16 rows of a tile side by side) then reach the L2 together and leave it as whole
+        // lines (example major, rounds 2 - 4: 16-byte partial lines once the planes outgrow the L2 - B = 64: +43 us for the packed outputs)
+        const unsigned chunk = item / (unsigned)A.batch;
+        I.b = (int)(item - chunk * (unsigned)A.batch);
+        I.tw0 = (int)chunk * FPW;
         I.n_b = A.row_samples ? A.row_samples[I.b] : (int)A.num_samples;
         I.xrow = (q == 0) ? A.x + (long long)I.b * A.x_row_stride
                           : A.s + ((long long)I.b * A.K + (q - 1)) * A.x_row_stride;
