@@ -9,7 +9,8 @@ dev = torch.device('cuda:0')
 torch.manual_seed(0)
 import os
 print('DBG', os.environ.get('PTMI_LSTM_DBG'))
-for B, T, H in [(32, 253, 600), (16, 253, 600), (1, 253, 600)]:
+BATCHES = [int(v) for v in sys.argv[sys.argv.index('--batches') + 1:]] if '--batches' in sys.argv else [32, 16, 1]
+for B, T, H in [(B_, 253, 600) for B_ in BATCHES]:
     lstm = torch.nn.LSTM(257, H, 1, bidirectional=True).to(dev)
     xs = [torch.randn(T, 257, device=dev, requires_grad=True) for _ in range(B)]
     for it in range(3):
