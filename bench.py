@@ -814,14 +814,16 @@ def main():
         local_ms = None
         if not args.dry:
             set_overlap(False)
-            trainer._skip_allreduce = True
+            # (a measurement bracket of this script, not a switch of the Trainer: on THIS object the data-parallel branch of
+            #  optimizer_step / clip_grad answers "no process group" - nothing on the product path reads a bench flag)
+            trainer._dp_active = lambda: False
             try:
                 for _ in range(2):
                     step(False)
                 nl = max(3, min(args.steps, 20))
                 local_ms = timed_loop(nl) / nl * 1e3
             finally:
-                trainer._skip_allreduce = False
+                del trainer._dp_active
         # which GPU every rank is bound to (one process per GPU: the ranks must sit on DISTINCT devices - two ranks on one GPU would
         # halve the recurrences' CUs under each other and deadlock RCCL's intra-node transport)
         if args.dry:

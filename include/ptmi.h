@@ -515,7 +515,10 @@ int32_t ptmi_gemm_planes_plan(int32_t m, int32_t n, int32_t k, int32_t split_k);
  *   is non-zero - the semantics of torch's fused Adam -, when `finite` (device fp32 scalar or NULL, e.g. the sum of the
  *   step's losses) or norm[0] is not finite; applied (device fp32 scalar or NULL) receives 1 / 0 = applied / skipped.  segments = device int64 [nseg][3]: parameter pointer, first flat
  *   index, element count, ascending and dense over [0, n).  exp_avg / exp_avg_sq: flat fp32 [n].  The caller
- *   advances `step` (a device fp32 scalar) afterwards. */
+ *   advances `step` (a device fp32 scalar) afterwards.
+ *   hyper (device doubles [6] = lr, beta1, beta2, eps, weight_decay, max_norm; 8-byte aligned; or NULL): when given, the kernel reads
+ *   the hyper-parameters from these words INSTEAD of the by-value arguments - a step replayed from a hipGraph has its kernel
+ *   arguments frozen, and padertorch's hooks rewrite param_group['lr'] between iterations (padertorch/train/hooks.py:736,1029). */
 /* ptmi_lstm_bias_grad_add: bias_ih_grad[d][i] += db[d][i] and bias_hh_grad[d][i] += db[d][i] for every direction d (HOST arrays of
  * ndir device pointers; db [ndir][n] = the bias gradient the persistent backward recurrence leaves in its scratch): torch.nn.LSTM
  * keeps two bias vectors per direction (pit/model.py:60-66) that receive the same gradient - one launch instead of 2 ndir. */
@@ -525,8 +528,8 @@ int64_t ptmi_grad_norm_workspace_elems(void);
 int ptmi_grad_norm(const float* flat, int64_t n, double* workspace, float* norm_out, ptmi_stream_t stream);
 int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const int64_t* segments, int32_t nseg, int64_t n,
                    const float* norm, float max_norm, const float* found_inf, const float* finite, float* applied,
-                   const float* step, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t zero_grad,
-                   ptmi_stream_t stream);
+                   const float* step, double lr, double beta1, double beta2, double eps, double weight_decay, const double* hyper,
+                   int32_t zero_grad, ptmi_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Data parallelism: the gradient exchange of padertorch/train/trainer.py:396-442 (parallel_apply over the devices of ONE

@@ -118,7 +118,7 @@ SIGNATURES = {
     'ptmi_grad_norm_workspace_elems': (c_int64, []),
     'ptmi_grad_norm': (c_int32, [_P, c_int64, _P, _P, _P]),
     'ptmi_adam_flat': (c_int32, [_P, _P, _P, _P, c_int32, c_int64, _P, c_float, _P, _P, _P, _P, c_double, c_double, c_double,
-                                 c_double, c_double, c_int32, _P]),
+                                 c_double, c_double, _P, c_int32, _P]),
 }
 
 _lib = None

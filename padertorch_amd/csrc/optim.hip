@@ -32,7 +32,11 @@ struct AdamArgs {
     float* applied;          // device scalar out: 1 when the update was applied, 0 when it was skipped, or NULL
     const float* step;       // device scalar: optimizer steps taken so far (this one is step + 1)
     double lr, beta1, beta2;  // bias corrections and lr / bc1 are evaluated in double, as torch does on the host
-    float beta2f, omb1, omb2, eps, weight_decay;      // float(beta2), float(1 - beta1), float(1 - beta2)
+    double eps, weight_decay;
+    // device doubles [6] = lr, beta1, beta2, eps, weight_decay, max_norm, or NULL.  When set they REPLACE the by-value arguments: a captured
+    // step (hipGraph) freezes kernel arguments, and the reference changes exactly these between iterations (hooks.py:736,1029:
+    // BackOffValidationHook / LRAnnealingHook write param_group['lr']) - a replay reads the words its owner rewrote instead
+    const double* hyper;
     int zero_grad;
 };
 
@@ -86,15 +90,16 @@ typedef __attribute__((address_space(1))) f32x4v gf32x4;
 
 struct AdamConsts {
     float clip, step_size, bc2_sqrt;
+    float beta2f, omb1, omb2, eps, weight_decay;      // float(beta2), float(1 - beta1), float(1 - beta2)
     bool skip;
 };
 
-__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, const AdamArgs& A, const AdamConsts& C) {
+__device__ __forceinline__ void adam_one(float& p, float& g, float& m, float& v, const AdamConsts& C) {
     float gg = g * C.clip;
-    if (A.weight_decay != 0.f) gg = fmaf(A.weight_decay, p, gg);
-    m = m + A.omb1 * (gg - m);                                          // torch: exp_avg.lerp_(grad, 1 - beta1)
-    v = A.beta2f * v + A.omb2 * gg * gg;
-    const float denom = sqrtf(v) / C.bc2_sqrt + A.eps;
+    if (C.weight_decay != 0.f) gg = fmaf(C.weight_decay, p, gg);
+    m = m + C.omb1 * (gg - m);                                          // torch: exp_avg.lerp_(grad, 1 - beta1)
+    v = C.beta2f * v + C.omb2 * gg * gg;
+    const float denom = sqrtf(v) / C.bc2_sqrt + C.eps;
     p -= C.step_size * (m / denom);
 }
 
@@ -110,12 +115,23 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
         c.skip = (A.found_inf != nullptr && A.found_inf[0] != 0.f) || (A.finite != nullptr && !isfinite(A.finite[0])) ||
                  (A.norm != nullptr && !isfinite(A.norm[0]));
         if (blockIdx.x == 0 && A.applied != nullptr) A.applied[0] = c.skip ? 0.f : 1.f;
+        double lr = A.lr, beta1 = A.beta1, beta2 = A.beta2, eps = A.eps, wd = A.weight_decay;
+        float max_norm = A.max_norm;
+        if (A.hyper != nullptr) {
+            lr = A.hyper[0]; beta1 = A.hyper[1]; beta2 = A.hyper[2]; eps = A.hyper[3]; wd = A.hyper[4];
+            max_norm = (float)A.hyper[5];
+        }
         const double t = (double)A.step[0] + 1.0;
-        const double bc1 = 1.0 - pow(A.beta1, t), bc2 = 1.0 - pow(A.beta2, t);
-        c.step_size = (float)(A.lr / bc1);
+        const double bc1 = 1.0 - pow(beta1, t), bc2 = 1.0 - pow(beta2, t);
+        c.step_size = (float)(lr / bc1);
         c.bc2_sqrt = (float)sqrt(bc2);
+        c.beta2f = (float)beta2;
+        c.omb1 = (float)(1.0 - beta1);
+        c.omb2 = (float)(1.0 - beta2);
+        c.eps = (float)eps;
+        c.weight_decay = (float)wd;
         c.clip = 1.f;
-        if (A.norm != nullptr) c.clip = fminf(A.max_norm / (A.norm[0] + 1e-6f), 1.f);
+        if (A.norm != nullptr) c.clip = fminf(max_norm / (A.norm[0] + 1e-6f), 1.f);
         consts = c;
     }
     __syncthreads();
@@ -146,10 +162,10 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
                 } else {
                     p = float4{pp[0], pp[1], pp[2], pp[3]};
                 }
-                adam_one(p.x, g.x, m.x, v.x, A, C);
-                adam_one(p.y, g.y, m.y, v.y, A, C);
-                adam_one(p.z, g.z, m.z, v.z, A, C);
-                adam_one(p.w, g.w, m.w, v.w, A, C);
+                adam_one(p.x, g.x, m.x, v.x, C);
+                adam_one(p.y, g.y, m.y, v.y, C);
+                adam_one(p.z, g.z, m.z, v.z, C);
+                adam_one(p.w, g.w, m.w, v.w, C);
                 if (al) *reinterpret_cast<gf32x4*>(pp) = f32x4v{p.x, p.y, p.z, p.w};
                 else { pp[0] = p.x; pp[1] = p.y; pp[2] = p.z; pp[3] = p.w; }
                 *reinterpret_cast<float4*>(A.m + i0) = m;
@@ -164,7 +180,7 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(const AdamArgs A) {
                 if (!C.skip) {
                     gfloat* pp = reinterpret_cast<gfloat*>(static_cast<unsigned long long>(A.segs[3 * s])) + (i - seg_off[s]);
                     float p = *pp, g = A.grad[i], m = A.m[i], v = A.v[i];
-                    adam_one(p, g, m, v, A, C);
+                    adam_one(p, g, m, v, C);
                     *pp = p;
                     A.m[i] = m;
                     A.v[i] = v;
@@ -230,16 +246,17 @@ int ptmi_grad_norm(const float* flat, int64_t n, double* workspace, float* norm_
 
 int ptmi_adam_flat(float* flat_grad, float* exp_avg, float* exp_avg_sq, const int64_t* segments, int32_t nseg, int64_t n,
                    const float* norm, float max_norm, const float* found_inf, const float* finite, float* applied, const float* step,
-                   double lr, double beta1, double beta2, double eps, double weight_decay, int32_t zero_grad, ptmi_stream_t stream) {
+                   double lr, double beta1, double beta2, double eps, double weight_decay, const double* hyper, int32_t zero_grad,
+                   ptmi_stream_t stream) {
     PTMI_RETURN_IF(flat_grad == nullptr || exp_avg == nullptr || exp_avg_sq == nullptr || segments == nullptr || step == nullptr,
                    PTMI_E_INVALID);
     PTMI_RETURN_IF(nseg < 1 || n < 1, PTMI_E_INVALID);
     PTMI_RETURN_IF(nseg > kMaxSegs, PTMI_E_UNSUPPORTED);
     PTMI_RETURN_IF(((reinterpret_cast<uintptr_t>(flat_grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                      reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) != 0, PTMI_E_INVALID);
+    PTMI_RETURN_IF((reinterpret_cast<uintptr_t>(hyper) & 7) != 0, PTMI_E_INVALID);
     AdamArgs A{flat_grad, exp_avg, exp_avg_sq, reinterpret_cast<const long long*>(segments), nseg, (long long)n, norm, max_norm,
-               found_inf, finite, applied, step, lr, beta1, beta2, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-               (float)weight_decay, zero_grad};
+               found_inf, finite, applied, step, lr, beta1, beta2, eps, weight_decay, hyper, zero_grad};
     const long long n4 = (n + 3) >> 2;
     const long long blocks = (n4 + 255) / 256;
     const int grid = (int)(blocks < 8192 ? blocks : 8192);                // 32 workgroups per CU, grid-stride beyond

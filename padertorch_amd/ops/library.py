@@ -292,16 +292,19 @@ def grad_norm(flat):
 
 @_register('adam_flat_(Tensor(a!) flat_grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, Tensor segments, Tensor(d!)[] params, '
            'Tensor? norm, float max_norm, Tensor? found_inf, Tensor? finite, Tensor step, float lr, float beta1, float beta2, '
-           'float eps, float weight_decay, bool zero_grad) -> Tensor')
+           'float eps, float weight_decay, bool zero_grad, Tensor? hyper=None) -> Tensor')
 def adam_flat_(flat_grad, exp_avg, exp_avg_sq, segments, params, norm, max_norm, found_inf, finite, step, lr, beta1, beta2, eps,
-               weight_decay, zero_grad):
+               weight_decay, zero_grad, hyper=None):
     # `params` are the tensors the segment table points into (listed so that the dispatcher sees what is written);
     # returns the 0-dim fp32 "applied" flag (0: the update was skipped)
+    # `hyper`: device fp64 [6] (lr, beta1, beta2, eps, weight_decay, max_norm) that the kernel reads INSTEAD of the float arguments
+    if hyper is not None:
+        assert hyper.dtype == torch.float64 and hyper.numel() >= 6 and hyper.device == flat_grad.device and hyper.is_contiguous(), hyper
     applied = torch.empty((), dtype=torch.float32, device=flat_grad.device)
     _lib.check(_lib.timed('adam_flat', _lib.load().ptmi_adam_flat, flat_grad.data_ptr(), exp_avg.data_ptr(),
                           exp_avg_sq.data_ptr(), segments.data_ptr(), segments.shape[0], flat_grad.numel(), _lib.ptr(norm),
                           max_norm, _lib.ptr(found_inf), _lib.ptr(finite), applied.data_ptr(), step.data_ptr(), lr, beta1, beta2,
-                          eps, weight_decay, int(zero_grad), _lib.stream(flat_grad.device)), 'ptmi_adam_flat')
+                          eps, weight_decay, _lib.ptr(hyper), int(zero_grad), _lib.stream(flat_grad.device)), 'ptmi_adam_flat')
     return applied
 
 

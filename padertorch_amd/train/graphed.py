@@ -13,8 +13,15 @@ raise in the iteration they belong to; the update itself is gated on the device 
 parameters untouched like the reference's raise in front of ``optimizer.step()``.
 
 What a capture needs from the ops is in ``ops.capture``.  Limits: fixed input shapes (a PackedSequence length pattern is part of the
-launch arguments - ragged batches of changing patterns stay on the eager path), one process group of one rank inside the graph (the
-data-parallel exchange stays outside: ``split_for_allreduce``), a constant learning rate (it is a kernel argument).
+launch arguments - ragged batches of changing patterns stay on the eager path) and one process group of one rank inside the graph (the
+data-parallel exchange stays outside: ``split_for_allreduce``).
+
+What the reference changes BETWEEN iterations is not frozen into the graph: the learning rate, betas, eps, weight decay and the clip
+value are device words the optimizer kernel reads (``Adam.refresh_device_hyper``; ``padertorch/train/hooks.py:736,1029`` rewrite
+``param_group['lr']``), the loss weights are device words the weighted sum multiplies with (``hooks.py:957-966`` rewrites
+``trainer.loss_weights``); every call compares the live values with what the device holds and copies on change.  A weight that moves
+between the categories {0, 1, other} changes the launches themselves (``trainer.py:608-620`` skips zero weights; a unit weight has no
+kernel here): the step is captured again.
 """
 import numpy as np
 import torch
@@ -25,9 +32,10 @@ __all__ = ['GraphedStep', 'signature']
 
 
 def signature(examples):
-    """What a captured step bakes in of its examples: structure, tensor shapes / dtypes / devices, and every python value (lengths,
+    """What a captured step bakes in of its examples: structure, tensor shapes / dtypes / devices, and every python NUMBER (lengths,
     frame counts: they become launch arguments).  Two lists of examples with equal signatures can share one graph; ``None`` when
-    an example holds a leaf this function does not know (the step then stays eager)."""
+    an example holds a leaf this function does not know (the step then stays eager).  Strings are metadata no kernel reads - the
+    reference's batches carry ``example_id`` (``pit/data.py:65``), unique per example - and stay out."""
     import numpy as np
     from ..ops.sequence.pack_module import PaddedList
     parts = []
@@ -47,7 +55,9 @@ def signature(examples):
             parts.append(('L', type(x).__name__, len(x)))
             for v in x:
                 walk(v)
-        elif x is None or isinstance(x, (bool, int, float, str)):
+        elif isinstance(x, str):
+            parts.append(('S',))
+        elif x is None or isinstance(x, (bool, int, float)):
             parts.append(('V', x))
         elif isinstance(x, np.generic):
             parts.append(('V', x.item()))
@@ -63,11 +73,35 @@ def signature(examples):
 class _StaticStage:
     """Pinned host words for the staged scalars of a captured step: the copy nodes of the graph write the same addresses at every replay."""
 
-    def __init__(self, words=1024):
+    def __init__(self, words=1024, device=None):
         self.f32 = torch.empty(words, dtype=torch.float32, pin_memory=True).fill_(float('nan'))
         self.i32 = torch.empty(words, dtype=torch.int32, pin_memory=True).fill_(torch.iinfo(torch.int32).min)
         self.used = {torch.float32: 0, torch.int32: 0}
         self.jobs = []          # [(what, host tensor(s), context, device value(s))] in the order the step staged them
+        # loss weights other than 0 and 1 as device words (Trainer._review_to_loss_and_summary multiplies with them while capturing)
+        self.lw_keys = []
+        self.lw_host = torch.zeros(64, dtype=torch.float32, pin_memory=True)
+        self.lw_dev = torch.zeros(64, dtype=torch.float32, device=device) if device is not None else None
+        self.lw_held = None
+
+    def loss_weight(self, key, weight):
+        """The device word of loss weight ``key`` (a 0-dim view), holding ``weight`` from now on."""
+        if key not in self.lw_keys:
+            assert len(self.lw_keys) < self.lw_host.numel(), 'too many weighted losses for a captured step'
+            self.lw_keys.append(key)
+        return self.lw_dev[self.lw_keys.index(key)]
+
+    def refresh_loss_weights(self, loss_weights):
+        """Live values of the weighted losses into the device words (a copy on the current stream when one changed)."""
+        if not self.lw_keys:
+            return
+        live = tuple(float(loss_weights[k]) for k in self.lw_keys)
+        if live != self.lw_held:
+            if self.lw_held is not None:
+                torch.cuda.current_stream(self.lw_dev.device).synchronize()      # (the last copy out of these pinned words has run)
+            self.lw_host[:len(live)] = torch.tensor(live, dtype=torch.float32)
+            self.lw_dev.copy_(self.lw_host, non_blocking=True)
+            self.lw_held = live
 
     def blank(self, shape, dtype):
         assert dtype in self.used, f'staged scalars are fp32 / int32 (got {dtype})'
@@ -97,10 +131,13 @@ class GraphedStep:
     with - and removed.)
     """
 
-    def __init__(self, trainer, examples, prepare=None, warmup=2):
+    def __init__(self, trainer, examples, prepare=None, warmup=2, clone_inputs=False):
         self.trainer = trainer
         self.prepare = prepare
-        self.examples = list(examples)
+        # ``clone_inputs``: the static inputs are COPIES of the examples' tensors.  Without it the caller's tensors become the static
+        # inputs and every later ``load`` overwrites them - fine for a loop that owns its buffers (bench.py), not for a dataset whose
+        # device-resident examples come round again in the next epoch (``Trainer.train`` clones)
+        self.examples = [self._clone(e) for e in examples] if clone_inputs else list(examples)
         self.device = trainer._flat.flat.device
         assert self.device.type == 'cuda', 'GraphedStep captures a hipGraph: the model has to live on an MI355X'
         for e in self.examples:
@@ -109,10 +146,28 @@ class GraphedStep:
         self._stage = None
         self._graph = None
         self._steps = 0
+        self._pattern = None
+        self.captures = 0
         self._eager(warmup)         # every lazily made table / stream / kernel attribute exists before the capture starts
         self._capture()
 
     # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _clone(example):
+        from ..ops.sequence.pack_module import PaddedList
+
+        def walk(x):
+            if torch.is_tensor(x):
+                return x.clone()
+            if isinstance(x, PaddedList) and x.intact():
+                return PaddedList(x.padded.clone(), x.lengths, x.batch_first, x.lengths_dev)
+            if isinstance(x, dict):
+                return type(x)((k, walk(v)) for k, v in x.items())
+            if isinstance(x, (list, tuple)):
+                return type(x)(walk(v) for v in x)
+            return x
+        return walk(example)
+
     @staticmethod
     def _tensors(example):
         """The device tensors of an example in a fixed order: the graph's static inputs (a ``PaddedList`` counts as its ONE padded buffer)."""
@@ -177,16 +232,30 @@ class GraphedStep:
             tr.deferred_checks = keep
         torch.cuda.synchronize(self.device)
 
+    def _weight_pattern(self):
+        """Which loss weights are 0 (term skipped), 1 (no kernel) or anything else (a device word): what the launches depend on."""
+        lw = self.trainer.loss_weights
+        if lw is None:
+            return None
+        return tuple((k, 0 if w == 0 else 1 if w == 1 else 2) for k, w in lw.items())
+
     def _capture(self):
         tr = self.trainer
         assert tr.world_size == 1 or tr._buckets is None, 'the data-parallel exchange is not captured: use split_for_allreduce'
         keep = tr.deferred_checks
         tr._check_pending(flush=True)
         tr.deferred_checks = True               # no host synchronisation inside the capture; this class does the checks
-        self._stage = tr._graph_stage = _StaticStage()
+        self._graph = None                      # (a re-capture lets the old graph - and its memory pool - go first)
+        self._stage = tr._graph_stage = _StaticStage(device=self.device)
+        opt = tr.optimizer
+        device_hyper = hasattr(opt, 'refresh_device_hyper') and getattr(opt, '_native_ok', lambda: False)()
+        if device_hyper:
+            opt.refresh_device_hyper(self.device)
+            opt.hyper_from_device = True
         graph = torch.cuda.CUDAGraph()
         running_summary = tr.train_summary
         tr.train_summary = type(running_summary)()      # (the capture's review entries point at the static words: not a step that ran)
+        opt_step = tr._opt_step
         try:
             with _capture.capture_mode():
                 with torch.cuda.graph(graph, capture_error_mode='thread_local'):
@@ -195,8 +264,33 @@ class GraphedStep:
             tr._graph_stage = None
             tr.deferred_checks = keep
             tr.train_summary = running_summary
+            tr._opt_step = opt_step             # the capture itself executed nothing: not an optimizer step
+            if device_hyper:
+                opt.hyper_from_device = False
         self._graph = graph
+        self._device_hyper = device_hyper
+        # what this graph has baked in of the hyper-parameters: where a value CANNOT be a device word (an optimizer off the native path)
+        # a change re-captures
+        self._baked = None if device_hyper else self._baked_hyper()
+        self._pattern = self._weight_pattern()
+        self.captures += 1
         # the capture itself executed nothing: parameters, moments, step counts and gradients are what the warm-up left
+
+    def _baked_hyper(self):
+        opt = getattr(self.trainer.optimizer, 'optimizer', None)
+        groups = getattr(opt, 'param_groups', None) or []
+        return (tuple(tuple(sorted((k, repr(v)) for k, v in g.items() if k != 'params')) for g in groups),
+                repr(getattr(self.trainer.optimizer, 'gradient_clipping', None)))
+
+    def _refresh(self):
+        """Bring everything a replay reads besides its examples up to date; capture again where a change alters the launches."""
+        tr = self.trainer
+        if self._weight_pattern() != self._pattern or (self._baked is not None and self._baked_hyper() != self._baked):
+            self._capture()
+        if self._device_hyper:
+            tr.optimizer.refresh_device_hyper(self.device)
+        if tr.loss_weights is not None:
+            self._stage.refresh_loss_weights(tr.loss_weights)
 
     # ------------------------------------------------------------------ the step
     def load(self, examples):
@@ -215,6 +309,7 @@ class GraphedStep:
         copied into the static inputs right behind this replay and in front of this step's synchronisation - a loop that knows its
         next batch (``data.DevicePrefetcher`` has it on the device already) then starts every step with the replay itself."""
         tr = self.trainer
+        self._refresh()
         if examples is not None and examples is not self.examples:
             self.load(examples)
         self._graph.replay()
@@ -222,6 +317,10 @@ class GraphedStep:
             self.load(then_load)
         tr._opt_step += 1
         self._steps += 1
+        # the replay rewrote the parameters through the graph's kernel nodes: nothing bumped their version counters, and the operand
+        # forms ops.gemm / ops.lstm cache per (version, pointer) for EAGER forwards between replays - a validation run, test_run, an
+        # eager step of another shape - would stay those of the first such forward
+        torch.autograd.graph.increment_version(tr._flat.params)
         # ONE synchronisation per optimizer step, behind everything the step consists of; the graph's own copy nodes have left the
         # step's scalars in the static pinned words
         torch.cuda.current_stream(self.device).synchronize()
@@ -246,11 +345,19 @@ class GraphedStep:
                             continue
                     if not torch.is_tensor(value):
                         scalars[key] = value
+                # python values of the capture's review that the run may have changed since: the live ones
+                lw = self.trainer.loss_weights
+                for key in list(scalars):
+                    if lw is not None and key.endswith('_loss_weight') and key[:-len('_loss_weight')] in lw:
+                        scalars[key] = lw[key[:-len('_loss_weight')]]
             elif what == 'grad_norm':
                 scalars['grad_norm'] = float(host[0][0])
                 for key, value in context.get('scalars', {}).items():
                     if not torch.is_tensor(value):
                         scalars[key] = value
+                groups = getattr(getattr(self.trainer.optimizer, 'optimizer', None), 'param_groups', None) or []
+                for i, group in enumerate(groups):
+                    scalars[f'lr/param_group_{i}'] = group['lr']
             self.trainer.train_summary.update({'scalars': scalars})
 
     def _summary(self):

@@ -136,6 +136,12 @@ class Adam(Optimizer):
         #: device scalar (e.g. the sum of the step's losses) whose NON-finiteness makes the next native step skip the update,
         #: next to a non-finite gradient norm; consumed by that step
         self.skip_if_not_finite = None
+        #: hyper-parameters as DEVICE words (fp64 [8]: lr, beta1, beta2, eps, weight_decay, gradient_clipping) for steps that are replayed
+        #: from a hipGraph (``train.graphed``): kernel arguments are frozen at capture, and the reference's hooks rewrite
+        #: ``param_group['lr']`` between iterations (``padertorch/train/hooks.py:736,1029``).  ``use_device_hyper`` switches the native step to
+        #: them, ``refresh_device_hyper`` copies the live values in whenever they differ from what the device holds.
+        self._hyper = None           # (pinned host fp64 [8], device fp64 [8], the python tuple the device holds)
+        self.hyper_from_device = False
 
     def set_parameters(self, parameters):
         self.parameters = tuple(parameters)
@@ -190,6 +196,30 @@ class Adam(Optimizer):
         self._bound = (m, v, steps, segs, keys, offs)
         return self._bound
 
+    # ---------------------------------------------------------------------------------- hyper-parameters on the device
+    def live_hyper(self):
+        """What the next step has to use, read from the places the reference's hooks write (``param_groups``, ``gradient_clipping``)."""
+        g = self.optimizer.param_groups[0]
+        return (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']),
+                float(self.gradient_clipping))
+
+    def refresh_device_hyper(self, device=None):
+        """Make the device words equal the live hyper-parameters (one 64-byte copy on the current stream when they changed, nothing
+        otherwise); returns the device tensor.  Stream-ordered: a replay enqueued behind this call reads the new values."""
+        live = self.live_hyper()
+        if self._hyper is None or (device is not None and self._hyper[1].device != torch.device(device)):
+            device = torch.device(device) if device is not None else self.flat_grads.flat.device
+            self._hyper = [torch.zeros(8, dtype=torch.float64, pin_memory=True), torch.zeros(8, dtype=torch.float64, device=device), None]
+        host, dev, held = self._hyper
+        if held != live:
+            if held is not None:
+                # (the previous copy may still be in flight from these pinned words: a changed value is rare - wait for it)
+                torch.cuda.current_stream(dev.device).synchronize()
+            host[:6] = torch.tensor(live, dtype=torch.float64)
+            dev.copy_(host, non_blocking=True)
+            self._hyper[2] = live
+        return dev
+
     def clip_grad(self):
         """Global-norm clipping (``optimizer.py:31-42``); returns the unclipped norm (0-dim tensor).  On the native path
         the scale ``min(1, clip / (norm + 1e-6))`` is applied to the gradients inside the next ``step()``."""
@@ -209,10 +239,13 @@ class Adam(Optimizer):
         finite, self.skip_if_not_finite = self.skip_if_not_finite, None
         if finite is not None:
             finite = finite.detach().reshape(1).float()
+        # (hyper_from_device: a step that is being captured / replayed - the kernel reads lr, betas, eps, weight decay and the clip value
+        #  from the device words; whoever replays refreshes them: GraphedStep.__call__)
+        hyper = self._hyper[1] if self.hyper_from_device else None
         applied = torch.ops.ptmi.adam_flat_(
             fg.flat, m, v, segs, list(fg.params), self._norm, float(self.gradient_clipping),
             None if found is None else found.reshape(1).float(), finite, steps, float(g['lr']), float(g['betas'][0]),
-            float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), bool(zero_grad))
+            float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), bool(zero_grad), hyper)
         # the kernel wrote the parameters through raw pointers: tell autograd (and everything that caches per parameter
         # version, e.g. the operand scales and stacked weights of ops.gemm / ops.lstm) that they changed
         torch.autograd.graph.increment_version(fg.params)

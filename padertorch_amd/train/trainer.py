@@ -205,6 +205,11 @@ class Trainer:
         self.graph_prepare = None
         self._graphs = {}            # signature -> GraphedStep (at most two: a graph owns the memory of a whole step)
         self._graph_seen = {}
+        self._graph_refused = set()  # signatures whose capture raised: eager from then on
+        self._graph_misses = 0
+        self.graph_capacity = 2
+        self.graph_eviction_cooldown = 32        # optimizer steps between two evictions
+        self._graph_evicted_at = -(1 << 30)
         #: this Trainer's switches / hooks of the in-place weight-gradient path, attached to every module of its model
         #: (ops.context): nothing process-global is set or reset around train()
         from ..ops import context as _context
@@ -367,7 +372,8 @@ class Trainer:
             try:
                 self._check_pending(flush=True)
             finally:
-                self._graphs, self._graph_seen = {}, {}
+                self._graphs, self._graph_seen, self._graph_refused = {}, {}, set()
+                self._graph_evicted_at = -(1 << 30)
                 self._close()
 
     def _graph_or_eager_step(self, group, device):
@@ -376,17 +382,43 @@ class Trainer:
         from .graphed import GraphedStep, signature
         examples = [self.model.example_to_device(e, device) for e in group]
         sig = signature(examples)
+        if sig in self._graph_refused:
+            sig = None
         graphed = self._graphs.get(sig) if sig is not None else None
-        if graphed is None and sig is not None and self._graph_seen.get(sig, 0) >= 1:
-            if len(self._graphs) >= 2:                  # a graph keeps a whole step's memory: the oldest one goes
-                self._graphs.pop(next(iter(self._graphs)))
-            graphed = self._graphs[sig] = GraphedStep(self, examples, prepare=self.graph_prepare, warmup=0)
         if graphed is not None:
+            self._graphs[sig] = self._graphs.pop(sig)       # (most recently used last)
+        room = len(self._graphs) < self.graph_capacity
+        if not room and self._opt_step - self._graph_evicted_at >= self.graph_eviction_cooldown:
+            # a graph keeps a whole step's memory: the least recently used one goes - at most once per cool-down: with more recurring
+            # shapes than graphs every step would otherwise evict one graph and capture another (a capture costs several eager
+            # steps); the shapes without a graph run eagerly meanwhile
+            room = 'evict'
+        if graphed is None and sig is not None and self._graph_seen.get(sig, 0) >= 1 and room:
+            if room == 'evict':
+                self._graphs.pop(next(iter(self._graphs)))
+                self._graph_evicted_at = self._opt_step
+            try:
+                graphed = self._graphs[sig] = GraphedStep(self, examples, prepare=self.graph_prepare, warmup=0, clone_inputs=True)
+            except Exception as e:      # noqa: a step that cannot be captured (an optimizer that synchronises, a host read in the model)
+                graphed = None
+                self._graph_refused.add(sig)
+                self._abandon_capture(device)
+                import warnings
+                warnings.warn(f'graph_steps: this step cannot be captured into a hipGraph ({type(e).__name__}: {e}); '
+                              'steps of this shape run eagerly')
+        if graphed is not None:
+            self._graph_misses = 0
             return graphed(examples)
         if sig is not None:
             if len(self._graph_seen) > 64:
                 self._graph_seen.clear()
             self._graph_seen[sig] = self._graph_seen.get(sig, 0) + 1
+        self._graph_misses += 1
+        if self._graph_misses == 50 and not self._graphs:
+            import warnings
+            warnings.warn('graph_steps: 50 optimizer steps without two examples of one signature (shapes, lengths, python numbers of the '
+                          'examples): every step runs eagerly.  Ragged batches need fixed shapes to share a graph: model.row_slots / '
+                          'padded buckets.')
         for example in examples:
             batch = self.graph_prepare(example) if self.graph_prepare is not None else example
             loss, _, _, review = self.train_step(self.model, batch, device)
@@ -396,6 +428,28 @@ class Trainer:
         summary = self.optimizer_step()
         self.train_summary.update(summary)
         return summary
+
+    def _abandon_capture(self, device):
+        """After a capture that raised: nothing of it has run, but the host-side queues of the step path still name its tensors and
+        events (weight-gradient closures waiting for their enqueue point, staged scalars, the device flag of the update gate)."""
+        from ..ops import capture as _capture, lstm as _lstm
+        del _lstm._PENDING_WGRAD[:]
+        self._stage_queue = []
+        self._graph_stage = None
+        self._loss_acc = None
+        if self._buckets is not None:
+            self._buckets.reset()
+        opt = self.optimizer
+        if getattr(opt, 'skip_if_not_finite', None) is not None:
+            opt.skip_if_not_finite = None
+        if hasattr(opt, '_norm'):
+            opt._norm = None
+        if hasattr(opt, 'hyper_from_device'):
+            opt.hyper_from_device = False
+        _capture.ACTIVE = False
+        _capture.reset_step_caches()
+        torch.cuda.synchronize(device)
+        # (gradients: the capture executed nothing - the bucket is what the last zero_grad left)
 
     # ------------------------------------------------------------------ hooks (fixed set)
     def _pre_step(self):
@@ -471,7 +525,7 @@ class Trainer:
         With W > 1 the flat gradient bucket is summed over all ranks first (one collective)."""
         from ..ops import lstm as _lstm
         _lstm.sync_deferred()          # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
-        if self._dp_active() and not getattr(self, '_skip_allreduce', False):      # (_skip_allreduce: bench.py's local-step measurement)
+        if self._dp_active():
             t0 = time.perf_counter()
             if self._buckets is not None:
                 self._buckets.finish()             # buckets not yet issued + wait for all of them
@@ -573,6 +627,9 @@ class Trainer:
             self._time('time_per_review', t0)
             return loss, example, model_out, summary
         except Exception:
+            from ..ops import capture as _capture
+            if _capture.ACTIVE:
+                raise       # inside a stream capture a state dump (device-to-host copies) would fail itself and mask this error
             data = {'state_dict': self.state_dict(), 'example': example}
             if 'model_out' in locals():
                 data['model_out'] = model_out
@@ -605,7 +662,12 @@ class Trainer:
                 weight = loss_weights[key] if loss_weights is not None else 1.
                 if weight != 0:
                     # 0. + 1 * value == value bit for bit: no kernels (forward or backward) for the trivial factors
-                    term = value if weight == 1 else weight * value
+                    if weight != 1 and self._graph_stage is not None:
+                        # a captured step (train.graphed): the factor is a DEVICE word the replaying loop rewrites when
+                        # trainer.loss_weights changes (hooks.py:957-966) - the same fp32 product as `weight * value`
+                        term = self._graph_stage.loss_weight(key, weight) * value
+                    else:
+                        term = value if weight == 1 else weight * value
                     loss = term if (isinstance(loss, float) and loss == 0.) else loss + term
                 review['scalars'][f'{key}_loss_weight'] = weight
             keys = list(losses)

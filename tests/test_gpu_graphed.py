@@ -165,3 +165,198 @@ def test_trainer_graph_prepare_captures_the_feature_front_end(tmp_path):
     assert ta.iteration == tb.iteration == 6 and len(tb._graphs) == 0          # (train() lets its graphs go at the end)
     for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
         np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
+
+
+def _manual(path, units=48, lw=None, **kw):
+    import padertorch_amd as pt
+    from padertorch_amd.ops import lstm as _lstm
+    m = _pit(units=units)
+    t = pt.Trainer(m, path, pt.optimizer.Adam(gradient_clipping=1.), loss_weights=dict(lw or LW), deferred_checks=True, **kw)
+    t.to(torch.device(DEV))
+    t._flat = t.optimizer.use_flat_grads()
+    t.op_context.defer_wgrad = True
+    _lstm.warm_side_stream(torch.device(DEV))
+    m.train()
+    return m, t
+
+
+def _eager_step(m, t, ex):
+    loss, _, _, _ = t.train_step(m, ex, DEV)
+    loss.backward()
+    t.optimizer_step()
+
+
+def test_replays_read_the_live_hyper_parameters_and_loss_weights(tmp_path):
+    """What the reference's hooks change BETWEEN iterations reaches a replayed step: ``param_group['lr'] *= 0.5``
+    (BackOffValidationHook / LRAnnealingHook, ``hooks.py:736,1029``), the clip value, betas / eps / weight decay (device words of the
+    optimizer kernel), ``trainer.loss_weights`` (LossWeightAnnealingHook, ``hooks.py:957-966``: device words of the weighted sum; a
+    weight crossing 0 or 1 changes the launches -> the step is captured again).  Parameters equal those of the eager loop under the
+    same schedule; the summary reports the live learning rate and weights."""
+    from padertorch_amd.train.graphed import GraphedStep
+    exs = _examples(9, B=6)
+    lw0 = dict(pit_ips_loss=1., pit_mse_loss=0.)
+    (ma, ta), (mb, tb) = _manual(tmp_path / 'a', lw=lw0), _manual(tmp_path / 'b', lw=lw0)
+
+    def schedule(t, i):
+        g = t.optimizer.optimizer.param_groups[0]
+        if i == 2:
+            g['lr'] *= 0.5
+        if i == 3:
+            t.loss_weights['pit_ips_loss'] = 0.5                 # 1 -> other: new launches (a multiply and its backward)
+            t.loss_weights['pit_mse_loss'] = 0.25                # 0 -> other: a new term
+        if i == 4:
+            t.loss_weights['pit_mse_loss'] = 0.125               # other -> other: a device word only
+            t.optimizer.gradient_clipping = 0.05
+        if i == 5:
+            g['betas'] = (0.8, 0.99)
+            g['eps'] = 1e-6
+            g['weight_decay'] = 0.01
+        if i == 6:
+            t.loss_weights['pit_mse_loss'] = 0.                  # back to one term
+            t.loss_weights['pit_ips_loss'] = 1.
+    for i, ex in enumerate(exs):
+        schedule(ta, i)
+        _eager_step(ma, ta, ex)
+    ta._check_pending(flush=True)
+    _eager_step(mb, tb, exs[0])
+    tb._check_pending(flush=True)
+    step = GraphedStep(tb, [exs[1]], warmup=0)
+    tb.train_summary.reset()
+    captures = []
+    for i, ex in enumerate(exs[1:], 1):
+        schedule(tb, i)
+        step([ex])
+        captures.append(step.captures)
+    assert captures == [1, 1, 2, 2, 2, 3, 3, 3], captures
+    for (k, v), (_, w) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
+    sc = tb.train_summary.data['scalars']
+    assert sc['lr/param_group_0'] == [1e-3] + [5e-4] * 7, sc['lr/param_group_0']
+    assert sc['pit_mse_loss_loss_weight'] == [0., 0., 0.25, 0.125, 0.125, 0., 0., 0.], sc['pit_mse_loss_loss_weight']
+
+
+def test_eager_forwards_between_replays_see_the_replayed_parameters(tmp_path):
+    """a replay rewrites the parameters through the graph's kernel nodes; the operand forms ``ops.gemm`` / ``ops.lstm``
+    cache per parameter version for eager forwards (a validation run between two iterations, ``trainer.py:467-510``) must not stay those
+    of the first such forward."""
+    from padertorch_amd.train.graphed import GraphedStep
+    exs = _examples(6, B=6)
+    (ma, ta), (mb, tb) = _manual(tmp_path / 'a'), _manual(tmp_path / 'b')
+
+    def validate(m):
+        m.eval()
+        try:
+            with torch.no_grad():
+                return [x.detach().clone() for x in m(exs[5])]
+        finally:
+            m.train()
+    for ex in exs[:5]:
+        _eager_step(ma, ta, ex)
+    ta._check_pending(flush=True)
+    want = validate(ma)
+    _eager_step(mb, tb, exs[0])
+    tb._check_pending(flush=True)
+    step = GraphedStep(tb, [exs[1]], warmup=0)
+    first = validate(mb)                          # fills the caches at the parameters' current versions
+    for ex in exs[1:5]:
+        step([ex])
+    got = validate(mb)
+    assert max(float((a - b).abs().max()) for a, b in zip(first, got)) > 1e-4         # (four steps did change the masks)
+    for a, b in zip(want, got):
+        torch.testing.assert_close(b, a, atol=1e-6, rtol=0)
+    # ... and through the Trainer: validation at every second iteration of a graph_steps run equals the eager run's
+    import padertorch_amd as pt
+    records = []
+    for graph in (False, True):
+        m = _pit(units=48)
+        t = pt.Trainer(m, tmp_path / f'v{int(graph)}', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW,
+                       summary_trigger=(1, 'iteration'), checkpoint_trigger=(2, 'iteration'), stop_trigger=(6, 'iteration'),
+                       graph_steps=graph)
+        t.register_validation_hook(exs[4:6])
+        t.train(exs[:4] * 2, device=DEV)
+        records.append([s[2]['loss'] for s in t.summaries if s[1] == 'validation'])
+    assert len(records[0]) == len(records[1]) >= 3
+    np.testing.assert_allclose(records[1], records[0], rtol=1e-5)
+    assert len(set(records[1])) == len(records[1]), records[1]
+
+
+def test_signature_ignores_strings_and_trainer_reuses_the_graph(tmp_path):
+    """the reference's batches carry a unique ``example_id`` per example (``pit/data.py:65``); a string is nothing a kernel
+    reads, so it is no part of the signature - ``graph_steps=True`` captures once and replays."""
+    import padertorch_amd as pt
+    from padertorch_amd.train import graphed as G
+    from padertorch_amd.train.graphed import signature
+    exs = [dict(e, example_id=[f'utt{i}_{b}' for b in range(4)], dataset=f'train{i}') for i, e in enumerate(_examples(6))]
+    assert signature([exs[0]]) == signature([exs[1]]) is not None
+    made = []
+    plain = G.GraphedStep.__init__
+
+    def counting(self, *a, **kw):
+        made.append(1)
+        return plain(self, *a, **kw)
+    G.GraphedStep.__init__ = counting
+    try:
+        t = _train(_pit(), exs, tmp_path, 6, vmb=1, graph_steps=True)
+    finally:
+        G.GraphedStep.__init__ = plain
+    assert t.iteration == 6 and len(made) == 1, made
+
+
+def test_trainer_runs_eagerly_when_a_step_cannot_be_captured(tmp_path):
+    """a step whose capture raises (here: SGD, whose gradient-norm check reads the norm on the host - a synchronisation
+    inside the capture) falls back to the eager step with a warning instead of ending ``train()``; same parameters as without
+    ``graph_steps``, and the shape is not tried again."""
+    import padertorch_amd as pt
+    from padertorch_amd.train import graphed as G
+    exs = _examples(5)
+    out = []
+    made = []
+    plain = G.GraphedStep.__init__
+
+    def counting(self, *a, **kw):
+        made.append(1)
+        return plain(self, *a, **kw)
+    G.GraphedStep.__init__ = counting
+    try:
+        for graph in (False, True):
+            m = _pit()
+            t = pt.Trainer(m, tmp_path / str(graph), pt.optimizer.SGD(gradient_clipping=1., lr=0.05), loss_weights=LW,
+                           summary_trigger=(1, 'iteration'), checkpoint_trigger=(1000, 'iteration'), stop_trigger=(5, 'iteration'),
+                           graph_steps=graph)
+            if graph:
+                with pytest.warns(UserWarning, match='cannot be captured'):
+                    t.train(exs, device=DEV)
+            else:
+                t.train(exs, device=DEV)
+            assert t.iteration == 5
+            out.append({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    finally:
+        G.GraphedStep.__init__ = plain
+    assert len(made) == 1, made
+    for k in out[0]:
+        np.testing.assert_allclose(out[1][k].numpy(), out[0][k].numpy(), rtol=0, atol=1e-6, err_msg=k)
+
+
+def test_three_recurring_shapes_do_not_capture_every_step(tmp_path):
+    """with more recurring shapes than graphs kept (two: a graph owns a whole step's memory) an eviction must not
+    be followed by a capture at the evicted shape's next sighting - capturing costs several eager steps."""
+    from padertorch_amd.train import graphed as G
+    shapes = [_examples(8, N=n, seed=n) for n in (6000, 6400, 6800)]
+    exs = [shapes[i % 3][i // 3] for i in range(24)]
+    made = []
+    plain = G.GraphedStep.__init__
+
+    def counting(self, *a, **kw):
+        made.append(1)
+        return plain(self, *a, **kw)
+    G.GraphedStep.__init__ = counting
+    try:
+        a, b = _pit(), _pit()
+        ta = _train(a, exs, tmp_path / 'a', 24, vmb=1)
+        tb = _train(b, exs, tmp_path / 'b', 24, vmb=1, graph_steps=True)
+    finally:
+        G.GraphedStep.__init__ = plain
+    assert ta.iteration == tb.iteration == 24
+    assert 2 <= len(made) <= 3, made
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
