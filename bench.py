@@ -97,6 +97,10 @@ def parse_args(argv=None):
                     help="SURVEY 8d's training distribution: example lengths ~ U[3 s, 6 s] (sorted, zero-padded waveforms) instead of "
                          'the fixed 4 s of the headline; a reported mode (no roofline entry)')
     ap.add_argument('--no-overlap-allreduce', action='store_true', help='one all-reduce of the flat buffer in optimizer_step')
+    ap.add_argument('--dp-graph', action='store_true',
+                    help='N = 1: run under a process group of ONE rank (RCCL) and time the captured DATA-PARALLEL step (two graphs with the '
+                         "'flat+words' exchange between them: train.graphed split_for_allreduce) - what N > 1 probes as schedule graph_split")
+    ap.add_argument('--no-graph-split', action='store_true', help='N > 1: do not probe the captured data-parallel step')
     ap.add_argument('--row-slots', action='store_true',
                     help='with --ragged: 2 x batch examples end to end in `batch` row slots (model.row_slots), the timed step itself '
                          '(the default line reports the same as value_ragged_row_slots)')
@@ -386,6 +390,9 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
 
 def main():
     args = parse_args()
+    if args.dp_graph:
+        assert args.gpus == 1, '--dp-graph: the one-rank process group of a single-GPU run (N > 1 probes the same step as schedule graph_split)'
+        args.no_extras = True
     if os.environ.get('PTMI_BENCH_TRACE'):
         import faulthandler
         faulthandler.dump_traceback_later(40, repeat=True, file=sys.stderr)
@@ -417,6 +424,12 @@ def main():
             dist.init_process_group(backend)
         else:
             dist.init_process_group(backend, device_id=device)
+    elif args.dp_graph and not args.dry:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        dist.init_process_group(backend, init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=device)
 
     import padertorch_amd as pt
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
@@ -601,9 +614,58 @@ def main():
     # use the faster one, and a watchdog timeout in the overlapped schedule - during the probe or the timed steps - falls back to
     # the un-overlapped one instead of ending the run.  Every decision is taken on all-reduced values: all ranks agree.
     schedule = None
+    graph_state = {}
+
+    def graph_split_step():
+        """The captured data-parallel step: graph A (forward + backward of every micro-step), the 'flat+words' exchange as two RCCL
+        calls, graph B (norm + clip + Adam) - train.graphed.GraphedStep with a process group."""
+        from padertorch_amd.train.graphed import GraphedStep
+        set_overlap(False)
+        trainer.dp_protocol = 'flat+words'
+        trainer._check_pending(flush=True)
+        if graph_state.get('step') is None:
+            graph_state['step'] = GraphedStep(trainer, [data] * micro, prepare=features, warmup=0)
+        return graph_state['step']
+
+    def graph_loop(nsteps):
+        graphed = graph_state['step']
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            graphed()
+        sync()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed
+
     if world > 1:
         probe = 3 if args.dry else max(3, min(10, args.steps))
         schedule = dict(probe_steps=probe, probe_ms_per_step={}, notes=[])
+        if not args.dry and not args.no_graph_split and not args.eager and not args.ragged and not args.sync_checks:
+            # every rank takes the same branch: the capture either works everywhere or raises everywhere (same code, same shapes); a
+            # rank-local failure is agreed on through an all-reduce before anybody enters the timed collectives
+            ok = 1.
+            try:
+                for _ in range(2):
+                    step(False)
+                trainer._check_pending(flush=True)
+                graph_split_step()
+                for _ in range(2):
+                    graph_state['step']()
+            except Exception as e:      # noqa
+                ok = 0.
+                schedule['notes'].append(f'graph_split: capture failed on rank {rank}: {type(e).__name__}: {e}')
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 1.:
+                schedule['probe_ms_per_step']['graph_split'] = graph_loop(probe) / probe * 1e3
+            else:
+                schedule['probe_ms_per_step']['graph_split'] = None
+                graph_state['step'] = None
+            trainer.dp_protocol = None
         for flag in ([False] if args.no_overlap_allreduce else [True, False]):
             name = 'overlap' if flag else 'no_overlap'
             set_overlap(flag)
@@ -622,11 +684,26 @@ def main():
             raise RuntimeError(f'bench.py: every all-reduce schedule timed out: {schedule}')
         schedule['used'] = 'overlap' if (args.dry and 'overlap' in ok) else min(ok, key=ok.get)      # (dry: stub timings mean nothing)
         set_overlap(schedule['used'] == 'overlap')
+        if schedule['used'] == 'graph_split':
+            graph_split_step()
 
     use_graph = bool(world == 1 and not args.dry and not args.eager and not args.ragged and not args.sync_checks)
-    graph_state = {}
+    use_graph_split = bool(schedule is not None and schedule.get('used') == 'graph_split')
 
     def measure():
+        if use_graph_split:
+            graphed = graph_state['step']
+            for _ in range(args.warmup):
+                graphed()
+            graphed.times = []                 # GPU time of graph A / the exchange / graph B per step, HIP events on the step's stream
+            elapsed_graph = graph_loop(args.steps)
+            graphed.times, graph_state['times'] = None, graphed.times
+            # per-kernel HIP events: an eager pass of the same step (same protocol) behind the timed region, as for N = 1
+            ev_steps = max(TIMER_EVERY, min(args.steps, 10 * TIMER_EVERY))
+            for _ in range(2):
+                step(False)
+            graph_state['eager_deferred_ms'] = timed_loop(ev_steps, timed=True) / ev_steps * 1e3
+            return elapsed_graph
         for _ in range(args.warmup):
             step(False)
         if not use_graph:
@@ -634,15 +711,28 @@ def main():
         # N = 1: the optimizer step as ONE captured hipGraph, checks at the end of the same step (reference semantics)
         from padertorch_amd.train.graphed import GraphedStep
         trainer._check_pending(flush=True)
+        if args.dp_graph:
+            trainer.dp_protocol = 'flat+words'
+            for h in state['hooks']:
+                h.remove()
+            state['hooks'], trainer._buckets = [], None
+            trainer.op_context.grad_ready_hook = trainer.op_context.grad_use_hook = None
         graphed = graph_state['step'] = GraphedStep(trainer, [data] * micro, prepare=features, warmup=0)
+        if args.dp_graph:
+            assert graphed.split
+            graphed.times = []
         for _ in range(3):
             graphed()
+        if args.dp_graph:
+            graphed.times = []
         sync()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             graphed()
         sync()
         elapsed_graph = time.perf_counter() - t0
+        if args.dp_graph:
+            graphed.times, graph_state['times'] = None, graphed.times
         # per-kernel HIP events cannot be recorded inside a replay: the same launches are bracketed in an eager pass of the same step
         # behind the timed region (rocprofv3's summary of this command sees the replays' kernels themselves: profiles/)
         ev_steps = max(TIMER_EVERY, min(args.steps, 10 * TIMER_EVERY))
@@ -862,6 +952,27 @@ def main():
                     bus_bandwidth_gbs=2. * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9,
                     time_per_all_reduce_host_ms=trainer.timer.get('time_per_all_reduce', 0.) / max(1, trainer._opt_step) * 1e3)
 
+    # where a rank's step time goes: wall-clock per step beside the GPU time of its parts - a first multi-GPU record
+    # then separates the cost of the wire (exchange_ms: both collectives, on the step's stream) from the host's
+    def part_times():
+        times = graph_state.get('times') or []
+        if not times:
+            return None
+        n = len(times)
+        return dict(graph_a_ms=sum(t[0] for t in times) / n, exchange_ms=sum(t[1] for t in times) / n,
+                    graph_b_ms=sum(t[2] for t in times) / n, steps=n)
+    mine = dict(rank=rank, wall_ms_per_step=elapsed / args.steps * 1e3, gpu_parts=part_times(),
+                host_ms_in_all_reduce_calls_per_step=trainer.timer.get('time_per_all_reduce', 0.) / max(1, trainer._opt_step) * 1e3)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    if rccl is not None:
+        rccl['per_rank'] = per_rank
+    elif args.dp_graph and not args.dry:
+        rccl = dict(world_size=1, backend=backend, schedule=dict(used='graph_split'), per_rank=per_rank,
+                    note='one-rank process group on one GPU: everything of the captured data-parallel step but the wire')
+
     if rank == 0:
         out = {
             'metric': 'training frames/sec (PIT mask-est, 2-spk 8 kHz)' if args.config == 'c2' else
@@ -892,9 +1003,13 @@ def main():
                           'backward recurrence hands on'),
                 'host_checks': ('same step (2 syncs)' if args.sync_checks else
                                 'end of the SAME optimizer step (one host synchronisation per step behind the captured step; errors raise in the '
-                                'iteration they belong to, optimizer update gated on the device): train.graphed.GraphedStep' if use_graph else
+                                'iteration they belong to, optimizer update gated on the device): train.graphed.GraphedStep'
+                                if (use_graph or use_graph_split) else
                                 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)'),
-                'step_driver': 'one hipGraph per optimizer step (train.graphed.GraphedStep), replayed' if use_graph else 'eager launches (python)',
+                'step_driver': ("two hipGraphs per optimizer step with the data-parallel exchange between them (train.graphed.GraphedStep, "
+                                "split_for_allreduce: forward + backward | all_reduce(flat bucket), all_reduce(2 words) | norm + clip + Adam)"
+                                if (use_graph_split or args.dp_graph) else
+                                'one hipGraph per optimizer step (train.graphed.GraphedStep), replayed' if use_graph else 'eager launches (python)'),
                 'optimizer': 'csrc/optim.hip: reproducible 2-norm + fused clip / Adam / zero_grad over the flat bucket',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',
             },
@@ -911,7 +1026,7 @@ def main():
             out['kernel_event_steps'] = counted[1]
             out['kernel_event_source'] = ('HIP events around the same launches in an eager pass of the same step behind the timed region (a graph '
                                           'replay takes no event records between its nodes); rocprofv3 --kernel-trace of this command times the '
-                                          "replays' kernels themselves (profiles/r5_kernel_trace_bench.txt)") if use_graph else 'HIP events inside the timed steps'
+                                          "replays' kernels themselves (profiles/r6_kernel_trace_bench.txt)") if (use_graph or use_graph_split) else 'HIP events inside the timed steps'
             out['event_bracket_overhead_us'] = overhead * 1e3
             # `roofline`: the ONE kernel with the most GPU time per step - what leads rocprofv3's summary of this command
             # (profiles/r4_kernel_trace_bench.txt); `roofline_family`: all planes GEMM launches together (round 3's headline entry)

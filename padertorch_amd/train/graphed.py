@@ -13,8 +13,16 @@ raise in the iteration they belong to; the update itself is gated on the device 
 parameters untouched like the reference's raise in front of ``optimizer.step()``.
 
 What a capture needs from the ops is in ``ops.capture``.  Limits: fixed input shapes (a PackedSequence length pattern is part of the
-launch arguments - ragged batches of changing patterns stay on the eager path) and one process group of one rank inside the graph (the
-data-parallel exchange stays outside: ``split_for_allreduce``).
+launch arguments - ragged batches of changing patterns stay on the eager path).
+
+Data parallel (``split_for_allreduce``): with a process group the step is TWO graphs - A: every micro-step's forward + backward and this
+rank's two words (sum of its losses, watchdog count); B: norm + clip + Adam + the staged copies - with the exchange between them as
+ordinary RCCL calls on the same stream (``Trainer._exchange``: all_reduce(SUM) of the flat gradient bucket, all_reduce(SUM) of the
+words; reference ``trainer.py:396-442``).  Nothing of RCCL is captured: a rank that replays and a rank that runs the same step eagerly
+(first sighting of a shape) issue the same two collectives, and the summed words give every rank the same update gate and the same
+errors in the same iteration.  The bucketed overlap of the eager loop is given up for it: a graph cannot hand a layer's gradients to
+a collective outside itself before it ends (cutting it at the bucket boundaries would serialise the weight-gradient queue against the
+recurrences at every cut - that costs more than the 0.3-1 ms of an un-overlapped 94 MB all-reduce at W = 8, ``DESIGN.md`` section 5).
 
 What the reference changes BETWEEN iterations is not frozen into the graph: the learning rate, betas, eps, weight decay and the clip
 value are device words the optimizer kernel reads (``Adam.refresh_device_hyper``; ``padertorch/train/hooks.py:736,1029`` rewrite
@@ -145,9 +153,17 @@ class GraphedStep:
         self._inputs = [self._tensors(e) for e in self.examples]
         self._stage = None
         self._graph = None
+        self._tail = None
+        self._words = None
         self._steps = 0
         self._pattern = None
         self.captures = 0
+        #: a process group is active: the step is TWO graphs with the data-parallel exchange between them (``split_for_allreduce``)
+        self.split = bool(trainer._dp_active())
+        if self.split:
+            assert trainer.dp_protocol == 'flat+words' and trainer._buckets is None, \
+                "a captured data-parallel step speaks the 'flat+words' protocol (Trainer.dp_protocol; Trainer.train sets it with graph_steps)"
+        self.times = None           # split steps: [(graph A, exchange, graph B) in ms of GPU time] of the calls made with record_times
         self._eager(warmup)         # every lazily made table / stream / kernel attribute exists before the capture starts
         self._capture()
 
@@ -207,8 +223,8 @@ class GraphedStep:
                     walk(v)
         walk(example)
 
-    def _one_step(self):
-        """What ``Trainer.train`` does between two iterations, on the static examples (``trainer.py:357-393``)."""
+    def _micro_steps(self):
+        """Forward, review and backward of every example of the optimizer step (``trainer.py:357-393``): gradients accumulate."""
         tr = self.trainer
         for i, example in enumerate(self.examples):
             if tr._buckets is not None:
@@ -218,7 +234,11 @@ class GraphedStep:
             tr.train_summary.update(review)
             loss.backward()
             del loss, review, batch
-        return tr.optimizer_step()
+
+    def _one_step(self):
+        """What ``Trainer.train`` does between two iterations, on the static examples (``trainer.py:357-393,512-532``)."""
+        self._micro_steps()
+        return self.trainer.optimizer_step()
 
     def _eager(self, n):
         tr = self.trainer
@@ -241,7 +261,7 @@ class GraphedStep:
 
     def _capture(self):
         tr = self.trainer
-        assert tr.world_size == 1 or tr._buckets is None, 'the data-parallel exchange is not captured: use split_for_allreduce'
+        assert not tr._dp_active() or self.split, 'the data-parallel exchange is not captured: split_for_allreduce'
         keep = tr.deferred_checks
         tr._check_pending(flush=True)
         tr.deferred_checks = True               # no host synchronisation inside the capture; this class does the checks
@@ -256,11 +276,31 @@ class GraphedStep:
         running_summary = tr.train_summary
         tr.train_summary = type(running_summary)()      # (the capture's review entries point at the static words: not a step that ran)
         opt_step = tr._opt_step
+        self._tail = self._words = None
         try:
             with _capture.capture_mode():
-                with torch.cuda.graph(graph, capture_error_mode='thread_local'):
-                    self._one_step()
+                if not self.split:
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                        self._one_step()
+                else:
+                    # split_for_allreduce: graph A = every micro-step's forward + backward, joined with the weight-gradient queue, and
+                    # this rank's two words; the exchange runs BETWEEN the graphs as ordinary RCCL calls on the same stream
+                    # (Trainer._exchange: all ranks issue the same two collectives whether they replay or run the step eagerly);
+                    # graph B = norm + clip + Adam (gated by the SUMMED loss word) + the staged scalars' copies.  One memory pool:
+                    # what B reads of A (the staged loss values, the words) stays where A left it.
+                    from ..ops import lstm as _lstm
+                    # (the words live OUTSIDE the graphs' pool: the collective between the graphs works on ordinary allocations)
+                    self._words = torch.zeros(2, dtype=torch.float32, device=self.device)
+                    with torch.cuda.graph(graph, capture_error_mode='thread_local'):
+                        self._micro_steps()
+                        _lstm.sync_deferred()
+                        self._words.copy_(tr._local_words())
+                    self._tail = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self._tail, pool=graph.pool(), capture_error_mode='thread_local'):
+                        tr._exchanged = self._words
+                        tr.optimizer_step()
         finally:
+            tr._exchanged = None
             tr._graph_stage = None
             tr.deferred_checks = keep
             tr.train_summary = running_summary
@@ -312,7 +352,21 @@ class GraphedStep:
         self._refresh()
         if examples is not None and examples is not self.examples:
             self.load(examples)
-        self._graph.replay()
+        if not self.split:
+            self._graph.replay()
+        else:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.times is not None else None
+            if ev:
+                ev[0].record()
+            self._graph.replay()
+            if ev:
+                ev[1].record()
+            tr._exchange(self._words)           # in place on graph A's words and on the flat bucket; stream-ordered between the graphs
+            if ev:
+                ev[2].record()
+            self._tail.replay()
+            if ev:
+                ev[3].record()
         if then_load is not None:
             self.load(then_load)
         tr._opt_step += 1
@@ -324,6 +378,8 @@ class GraphedStep:
         # ONE synchronisation per optimizer step, behind everything the step consists of; the graph's own copy nodes have left the
         # step's scalars in the static pinned words
         torch.cuda.current_stream(self.device).synchronize()
+        if self.split and self.times is not None:
+            self.times.append(tuple(ev[i].elapsed_time(ev[i + 1]) for i in range(3)))
         jobs = [(what, host, context) for what, host, context, _ in self._stage.jobs]
         self._inspect(jobs)
         self._record_summary(jobs)
@@ -382,6 +438,7 @@ class GraphedStep:
                 norm, timeouts = float(host[0][0]), int(host[1][0])
                 if _lstm.errors_since_last_report(self.device, timeouts):
                     _lstm.raise_timeout(self.device)
+                tr._check_other_ranks_loss(host)
                 if not np.isfinite(norm):
                     path = tr.log_error_state({'state_dict': tr.state_dict(), 'optimizer_summary': context})
                     raise RuntimeError(f'The grad_norm ({norm}) is not finite.\n'

@@ -220,6 +220,14 @@ class Trainer:
         self._graph_stage = None     # train.graphed: the static pinned words of a step that is being captured
         self._opt_step = 0
         self._loss_acc = None        # device scalar: sum of the losses of the current optimizer step (non-finite -> skip)
+        #: how the ranks exchange an optimizer step's results (data parallel).  None: the layer buckets / one all-reduce of the flat
+        #: bucket plus a MAX all-reduce of the update gate (the eager loop).  'flat+words' (``graph_steps`` with a process group): exactly
+        #: TWO collectives per optimizer step on every rank whatever the rank does in between - all_reduce(SUM) of the flat bucket, then
+        #: all_reduce(SUM) of two words [sum of the step's losses, recurrence watchdog count] - so that a rank that replays a captured
+        #: step (``train.graphed``: graph A = forward + backward, the exchange, graph B = norm + clip + Adam) and a rank that runs the
+        #: same step eagerly (first sighting of a shape) stay in lockstep; the update is gated on the device by the SUMMED loss word.
+        self.dp_protocol = None
+        self._exchanged = None       # the words of an exchange that has run for the current optimizer step
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
         self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)
         self.stop_trigger = EndTrigger.new(stop_trigger)
@@ -295,7 +303,20 @@ class Trainer:
         oc.defer_wgrad = bool(self.overlap_wgrad) and self._flat.flat.is_cuda
         if oc.defer_wgrad:
             _lstm.warm_side_stream(self._flat.flat.device)
-        hooks = self.enable_bucketed_allreduce()
+        # graph_steps with a process group: the 'flat+words' protocol (see dp_protocol) for EVERY optimizer step of this run - replayed or
+        # eager -, the checks at the end of the step they belong to (what a replayed step does anyway); no layer buckets
+        dp_graph = bool(self.graph_steps and self._dp_active() and self._flat.flat.is_cuda)
+        if dp_graph and not (getattr(self.optimizer, '_native_ok', None) is not None and self.optimizer._native_ok()):
+            import warnings
+            warnings.warn('graph_steps with a process group needs the native Adam step on a GPU bucket; running the eager data-parallel loop')
+            dp_graph = False
+        checks_before, protocol_before = self.deferred_checks, self.dp_protocol
+        if dp_graph:
+            self.dp_protocol, self.deferred_checks = 'flat+words', 'step'
+        if self.dp_protocol == 'flat+words':
+            hooks, self._buckets = [], None         # ONE all-reduce of the flat bucket per optimizer step: no layer buckets
+        else:
+            hooks = self.enable_bucketed_allreduce()
 
         try:
             train_iterable = None
@@ -306,7 +327,7 @@ class Trainer:
                     self._pre_step()            # hooks run between the epochs (trainer.py:348-353)
                     train_iterable = iter(train_dataset)
                 optimize = True
-                if self.graph_steps and W == 1 and not self._dp_active() and self._flat.flat.is_cuda:
+                if self.graph_steps and self._flat.flat.is_cuda and (dp_graph or not self._dp_active()):
                     t0 = time.perf_counter()
                     whole = list(itertools.islice(train_iterable, self.virtual_minibatch_size))
                     self._time('time_per_data_loading', t0)
@@ -316,7 +337,8 @@ class Trainer:
                         else:
                             self._pre_step()
                         t0 = time.perf_counter()
-                        self._graph_or_eager_step(whole, device)
+                        # (data parallel: of every group of W consecutive examples rank j takes the j-th, as the plain loop below does)
+                        self._graph_or_eager_step(whole[self.rank::W], device)
                         self._time('time_per_optimize', t0)
                         self.iteration += 1
                         continue
@@ -364,6 +386,7 @@ class Trainer:
             oc.grad_ready_hook = None
             oc.grad_use_hook = None
             self._buckets = None
+            self.deferred_checks, self.dp_protocol, self._exchanged = checks_before, protocol_before, None
             _lstm.sync_deferred()
             oc.defer_wgrad = defer_before
             opt = self.optimizer.optimizer
@@ -524,10 +547,16 @@ class Trainer:
         """clip (global norm) -> lr summary -> optimizer.step -> zero_grad (trainer.py:512-532).
         With W > 1 the flat gradient bucket is summed over all ranks first (one collective)."""
         from ..ops import lstm as _lstm
-        _lstm.sync_deferred()          # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
+        if self._exchanged is None:
+            _lstm.sync_deferred()      # side-stream weight-gradient accumulations (ops.lstm.DEFER_WGRAD)
+        # (else: the second graph of a captured data-parallel step - the first one has joined the weight-gradient queue and the exchange
+        #  has run behind it; a wait for a queue that holds nothing of THIS capture would be no edge of the graph)
         if self._dp_active():
             t0 = time.perf_counter()
-            if self._buckets is not None:
+            if self.dp_protocol == 'flat+words':
+                if self._exchanged is None:        # (a captured step has run its exchange between its two graphs already)
+                    self._exchanged = self._exchange()
+            elif self._buckets is not None:
                 self._buckets.finish()             # buckets not yet issued + wait for all of them
             else:
                 dist.all_reduce(self._flat.flat, op=dist.ReduceOp.SUM)
@@ -556,11 +585,22 @@ class Trainer:
         summary.setdefault('histograms', {})
         from ..ops import lstm as _lstm
         grad_norm = self.optimizer.clip_grad()
+        exchanged, self._exchanged = self._exchanged, None
         if self._deferred(grad_norm):
             self._check_pending()                          # the PREVIOUS optimizer step's loss / norm / watchdog
             loss_acc, self._loss_acc = self._loss_acc, None
             opt = self.optimizer.optimizer
             native = getattr(self.optimizer, '_native_ok', None)
+            if exchanged is not None:
+                # 'flat+words': every rank holds the same summed gradients, the same sum of all ranks' losses and the same watchdog
+                # count - the same gate and the same checks everywhere without another collective
+                assert native is not None and native(), "dp_protocol 'flat+words' needs the native Adam step (csrc/optim.hip)"
+                self.optimizer.skip_if_not_finite = exchanged[0]
+                opt.found_inf = None
+                host = self._stage('grad_norm', [grad_norm.detach().reshape(1), exchanged[1:2].to(torch.int32), exchanged[0:1]], summary)
+                summary['scalars']['grad_norm'] = host[0][0]
+                summary['histograms']['grad_norm_'] = host[0]
+                return summary
             if self.world_size == 1 and native is not None and native():
                 # the update kernel itself skips on a non-finite gradient norm or loss sum (csrc/optim.hip): no flag kernels
                 self.optimizer.skip_if_not_finite = loss_acc
@@ -588,7 +628,14 @@ class Trainer:
             summary['histograms']['grad_norm_'] = host[0]
             return summary
         grad_norm = float(grad_norm)                       # host sync
-        if self._dp_active() and self._flat is not None and self._flat.flat.is_cuda:
+        if exchanged is not None:
+            # 'flat+words' without device-gated checks (a CPU bucket, an optimizer without a fused step): the summed words on the host
+            loss_sum, count = (float(v) for v in exchanged.tolist())
+            if self._flat.flat.is_cuda and _lstm.errors_since_last_report(self._flat.flat.device, int(count)):
+                _lstm.raise_timeout(self._flat.flat.device)
+            if not np.isfinite(loss_sum):
+                raise RuntimeError('The loss of another rank is not finite (see its error state).')
+        elif self._dp_active() and self._flat is not None and self._flat.flat.is_cuda:
             # persistent-kernel watchdog: every rank learns about a timeout on ANY rank before the next collective
             cnt = _lstm.error_count(self._flat.flat.device).reshape(1).clone()
             dist.all_reduce(cnt, op=dist.ReduceOp.MAX)
@@ -603,6 +650,23 @@ class Trainer:
         summary['scalars']['grad_norm'] = grad_norm
         summary['histograms']['grad_norm_'] = torch.Tensor([grad_norm])
         return summary
+
+    def _local_words(self):
+        """[sum of this rank's losses of the step, watchdog count] as a device fp32 [2] (consumes the running loss sum)."""
+        from ..ops import lstm as _lstm
+        dev = self._flat.flat.device
+        loss_acc, self._loss_acc = self._loss_acc, None
+        loss = loss_acc.detach().reshape(1).to(torch.float32) if loss_acc is not None else torch.zeros(1, device=dev)   # (an idle rank)
+        count = _lstm.error_count(dev).reshape(1).to(torch.float32) if dev.type == 'cuda' else torch.zeros(1, device=dev)
+        return torch.cat([loss, count])
+
+    def _exchange(self, words=None):
+        """The 'flat+words' protocol's two collectives; returns the summed words."""
+        if words is None:
+            words = self._local_words()
+        dist.all_reduce(self._flat.flat, op=dist.ReduceOp.SUM)
+        dist.all_reduce(words, op=dist.ReduceOp.SUM)
+        return words
 
     def train_step(self, model, example, device):
         return self.step(model, example, device, 'train')
@@ -775,10 +839,19 @@ class Trainer:
                 norm, timeouts = float(host[0][0]), int(host[1][0])
                 if _lstm.errors_since_last_report(self._flat.flat.device, timeouts):
                     _lstm.raise_timeout(self._flat.flat.device)
+                self._check_other_ranks_loss(host)
                 if not np.isfinite(norm):
                     path = self.log_error_state({'state_dict': self.state_dict(), 'optimizer_summary': context})
                     raise RuntimeError(f'The grad_norm ({norm}) is not finite.\n'
                                        f'See error states (model, example, model_out and review) in {path}.')
+
+    @staticmethod
+    def _check_other_ranks_loss(host):
+        """'flat+words': the third staged value is the sum of ALL ranks' losses.  This rank's own loss has been inspected before (its
+        own error); a non-finite sum then means another rank's loss - every rank raises in the same iteration, nobody is left in the
+        next collective."""
+        if len(host) > 2 and not np.isfinite(float(host[2][0])):
+            raise RuntimeError('The loss of another rank is not finite (see its error state).')
 
     def log_error_state(self, data_dict, folder='log'):
         """trainer.py:640-690: one file per object so a non-picklable one does not lose the rest."""

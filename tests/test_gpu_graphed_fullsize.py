@@ -216,7 +216,7 @@ def _graphed_case(tmp_path, kind, B, fs, K, micro, replays, seed, n=None, **mode
     checked = 0
     for k, vr in ref.state_dict().items():
         du, dr = params[k] - before[k], vr - before[k]
-        assert float(du.abs().max()) <= replays * 1.001e-3 + 1e-7, k            # no entry moves by more than lr per step
+        assert float(du.abs().max()) <= replays * 1.01e-3 + 1e-7, k             # no entry moves by more than ~lr per step (Adam: |m^| / sqrt(v^) <= 1 + O(1e-3))
         if k in firm and firm[k].any():
             # well-conditioned entries (|g| >= 5 % of the gradient's largest entry in EVERY step, i.e. >= 250 x the gradient gate): the
             # Adam update follows the oracle's to a few per cent of one step

@@ -113,7 +113,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _dp_worker(rank, world, port, g6_path, n_examples, out_dir, overlap=True, poison_rank=None):
+def _dp_worker(rank, world, port, g6_path, n_examples, out_dir, overlap=True, poison_rank=None, protocol=None):
     import json
     torch.set_num_threads(1)
     g6 = dict(np.load(g6_path, allow_pickle=False))
@@ -134,9 +134,14 @@ def _dp_worker(rank, world, port, g6_path, n_examples, out_dir, overlap=True, po
                    loss_weights=LW, summary_trigger=(1000, 'iteration'),
                    checkpoint_trigger=(1000, 'iteration'), stop_trigger=(1, 'epoch'),
                    virtual_minibatch_size=2, overlap_allreduce=overlap)
+    t.dp_protocol = protocol
+    issued = []
+    real = torch.distributed.all_reduce
+    torch.distributed.all_reduce = lambda tensor, *a, **k: (issued.append(tensor.numel()), real(tensor, *a, **k))[1]
     if poison_rank is None:
         t.train(exs, device='cpu')
         torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f'sd{rank}.pth'))
+        torch.save(issued, os.path.join(out_dir, f'issued{rank}.pth'))
     else:
         try:
             t.train(exs, device='cpu')
@@ -168,6 +173,34 @@ def test_data_parallel_gloo_matches_single_process(g6, tmp_path, n_examples, ove
                    stop_trigger=(1, 'epoch'), virtual_minibatch_size=2)
     t.train(exs, device='cpu')
     assert t.iteration == 4
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(sd0[k].numpy(), v.numpy(), atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize('n_examples', [8, 7])
+def test_data_parallel_flat_and_words_protocol(g6, tmp_path, n_examples):
+    """The protocol of captured data-parallel steps (``Trainer.dp_protocol = 'flat+words'``, what ``graph_steps`` switches on under a
+    process group; the graphs themselves need a GPU: ``tests/test_gpu_graphed_dp.py``) on its eager path, W = 2: per optimizer step
+    every rank issues all_reduce(flat bucket) then all_reduce(2 words) - also the rank WITHOUT an example in the short last group of 7
+    -, same order on both ranks, replicas bit-identical and equal to the single process."""
+    import torch.multiprocessing as mp
+    from conftest import GOLDEN
+    mp.spawn(_dp_worker, args=(2, _free_port(), str(GOLDEN / 'g6_models.npz'), n_examples, str(tmp_path), True, None, 'flat+words'),
+             nprocs=2, join=True)
+    sd0, sd1 = torch.load(tmp_path / 'sd0.pth'), torch.load(tmp_path / 'sd1.pth')
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k
+    issued = [torch.load(tmp_path / f'issued{r}.pth') for r in range(2)]
+    nflat = sum(v.numel() for v in _model(g6).parameters())
+    assert issued[0] == issued[1]
+    big = [n for n in issued[0] if n > 1]
+    assert big == [nflat, 2] * 4, issued[0]                   # four optimizer steps; (the 1-element entries: the sync loss checks)
+    model = _model(g6)
+    exs = (_examples(g6) * 2)[:n_examples]
+    t = pt.Trainer(model, tmp_path / 'single', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW,
+                   summary_trigger=(1000, 'iteration'), checkpoint_trigger=(1000, 'iteration'),
+                   stop_trigger=(1, 'epoch'), virtual_minibatch_size=2)
+    t.train(exs, device='cpu')
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(sd0[k].numpy(), v.numpy(), atol=2e-6, err_msg=k)
 
