@@ -877,6 +877,62 @@ def main():
                     model.row_slots = None
                 trace('row-slot variant done')
             variant.update(ragged=False, frames=frames_per_micro, data=data)
+            if use_graph and cfg['model'] == 'pit' and cfg['batch'] <= 64:
+                # the same two ragged workloads as ONE captured step each: the length pattern is device data
+                # (ops.sequence.StaticSlots: a row-slot grid of fixed capacity, index tables / row masks / frame counts as tensors), so a
+                # graph serves every batch that fits.  Every step brings a NEW pattern (8 draws in turn): its tables are made on the host
+                # (numpy) and copied in while the GPU replays the step before.
+                from padertorch_amd.ops.sequence import SlotLayout, StaticSlots
+                from padertorch_amd.train.graphed import GraphedStep
+
+                def features_slots(src):
+                    feats = pt.ops.pit_features(src['y'], src['s'], src['num_samples'], num_frames_dev=src['slots'].frames)
+                    return dict(feats, slots=src['slots'])
+
+                def ragged_graph(examples, slots, seed):
+                    import random
+                    rnd = random.Random(seed)
+                    n_max = 6 * cfg['fs']
+                    T_max = frames_of(n_max)
+                    pats = []
+                    for p in range(8):
+                        rl = sorted((rnd.randint(3 * cfg['fs'], n_max) for _ in range(examples)), reverse=True)
+                        b = synthetic_batch(seed + p, examples, K, n_max, device, rl)
+                        pats.append(dict(y=b['y'], s=b['s'], num_samples=torch.tensor(rl, dtype=torch.int32, device=device),
+                                         frames=[frames_of(v) for v in rl]))
+                    need = max(SlotLayout(p['frames'], slots).T for p in pats)
+                    steps_cap = T_max if examples == slots else (need + 7) // 8 * 8
+                    ring = [StaticSlots(examples, slots, steps_cap, T_max, device) for _ in range(2)]
+
+                    def batch(i):
+                        p = pats[i % len(pats)]
+                        return dict(y=p['y'], s=p['s'], num_samples=p['num_samples'], slots=ring[i % 2].set(p['frames']))
+                    trainer._check_pending(flush=True)
+                    g = GraphedStep(trainer, [batch(0)], prepare=features_slots, warmup=2, clone_inputs=True)
+                    for i in range(3):
+                        g([batch(i)])
+                    g.load([batch(0)])
+                    sync()
+                    t0 = time.perf_counter()
+                    for i in range(nx):
+                        g(None, then_load=lambda i=i: [batch(i + 1)])
+                    sync()
+                    ms = (time.perf_counter() - t0) / nx * 1e3
+                    frames = sum(sum(pats[i % len(pats)]['frames']) for i in range(nx)) / nx
+                    occupancy = frames / (steps_cap * slots)
+                    assert g.captures == 1
+                    del g
+                    return dict(ms_per_step=ms, frames_per_step=frames * world, value=frames * world / (ms * 1e-3), examples_per_step=examples * world,
+                                row_slots=slots, grid_steps=steps_cap, occupancy=occupancy, patterns=len(pats),
+                                step_driver='one hipGraph for every length pattern (ops.sequence.StaticSlots), a new pattern every step')
+                extras['ragged_graph'] = ragged_graph(cfg['batch'], cfg['batch'], 5000)
+                extras['ms_per_step_ragged_graph'] = extras['ragged_graph']['ms_per_step']
+                extras['value_ragged_graph'] = extras['ragged_graph']['value']
+                trace('ragged captured step done')
+                extras['ragged_row_slots_graph'] = ragged_graph(2 * cfg['batch'], cfg['batch'], 6000)
+                extras['ms_per_step_ragged_row_slots_graph'] = extras['ragged_row_slots_graph']['ms_per_step']
+                extras['value_ragged_row_slots_graph'] = extras['ragged_row_slots_graph']['value']
+                trace('ragged row-slot captured step done')
     rccl = None
     if world > 1:
         flat = trainer._flat.flat

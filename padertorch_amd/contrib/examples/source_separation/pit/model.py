@@ -77,7 +77,9 @@ class PermutationInvariantTrainingModel(base.Model):
         """Waveforms -> features on the device when the batch does not carry them yet."""
         if 'Y_abs' in batch or 'y' not in batch:
             return batch
-        feats = ops.pit_features(batch['y'], batch.get('s'), batch.get('num_samples'))
+        slots = batch.get('slots')
+        feats = ops.pit_features(batch['y'], batch.get('s'), batch.get('num_samples'),
+                                 num_frames_dev=slots.frames if isinstance(slots, ops.sequence.StaticSlots) else None)
         out = dict(batch)
         out.update(feats)
         return out
@@ -93,6 +95,8 @@ class PermutationInvariantTrainingModel(base.Model):
         Returns: List of mask tensors, each list element has shape (T, K, F)
         """
         batch = self.prepare_batch(batch)
+        if isinstance(batch.get('slots'), ops.sequence.StaticSlots):
+            return self._forward_static_slots(batch['Y_abs'], batch['slots'])
         if self.row_slots and self.hip_blstm:
             out = self._forward_row_slots(batch['Y_abs'])
             if out is not None:
@@ -166,6 +170,21 @@ class PermutationInvariantTrainingModel(base.Model):
         h = self._dense(self.dropout_linear(h))
         masks = layout.gather_rows(h.view(-1, self.K, self.F), padded.shape[1])   # 'tb (k f) -> tb k f', back to one example per row
         return PaddedList(masks, lengths, True, lengths_dev)
+
+    def _forward_static_slots(self, Y_abs, slots):
+        """``forward`` on a row-slot layout of fixed capacity whose length pattern is device data (``ops.sequence.StaticSlots``, carried
+        by the batch as ``batch['slots']``): the same network and results as :meth:`_forward_row_slots`, but no launch depends on the
+        examples' lengths - what a captured optimizer step needs to serve ragged batches (``train.graphed``)."""
+        padded = Y_abs.padded if isinstance(Y_abs, PaddedList) and Y_abs.intact() else as_padded(Y_abs)[0]
+        why = ops.lstm.unsupported_reason(self.blstm, padded)
+        assert why is None and self.hip_blstm, f'StaticSlots batches run on the HIP recurrence only ({why})'
+        assert padded.shape[-1] == self.F, f'self.F = {self.F} != F = {padded.shape[-1]}'
+        x = ops.sequence.log1p(self.dropout_input(slots.scatter_rows(padded)))    # log1p(0) = 0: idle rows stay zero
+        T, S = slots.steps, slots.slots
+        h = ops.packed_lstm(self.blstm, PackedSequence(x, torch.full((T,), S, dtype=torch.int64)), meta=slots.meta).data
+        h = self._dense(self.dropout_linear(h))
+        masks = slots.gather_rows(h.view(-1, self.K, self.F))                     # [B, padded_time, K, F], padding frames zero
+        return PaddedList(masks, [slots.padded_time] * slots.examples, True, slots.frames)
 
     @torch.no_grad()
     def separate(self, y, num_samples=None, stft=None):

@@ -587,12 +587,21 @@ __global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdA
 // cos(angle(Y) - angle(X)) = Re(y_hat conj x_hat)  (angle(0) := 0 like np.angle) on the way out.
 __device__ __forceinline__ void mag_phasor(cpx X, float& mag, cpx& ph) {
     const float p = X.x * X.x + X.y * X.y;
-    const float r = __builtin_amdgcn_rsqf(p);            // 1/|X|; inf at 0, selected away below
-    // (the select tests for ZERO, not for "positive": a NaN bin - a NaN sample in the frame - stays NaN in the magnitude and in the
-    //  phasor like np.abs / np.angle of the reference's features (pit/data.py:67-75), so that the loss and with it the Trainer's
-    //  non-finite check see it; `p > 0 ? ... : 0` had turned it into magnitude 0 / phase 0)
-    mag = p == 0.f ? 0.f : p * r;
-    ph = p == 0.f ? cpx{1.f, 0.f} : cpx{X.x * r, X.y * r};
+    const float r = __builtin_amdgcn_rsqf(p);            // 1/|X|; inf at 0 and for a DENORMAL p (the hardware flushes the operand)
+    mag = p * r;
+    ph = cpx{X.x * r, X.y * r};
+    // (a NaN bin - a NaN sample in the frame - fails the comparison and stays NaN in the magnitude and in the phasor like np.abs /
+    //  np.angle of the reference's features (pit/data.py:67-75), so that the loss and with it the Trainer's non-finite check see it)
+    if (__builtin_expect(p < 1.1754944e-38f, 0)) {
+        // zero or below the normal range (rare: a frame whose only samples meet window taps of ~1e-17 - a Blackman window's first tap
+        // - gives |X|^2 ~ 1e-38; `p * rsq(p)` was inf there, round 6): the same arithmetic on 2^64 X
+        const cpx Xs{X.x * 0x1p64f, X.y * 0x1p64f};
+        const float ps = Xs.x * Xs.x + Xs.y * Xs.y;
+        const float rs = __builtin_amdgcn_rsqf(ps);
+        const bool zero = ps < 1.1754944e-38f;           // |X| < 2^-127: zero like the exact zero (angle(0) := 0)
+        mag = zero ? 0.f : ps * rs * 0x1p-64f;
+        ph = zero ? cpx{1.f, 0.f} : cpx{Xs.x * rs, Xs.y * rs};
+    }
 }
 
 template <class PL>

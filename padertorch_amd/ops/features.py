@@ -68,6 +68,29 @@ class PackedLog1p:
         return None
 
 
+def _pit_features_device_lengths(y, s, ns_dev, frames_dev, stft):
+    """:func:`pit_features` for a padded batch whose example lengths are DEVICE data (``ns_dev`` samples, ``frames_dev`` frames per
+    example, both int32 ``[B]``): the launch depends on the padded shape only."""
+    assert ns_dev.dtype == torch.int32 and ns_dev.is_cuda and frames_dev is not None and frames_dev.dtype == torch.int32, \
+        'device-side lengths: num_samples and num_frames_dev as int32 device tensors'
+    B, N = y.shape
+    if s is not None:
+        assert s.dim() == 3 and s.shape[0] == B and s.shape[2] == N and s.dtype == torch.float32
+        s = s.contiguous()
+    T = int(_lib.load().ptmi_stft_num_frames(stft._geom, N))
+    tb = stft._tables.get(y.device)
+    g = stft._geom
+    geom = [g.size, g.shift, g.window_length, g.pad_left, g.pad_right, g.pad]
+    Y_abs, X_abs, cos_pd = torch.ops.ptmi.pit_features(y, s, ns_dev, tb['window'], tb['twiddle'], geom, T)
+    frames = [T] * B
+    out = dict(Y_abs=PaddedList(Y_abs, frames, True, frames_dev), num_frames=frames_dev)
+    out['Y_abs'].packed_log1p = None
+    if s is not None:
+        out['X_abs'] = PaddedList(X_abs, frames, True, frames_dev)
+        out['cos_phase_difference'] = PaddedList(cos_pd, frames, True, frames_dev)
+    return out
+
+
 def _pad_rows(rows, dim_last_pad_to):
     out = rows[0].new_zeros((len(rows),) + tuple(rows[0].shape[:-1]) + (dim_last_pad_to,))
     for b, r in enumerate(rows):
@@ -75,7 +98,7 @@ def _pad_rows(rows, dim_last_pad_to):
     return out
 
 
-def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=True):
+def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=True, num_frames_dev=None):
     """Waveforms -> ``dict(Y_abs, X_abs, cos_phase_difference, num_frames)`` (model batch contract).
 
     Args:
@@ -85,6 +108,10 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
         stft: an :class:`STFT` (default ``STFT(512, 128)`` = paderbox defaults used by the example)
         packed_log1p: also write ``log1p(Y_abs)`` in PackedSequence order (``Y_abs.packed_log1p``: :class:`PackedLog1p`), the
             first BLSTM layer's input of both example models, so that no pack / log1p / scale / split pass follows the kernel
+        num_frames_dev: with ``num_samples`` as an int32 DEVICE tensor ``[B]`` (a batch whose length pattern is device data,
+            ``ops.sequence.StaticSlots``): the examples' frame counts as an int32 device tensor; the host then knows only the padded
+            shapes - every list entry spans all ``T`` frames of the padded tensors (frames past an example's own count are zero),
+            ``lengths_dev`` carries the true counts to the kernels that need them (the losses)
     Every entry of the result is a :class:`PaddedList` (list of per-example views, e.g.
     ``Y_abs[b]: (T_b, F)``, ``X_abs[b]: (T_b, K, F)``).
     """
@@ -102,6 +129,8 @@ def pit_features(y, s=None, num_samples=None, stft: STFT = None, packed_log1p=Tr
     assert y.dim() == 2 and y.dtype == torch.float32, (y.shape, y.dtype)
     y = y.contiguous()
     B, N = y.shape
+    if torch.is_tensor(num_samples):
+        return _pit_features_device_lengths(y, s, num_samples, num_frames_dev, stft)
     K = 0
     if s is not None:
         assert s.dim() == 3 and s.shape[0] == B and s.shape[2] == N and s.dtype == torch.float32

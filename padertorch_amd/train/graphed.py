@@ -63,6 +63,8 @@ def signature(examples):
             parts.append(('L', type(x).__name__, len(x)))
             for v in x:
                 walk(v)
+        elif hasattr(x, 'static_tensors') and hasattr(x, 'signature'):
+            parts.append(('O',) + tuple(x.signature()))      # (e.g. ops.sequence.StaticSlots: fixed shapes, the pattern is device data)
         elif isinstance(x, str):
             parts.append(('S',))
         elif x is None or isinstance(x, (bool, int, float)):
@@ -177,6 +179,8 @@ class GraphedStep:
                 return x.clone()
             if isinstance(x, PaddedList) and x.intact():
                 return PaddedList(x.padded.clone(), x.lengths, x.batch_first, x.lengths_dev)
+            if hasattr(x, 'static_tensors') and hasattr(x, 'clone'):
+                return x.clone()
             if isinstance(x, dict):
                 return type(x)((k, walk(v)) for k, v in x.items())
             if isinstance(x, (list, tuple)):
@@ -195,6 +199,8 @@ class GraphedStep:
                 out.append(x)
             elif isinstance(x, PaddedList) and x.intact():
                 out.append(x.padded)
+            elif hasattr(x, 'static_tensors'):
+                out.extend(x.static_tensors())
             elif isinstance(x, dict):
                 for v in x.values():
                     walk(v)
@@ -368,7 +374,8 @@ class GraphedStep:
             if ev:
                 ev[3].record()
         if then_load is not None:
-            self.load(then_load)
+            # (a callable: the next batch is MADE here - host work such as a length pattern's index tables runs while the GPU replays)
+            self.load(then_load() if callable(then_load) else then_load)
         tr._opt_step += 1
         self._steps += 1
         # the replay rewrote the parameters through the graph's kernel nodes: nothing bumped their version counters, and the operand

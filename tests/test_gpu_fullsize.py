@@ -11,7 +11,7 @@ the same weights and the same input features:
 
 A hand-off race in the persistent recurrence (a stale tile, a missed flag) would show up here as a wrong mask; tolerances:
 masks / embeddings atol 1e-5, losses 1e-4 (BASELINE.json north_star) against the fp32 oracle; gradients within 2e-4 of each parameter's largest gradient
-entry against the SAME oracle step in fp64 (``_grad_check``; the largest cases keep the fp32 oracle for the suite's run time).
+entry against the SAME oracle step in fp64 (``_grad_check``; round 6: the double run goes through torch's native kernels on the GPU, so every case has it).
 """
 import numpy as np
 import pytest
@@ -33,24 +33,26 @@ def _double_oracle(ref, run):
     """The same oracle step in fp64 (``run(model64, to64)`` does forward, review and backward): what both fp32 gradients - the HIP
     path's and the CPU oracle's - are measured against."""
     import copy
-    ref64 = copy.deepcopy(ref).double()
+    # (on the GPU, through torch's native double kernels - MIOpen has no double LSTM -: a second instead of minutes on the CPU; test
+    #  infrastructure, nothing of libptmi.so runs here)
+    ref64 = copy.deepcopy(ref).double().to(DEV)
     for p in ref64.parameters():
         p.grad = None
-    run(ref64, lambda t: t.detach().cpu().double())
-    return ref64
+    run(ref64, lambda t: t.detach().double().to(DEV))
+    return ref64.cpu()
 
 
 def _grad_check(model, ref, ref64=None, tol=2e-4):
     """Every parameter gradient of the HIP step against the fp64 oracle (the fp32 CPU oracle where a case skips the double run): within
     ``tol`` of the gradient's largest entry.  With the fp64 run both fp32 gradients - the HIP path's and the CPU oracle's - are measured
     against the same truth (``PTMI_GRAD_REPORT=<file>`` appends them per parameter: ``profiles/r5_grad_errors_vs_fp64.txt``): over all
-    other cases the HIP path's error is 1e-6 in the median and 4.8e-5 at worst, the CPU's 3e-7 / 1.0e-4.  The exception is the B = 100
-    row-slot case (3 x BLSTM-64, 28 k rows, most of them with gradients orders of magnitude below the largest): ``linear1.weight`` is
-    off by 3.3e-4 of its largest entry and the first layer's ``weight_ih`` by 1.75e-4 where the CPU's fp32 gradient is exact to
-    1.4e-7 / 9e-7 - i.e. the error IS the HIP path's own, not the CPU's summation order as round 4's comment had it: the
-    weight-gradient GEMMs multiply 16-bit (hi, lo) planes of the gradient operand under ONE scale per tensor (fp16 planes: entries
-    below 2^-16 of the largest lose their lo half; bf16 planes: 2^-17 per product), and the result is a sum with ~100-fold cancellation.
-    That case keeps its 5e-4 gate, now with the right reason."""
+    other cases the HIP path's error is 1e-6 in the median and 4.8e-5 at worst, the CPU's 3e-7 / 1.0e-4.  Two row-slot cases keep a 5e-4
+    gate: B = 100 in 64 slots (3 x BLSTM-64; ``linear1.weight`` off by 3.3e-4) and B = 70 in 32 static slots (2 x BLSTM-600; 2.8e-4).
+    Round 5 blamed the 16-bit planes of the gradient operand; round 6 measured it (``scripts/dbg_wgrad.py``,
+    ``profiles/r6_relu_tie.txt``): the weight-gradient GEMMs are exact to 2e-7 on their own inputs, and in both cases ONE ReLU of
+    ``linear1`` whose pre-activation is 1e-10 / 1e-9 takes the other branch than in the fp64 chain - with the HIP path's own ReLU
+    pattern the whole fp64 chain reproduces the HIP gradient to 2e-7.  A subgradient tie, not a precision loss: the gate of those
+    cases covers one such flip."""
     worst = {}
     truth = ref64 if ref64 is not None else ref
     report = []
@@ -72,7 +74,8 @@ def _grad_check(model, ref, ref64=None, tol=2e-4):
     return worst
 
 
-def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, in_place=False, double=True, **model_kw):
+def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, in_place=False, double=True, static_slots=None,
+              device_lengths=False, **model_kw):
     import padertorch_amd as pt
     from padertorch_amd.contrib.examples.source_separation.pit.model import PermutationInvariantTrainingModel
     from padertorch_amd.ops import lstm as _lstm
@@ -87,6 +90,19 @@ def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, i
     model.row_slots = row_slots
     s = _waveforms(B, model_kw.get('K', 2), n, lens, seed + 1).to(DEV)
     feats = pt.ops.pit_features(s.sum(1), s, lens)
+    if static_slots is not None:
+        # a row-slot layout of FIXED capacity whose pattern is device data (ops.sequence.StaticSlots): (slots, spare steps)
+        from padertorch_amd.ops.sequence import SlotLayout, StaticSlots
+        frames = list(feats['num_frames'])
+        need = SlotLayout(frames, static_slots[0]).T
+        slots = StaticSlots(B, static_slots[0], need + static_slots[1], max(frames), DEV).set(frames)
+        if device_lengths:      # ... and the features made from device-side lengths too (the launch knows the padded shape only)
+            ns = torch.tensor(lens, dtype=torch.int32, device=DEV)
+            dev_feats = pt.ops.pit_features(s.sum(1), s, ns, num_frames_dev=slots.frames)
+            for k in ('Y_abs', 'X_abs', 'cos_phase_difference'):
+                assert torch.equal(dev_feats[k].padded, feats[k].padded), k
+            true_feats, feats = feats, dev_feats
+        feats = dict(feats, slots=slots)
     _lstm.CHECK_PERSISTENT_ERRORS = True
     if in_place:        # the Trainer's route: weight gradients accumulated into existing .grad buffers on the side stream (ops.context)
         from padertorch_amd.ops import context as _context
@@ -102,6 +118,12 @@ def _pit_case(B, fs, lens=None, seed=0, n=None, row_slots=None, grad_tol=2e-4, i
     finally:
         _lstm.CHECK_PERSISTENT_ERRORS = False
     torch.cuda.synchronize()
+    if static_slots is not None:
+        if device_lengths:
+            feats = true_feats
+        for m, t in zip(masks, feats['num_frames']):
+            assert float(m[t:].abs().sum()) == 0.           # padding frames of the padded mask tensor are zero
+        masks = [m[:t] for m, t in zip(masks, feats['num_frames'])]
     # oracle: same features (copied), same weights
     torch.set_num_threads(min(16, torch.get_num_threads() or 16))
     rb = {k: [t.detach().cpu() for t in feats[k]] for k in ('Y_abs', 'X_abs', 'cos_phase_difference')}
@@ -157,10 +179,26 @@ def test_pit_step_on_row_slots_vs_oracle(B, slots, units, layers, in_place):
     layout = SlotLayout(frames, slots)
     per_slot = np.bincount(layout.slot, minlength=slots)
     assert per_slot.max() >= 2 and layout.T == max(np.bincount(layout.slot, weights=frames, minlength=slots)), (per_slot, layout.T)
-    # (B = 100: linear1.weight's gradient is off by 3.3e-4 of its largest entry AGAINST THE FP64 ORACLE, with or without slots, where the
-    #  fp32 CPU oracle is exact to 1.4e-7: the HIP path's own operand format under heavy cancellation, see _grad_check)
+    # (B = 100: linear1.weight's gradient is off by 3.3e-4 of its largest entry against the fp64 oracle: ONE ReLU tie at a pre-activation
+    #  of 1e-9, see _grad_check and profiles/r6_relu_tie.txt)
     _pit_case(B, 8000, lens=lens, seed=B, n=n, row_slots=slots, grad_tol=5e-4 if B == 100 else 2e-4, in_place=in_place, units=units,
-              recurrent_layers=layers, K=2 + B % 2, double=B in (100, 10, 5))
+              recurrent_layers=layers, K=2 + B % 2)
+
+
+@pytest.mark.parametrize('B,slots,spare,units,layers,device_lengths', [(10, 4, 0, 24, 2, False), (40, 16, 5, 100, 1, True), (70, 32, 9, 600, 2, True),
+                                                                       (32, 32, 3, 600, 1, True), (5, 1, 2, 8, 2, False)])
+def test_pit_step_on_static_slots_vs_oracle(B, slots, spare, units, layers, device_lengths):
+    """The row-slot layout whose length pattern is DEVICE data (``ops.sequence.StaticSlots``: fixed grid ``[steps, slots]``, index tables,
+    row masks and frame counts as tensors; spare steps at the end idle in every slot) - what lets ONE captured step serve ragged
+    batches: the whole step against the oracle as for ``SlotLayout``; ``device_lengths``: the feature kernel reads the sample counts
+    from the device too and returns bit for bit what the host-side lengths give."""
+    rng = np.random.RandomState(B + slots)
+    n = 4400
+    lens = sorted((int(x) for x in rng.randint(900, n + 1, B)), reverse=True)
+    lens[0] = n
+    # (B = 70: one ReLU tie of linear1 at a pre-activation of 1e-10 moves linear1.weight's gradient by 2.8e-4, profiles/r6_relu_tie.txt)
+    _pit_case(B, 8000, lens=lens, seed=B, n=n, static_slots=(slots, spare), device_lengths=device_lengths, in_place=True, units=units,
+              recurrent_layers=layers, K=2 + B % 2, grad_tol=5e-4 if B == 70 else 2e-4)
 
 
 def test_row_slot_masks_equal_the_packed_sequence_path():
@@ -189,7 +227,7 @@ def test_pit_step_config3_rows_and_steps_vs_oracle():
     shorter examples make the batch ragged at the end (the hand-off bookkeeping of shrinking steps)."""
     n = 64000
     lens = [n] * 36 + [n - 128 * 7, n - 128 * 40, n - 128 * 41, n - 128 * 200]
-    _pit_case(40, 16000, lens=lens, seed=3, double=False)        # (20 k rows x 3 x BLSTM-600 in fp64 on the CPU: minutes)
+    _pit_case(40, 16000, lens=lens, seed=3)
 
 
 def _dc_case(B, K, n, lens, seed, padded_target=False, row_slots=None, double=True, **model_kw):
@@ -249,7 +287,7 @@ def test_dc_step_on_row_slots_vs_oracle(B, slots, transform):
 
 def test_dc_step_config5_shape_vs_oracle():
     n = 64000
-    _dc_case(34, 3, n, [n] * 30 + [n - 128 * 3, n - 128 * 90, n - 128 * 91, n - 128 * 300], 5, double=False)
+    _dc_case(34, 3, n, [n] * 30 + [n - 128 * 3, n - 128 * 90, n - 128 * 91, n - 128 * 300], 5)
 
 
 @pytest.mark.parametrize('seed', range(8))
@@ -279,7 +317,7 @@ def test_dc_step_config5_full_batch_vs_oracle():
     """BASELINE configs[4] at its full batch (64 x 4 s at 16 kHz, K = 3, equal lengths): `bench.py --config c5` (incl. its PaddedList of
     target masks)."""
     n = 64000
-    _dc_case(64, 3, n, [n] * 64, 15, padded_target=True, double=False)
+    _dc_case(64, 3, n, [n] * 64, 15, padded_target=True)
 
 
 def test_config4_four_micro_steps_one_optimizer_step_vs_oracle(tmp_path):

@@ -402,3 +402,29 @@ def test_pit_features_keep_a_nan_sample_like_the_reference():
     nan_rows = set(np.nonzero(torch.isnan(packed.data).any(1).cpu().numpy())[0].tolist())
     want_rows = {int(offs[t]) for t in np.nonzero(np.isnan(ref[0]['Y_abs']).any(1))[0]}
     assert nan_rows == want_rows
+
+
+def test_pit_features_of_a_frame_below_the_normal_range_are_finite():
+    """A last frame that holds ONE sample, under the window's first tap (a Blackman window's is ~1e-17, not 0): |X|^2 ~ 1e-38 lies below
+    fp32's normal range, where the hardware's reciprocal square root flushes its operand - until round 6 the magnitude came out as inf
+    and the cosine as NaN (3841 = 30 x 128 + 1 samples; found by a ragged batch of the training distribution, ``pit/data.py:20-33``).
+    Magnitudes within the usual tolerance of the oracle, every value finite, the cosine of the tiny bins in [-1, 1]."""
+    from padertorch_amd.ops import pit_features
+    rng = np.random.RandomState(11)
+    hit = 0
+    for n in (3841, 3969, 4097, 2561):
+        exs = [features_np.synthetic_mixture(rng, n), features_np.synthetic_mixture(rng, n - 700)]
+        ref = [features_np.pre_batch_transform(s, y) for s, y in exs]
+        f = pit_features([torch.from_numpy(y).to(DEV) for _, y in exs], [torch.from_numpy(s).to(DEV) for s, _ in exs])
+        for b, r in enumerate(ref):
+            for key in ('Y_abs', 'X_abs', 'cos_phase_difference'):
+                got = f[key][b].cpu().numpy()
+                assert np.isfinite(got).all(), (n, b, key)
+                if key != 'cos_phase_difference':
+                    np.testing.assert_allclose(got, r[key], atol=2e-5)
+                else:
+                    assert np.abs(got).max() <= 1. + 1e-5
+            hit += int((r['Y_abs'][-1] < 1e-15).all())
+        packed = f['Y_abs'].packed_log1p
+        assert packed is not None and bool(torch.isfinite(packed.data).all())
+    assert hit >= 4, hit         # (the cases do contain such frames)
