@@ -78,6 +78,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-variant', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-batch', type=int, default=4, help=argparse.SUPPRESS)
+    ap.add_argument('--no-kernel-events', action='store_true',
+                    help='no eager pass with per-kernel HIP events behind the timed replays (profiling runs: the trace then holds the '
+                         'warm-up steps and the replays only)')
     ap.add_argument('--no-extras', action='store_true', help='skip the sync-checks / host-to-device / all-reduce side measurements')
     ap.add_argument('--library-gemms', action='store_true',
                     help='dense layers on the BLAS library (TunableOp selections of scripts/tuned) instead of csrc/gemm.hip')
@@ -153,10 +156,16 @@ def cpu_baseline_variant(threads, max_seconds=12., b=4):
         torch_ref.train_step(model, opt, [feats], LOSS_WEIGHTS, 1.)
         return sum(feats['num_frames'])
 
-    frames = step()          # warm-up
     times = []
-    t_all = time.perf_counter()
-    while len(times) < 12 and (time.perf_counter() - t_all) < max_seconds:
+    if b > 4:                # (the GPU's batch: a step takes ~1 min on this host whatever the thread count - no warm-up step, up to 5 timed)
+        max_seconds = 50.
+        t0 = time.perf_counter()
+        frames = step()
+        times.append(time.perf_counter() - t0)
+    else:
+        frames = step()      # warm-up
+    t_all = time.perf_counter() - sum(times)
+    while len(times) < (12 if b <= 4 else 5) and (time.perf_counter() - t_all) < max_seconds:
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
@@ -189,11 +198,41 @@ def cpu_baseline(max_seconds=12., variant_timeout=60.):
     variants = [run(threads, 4, variant_timeout) for threads in sorted({1, min(16, ncpu), min(64, ncpu)})]
     done = [v for v in variants if v.get('value')]
     best = max(done, key=lambda v: v['value'])
-    b32 = run(best['cores'], 32, 2 * variant_timeout)           # the GPU run's batch, once (a step is ~8 x the batch-4 one)
+    # the GPU run's own batch (32 x 4 s: a step is ~8 x the batch-4 one) at OMP_NUM_THREADS=1 (pit/README.md:15) and at 8 / 16 / 32
+    # threads - "the CPU at the GPU's batch" as a number with its best thread count.  The four legs run SIDE BY
+    # SIDE, each in its own process on its own threads (57 of the host's cores), so that the bench stays within minutes; each takes up
+    # to 5 timed steps within its limit and reports how many it got.
+    from concurrent.futures import ThreadPoolExecutor
+    legs = sorted({1, min(8, ncpu), min(16, ncpu), min(32, ncpu)})
+    if sum(legs) <= ncpu:
+        with ThreadPoolExecutor(len(legs)) as pool:
+            b32 = list(pool.map(lambda t: run(t, 32, 2 * variant_timeout), legs))
+    else:
+        b32 = [run(t, 32, 2 * variant_timeout) for t in legs[-1:]]
+    done32 = [v for v in b32 if v.get('value')]
+    best32 = max(done32, key=lambda v: v['value']) if done32 else None
     return dict(value=best['value'], unit='frames/s', cores=best['cores'], kind='port',
                 sample=f'batch 4 x {SECONDS} s @ 8000 Hz ({best["frames_per_step"]} frames/step), PIT defaults fp32, median of up to 12 '
                        f'timed steps (<= {max_seconds:.0f} s) after 1 warm-up per thread count (own process each), os.cpu_count()={ncpu}',
-                variants=variants, batch32=b32)
+                variants=variants, batch32=best32, batch32_variants=b32,
+                batch32_sample=f'batch 32 x {SECONDS} s @ 8000 Hz (8096 frames/step = the GPU run\'s step), up to 5 timed steps (<= 50 s, no warm-up step: one step takes about a minute) '
+                               f'per thread count, thread counts {legs} side by side')
+
+
+def replay_profile(symbol, config):
+    """Average launch duration (ms) of the kernel whose name contains ``symbol`` in the committed rocprofv3 summary of THIS command's
+    replays (``profiles/r6_kernel_trace_replay_<config>.txt``: ``rocprofv3 --kernel-trace --stats -- python bench.py --config <config>
+    --no-extras --no-kernel-events --no-cpu-baseline``: the warm-up steps and the replayed graph, no eager measurement passes).  A
+    replay takes no event records between its nodes (external events are refused on ROCm: ``scripts/mb/graph_events.py``), so this
+    is where the kernels of the TIMED mode are timed; None without a committed profile."""
+    f = REPO / 'profiles' / f'r6_kernel_trace_replay_{config}.txt'
+    if not f.exists():
+        return None
+    for line in f.read_text().splitlines():
+        parts = line.split(None, 11)
+        if len(parts) == 12 and symbol in parts[11] and parts[0].isdigit():
+            return float(parts[2]) * 1e-3
+    return None
 
 
 def measured_traffic(kernel):
@@ -206,6 +245,8 @@ def measured_traffic(kernel):
     return json.loads(f.read_text()).get(kernel, {}).get('hbm_bytes_per_launch')
 
 
+SYMBOLS = {'pit_features': 'pit_features_kernel', 'pit_pairwise_sse': 'pit_pairwise_kernel', 'pit_backward': 'pit_backward_kernel',
+           'lstm_forward': 'lstm_fwd_daf_kernel', 'lstm_backward': 'lstm_bwd_split_kernel'}
 TILE_NAMES = {0: '8, 5 (256 x 320)', 1: '8, 4 (256 x 256)', 2: '8, 3 (256 x 192)', 3: '4, 5 (128 x 320)', 4: '4, 4 (128 x 256)'}
 
 
@@ -269,7 +310,7 @@ def standalone_front_end(device, overhead_ms, rows=192, samples=64000):
     return out
 
 
-def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_mode=3, overhead_ms=0.):
+def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_mode=3, overhead_ms=0., config=None):
     """One entry per hand-written KERNEL seen in the timed steps, named as rocprofv3's summary of the same command names it (the
     planes GEMMs by kernel, plane type and workgroup tile: ``ptmi_gemm_planes_plan`` tells which one a call runs as): HIP-event time
     of every launch (events recorded on the launch stream around the C-ABI call) minus the bracket of an empty launch, against the
@@ -357,6 +398,13 @@ def kernel_report(timers, steps, cfg, frames_per_step, hidden, micro, products_m
             e['us_per_timestep'] = ms * 1e3 / T
             e['frac_of_fp32_mfma_peak'] = achieved / FP32_MFMA_PEAK_TFLOPS       # the measure of round 1 (exact-fp32 MFMA kernels)
             e['peak_note'] = rec_note
+        # the same kernel as rocprofv3 times it INSIDE the replayed graph (committed profile of this command; the event bracket above is
+        # taken in an eager pass beside other queues' work): what `frac` becomes on that duration
+        rp = replay_profile(SYMBOLS[n], config) if config else None
+        if rp:
+            e['avg_launch_ms_replay_profile'] = rp
+            e['frac_replay_profile'] = work / (rp * 1e-3) / (1e9 if bound == 'hbm' else 1e12) / peak
+            e['replay_profile'] = f'profiles/r6_kernel_trace_replay_{config}.txt'
         kernels.append(e)
     for (label, products, what), e in gemm.items():
         if not e['launches']:
@@ -735,6 +783,9 @@ def main():
             graphed.times, graph_state['times'] = None, graphed.times
         # per-kernel HIP events cannot be recorded inside a replay: the same launches are bracketed in an eager pass of the same step
         # behind the timed region (rocprofv3's summary of this command sees the replays' kernels themselves: profiles/)
+        if args.no_kernel_events:
+            graph_state['eager_deferred_ms'] = None
+            return elapsed_graph
         ev_steps = max(TIMER_EVERY, min(args.steps, 10 * TIMER_EVERY))
         for _ in range(2):
             step(False)
@@ -1078,7 +1129,8 @@ def main():
             trace('extras done')
             overhead = event_bracket_overhead_ms(device)
             kernels, family = ([], None) if args.ragged else kernel_report(
-                timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro, 1 if args.bf16 else 3, overhead)
+                timers, max(1, counted[1]), cfg, frames_per_micro, model.blstm.hidden_size, micro, 1 if args.bf16 else 3, overhead,
+                config=args.config if (use_graph and not args.bf16) else None)
             out['kernel_event_steps'] = counted[1]
             out['kernel_event_source'] = ('HIP events around the same launches in an eager pass of the same step behind the timed region (a graph '
                                           'replay takes no event records between its nodes); rocprofv3 --kernel-trace of this command times the '
