@@ -373,8 +373,10 @@ __device__ __forceinline__ void split_vals(cpx z1, cpx z2, cpx w, cpx& Xk, cpx& 
 // MEL = false: spectrum out.  MEL = true: |X|^power -> band-compressed mel filterbank -> log(. + eps)
 // out [rows, frames, mel_M] (contrib/je/modules/features.py:171-176, 297-330): the spectrum never
 // leaves LDS, HBM traffic per frame drops from 512 + 2056 B to 512 + 4 * mel_M B.
+// (the fused (log-)mel instantiation of the 512-point plan needs 169 registers: at three workgroups per CU - a budget of 168 - it spilled ONE
+//  into scratch; it runs at two, the plain instantiation keeps three)
 template <class PL, bool MEL>
-__global__ __launch_bounds__(256, PL::INV_WAVES) void stft_fwd_kernel(const FwdArgs A) {
+__global__ __launch_bounds__(256, (MEL && PL::INV_WAVES > 2) ? 2 : PL::INV_WAVES) void stft_fwd_kernel(const FwdArgs A) {
     constexpr int M = PL::M, F = PL::F, FPW = PL::FPW, FS = PL::FS, LPF = PL::LPF;
     constexpr int NP = M / 2 + 1;   // bin pairs (k, M-k) per frame
     extern __shared__ __attribute__((aligned(16))) char smem[];
