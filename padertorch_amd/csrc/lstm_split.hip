@@ -187,6 +187,17 @@ __device__ __forceinline__ unsigned pair_word(float v, int lane, int* plane) {
 // operand tiles at once and again until none of their 16-bit values is the pattern: one store and one load round trip.
 // Every 4-byte word is written exactly once per launch and checked by the lane that uses it, so no ordering between
 // stores is assumed.  The partial sums are double-buffered in LDS (one barrier per step is left).
+// Timing ablations of the step's terms (scripts/exp_lstm.py with a library built with -DPTMI_LSTM_ABLATE: profiles/r6_lstm_ablations.txt;
+// results void).  PTMI_LSTM_DBG bits: 64 no MFMAs, 128 operand values not waited for, 1024 no look-ahead loads of the next step's input
+// pre-activations (forward), 2048 no row-major / plane stores, 16384 no hand-off stores, 32768 no clock read behind the barrier, 65536 no
+// LDS reduction / barrier, 131072 no transcendentals (forward); 4096 / 8192 exist in every build.  The product
+// build compiles none of it (ABL is false: the branches fold away).
+#ifdef PTMI_LSTM_ABLATE
+constexpr bool ABL = true;
+#else
+constexpr bool ABL = false;
+#endif
+
 template <int JT, int NW, int CB, int MTL, int RED_PAD = 4>
 __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPersistArgs A) {
     constexpr int NC = 4 * JT;
@@ -240,6 +251,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             const f32x4 w1 = (in && k + 8 <= A.KP) ? *reinterpret_cast<const f32x4*>(bp + (k + 8 <= A.KP ? k + 4 : 0)) : zero;
             const float v[8] = {w0[0] * ws, w0[1] * ws, w0[2] * ws, w0[3] * ws, w1[0] * ws, w1[1] * ws, w1[2] * ws, w1[3] * ws};
             split8<false>(v, &bh[i][nt], &bl[i][nt]);
+            // the halves are what the time loop keeps in registers: without this the compiler holds the fp32 weights instead (the same 8
+            // registers per fragment) and REPEATS scale + split in every time step - 146 v_fma_mixlo_f16 + 72 v_or_b32_sdwa + 78 shifts
+            // of the loop's 785 vector instructions (scripts/loop_instr_count.py; round 6)
+            asm volatile("" : "+v"(bh[i][nt].x), "+v"(bh[i][nt].y), "+v"(bh[i][nt].z), "+v"(bh[i][nt].w), "+v"(bl[i][nt].x), "+v"(bl[i][nt].y),
+                              "+v"(bl[i][nt].z), "+v"(bl[i][nt].w));
         }
     }
     const size_t tile_elems = (size_t)A.KP32 * 16;
@@ -306,6 +322,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
         const long long row1 = more ? offs_at(t1) : 0;
         const u64 amask1 = more ? alive_at(t1) : 0ull;
         auto prefetch = [&]() {
+            if (ABL && (A.dbg & 1024)) return;
             if (tid < MR * JT && b < nb1 && bit(amask1, b) && j0 + u < H) {
                 const float* np = A.gx + (row1 + b) * ld_g + (long long)dir * G + j0 + u;
 #pragma unroll
@@ -337,6 +354,10 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                     a[f] = __builtin_bit_cast(uint4, mt == 0 ? __builtin_amdgcn_raw_buffer_load_b128(h_rsrc0, vb0, (min(rem >> 1, ilast) * 2 + (rem & 1)) * 1024, 16)
                                                              : __builtin_amdgcn_raw_buffer_load_b128(h_rsrc1, vb1, (min(rem >> 1, ilast) * 2 + (rem & 1)) * 1024, 16));
                 }
+                if (ABL && (A.dbg & 128)) {           // timing ablation: the operands' values are not waited for
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) a[f] = make_uint4(0x3c003c00u + s, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+                }
                 unsigned m = 0u;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) m = fold_max16(a[f], m);
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = zero;
+            if (!(ABL && (A.dbg & 64)))
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
@@ -370,6 +392,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = mma16<false>(ah, bh[i][nt], acc[mt][nt]);
                 }
+            if (!(ABL && (A.dbg & 65536))) {
 #pragma unroll
             for (int mt = 0; mt < MTL; ++mt)
 #pragma unroll
@@ -377,12 +400,13 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
 #pragma unroll
                     for (int q = 0; q < 4; ++q) red[s & 1][wave][mt * 16 + g4 * 4 + q][nt * 16 + r] = acc[mt][nt][q];
             __syncthreads();
-            dd.mark();
+            }
+            if (!(ABL && (A.dbg & 32768))) dd.mark();
             fill_some(s + 1 == A.T);          // (behind the barrier: the wavefronts without elements have nothing else to do there, and in front
                                               //  of it the whole workgroup waited for their stores to be issued)
 #pragma unroll
             for (int q = 0; q < 4; ++q) pre[q] = pre_n[q];
-            if (tid < MR * JT) {
+            if (tid < MR * JT && !(ABL && (A.dbg & 65536))) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int cidx = q * JT + u;
@@ -401,7 +425,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             prefetch();
         }
         float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, h = 0.f;
-        if (act) {
+        if (act && ABL && (A.dbg & 131072)) {
+            ig = pre[0]; fg = pre[1]; gg = pre[2]; og = pre[3];
+            c_reg = fg + ig * gg;
+            h = og * c_reg;
+        } else if (act) {
             ig = sigmoidf_(pre[0]);
             fg = sigmoidf_(pre[1]);
             gg = tanhf_(pre[2]);
@@ -414,7 +442,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
             const unsigned word = pair_word<false>(h * kHScale, lane, &plane);
             // (row-slot batches: an idle slot step writes ZEROS - nobody in this launch waits for them, but the planes then are a
             //  valid operand of the GEMMs that follow, like those of an equal-length batch)
-            if (act || (masked && tid < MR * JT && b < nb && j0 + u < H)) {
+            if ((act || (masked && tid < MR * JT && b < nb && j0 + u < H)) && !(ABL && (A.dbg & 16384))) {
                 // (the thread's slot inside a (time, tile, direction) block is a constant - hs_thr -, the block's offset wave-uniform:
                 //  one vector add in front of the store instead of three 64-bit multiplications)
                 unsigned* dst = reinterpret_cast<unsigned*>(A.hyt) + ((long long)t * hs_step + hs_thr);
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
                 }
             }
         }
-        if (act) {
+        if (act && !(ABL && (A.dbg & 2048))) {
             // saved activations / row-major outputs: nobody in this launch reads them again - stored with the non-temporal hint, so that
             // they do not displace the operand panels the co-running weight-gradient GEMMs share through the L2s (with the matching
             // loads in the backward kernel: 7.16 -> 7.12 ms per step, profiles/r4_ab_step.txt)
@@ -479,7 +507,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     auto flush_tp = [&](int par, int tt) {
         // 2 planes x MR / 8 row groups x 64 columns = 16 MR chunks of 16 B: one per thread; a wavefront reads 1 KB of LDS lane-linear
         // and writes runs of 16 chunks (256 B: the 16 units of one gate) into the planes
-        if (TP && tid < 16 * MR) {
+        if (TP && tid < 16 * MR && !(ABL && (A.dbg & 2048))) {
             const int unit = tid & 15, gate = (tid >> 4) & 3, plane = (tid >> 6) & 1, rg = tid >> 7;
             if (n0 + unit < H && m0 + rg * 8 < A.max_batch) {
                 const int col = gate * H + n0 + unit;
@@ -700,6 +728,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                     request(pass, set);
                 }
                 if (pass + 1 < NP) request(pass + 1, set ^ 1);
+                if (ABL && (A.dbg & 128)) {           // timing ablation: the operands' values are not waited for
+#pragma unroll
+                    for (int i = 0; i < CAB; ++i) fh[set][i] = fl[set][i] = make_uint4(0x3c003c00u + s, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+                }
+                if (!(ABL && (A.dbg & 64)))
 #pragma unroll
                 for (int i = 0; i < CAB; ++i) {
                     const int blk = pass * CAB + i;
@@ -765,7 +798,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const unsigned w3 = pair_word<true>(go, lane, &plane);
             t_flush = (TP && has_rec) ? t_pend : -1;      // the previous step's chunks: behind the hand-off stores
             if (TP) t_pend = t;          // (every thread: the flush in a step without the chain's barrier brings its own barrier)
-            if (act || (masked && tid < 16 * MR && b < nb && j < H)) {       // (row slots: zeros for an idle slot step, see the forward kernel)
+            if ((act || (masked && tid < 16 * MR && b < nb && j < H)) && !(ABL && (A.dbg & 16384))) {       // (row slots: zeros for an idle slot step, see the forward kernel)
                 // (block offset wave-uniform, the thread's four slots constants: see the forward kernel)
                 unsigned* tq = reinterpret_cast<unsigned*>(A.dgt) + ((long long)t * hs_step + hs_thr);
                 const unsigned ws_[4] = {w0, w1, w2, w3};
