@@ -463,12 +463,16 @@ def main():
         backend = 'gloo'
     else:
         assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (--dry for the launcher check on CPU)'
-        torch.cuda.set_device(local_rank)
-        device = torch.device('cuda', local_rank)
-        backend = 'nccl'
+        # PTMI_BENCH_SHARE_GPU=1 (a functional pre-flight of the N > 1 code path on a ONE-GPU box: every rank on cuda:0, the collectives
+        # through gloo - the timings mean nothing, the ranks' recurrences take turns on the CUs): not what the driver runs
+        share = bool(os.environ.get('PTMI_BENCH_SHARE_GPU'))
+        dev_index = 0 if share else local_rank
+        torch.cuda.set_device(dev_index)
+        device = torch.device('cuda', dev_index)
+        backend = 'gloo' if share else 'nccl'
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        if args.dry:
+        if args.dry or backend == 'gloo':
             dist.init_process_group(backend)
         else:
             dist.init_process_group(backend, device_id=device)
@@ -498,7 +502,10 @@ def main():
     if args.bf16:
         _gemm.PRODUCTS = 1
     micro = cfg['micro']
-    model = PermutationInvariantTrainingModel() if cfg['model'] == 'pit' else DeepClusteringModel()
+    # (PTMI_BENCH_UNITS: a smaller BLSTM for functional pre-flights - not the benchmark's model; the JSON line says so)
+    units_override = int(os.environ['PTMI_BENCH_UNITS']) if os.environ.get('PTMI_BENCH_UNITS') else None
+    model_kw = dict(units=units_override) if units_override else {}
+    model = PermutationInvariantTrainingModel(**model_kw) if cfg['model'] == 'pit' else DeepClusteringModel(**model_kw)
     trainer = pt.Trainer(model, f'/tmp/ptmi_bench_{rank}', pt.optimizer.Adam(gradient_clipping=1.),
                          loss_weights=LOSS_WEIGHTS if cfg['model'] == 'pit' else None,
                          virtual_minibatch_size=world * micro, deferred_checks=not args.sync_checks,
@@ -708,10 +715,18 @@ def main():
                 schedule['notes'].append(f'graph_split: capture failed on rank {rank}: {type(e).__name__}: {e}')
             flag = torch.tensor([ok], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            schedule['probe_ms_per_step']['graph_split'] = None
             if float(flag.item()) == 1.:
-                schedule['probe_ms_per_step']['graph_split'] = graph_loop(probe) / probe * 1e3
-            else:
-                schedule['probe_ms_per_step']['graph_split'] = None
+                try:
+                    schedule['probe_ms_per_step']['graph_split'] = graph_loop(probe) / probe * 1e3
+                except RuntimeError as e:
+                    # (a recurrence watchdog timeout is raised by EVERY rank in the same step - the count travels in the summed words -,
+                    #  behind that step's collectives: the ranks are aligned and go on to the eager schedules together)
+                    if not timed_out(e):
+                        raise
+                    recover()
+                    schedule['notes'].append('graph_split: recurrence watchdog timeout during the probe')
+            if schedule['probe_ms_per_step']['graph_split'] is None:
                 graph_state['step'] = None
             trainer.dp_protocol = None
         for flag in ([False] if args.no_overlap_allreduce else [True, False]):
@@ -736,10 +751,11 @@ def main():
             graph_split_step()
 
     use_graph = bool(world == 1 and not args.dry and not args.eager and not args.ragged and not args.sync_checks)
-    use_graph_split = bool(schedule is not None and schedule.get('used') == 'graph_split')
+    use_graph_split = bool(schedule is not None and schedule.get('used') == 'graph_split')      # (as probed; split_state['on']: as timed)
+    split_state = dict(on=use_graph_split)
 
     def measure():
-        if use_graph_split:
+        if split_state['on']:
             graphed = graph_state['step']
             for _ in range(args.warmup):
                 graphed()
@@ -795,11 +811,14 @@ def main():
     try:
         elapsed = measure()
     except RuntimeError as e:
-        if not (timed_out(e) and trainer._buckets is not None):
+        if not (timed_out(e) and (trainer._buckets is not None or split_state['on'])):
             raise
         recover()
-        schedule['notes'].append('overlap: recurrence watchdog timeout during the timed steps; rerun un-overlapped')
+        schedule['notes'].append(f"{schedule['used']}: recurrence watchdog timeout during the timed steps; rerun un-overlapped (eager)")
         schedule['used'] = 'no_overlap'
+        split_state['on'] = False
+        trainer.dp_protocol = None
+        graph_state['step'] = None
         set_overlap(False)
         if not args.dry:
             timers.clear()
@@ -1033,7 +1052,7 @@ def main():
         ranks = [None] * world
         dist.all_gather_object(ranks, me)
         ids = [(r.get('uuid'), r.get('pci_bus_id')) for r in ranks]
-        assert len(set(ids)) == world, f'ranks share a GPU: {ranks}'
+        assert len(set(ids)) == world or os.environ.get('PTMI_BENCH_SHARE_GPU'), f'ranks share a GPU: {ranks}'
         try:
             rccl_version = '.'.join(str(v) for v in torch.cuda.nccl.version()) if not args.dry else None
         except Exception:       # (a build without the binding)
@@ -1094,7 +1113,7 @@ def main():
             'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'fp16/bf16 operands, f32 accumulate (reduced precision)' if args.bf16 else 'f32',
-            'data': 'synthetic',
+            'data': 'synthetic' + (f' (PRE-FLIGHT: units = {units_override}, not the benchmark model)' if units_override else ''),
             'config': {
                 'workload': f'{cfg["label"]}, {(2 if args.row_slots else 1) * cfg["batch"]} x {("3-6 s (ragged, U[3 s, 6 s]" + (", end to end in " + str(cfg["batch"]) + " row slots)" if args.row_slots else ")")) if args.ragged else str(SECONDS) + " s"} {K}-spk {cfg["fs"]} Hz mixtures per GPU and '
                             f'micro-step ({frames_per_micro} frames), {micro} micro-step(s) per optimizer step, STFT '
@@ -1111,11 +1130,11 @@ def main():
                 'host_checks': ('same step (2 syncs)' if args.sync_checks else
                                 'end of the SAME optimizer step (one host synchronisation per step behind the captured step; errors raise in the '
                                 'iteration they belong to, optimizer update gated on the device): train.graphed.GraphedStep'
-                                if (use_graph or use_graph_split) else
+                                if (use_graph or split_state['on']) else
                                 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)'),
                 'step_driver': ("two hipGraphs per optimizer step with the data-parallel exchange between them (train.graphed.GraphedStep, "
                                 "split_for_allreduce: forward + backward | all_reduce(flat bucket), all_reduce(2 words) | norm + clip + Adam)"
-                                if (use_graph_split or args.dp_graph) else
+                                if (split_state['on'] or args.dp_graph) else
                                 'one hipGraph per optimizer step (train.graphed.GraphedStep), replayed' if use_graph else 'eager launches (python)'),
                 'optimizer': 'csrc/optim.hip: reproducible 2-norm + fused clip / Adam / zero_grad over the flat bucket',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',
@@ -1134,7 +1153,7 @@ def main():
             out['kernel_event_steps'] = counted[1]
             out['kernel_event_source'] = ('HIP events around the same launches in an eager pass of the same step behind the timed region (a graph '
                                           'replay takes no event records between its nodes); rocprofv3 --kernel-trace of this command times the '
-                                          "replays' kernels themselves (profiles/r6_kernel_trace_bench.txt)") if (use_graph or use_graph_split) else 'HIP events inside the timed steps'
+                                          "replays' kernels themselves (profiles/r6_kernel_trace_bench.txt)") if (use_graph or split_state['on']) else 'HIP events inside the timed steps'
             out['event_bracket_overhead_us'] = overhead * 1e3
             # `roofline`: the ONE kernel with the most GPU time per step - what leads rocprofv3's summary of this command
             # (profiles/r4_kernel_trace_bench.txt); `roofline_family`: all planes GEMM launches together (round 3's headline entry)
