@@ -157,3 +157,61 @@ def test_split_step_at_baseline_size_equals_the_single_graph(tmp_path, one_rank_
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
     assert len(times) == 3 and all(a > 0 and x >= 0 and b > 0 for a, x, b in times), times
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# TWO ranks for real: two processes share cuda:0, the collectives go through gloo (a one-GPU box cannot form an RCCL group of two).
+def _two_rank_worker(rank, world, port, out_dir, graph, odd_on_rank1):
+    import torch.distributed as dist
+    import padertorch_amd as pt
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    try:
+        exs = _examples(11, B=4, N=6000, seed=5)                 # 11 examples: five full groups of two and a short last one (rank 1 idle)
+        if odd_on_rank1:
+            # the example rank 1 takes in the fourth group has another length: rank 1 runs that step eagerly while rank 0 replays
+            odd = _examples(1, B=4, N=6400, seed=9)[0]
+            exs[7] = odd
+        model = _pit(seed=3 + rank)                               # ranks start different: the step-0 broadcast fixes it
+        issued = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda tensor, *a, **k: (issued.append(tensor.numel()), real(tensor, *a, **k))[1]
+        t = pt.Trainer(model, f'{out_dir}/r{rank}_{int(graph)}', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW, summary_trigger=(1000, 'iteration'),
+                       checkpoint_trigger=(1000, 'iteration'), stop_trigger=(1, 'epoch'), virtual_minibatch_size=2, graph_steps=graph)
+        made = []
+        from padertorch_amd.train import graphed as G
+        plain = G.GraphedStep.__init__
+        G.GraphedStep.__init__ = lambda self, *a, **k: (made.append(1), plain(self, *a, **k))[1]
+        t.train(exs, device=DEV)
+        torch.cuda.synchronize()
+        torch.save(dict(sd={k: v.detach().cpu() for k, v in model.state_dict().items()}, issued=issued, captures=len(made), iteration=t.iteration),
+                   f'{out_dir}/out{rank}_{int(graph)}.pth')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('odd_on_rank1', [False, True])
+def test_two_ranks_train_with_captured_steps(tmp_path, odd_on_rank1):
+    """W = 2 with replayed steps on BOTH ranks (gloo between two processes on one GPU): six optimizer steps - eager first sighting, capture,
+    replays, a short last group with rank 1 idle; with ``odd_on_rank1`` one step in which rank 1 sees a new shape and runs eagerly while
+    rank 0 replays.  Every rank issues [flat bucket, 2 words] per step and nothing else after the step-0 broadcast, replicas end
+    bit-identical and equal the eager data-parallel run's parameters."""
+    import torch.multiprocessing as mp
+    out = {}
+    for graph in (False, True):
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = s.getsockname()[1]
+        mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), graph, odd_on_rank1), nprocs=2, join=True)
+        out[graph] = [torch.load(tmp_path / f'out{r}_{int(graph)}.pth') for r in range(2)]
+    g0, g1 = out[True]
+    assert g0['iteration'] == g1['iteration'] == 6
+    for k in g0['sd']:
+        assert torch.equal(g0['sd'][k], g1['sd'][k]), k                  # replicas identical
+        np.testing.assert_allclose(g0['sd'][k].numpy(), out[False][0]['sd'][k].numpy(), rtol=0, atol=2e-6, err_msg=k)
+    nflat = sum(v.numel() for k, v in g0['sd'].items())
+    for r in (g0, g1):
+        big = [n for n in r['issued'] if n > 1]
+        assert big == [nflat, 2] * 6, big
+        assert r['captures'] >= 1
+    assert g0['captures'] == 1 and g1['captures'] == (1 if not odd_on_rank1 else 1)
