@@ -268,7 +268,11 @@ def log1p_mse_loss(estimate: torch.Tensor, target: torch.Tensor, reduction: str 
 
 def source_aggregated_sdr_loss(estimate: torch.Tensor, target: torch.Tensor,
                                soft_sdr_max: float = None) -> torch.Tensor:
-    """SDR of the squares summed over ALL rows (``regression.py:344-392``); doctest pair: -4.6133."""
+    """SDR of the squares summed over ALL rows (``regression.py:344-392``); doctest pair: -4.6133.  complex64 signals: the reference
+    takes ``torch.abs`` first (``_sqnorm``, ``regression.py:4-10``) - the sums of squares of the (re, im) rows."""
+    if isinstance(estimate, torch.Tensor) and isinstance(target, torch.Tensor) and (estimate.is_complex() or target.is_complex()):
+        assert estimate.is_complex() and target.is_complex(), (estimate.dtype, target.dtype)
+        estimate, target = _complex_as_real(estimate), _complex_as_real(target)
     estimate, target = _as_rows(estimate, 'estimate'), _as_rows(target, 'target')
     assert estimate.shape == target.shape, (estimate.shape, target.shape)
     T = estimate.shape[-1]

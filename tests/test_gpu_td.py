@@ -205,12 +205,17 @@ def test_complex_signals_error_energy_losses():
             return torch.log10(x).sum()
         if name == 'log1p_mse':
             return torch.log10(1 + mse).sum()
+        if name == 'sa_sdr':                                 # regression.py:344-392: the squares summed over ALL signals first
+            num = (t.abs() ** 2).sum()
+            den = err.sum() + (10 ** (-soft / 10) * num if soft else 0)
+            return -10 * torch.log10(num / den)
         num = (t.abs() ** 2).sum(-1)
         den = err.sum(-1) + (10 ** (-soft / 10) * num if soft else 0)
         return (-10 * torch.log10(num / den)).mean()
 
     cases = [('mse', R.mse_loss, {}), ('log_mse', R.log_mse_loss, {}), ('log_mse', R.log_mse_loss, dict(soft_sdr_max=20)),
-             ('log1p_mse', R.log1p_mse_loss, {}), ('sdr', R.sdr_loss, {}), ('sdr', R.sdr_loss, dict(soft_sdr_max=30))]
+             ('log1p_mse', R.log1p_mse_loss, {}), ('sdr', R.sdr_loss, {}), ('sdr', R.sdr_loss, dict(soft_sdr_max=30)),
+             ('sa_sdr', R.source_aggregated_sdr_loss, {}), ('sa_sdr', R.source_aggregated_sdr_loss, dict(soft_sdr_max=25))]
     for name, fn, kw in cases:
         ed = e.to(torch.complex128).requires_grad_(True)
         want = ref(name, ed, t.to(torch.complex128), kw.get('soft_sdr_max'))
