@@ -651,6 +651,7 @@ def main():
         """After a recurrence watchdog timeout.  Every rank raises it in the SAME optimizer step (the timeout count travels with
         the finiteness flag through one all-reduce, Trainer.clip_grad), behind that step's collectives: the ranks are aligned."""
         trainer._pending, trainer._stage_queue, trainer._loss_acc = [], [], None
+        trainer._exchanged = None
         if trainer._buckets is not None:
             trainer._buckets.reset()
         opt_ = trainer.optimizer.optimizer

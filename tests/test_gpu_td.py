@@ -244,5 +244,7 @@ def test_complex_si_sdr_vs_reference(g7):
         assert got.shape == want.shape, (name, got.shape, want.shape)
         np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=2e-5, atol=2e-5, err_msg=name)
         np.testing.assert_allclose(eg.grad.cpu().numpy(), wgrad, rtol=2e-4, atol=2e-6 * float(np.abs(wgrad).max() / 1e-3 + 1), err_msg=name)
-    with pytest.raises(NotImplementedError):
-        R.source_aggregated_sdr_loss(e.cuda(), t.cuda())
+    # (round 6: the source-aggregated SDR takes complex signals too - test_complex_signals_error_energy_losses has values and gradients)
+    e64, t64 = e.to(torch.complex128), t.to(torch.complex128)
+    want = -10 * torch.log10((t64.abs() ** 2).sum() / ((e64 - t64).abs() ** 2).sum())
+    assert abs(float(R.source_aggregated_sdr_loss(e.cuda(), t.cuda())) - float(want)) < 2e-5 * max(1., abs(float(want)))
