@@ -765,21 +765,40 @@ __global__ __launch_bounds__(256, 2) void pit_features_kernel(const FwdArgs A) {
                 // fp16 (hi, lo) planes of 2^9 log1p|Y| in MFMA-fragment order: chunk (bins 8 c .. 8 c + 7 of one packed row) = one
                 // 16-byte store per plane; bins past F are zero (csrc/gemm_planes.hip reads whole 32-wide blocks)
                 wave_sync();
-                const int chunks = A.lp_kb * 4;
+                // (round 6: the chunk count is the plan's - F is a template constant, the host passes lp_kb = (F + 31) / 32 -, so the
+                //  split of a chunk index into (frame, chunk) is a multiplication; full chunks take no per-bin validity select; the
+                //  conversions are written on 2-vectors: v_pk_mul_f32 / v_cvt_pk_f16_f32 / v_pk_add_f32 on gfx950, bit for bit the
+                //  scalar round-to-nearest conversions)
+                constexpr int KBC = (F + 31) / 32, chunks = KBC * 4, FULL = F / 8;
+                typedef float f2v __attribute__((ext_vector_type(2)));
+                typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+                typedef _Float16 h8v __attribute__((ext_vector_type(8)));
                 for (int c = lane; c < nfr * chunks; c += 64) {
                     const int f = c / chunks, ch = c - f * chunks, t = tw0 + f;
                     if (t >= frames_b) continue;
                     const long long prow = (A.lp_offs ? A.lp_offs[t] : (long long)t * A.batch) + b;
-                    typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+                    const float* src = reinterpret_cast<const float*>(wbuf + f * FS + ch * 8);          // the parked values: every second float
+                    f2v sv[4];
+                    if (ch < FULL) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) sv[e] = f2v{src[4 * e], src[4 * e + 2]};
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            sv[e] = f2v{ch * 8 + 2 * e < F ? src[4 * e] : 0.f, ch * 8 + 2 * e + 1 < F ? src[4 * e + 2] : 0.f};
+                    }
                     h8v hi, lo;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int kk = ch * 8 + e;
-                        const float sv = kk < F ? wbuf[f * FS + kk].x * 512.f : 0.f;
-                        hi[e] = (_Float16)sv;
-                        lo[e] = (_Float16)(sv - (float)hi[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const f2v v = sv[e] * 512.f;
+                        const h2v h = __builtin_convertvector(v, h2v);
+                        const h2v l = __builtin_convertvector(v - __builtin_convertvector(h, f2v), h2v);
+                        hi[2 * e] = h[0];
+                        hi[2 * e + 1] = h[1];
+                        lo[2 * e] = l[0];
+                        lo[2 * e + 1] = l[1];
                     }
-                    _Float16* o = A.lp_planes + (((prow >> 4) * A.lp_kb + (ch >> 2)) * 2) * 512 + ((ch & 3) * 16 + (prow & 15)) * 8;
+                    _Float16* o = A.lp_planes + (((prow >> 4) * KBC + (ch >> 2)) * 2) * 512 + ((ch & 3) * 16 + (prow & 15)) * 8;
                     *reinterpret_cast<h8v*>(o) = hi;
                     *reinterpret_cast<h8v*>(o + 512) = lo;
                 }
