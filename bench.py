@@ -447,6 +447,10 @@ def main():
     if args.cpu_baseline_variant:
         print(json.dumps(cpu_baseline_variant(args.cpu_baseline_variant, b=args.cpu_baseline_batch)), flush=True)
         return
+    # stdout carries ONE JSON line: RCCL's log (the image exports NCCL_DEBUG=VERSION: a five-line banner) goes to stderr
+    os.environ.setdefault('NCCL_DEBUG_FILE', '/dev/stderr')
+    if os.environ.get('NCCL_DEBUG') == 'VERSION':        # (printed with printf at process exit, behind the JSON line, whatever NCCL_DEBUG_FILE says)
+        del os.environ['NCCL_DEBUG']
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(args)
     import numpy as np
@@ -782,7 +786,8 @@ def main():
                 h.remove()
             state['hooks'], trainer._buckets = [], None
             trainer.op_context.grad_ready_hook = trainer.op_context.grad_use_hook = None
-        graphed = graph_state['step'] = GraphedStep(trainer, [data] * micro, prepare=features, warmup=0)
+        # (--warmup 0 / 1: the capture still needs every lazily made table, stream and kernel attribute to exist: its own untimed eager steps)
+        graphed = graph_state['step'] = GraphedStep(trainer, [data] * micro, prepare=features, warmup=max(0, 2 - args.warmup))
         if args.dp_graph:
             assert graphed.split
             graphed.times = []
@@ -1181,11 +1186,13 @@ def main():
             out['rccl'] = rccl
         if world == 1 and not args.no_cpu_baseline and not args.dry:
             out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     for h in hooks:
         h.remove()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line is the last thing on stdout (RCCL's version banner - the image exports NCCL_DEBUG=VERSION - used to follow it)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':
