@@ -53,6 +53,8 @@ class DeepClusteringModel(base.Model):
             transform = self._TRANSFORMS[self.input_feature_transform]
         except KeyError:
             raise NotImplementedError(self.input_feature_transform) from None
+        if isinstance(batch.get('slots'), ops.sequence.StaticSlots):
+            return self._forward_static_slots(batch['Y_abs'], batch['slots'], transform)
         if self.row_slots and self.hip_blstm:
             out = self._forward_row_slots(batch['Y_abs'], transform)
             if out is not None:
@@ -94,6 +96,21 @@ class DeepClusteringModel(base.Model):
         h = ops.packed_lstm(self.blstm, x, meta=layout.meta).data
         e = layout.gather_rows(self._embed_rows(h), padded.shape[1])                                             # [B, T_max, E, F]
         return PaddedList(e, lengths, True, lengths_dev)
+
+    def _forward_static_slots(self, Y_abs, slots, transform):
+        """``forward`` on a row-slot layout of fixed capacity whose length pattern is device data (``ops.sequence.StaticSlots`` carried by
+        the batch as ``batch['slots']``): no launch depends on the examples' lengths - one captured optimizer step serves ragged batches
+        (``train.graphed``).  Same results per example as :meth:`_forward_row_slots`."""
+        padded = Y_abs.padded if isinstance(Y_abs, PaddedList) and Y_abs.intact() else as_padded(Y_abs)[0]
+        why = ops.lstm.unsupported_reason(self.blstm, padded)
+        assert why is None and self.hip_blstm, f'StaticSlots batches run on the HIP recurrence only ({why})'
+        assert self.input_feature_transform != 'log', "log(0 + 1e-10) of the idle rows is not zero: 'identity' / 'log1p' only on row slots"
+        assert padded.shape[-1] == self.F, f'self.F = {self.F} != F = {padded.shape[-1]}'
+        T, S = slots.steps, slots.slots
+        x = transform(PackedSequence(slots.scatter_rows(padded), torch.full((T,), S, dtype=torch.int64)))
+        h = ops.packed_lstm(self.blstm, x, meta=slots.meta).data
+        e = slots.gather_rows(self._embed_rows(h))                               # [B, padded_time, E, F], padding frames zero
+        return PaddedList(e, [slots.padded_time] * slots.examples, True, slots.frames)
 
     def review(self, batch, model_out):
         """Mean deep-clustering loss of the batch (reference ``dc.py:73-84``: per-example loop over

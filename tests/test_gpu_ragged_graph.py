@@ -107,3 +107,80 @@ def test_a_batch_that_does_not_fit_is_refused():
     with pytest.raises(ValueError):
         st.set([5, 5, 5])
     assert st.fits([20, 10, 10, 9]) and not st.fits([20, 20, 20, 20])
+
+
+def test_dc_model_on_static_slots_equals_row_slots_and_shares_one_graph(tmp_path):
+    """The deep-clustering model (``contrib/tcl/dc.py``; BASELINE configs[4]'s model) on the device-data layout: embeddings, loss and every
+    gradient equal those of the host-side row-slot layout (``model.row_slots``: itself held against the oracle in
+    ``tests/test_gpu_fullsize.py``), and five length patterns replay through one captured step with the eager loop's parameters."""
+    import padertorch_amd as pt
+    from padertorch_amd.contrib.tcl.dc import DeepClusteringModel
+    from padertorch_amd.ops.sequence.pack_module import PaddedList
+    from padertorch_amd.train.graphed import GraphedStep
+    B, S, n_max, K = 24, 16, 6400, 3
+
+    def dc_batch(seed):
+        src, lens, frames = _batch(seed, B, n_max, S, 96)
+        g = torch.Generator().manual_seed(seed + 1)
+        s3 = 0.1 * torch.randn(B, K, n_max, generator=g)
+        for b, l in enumerate(lens):
+            s3[b, :, l:] = 0.
+        return dict(y=s3.sum(1).to(DEV), s=s3.to(DEV), num_samples=src['num_samples'], slots=src['slots']), lens, frames
+
+    def features(src, host_lens=None):
+        if host_lens is None:
+            feats = pt.ops.pit_features(src['y'], src['s'], src['num_samples'], num_frames_dev=src['slots'].frames)
+        else:
+            feats = pt.ops.pit_features(src['y'], src['s'], host_lens)
+        X = feats['X_abs'].padded
+        target = torch.nn.functional.one_hot(X.argmax(2), K).permute(0, 1, 3, 2).to(torch.float32, memory_format=torch.contiguous_format)
+        out = dict(Y_abs=feats['Y_abs'], target_mask=PaddedList(target, feats['Y_abs'].lengths, True, feats['Y_abs'].lengths_dev))
+        if host_lens is None:
+            out['slots'] = src['slots']
+        return out
+
+    def model():
+        torch.manual_seed(2)
+        return DeepClusteringModel(units=64, recurrent_layers=2, E=8, input_feature_transform='log1p')
+    src, lens, frames = dc_batch(300)
+    ma, mb = model().to(DEV).train(), model().to(DEV).train()
+    mb.row_slots = S
+    fa, fb = features(src), features(src, lens)
+    ea, eb = ma(fa), mb(fb)
+    for b, t in enumerate(frames):
+        torch.testing.assert_close(ea[b][:t], eb[b], atol=1e-6, rtol=0)
+        assert float(ea[b][t:].abs().sum()) == 0.
+    la, lb = ma.review(fa, ea)['losses']['dc_loss'], mb.review(fb, eb)['losses']['dc_loss']
+    assert abs(float(la) - float(lb)) < 1e-6 * max(1., abs(float(lb)))
+    la.backward()
+    lb.backward()
+    for (k, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        scale = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) <= 1e-5 * scale + 1e-12, k
+    # one graph, five patterns
+    batches = [dc_batch(310 + i)[0] for i in range(6)]
+    m1, m2 = model(), model()
+
+    def trainer(m, path):
+        t = pt.Trainer(m, path, pt.optimizer.Adam(gradient_clipping=1.), deferred_checks=True)
+        t.to(torch.device(DEV))
+        t._flat = t.optimizer.use_flat_grads()
+        t.op_context.defer_wgrad = True
+        m.train()
+        return t
+    t1, t2 = trainer(m1, tmp_path / '1'), trainer(m2, tmp_path / '2')
+    for srcb in batches:
+        loss, _, _, _ = t1.train_step(m1, features(srcb), DEV)
+        loss.backward()
+        t1.optimizer_step()
+    t1._check_pending(flush=True)
+    loss, _, _, _ = t2.train_step(m2, features(batches[0]), DEV)
+    loss.backward()
+    t2.optimizer_step()
+    t2._check_pending(flush=True)
+    step = GraphedStep(t2, [batches[1]], prepare=features, warmup=0, clone_inputs=True)
+    for srcb in batches[1:]:
+        step([srcb])
+    assert step.captures == 1
+    for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
