@@ -1,6 +1,6 @@
 """``collate_fn`` (``padertorch/data/utils.py:21-69``): list of examples -> example of lists."""
 
-__all__ = ['collate_fn', 'row_slot_batches']
+__all__ = ['StaticSlotBatcher', 'collate_fn', 'row_slot_batches']
 
 
 def collate_fn(batch):
@@ -47,3 +47,71 @@ def row_slot_batches(examples, row_slots=32, fill=2.0, key='num_samples', collat
     if group:
         group.sort(key=get, reverse=True)
         yield collate_fn(group) if collate else group
+
+
+class StaticSlotBatcher:
+    """Collated waveform batches (``y``: list of ``(N_b,)``, ``s``: list of ``(K, N_b)``, ``num_samples``; the keys of the reference's
+    ``pre_batch_transform`` input, ``pit/data.py:49-77``) -> examples whose length pattern is DEVICE data, so that one captured optimizer
+    step serves all of them (``ops.sequence.StaticSlots``, ``train.graphed``; the models read ``batch['slots']``)::
+
+        batcher = StaticSlotBatcher(examples=64, slots=32, max_samples=6 * 8000, device='cuda:0')
+        for batch in row_slot_batches(stream, row_slots=32, fill=2.0):
+            example = batcher(batch)          # dict(y [B, max_samples], s [B, K, max_samples], num_samples int32 [B], slots)
+
+    ``steps``: the grid's capacity in time steps (default: enough for every batch whose frames sum to ``headroom`` x the mean of a
+    U[max / 2, max] length distribution, rounded up to 8).  A batch that does not fit - more examples, a longer example, more frames than
+    the grid has room for - comes back as it is (the model then takes its host-side route: ``model.row_slots`` / PackedSequence, eagerly);
+    ``refused`` counts them.  Two layouts are used in turn: the tables of batch i + 1 may be written while batch i's step still reads its
+    own.  The padded tensors are made on ``device`` from the host tensors of the batch (pinned memory makes the copies asynchronous).
+    """
+
+    def __init__(self, examples, slots, max_samples, device, stft=None, steps=None, headroom=1.08):
+        import torch
+        from ..ops import STFT
+        from ..ops.sequence import StaticSlots
+        self.stft = stft if stft is not None else STFT(512, 128)
+        self.examples, self.slots, self.max_samples = int(examples), int(slots), int(max_samples)
+        self.device = torch.device(device)
+        self.padded_time = int(self.stft.samples_to_frames(self.max_samples))
+        if steps is None:
+            mean = 0.75 * self.padded_time * self.examples / self.slots
+            steps = max(self.padded_time, int(-(-headroom * mean // 8) * 8))
+        self.steps = int(steps)
+        self._ring = [StaticSlots(self.examples, self.slots, self.steps, self.padded_time, self.device) for _ in range(2)]
+        self._turn = 0
+        self.refused = 0
+
+    def frames_of(self, num_samples):
+        return [int(self.stft.samples_to_frames(int(n))) for n in num_samples]
+
+    def __call__(self, batch):
+        import numpy as np
+        import torch
+        from ..ops.sequence import SlotLayout
+        num_samples = [int(n) for n in batch['num_samples']]
+        frames = self.frames_of(num_samples)
+        ok = len(frames) == self.examples and max(num_samples) <= self.max_samples and min(frames) >= 1 and sum(frames) <= self.steps * self.slots
+        if ok:
+            probe = SlotLayout.__new__(SlotLayout)
+            SlotLayout._place(probe, frames, self.slots)
+            ok = probe.T <= self.steps
+        if not ok:
+            self.refused += 1
+            return batch
+        B, N = self.examples, self.max_samples
+
+        def padded(rows, lead):
+            out = torch.zeros((B,) + lead + (N,), dtype=torch.float32)
+            for b, r in enumerate(rows):
+                r = torch.as_tensor(np.asarray(r) if not torch.is_tensor(r) else r, dtype=torch.float32)
+                out[b, ..., :r.shape[-1]] = r
+            return out.pin_memory().to(self.device, non_blocking=True) if self.device.type == 'cuda' else out
+        out = {k: v for k, v in batch.items() if k not in ('y', 's', 'num_samples')}
+        out['y'] = padded(batch['y'], ())
+        if batch.get('s') is not None:
+            K = int(np.asarray(batch['s'][0]).shape[0]) if not torch.is_tensor(batch['s'][0]) else int(batch['s'][0].shape[0])
+            out['s'] = padded(batch['s'], (K,))
+        out['num_samples'] = torch.tensor(num_samples, dtype=torch.int32).to(self.device)
+        self._turn ^= 1
+        out['slots'] = self._ring[self._turn].set(frames)
+        return out

@@ -184,3 +184,43 @@ def test_dc_model_on_static_slots_equals_row_slots_and_shares_one_graph(tmp_path
     assert step.captures == 1
     for (k, v), (_, w) in zip(m1.state_dict().items(), m2.state_dict().items()):
         np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
+
+
+def test_trainer_trains_a_ragged_stream_on_one_graph(tmp_path):
+    """The user's path end to end: a stream of variable-length utterances (``pit/data.py:20-33``) -> ``data.row_slot_batches`` ->
+    ``data.StaticSlotBatcher`` -> ``Trainer.train(graph_steps=True)``.  ``example_to_device`` makes the features from the device-side
+    lengths, the first batch runs eagerly, the second captures, all later ones replay through that ONE graph although every batch has
+    its own length pattern; a batch that does not fit the grid runs eagerly in between.  Parameters equal those of the eager loop."""
+    import padertorch_amd as pt
+    from padertorch_amd.data import StaticSlotBatcher, row_slot_batches
+    from padertorch_amd.train import graphed as G
+    rng = np.random.RandomState(4)
+    lens = [int(v) for v in rng.randint(3200, 6401, 8 * 7)]
+    lens[8 * 3:8 * 4] = [6400] * 8                                  # the fourth batch is too long for the grid: handed back, eager
+    stream = [dict(y=(0.1 * rng.randn(n)).astype(np.float32), s=(0.1 * rng.randn(2, n)).astype(np.float32), num_samples=n, example_id=f'u{i}')
+              for i, n in enumerate(lens)]
+
+    def run(graph, path):
+        batcher = StaticSlotBatcher(examples=8, slots=4, max_samples=6400, device=DEV, steps=96)
+        data = [batcher(b) for b in row_slot_batches(stream, row_slots=4, fill=2.0)]
+        assert batcher.refused == 1 and 'slots' not in data[3]
+        model = _pit(48)
+        model.row_slots = 4                                          # (the route of a batch that was handed back)
+        made = []
+        plain = G.GraphedStep.__init__
+        G.GraphedStep.__init__ = lambda self, *a, **k: (made.append(1), plain(self, *a, **k))[1]
+        try:
+            t = pt.Trainer(model, path, pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW, summary_trigger=(1, 'iteration'),
+                           checkpoint_trigger=(1000, 'iteration'), stop_trigger=(7, 'iteration'), graph_steps=graph)
+            t.train(data, device=DEV)
+        finally:
+            G.GraphedStep.__init__ = plain
+        return model, t, len(made)
+    ma, ta, _ = run(False, tmp_path / 'a')
+    mb, tb, captures = run(True, tmp_path / 'b')
+    assert ta.iteration == tb.iteration == 7 and captures == 1, captures
+    for (k, v), (_, w) in zip(ma.state_dict().items(), mb.state_dict().items()):
+        np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
+    la = [s[2]['loss'] for s in ta.summaries if s[1] == 'training']
+    lb = [s[2]['loss'] for s in tb.summaries if s[1] == 'training']
+    np.testing.assert_allclose(lb, la, rtol=1e-5)

@@ -149,3 +149,35 @@ def test_device_prefetcher_release_mode_follows_what_to_device_does():
     pl.packed_log1p = Rec()
     found = list(_tensors(dict(Y_abs=pl, n=[5, 4])))
     assert any(t is pad for t in found) and any(t is pl.lengths_dev for t in found) and any(t is Rec.data for t in found)
+
+
+def test_static_slot_batcher_makes_device_data_examples_or_hands_the_batch_back():
+    """``data.StaticSlotBatcher`` (host side; the kernels that read its tables: tests/test_gpu_ragged_graph.py): a batch that fits becomes
+    padded waveforms + sample counts + a ``StaticSlots`` layout whose tables describe exactly that batch; one that does not fit (too many
+    frames for the grid, another number of examples) comes back untouched and is counted."""
+    import numpy as np
+    import torch
+    from padertorch_amd.data import StaticSlotBatcher, row_slot_batches
+    from padertorch_amd.ops.sequence import SlotLayout, StaticSlots
+    rng = np.random.RandomState(0)
+    stream = [dict(y=rng.randn(n).astype(np.float32), s=rng.randn(2, n).astype(np.float32), num_samples=int(n), example_id=f'u{i}')
+              for i, n in enumerate(rng.randint(2400, 4801, 20))]
+    batcher = StaticSlotBatcher(examples=8, slots=4, max_samples=4800, device='cpu', steps=80)
+    outs = [batcher(b) for b in row_slot_batches(stream, row_slots=4, fill=2.0)]
+    assert [isinstance(o.get('slots'), StaticSlots) for o in outs] == [True, True, False] and batcher.refused == 1
+    assert outs[2]['num_samples'] == sorted(outs[2]['num_samples'], reverse=True) and len(outs[2]['y']) == 4      # handed back as it came
+    for o in outs[:2]:
+        ns = o['num_samples'].tolist()
+        assert ns == sorted(ns, reverse=True) and o['y'].shape == (8, 4800) and o['s'].shape == (8, 2, 4800)
+        for i, n in enumerate(ns):
+            assert float(o['y'][i, n:].abs().sum()) == 0. and float(o['s'][i, :, n:].abs().sum()) == 0. and float(o['y'][i, :n].abs().sum()) > 0
+        st, frames = o['slots'], batcher.frames_of(ns)
+        assert st.frames.tolist() == frames and len(o['example_id']) == 8
+        lay = SlotLayout(frames, 4)
+        rows = st.grid_of_flat.view(8, st.padded_time)
+        for b, t in enumerate(frames):                       # frame t of example b sits where the host-side layout puts it; padding -> the zero row
+            assert rows[b, :t].tolist() == [(lay.t0[b] + k) * 4 + lay.slot[b] for k in range(t)]
+            assert (rows[b, t:] == st.steps * 4).all()
+    assert outs[0]['slots'] is not outs[1]['slots']          # two layouts in turn
+    tight = StaticSlotBatcher(examples=8, slots=4, max_samples=4800, device='cpu', steps=41)
+    assert not isinstance(tight(next(row_slot_batches(stream, row_slots=4, fill=2.0))).get('slots'), StaticSlots) and tight.refused == 1
