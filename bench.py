@@ -965,7 +965,7 @@ def main():
                     feats = pt.ops.pit_features(src['y'], src['s'], src['num_samples'], num_frames_dev=src['slots'].frames)
                     return dict(feats, slots=src['slots'])
 
-                def ragged_graph(examples, slots, seed):
+                def ragged_graph(examples, slots, seed, nbuckets=1):
                     import random
                     rnd = random.Random(seed)
                     n_max = 6 * cfg['fs']
@@ -974,38 +974,60 @@ def main():
                     for p in range(8):
                         rl = sorted((rnd.randint(3 * cfg['fs'], n_max) for _ in range(examples)), reverse=True)
                         b = synthetic_batch(seed + p, examples, K, n_max, device, rl)
-                        pats.append(dict(y=b['y'], s=b['s'], num_samples=torch.tensor(rl, dtype=torch.int32, device=device),
-                                         frames=[frames_of(v) for v in rl]))
-                    need = max(SlotLayout(p['frames'], slots).T for p in pats)
-                    steps_cap = T_max if examples == slots else (need + 7) // 8 * 8
-                    ring = [StaticSlots(examples, slots, steps_cap, T_max, device) for _ in range(2)]
+                        fr = [frames_of(v) for v in rl]
+                        pats.append(dict(y=b['y'], s=b['s'], num_samples=torch.tensor(rl, dtype=torch.int32, device=device), frames=fr,
+                                         need=SlotLayout(fr, slots).T))
+                    # grid capacities (buckets): a batch takes the smallest grid it fits - one captured graph per bucket (what
+                    # data.StaticSlotBatcher(steps=[...]) does in a pipeline); one example per slot: the padded length
+                    needs = sorted(p['need'] for p in pats)
+                    if examples == slots:
+                        caps = [T_max]
+                    else:
+                        caps = sorted({(needs[(len(needs) * (k + 1)) // nbuckets - 1] + 7) // 8 * 8 for k in range(nbuckets)})
+                    rings = {c: [StaticSlots(examples, slots, c, T_max, device) for _ in range(2)] for c in caps}
+                    turn = {c: 0 for c in caps}
 
                     def batch(i):
                         p = pats[i % len(pats)]
-                        return dict(y=p['y'], s=p['s'], num_samples=p['num_samples'], slots=ring[i % 2].set(p['frames']))
+                        c = next(c for c in caps if p['need'] <= c)
+                        turn[c] ^= 1
+                        return c, dict(y=p['y'], s=p['s'], num_samples=p['num_samples'], slots=rings[c][turn[c]].set(p['frames']))
                     trainer._check_pending(flush=True)
-                    g = GraphedStep(trainer, [batch(0)], prepare=features_slots, warmup=2, clone_inputs=True)
-                    for i in range(3):
-                        g([batch(i)])
-                    g.load([batch(0)])
+                    graphs = {}
+                    for i in range(len(pats)):          # one capture per bucket, on the first batch that takes it
+                        c, ex = batch(i)
+                        if c not in graphs:
+                            graphs[c] = GraphedStep(trainer, [ex], prepare=features_slots, warmup=2, clone_inputs=True)
+                    state = {}
+
+                    def prepare(i):
+                        state['next'] = batch(i)
+
+                    def loop(n):
+                        prepare(0)
+                        for i in range(n):
+                            c, ex = state['next']
+                            # the NEXT batch's tables are made on the host (numpy) and copied to its layout while this step replays
+                            graphs[c]([ex], then_load=lambda i=i: prepare(i + 1))
+                    loop(4)
                     sync()
                     t0 = time.perf_counter()
-                    for i in range(nx):
-                        g(None, then_load=lambda i=i: [batch(i + 1)])
+                    loop(nx)
                     sync()
                     ms = (time.perf_counter() - t0) / nx * 1e3
                     frames = sum(sum(pats[i % len(pats)]['frames']) for i in range(nx)) / nx
-                    occupancy = frames / (steps_cap * slots)
-                    assert g.captures == 1
-                    del g
+                    steps_run = sum(next(c for c in caps if pats[i % len(pats)]['need'] <= c) for i in range(nx)) / nx
+                    assert all(g.captures == 1 for g in graphs.values())
+                    del graphs
                     return dict(ms_per_step=ms, frames_per_step=frames * world, value=frames * world / (ms * 1e-3), examples_per_step=examples * world,
-                                row_slots=slots, grid_steps=steps_cap, occupancy=occupancy, patterns=len(pats),
-                                step_driver='one hipGraph for every length pattern (ops.sequence.StaticSlots), a new pattern every step')
+                                row_slots=slots, grid_steps=caps, mean_grid_steps=steps_run, occupancy=frames / (steps_run * slots),
+                                patterns=len(pats), graphs=len(caps),
+                                step_driver='one hipGraph per grid capacity for every length pattern (ops.sequence.StaticSlots), a new pattern every step')
                 extras['ragged_graph'] = ragged_graph(cfg['batch'], cfg['batch'], 5000)
                 extras['ms_per_step_ragged_graph'] = extras['ragged_graph']['ms_per_step']
                 extras['value_ragged_graph'] = extras['ragged_graph']['value']
                 trace('ragged captured step done')
-                extras['ragged_row_slots_graph'] = ragged_graph(2 * cfg['batch'], cfg['batch'], 6000)
+                extras['ragged_row_slots_graph'] = ragged_graph(2 * cfg['batch'], cfg['batch'], 6000, nbuckets=2)
                 extras['ms_per_step_ragged_row_slots_graph'] = extras['ragged_row_slots_graph']['ms_per_step']
                 extras['value_ragged_row_slots_graph'] = extras['ragged_row_slots_graph']['value']
                 trace('ragged row-slot captured step done')

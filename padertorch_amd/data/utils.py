@@ -58,7 +58,7 @@ class StaticSlotBatcher:
         for batch in row_slot_batches(stream, row_slots=32, fill=2.0):
             example = batcher(batch)          # dict(y [B, max_samples], s [B, K, max_samples], num_samples int32 [B], slots)
 
-    ``steps``: the grid's capacity in time steps (default: enough for every batch whose frames sum to ``headroom`` x the mean of a
+    ``steps``: the grid's capacity in time steps, or a LIST of capacities (buckets: a batch takes the smallest grid it fits; default: enough for every batch whose frames sum to ``headroom`` x the mean of a
     U[max / 2, max] length distribution, rounded up to 8).  A batch that does not fit - more examples, a longer example, more frames than
     the grid has room for - comes back as it is (the model then takes its host-side route: ``model.row_slots`` / PackedSequence, eagerly);
     ``refused`` counts them.  Two layouts are used in turn: the tables of batch i + 1 may be written while batch i's step still reads its
@@ -76,10 +76,14 @@ class StaticSlotBatcher:
         if steps is None:
             mean = 0.75 * self.padded_time * self.examples / self.slots
             steps = max(self.padded_time, int(-(-headroom * mean // 8) * 8))
-        self.steps = int(steps)
-        self._ring = [StaticSlots(self.examples, self.slots, self.steps, self.padded_time, self.device) for _ in range(2)]
-        self._turn = 0
+        # several capacities = BUCKETS: a batch takes the smallest grid it fits (a step costs its grid's time steps, used or idle), and
+        # every bucket is one example signature, i.e. one captured graph (Trainer.graph_capacity of them are kept)
+        self.buckets = sorted({int(v) for v in (steps if isinstance(steps, (list, tuple)) else [steps])})
+        self.steps = self.buckets[-1]
+        self._rings = {cap: [StaticSlots(self.examples, self.slots, cap, self.padded_time, self.device) for _ in range(2)] for cap in self.buckets}
+        self._turn = {cap: 0 for cap in self.buckets}
         self.refused = 0
+        self.taken = {cap: 0 for cap in self.buckets}
 
     def frames_of(self, num_samples):
         return [int(self.stft.samples_to_frames(int(n))) for n in num_samples]
@@ -91,13 +95,15 @@ class StaticSlotBatcher:
         num_samples = [int(n) for n in batch['num_samples']]
         frames = self.frames_of(num_samples)
         ok = len(frames) == self.examples and max(num_samples) <= self.max_samples and min(frames) >= 1 and sum(frames) <= self.steps * self.slots
+        cap = None
         if ok:
             probe = SlotLayout.__new__(SlotLayout)
             SlotLayout._place(probe, frames, self.slots)
-            ok = probe.T <= self.steps
-        if not ok:
+            cap = next((c for c in self.buckets if probe.T <= c), None)
+        if cap is None:
             self.refused += 1
             return batch
+        self.taken[cap] += 1
         B, N = self.examples, self.max_samples
 
         def padded(rows, lead):
@@ -112,6 +118,6 @@ class StaticSlotBatcher:
             K = int(np.asarray(batch['s'][0]).shape[0]) if not torch.is_tensor(batch['s'][0]) else int(batch['s'][0].shape[0])
             out['s'] = padded(batch['s'], (K,))
         out['num_samples'] = torch.tensor(num_samples, dtype=torch.int32).to(self.device)
-        self._turn ^= 1
-        out['slots'] = self._ring[self._turn].set(frames)
+        self._turn[cap] ^= 1
+        out['slots'] = self._rings[cap][self._turn[cap]].set(frames)
         return out

@@ -375,7 +375,9 @@ class GraphedStep:
                 ev[3].record()
         if then_load is not None:
             # (a callable: the next batch is MADE here - host work such as a length pattern's index tables runs while the GPU replays)
-            self.load(then_load() if callable(then_load) else then_load)
+            nxt = then_load() if callable(then_load) else then_load
+            if nxt is not None:             # (a callable may only PREPARE the next batch - e.g. for another graph's static inputs)
+                self.load(nxt)
         tr._opt_step += 1
         self._steps += 1
         # the replay rewrote the parameters through the graph's kernel nodes: nothing bumped their version counters, and the operand
