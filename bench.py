@@ -104,6 +104,9 @@ def parse_args(argv=None):
                     help='N = 1: run under a process group of ONE rank (RCCL) and time the captured DATA-PARALLEL step (two graphs with the '
                          "'flat+words' exchange between them: train.graphed split_for_allreduce) - what N > 1 probes as schedule graph_split")
     ap.add_argument('--no-graph-split', action='store_true', help='N > 1: do not probe the captured data-parallel step')
+    ap.add_argument('--capture-rccl', action='store_true',
+                    help="with --dp-graph: ONE graph per step that contains the layer buckets' RCCL all-reduces (Trainer.graph_exchange = "
+                         "'captured': opt-in, validated with a one-rank group only; not probed at N > 1 - a hang there would cost the run)")
     ap.add_argument('--row-slots', action='store_true',
                     help='with --ragged: 2 x batch examples end to end in `batch` row slots (model.row_slots), the timed step itself '
                          '(the default line reports the same as value_ragged_row_slots)')
@@ -441,6 +444,7 @@ def main():
     if args.dp_graph:
         assert args.gpus == 1, '--dp-graph: the one-rank process group of a single-GPU run (N > 1 probes the same step as schedule graph_split)'
         args.no_extras = True
+    assert not args.capture_rccl or args.dp_graph, '--capture-rccl goes with --dp-graph (N = 1)'
     if os.environ.get('PTMI_BENCH_TRACE'):
         import faulthandler
         faulthandler.dump_traceback_later(40, repeat=True, file=sys.stderr)
@@ -780,7 +784,9 @@ def main():
         # N = 1: the optimizer step as ONE captured hipGraph, checks at the end of the same step (reference semantics)
         from padertorch_amd.train.graphed import GraphedStep
         trainer._check_pending(flush=True)
-        if args.dp_graph:
+        if args.dp_graph and args.capture_rccl:
+            trainer.graph_exchange = 'captured'          # (the layer buckets stay: their all-reduces become nodes of the graph)
+        elif args.dp_graph:
             trainer.dp_protocol = 'flat+words'
             for h in state['hooks']:
                 h.remove()
@@ -788,12 +794,12 @@ def main():
             trainer.op_context.grad_ready_hook = trainer.op_context.grad_use_hook = None
         # (--warmup 0 / 1: the capture still needs every lazily made table, stream and kernel attribute to exist: its own untimed eager steps)
         graphed = graph_state['step'] = GraphedStep(trainer, [data] * micro, prepare=features, warmup=max(0, 2 - args.warmup))
-        if args.dp_graph:
+        if args.dp_graph and not args.capture_rccl:
             assert graphed.split
             graphed.times = []
         for _ in range(3):
             graphed()
-        if args.dp_graph:
+        if args.dp_graph and not args.capture_rccl:
             graphed.times = []
         sync()
         t0 = time.perf_counter()
@@ -1124,7 +1130,7 @@ def main():
     if rccl is not None:
         rccl['per_rank'] = per_rank
     elif args.dp_graph and not args.dry:
-        rccl = dict(world_size=1, backend=backend, schedule=dict(used='graph_split'), per_rank=per_rank,
+        rccl = dict(world_size=1, backend=backend, schedule=dict(used='graph_captured' if args.capture_rccl else 'graph_split'), per_rank=per_rank,
                     note='one-rank process group on one GPU: everything of the captured data-parallel step but the wire')
 
     if rank == 0:
@@ -1162,7 +1168,7 @@ def main():
                                 'loss / grad-norm finiteness inspected one step late, optimizer update gated on the device (Trainer deferred_checks)'),
                 'step_driver': ("two hipGraphs per optimizer step with the data-parallel exchange between them (train.graphed.GraphedStep, "
                                 "split_for_allreduce: forward + backward | all_reduce(flat bucket), all_reduce(2 words) | norm + clip + Adam)"
-                                if (split_state['on'] or args.dp_graph) else
+                                if (split_state['on'] or (args.dp_graph and not args.capture_rccl)) else
                                 'one hipGraph per optimizer step (train.graphed.GraphedStep), replayed' if use_graph else 'eager launches (python)'),
                 'optimizer': 'csrc/optim.hip: reproducible 2-norm + fused clip / Adam / zero_grad over the flat bucket',
                 'lstm_weight_gradients': 'autograd, main stream' if args.no_overlap else 'in place, side stream next to the next recurrence',

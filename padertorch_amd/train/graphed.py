@@ -161,10 +161,17 @@ class GraphedStep:
         self._pattern = None
         self.captures = 0
         #: a process group is active: the step is TWO graphs with the data-parallel exchange between them (``split_for_allreduce``)
-        self.split = bool(trainer._dp_active())
+        self.split = bool(trainer._dp_active()) and trainer.graph_exchange != 'captured'
+        #: OPT-IN (``Trainer.graph_exchange = 'captured'``): ONE graph whose nodes include the layer buckets' RCCL all-reduces on the
+        #: weight-gradient queue - the eager loop's overlap inside the replay.  RCCL collectives do capture into a hipGraph
+        #: (``scripts/mb/rccl_in_graph.py``), but only a group of ONE rank can be formed on the boxes this was built on: with more ranks
+        #: it is untested, and every rank has to replay or run eagerly in the same steps (equal shapes on all ranks).
+        self.captured_exchange = bool(trainer._dp_active()) and not self.split
         if self.split:
             assert trainer.dp_protocol == 'flat+words' and trainer._buckets is None, \
                 "a captured data-parallel step speaks the 'flat+words' protocol (Trainer.dp_protocol; Trainer.train sets it with graph_steps)"
+        if self.captured_exchange:
+            assert trainer.dp_protocol is None, "graph_exchange = 'captured' keeps the eager loop's collectives (layer buckets, update gate)"
         self.times = None           # split steps: [(graph A, exchange, graph B) in ms of GPU time] of the calls made with record_times
         self._eager(warmup)         # every lazily made table / stream / kernel attribute exists before the capture starts
         self._capture()
@@ -267,7 +274,7 @@ class GraphedStep:
 
     def _capture(self):
         tr = self.trainer
-        assert not tr._dp_active() or self.split, 'the data-parallel exchange is not captured: split_for_allreduce'
+        assert not tr._dp_active() or self.split or self.captured_exchange
         keep = tr.deferred_checks
         tr._check_pending(flush=True)
         tr.deferred_checks = True               # no host synchronisation inside the capture; this class does the checks

@@ -227,6 +227,10 @@ class Trainer:
         #: step (``train.graphed``: graph A = forward + backward, the exchange, graph B = norm + clip + Adam) and a rank that runs the
         #: same step eagerly (first sighting of a shape) stay in lockstep; the update is gated on the device by the SUMMED loss word.
         self.dp_protocol = None
+        #: how a captured step (``graph_steps``) exchanges under a process group: 'split' (default) = two graphs around the 'flat+words'
+        #: exchange, nothing of RCCL captured; 'captured' (opt-in, validated with a one-rank group only) = one graph that contains the layer
+        #: buckets' all-reduces and the update gate's - the eager loop's overlap inside the replay
+        self.graph_exchange = 'split'
         self._exchanged = None       # the words of an exchange that has run for the current optimizer step
         self.summary_trigger = IntervalTrigger.new(summary_trigger)
         self.checkpoint_trigger = IntervalTrigger.new(checkpoint_trigger)
@@ -311,7 +315,9 @@ class Trainer:
             warnings.warn('graph_steps with a process group needs the native Adam step on a GPU bucket; running the eager data-parallel loop')
             dp_graph = False
         checks_before, protocol_before = self.deferred_checks, self.dp_protocol
-        if dp_graph:
+        if dp_graph and self.graph_exchange == 'captured':
+            self.deferred_checks = 'step'           # (the eager loop's collectives, captured: train.graphed.GraphedStep.captured_exchange)
+        elif dp_graph:
             self.dp_protocol, self.deferred_checks = 'flat+words', 'step'
         if self.dp_protocol == 'flat+words':
             hooks, self._buckets = [], None         # ONE all-reduce of the flat bucket per optimizer step: no layer buckets

@@ -215,3 +215,36 @@ def test_two_ranks_train_with_captured_steps(tmp_path, odd_on_rank1):
         assert big == [nflat, 2] * 6, big
         assert r['captures'] >= 1
     assert g0['captures'] == 1 and g1['captures'] == (1 if not odd_on_rank1 else 1)
+
+
+def test_opt_in_captured_exchange_with_a_one_rank_group(tmp_path, one_rank_group):
+    """``Trainer.graph_exchange = 'captured'`` (opt-in): ONE graph per optimizer step whose nodes include the layer buckets' RCCL
+    all-reduces on the weight-gradient queue and the update gate's - RCCL collectives do capture into a hipGraph
+    (``scripts/mb/rccl_in_graph.py``).  A one-rank group is all a one-GPU box can form: same parameters and losses as the eager
+    data-parallel loop; no collective is issued outside the replays."""
+    dist = one_rank_group
+    exs = _examples(12)
+    a, b = _pit(), _pit()
+    ta = _train(a, exs, tmp_path / 'a', 6)
+    import padertorch_amd as pt
+    tb = pt.Trainer(b, tmp_path / 'b', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=LW, summary_trigger=(1, 'iteration'),
+                    checkpoint_trigger=(1000, 'iteration'), stop_trigger=(6, 'iteration'), virtual_minibatch_size=2, graph_steps=True)
+    tb.graph_exchange = 'captured'
+    issued = []
+    real = dist.all_reduce
+    dist.all_reduce = lambda tensor, *args, **kw: (issued.append(tensor.numel()), real(tensor, *args, **kw))[1]
+    try:
+        tb.train(exs, device=DEV)
+    finally:
+        dist.all_reduce = real
+    assert ta.iteration == tb.iteration == 6
+    # python saw the collectives of the eager first step and of the capture (which executes nothing); the four replays issue theirs as nodes
+    per_step = len([n for n in issued]) // 2
+    assert len(issued) == 2 * per_step and per_step >= 4, issued
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        np.testing.assert_allclose(w.cpu().numpy(), v.cpu().numpy(), rtol=0, atol=1e-6, err_msg=k)
+    sa = [s[2] for s in ta.summaries if s[1] == 'training']
+    sb = [s[2] for s in tb.summaries if s[1] == 'training']
+    for x, y in zip(sa, sb):
+        for key in x:
+            np.testing.assert_allclose(y[key], x[key], rtol=1e-5, atol=1e-7, err_msg=key)
