@@ -77,7 +77,7 @@ class StaticSlotBatcher:
             mean = 0.75 * self.padded_time * self.examples / self.slots
             steps = max(self.padded_time, int(-(-headroom * mean // 8) * 8))
         # several capacities = BUCKETS: a batch takes the smallest grid it fits (a step costs its grid's time steps, used or idle), and
-        # every bucket is one example signature, i.e. one captured graph (Trainer.graph_capacity of them are kept)
+        # every bucket is one example signature, i.e. one captured graph (set ``trainer.graph_capacity`` to the number of buckets: two are kept by default)
         self.buckets = sorted({int(v) for v in (steps if isinstance(steps, (list, tuple)) else [steps])})
         self.steps = self.buckets[-1]
         self._rings = {cap: [StaticSlots(self.examples, self.slots, cap, self.padded_time, self.device) for _ in range(2)] for cap in self.buckets}
