@@ -528,7 +528,11 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     // row-slot batches (LstmPersistBwdArgs::masks; not in the UNI instantiations): per-step row masks instead of the prefix rules
     typedef unsigned long long u64;
     const bool masked = MSK || (!UNI && A.masks != nullptr);
-    auto bit = [](u64 m, int i) { return ((m >> (i & 63)) & 1ull) != 0ull; };
+    // (round 6: a workgroup keeps only ITS rows' bits of a mask word - bit i = row m0 + i, 32-bit - : nine 64-bit mask values in a kernel that
+    //  is short of scalar registers cost 59 more v_readlane per step than the uniform instantiation has)
+    typedef unsigned u32;
+    auto lbit = [&](u32 m, int row) { return ((m >> ((row - m0) & 31)) & 1u) != 0u; };
+    auto local = [&](u64 m) { return (u32)(m >> m0) & (MR >= 32 ? 0xffffffffu : ((1u << (MR & 31)) - 1u)); };
 
     const int nblk = A.G32 >> 5;
     const int base = nblk / NW, extra = nblk - base * NW;
@@ -591,13 +595,13 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
     // row-slot batches: the mask words of this step's time index (alive rows, rows at a sequence boundary in this direction's sense)
     // and of the previously processed one
     const int msel = dir == 0 ? 1 : 2;
-    u64 mk_a = 0ull, mk_b = 0ull, pv_a = 0ull, pv_b = 0ull;
+    u32 mk_a = 0u, mk_b = 0u, pv_a = 0u, pv_b = 0u;
     if (masked) {
-        mk_a = ld_const64(A.masks, 3 * tindex(s0));
-        mk_b = ld_const64(A.masks, 3 * tindex(s0) + msel);
+        mk_a = local(ld_const64(A.masks, 3 * tindex(s0)));
+        mk_b = local(ld_const64(A.masks, 3 * tindex(s0) + msel));
         if (s0 > 0) {
-            pv_a = ld_const64(A.masks, 3 * tindex(s0 - 1));
-            pv_b = ld_const64(A.masks, 3 * tindex(s0 - 1) + msel);
+            pv_a = local(ld_const64(A.masks, 3 * tindex(s0 - 1)));
+            pv_b = local(ld_const64(A.masks, 3 * tindex(s0 - 1) + msel));
         }
     }
     for (int s = s0; s < s1; ++s) {
@@ -623,22 +627,22 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
         // state c_{t-1} (forward sense of this direction) exists
         // (the mask words arrive one iteration ahead - mk_a / mk_b below - and the previously processed index's are kept: loaded at
         //  the loop head they put a scalar-load round trip into every step of the chain: 4.8 instead of 3.9 us per step)
-        u64 amask = ~0ull, smask = ~0ull, cmask = ~0ull;
+        u32 amask = ~0u, smask = ~0u, cmask = ~0u;
         if (masked) {
-            const u64 cur_a = mk_a, cur_b = mk_b;
+            const u32 cur_a = mk_a, cur_b = mk_b;
             const int t2m = tindex(min(s + 1, A.T - 1));          // clamped, unconditional
-            mk_a = ld_const64(A.masks, 3 * t2m);
-            mk_b = ld_const64(A.masks, 3 * t2m + msel);
+            mk_a = local(ld_const64(A.masks, 3 * t2m));
+            mk_b = local(ld_const64(A.masks, 3 * t2m + msel));
             amask = cur_a;
             const bool tn_ok = tn >= 0 && tn < A.T;
-            smask = tn_ok ? pv_a & ~pv_b : 0ull;
+            smask = tn_ok ? pv_a & ~pv_b : 0u;
             cmask = cur_a & ~cur_b;
             pv_a = cur_a;
             pv_b = cur_b;
         }
-        auto has_succ = [&](int row) { return row < nnext && bit(smask, row); };
-        const bool has_rec = masked ? ((smask >> m0) & ((1ull << MR) - 1ull)) != 0ull && nnext > m0 : nnext > m0;
-        const bool act = tid < 16 * MR && b < nb && bit(amask, b) && j < H;
+        auto has_succ = [&](int row) { return row < nnext && lbit(smask, row); };
+        const bool has_rec = masked ? smask != 0u && nnext > m0 : nnext > m0;
+        const bool act = tid < 16 * MR && b < nb && lbit(amask, b) && j < H;
         // The saved activations of this thread's element: UNCONDITIONAL loads from clamped addresses in the wavefronts that own
         // elements (a wave-uniform branch).  With `if (act) x = load` the compiler zero-initialises the destination registers at
         // the loop head and, to protect them, waits there for every memory operation of the previous step (s_waitcnt
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
                         // where it brings the wait back)
             asm volatile("" : "=v"(dh), "=v"(ig), "=v"(fg), "=v"(gg), "=v"(og), "=v"(cn), "=v"(cprev));
         }
-        const bool has_prev_c = b < npv && bit(cmask, b);
+        const bool has_prev_c = b < npv && lbit(cmask, b);
         // (the initial cell state of this thread's element is c0_own, loaded once in front of the loop: as `c0v = 0; if (...) c0v =
         //  A.c0[...]` at this point, the zero-initialisation of a register that a load of the previous iteration may still own made the
         //  compiler wait HERE with s_waitcnt vmcnt(0) - for the cold loads just issued and for the previous step's stores, in front of the
@@ -823,7 +827,7 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_bwd_split_kernel(const LstmPe
             const int pw2 = (A.G32 - G) >> 1;
             for (int e = tid; e < MR * pw2 * 2; e += NW * 64) {
                 const int rl = e / (pw2 * 2), rem = e - rl * pw2 * 2, plane = rem / pw2, ce = G + 2 * (rem - plane * pw2);
-                if (m0 + rl < nb && (masked || bit(amask, m0 + rl))) {
+                if (m0 + rl < nb && (masked || lbit(amask, m0 + rl))) {
                     unsigned* tq = reinterpret_cast<unsigned*>(A.dgt + (((size_t)t * A.nt16 + tile16 + (rl >> 4)) * A.ndir + dir) * tile_elems);
                     __hip_atomic_store(tq + handoff_index(ce, plane, rl & 15) / 2, 0u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
