@@ -620,7 +620,7 @@ def main():
                 feats = features(src)
                 assert sum(feats['num_frames']) == variant['frames'], (sum(feats['num_frames']), variant['frames'])
                 loss, _, _, _ = trainer.train_step(model, feats, device)
-                loss.backward()
+                trainer.backward(loss)
             trainer.optimizer_step()
 
     def sync():
@@ -899,7 +899,7 @@ def main():
                 for src in DevicePrefetcher((host for _ in range(n)), device):
                     feats = features(src)
                     loss, _, _, _ = trainer.train_step(model, feats, device)
-                    loss.backward()
+                    trainer.backward(loss)
                     trainer.optimizer_step()
                 trainer._check_pending(flush=True)
                 sync()

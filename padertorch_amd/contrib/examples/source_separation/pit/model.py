@@ -233,7 +233,8 @@ class PermutationInvariantTrainingModel(base.Model):
         # MSE loss and ideal-phase-sensitive loss of every example, batch means (reference :117-140)
         loss, _, _ = ops.losses.pit_mse_ips_losses(
             mask, Y, X, C, lengths_dev, mask_batch_first=mask_bf)
-        review = dict(losses={'pit_mse_loss': loss[0], 'pit_ips_loss': loss[1]})
+        # (ops.scalars.pick: loss[i] whose backward costs no launch)
+        review = dict(losses={'pit_mse_loss': ops.scalars.pick(loss, 0), 'pit_ips_loss': ops.scalars.pick(loss, 1)})
 
         if self.create_snapshot:
             # tensorboard images of the batch's first example (reference :141-150; note its quirk: every 'estimation_<k>' shows

@@ -2,6 +2,7 @@ from .losses import *  # noqa: F401,F403
 from . import losses
 from . import sequence
 from . import mappings
+from . import scalars  # noqa: F401
 
 from ._stft import STFT  # noqa: F401
 from .einsum import *  # noqa: F401,F403

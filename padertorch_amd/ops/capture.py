@@ -12,12 +12,22 @@ import contextlib
 
 import torch
 
-__all__ = ['ACTIVE', 'capture_mode', 'zero_word', 'reset_step_caches']
+__all__ = ['ACTIVE', 'capture_mode', 'zero_word', 'zero_block', 'reset_step_caches']
 
 #: True while a step is being captured (host thread of the capture AND autograd's worker threads read it)
 ACTIVE = False
 
 _zero_blocks = []       # [[block of zeroed int32 words (allocated and zero-filled INSIDE the capture), words handed out, stream]]
+_shared = []            # [block zero-filled by the FIRST node of the capture, words handed out]: every stream of the capture forks behind it
+
+
+def zero_block(device, words=4096):
+    """Call as the first thing inside ``torch.cuda.graph(...)``: ONE fill node at the head of the graph zeroes the words every
+    accumulating epilogue of the step starts from, whatever stream it runs on - a stream joins a capture only by waiting for an
+    event recorded behind this node.  (Round 5 filled a block per stream and pool, 64 / 256 words each: five or six 5 us fill
+    launches per replay, most of them on the critical path between the dense layers.)"""
+    assert ACTIVE
+    _shared[:] = [torch.zeros(words, dtype=torch.int32, device=device), 0]
 
 
 def zero_word(device, block_words=64):
@@ -26,6 +36,9 @@ def zero_word(device, block_words=64):
     eager pools hand out words of blocks that were filled once, when they were allocated; a replay would accumulate into the last
     replay's maximum.)"""
     # (a block belongs to the stream it was zero-filled on: a word handed to another stream's kernel would not be ordered behind the fill)
+    if _shared and _shared[0].device == device and _shared[1] < _shared[0].numel():
+        _shared[1] += 1
+        return _shared[0][_shared[1] - 1:_shared[1]]
     stream = torch.cuda.current_stream(device).cuda_stream
     ent = next((e for e in reversed(_zero_blocks) if e[2] == stream and e[0].device == device and e[1] < e[0].numel()), None)
     if ent is None:
@@ -38,7 +51,10 @@ def zero_word(device, block_words=64):
 def reset_step_caches():
     """Forget everything the ops have cached from earlier steps that orders work (events) or stands for parameter values (forms)."""
     from . import gemm as _gemm, lstm as _lstm
-    _gemm.invalidate()              # operand scales / planes / stacked LSTM forms / the optimizer's update event / learned prefetches
+    known = dict(_gemm._KNOWN)      # which forms the dense layers' parameters are used in: knowledge, not state - kept
+    _gemm.invalidate()              # operand scales / planes / stacked LSTM forms / the optimizer's update event
+    _gemm._KNOWN.update(known)
+    _lstm._EARLY_FORK.clear()
     _gemm._WAITED.clear()
     _lstm._WGRAD_DONE.clear()
 
@@ -50,10 +66,14 @@ def capture_mode():
     assert not ACTIVE, 'nested capture'
     reset_step_caches()
     del _zero_blocks[:]
+    del _shared[:]
     ACTIVE = True
     try:
         yield
     finally:
         ACTIVE = False
+        if _shared:
+            _zero_blocks.append([_shared[0], _shared[0].numel(), None])       # (stays alive with the graph like the others)
+            del _shared[:]
         reset_step_caches()
         # (the zero blocks stay alive with the graph: its nodes write them)

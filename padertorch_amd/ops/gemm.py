@@ -172,7 +172,7 @@ def _cached(cache, key, p, make, limit, form=None):
     return v
 
 
-def prefetch_known(device):
+def prefetch_known(device, everything=False):
     """Re-make, on the CURRENT stream (a side stream ordered behind the optimizer kernel: ``ops.lstm.packed_lstm``), the operand
     forms - maximum, fp16 planes in either orientation - that the dense layers asked for in earlier steps and that an optimizer step
     has made stale: a handful of small launches (~5 us each, 45 us per step of the PIT model) that otherwise sit in front of the
@@ -189,7 +189,8 @@ def prefetch_known(device):
             del _KNOWN[pid]
         elif q.device == device and q.dim() == 2:
             e = covered.get(id(q))
-            if e is not None and e[0]() is q and e[1] == q._version:
+            # (everything: a captured step - the stream forks at the head of the graph, behind the previous replay's optimizer kernel)
+            if everything or (e is not None and e[0]() is q and e[1] == q._version):
                 todo.append((q, sorted(forms, key=str)))
     if not todo or _PREFETCHING[0] is not None:
         return

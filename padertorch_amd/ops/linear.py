@@ -52,6 +52,7 @@ class _LinearFn(torch.autograd.Function):
                 torch.ops.ptmi.gemm_planes_relu_(y, a[0], a[1], b[0], b[1], bias, x.shape[0], weight.shape[0], K, split, amax_y)
                 ctx.save_for_backward(x, weight, y)
                 ctx.mark_non_differentiable(amax_y)
+                ctx.set_materialize_grads(False)        # (no zero-filled "gradient" of the maximum word: a fill launch per step)
                 return y, amax_y
             ctx.save_for_backward(x, weight)
             torch.ops.ptmi.gemm_planes_(y, a[0], a[1], b[0], b[1], bias, x.shape[0], weight.shape[0], K, False, split)
@@ -62,6 +63,8 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g_amax=None):
+        if g is None:
+            return None, None, None, None, None, None
         x, weight = ctx.saved_tensors[:2]
         mod = ctx.module
         amax_x, amax_w = ctx.amax

@@ -40,10 +40,13 @@ class _DcFn(torch.autograd.Function):
         # length; the generic layout path touches valid rows only (its output has to start from zeros)
         ctx.geom = (B, T, E, K, F, strides, row_frames is not None and not (xs[3] == 1 and ts[3] == 1))
         ctx.mark_non_differentiable(ex_loss)
+        ctx.set_materialize_grads(False)        # (no zero-filled stand-in for the per-example losses' gradient: a 5 us fill launch)
         return loss[0], ex_loss
 
     @staticmethod
     def backward(ctx, g_loss, _g_ex):
+        if g_loss is None:
+            return None, None, None, None
         x, t, row_frames, gram = ctx.saved_tensors
         B, T, E, K, F, strides, zero_fill = ctx.geom
         dx = torch.ops.ptmi.dc_loss_backward(x, t, gram, g_loss.to(torch.float32).reshape(1).contiguous(), row_frames,
@@ -145,10 +148,15 @@ class _PitFn(torch.autograd.Function):
         ctx.save_for_backward(est, obs, tgt, scale, row_frames, perm)
         ctx.geom = (B, T, K, F, strides)
         ctx.mark_non_differentiable(perm, ex_loss, sse)
+        # no zero-filled stand-ins for the gradients of perm / ex_loss / sse: three 5 us fill launches between the loss and its
+        # backward kernel, on the step's critical path (scripts/dbg_ops_between.py)
+        ctx.set_materialize_grads(False)
         return loss, perm, ex_loss, sse
 
     @staticmethod
     def backward(ctx, g_loss, _gp, _ge, _gs):
+        if g_loss is None:
+            return None, None, None, None, None, None
         est, obs, tgt, scale, row_frames, perm = ctx.saved_tensors
         B, T, K, F, strides = ctx.geom
         grad = torch.ops.ptmi.pit_loss_backward(est, obs, tgt, scale, perm, g_loss.to(torch.float32).contiguous(), row_frames,

@@ -308,11 +308,52 @@ _STACKED = {}
 _PREP_STREAMS = {}
 
 
-def _prep_stream(device):
-    key = (device.type, device.index)
+def _prep_stream(device, first_layer=False):
+    """The parameter-form queue (``first_layer``: a second one, for the first BLSTM layer's forms of a captured step - see
+    :func:`begin_captured_step`)."""
+    key = (device.type, device.index, bool(first_layer))
     if key not in _PREP_STREAMS:
         _PREP_STREAMS[key] = torch.cuda.Stream(device=device)
     return _PREP_STREAMS[key]
+
+
+_EARLY_FORK = {}            # (device type, index) -> the preparation streams a captured step has forked at its very start
+
+#: where a captured step makes the parameter forms (A/B switch): 'off' = as the eager step orders them (first layer's on the main
+#: queue behind the feature kernel, the others' on a queue that forks at the first BLSTM call); 'one' = the others' queue forks at the
+#: head of the graph; 'two' = that, and the first layer's forms on a second queue forked there too
+CAPTURE_FORK = 'two'
+
+
+def begin_captured_step(device):
+    """First thing inside the capture of an optimizer step (``train.graphed``, behind ``ops.capture.zero_block``): the preparation
+    queue forks HERE - in front of the front-end kernels - instead of at the first BLSTM call, so that a replay makes every parameter
+    form (all BLSTM layers', the dense layers' of the earlier steps) NEXT TO the feature kernel instead of behind it.  They read the
+    parameters only, which the previous replay's optimizer kernel wrote.  (Round 5's replay: first recurrence at 490 us of the step;
+    with this and the shorter ``lstm_weight_prep`` at 280 - of which the step keeps 40-60 us, the forms now run beside the first
+    recurrence and slow it: DESIGN 4.4, ``profiles/r6_head_of_step.txt``.)"""
+    from . import capture as _capture
+    assert _capture.ACTIVE
+    device = torch.device(device)
+    if CAPTURE_FORK == 'off':
+        return
+    pre, pre0 = _prep_stream(device), (_prep_stream(device, True) if CAPTURE_FORK == 'two' else None)
+    pre.wait_stream(torch.cuda.current_stream(device))
+    if pre0 is not None:
+        pre0.wait_stream(torch.cuda.current_stream(device))
+    _EARLY_FORK[(device.type, device.index)] = (pre, pre0)
+    # (Only the forks: the work itself is enqueued where it always was, by the first BLSTM call - a replay submits its nodes in
+    #  capture order, and with the forms captured FIRST the feature kernel, head of the critical path, started 170 us later.  Two
+    #  queues: a replay runs the nodes of one captured stream in order, and the first projection - whose operands are the feature
+    #  kernel's output and the FIRST layer's forms - landed on the form queue behind all the other layers' forms, at 350 us.)
+
+
+def end_captured_step(device):
+    """Last thing inside the capture: every side queue the step has forked joins the capturing stream."""
+    device = torch.device(device)
+    for side in _EARLY_FORK.pop((device.type, device.index), None) or ():
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
 
 
 def _stacked_stale(params):
@@ -1037,21 +1078,28 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # doing (the front-end kernels, the first projection), instead of one launch in front of every layer's projection
         pre = forked = _prep_stream(data.device)
         updated = _gemm.update_event(flat_params)
-        if updated is not None:
+        from . import capture as _capture_
+        early = _EARLY_FORK.get((data.device.type, data.device.index)) if _capture_.ACTIVE else None
+        pre0 = early[1] if early else None
+        early = bool(early)
+        if early:
+            pass                          # a captured step: forked at the head of the graph (begin_captured_step), nothing to wait for
+        elif updated is not None:
             pre.wait_event(updated)       # behind the optimizer kernel, i.e. next to the step's front-end, not behind it
         else:
             pre.wait_stream(torch.cuda.current_stream(data.device))
         for layer, ps_ in enumerate(all_params):
-            if _stacked_stale(ps_) and layer > 0:
-                _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre)
-        if updated is not None:
+            # (the first layer's too in a captured step: a cross-queue edge of a graph costs no host time)
+            if _stacked_stale(ps_) and (layer > 0 or pre0 is not None):
+                _stacked_weights(ps_, (H + 15) // 16 * 16, stream=pre if layer > 0 else pre0)
+        if updated is not None or early:
             with torch.cuda.stream(pre):
-                _gemm.prefetch_known(data.device)         # the dense layers' operand forms of the last steps, behind them
+                _gemm.prefetch_known(data.device, everything=early)       # the dense layers' operand forms of the last steps, behind them
         # the first layer's forms are needed at once: on the main queue itself (a cross-queue wait in front of the first
         # projection was measured to cost the main queue 110-260 us; the later layers' forms are long done when their
         # projection is reached, and a wait for a finished event costs nothing)
     else:
-        forked = None
+        forked = pre0 = None
     prev_handoff = None
     for layer in range(lstm.num_layers):
         params = all_params[layer]
@@ -1100,6 +1148,8 @@ def packed_lstm(lstm: torch.nn.LSTM, packed: PackedSequence, training=None, hx=N
         # a captured step: the preparation stream has forked from the capturing stream (above) and must join it again, whether or not
         # a layer has waited for its forms (by now they are long done: the wait is free)
         torch.cuda.current_stream(data.device).wait_stream(forked)
+        if pre0 is not None:
+            torch.cuda.current_stream(data.device).wait_stream(pre0)
     if not (torch.is_grad_enabled() and h.requires_grad):
         # inference: nobody will run Trainer.clip_grad (which reads the watchdog words of the persistent kernels during
         # training) - check them here, so that results of a timed-out launch are never returned silently

@@ -239,13 +239,26 @@ class GraphedStep:
     def _micro_steps(self):
         """Forward, review and backward of every example of the optimizer step (``trainer.py:357-393``): gradients accumulate."""
         tr = self.trainer
+        capturing = _capture.ACTIVE
+        if capturing:
+            # the head of the graph: ONE fill node zeroes every accumulation word of the step; the parameter-form queue forks here,
+            # in front of the front-end kernels (it joins again below: in front of the optimizer kernel that rewrites what it reads)
+            from ..ops import lstm as _lstm
+            _capture.zero_block(self.device)
+            _lstm.begin_captured_step(self.device)
+        self._forward_backward()
+        if capturing:       # (a failed capture leaves through ops.capture.capture_mode, which forgets the fork)
+            _lstm.end_captured_step(self.device)
+
+    def _forward_backward(self):
+        tr = self.trainer
         for i, example in enumerate(self.examples):
             if tr._buckets is not None:
                 tr._buckets.active = i + 1 == len(self.examples)
             batch = self.prepare(example) if self.prepare is not None else example
             loss, _, _, review = tr.train_step(tr.model, batch, self.device)
             tr.train_summary.update(review)
-            loss.backward()
+            tr.backward(loss)
             del loss, review, batch
 
     def _one_step(self):
@@ -291,6 +304,7 @@ class GraphedStep:
         opt_step = tr._opt_step
         self._tail = self._words = None
         try:
+            from ..ops import lstm as _lstm
             with _capture.capture_mode():
                 if not self.split:
                     with torch.cuda.graph(graph, capture_error_mode='thread_local'):
@@ -301,7 +315,6 @@ class GraphedStep:
                     # (Trainer._exchange: all ranks issue the same two collectives whether they replay or run the step eagerly);
                     # graph B = norm + clip + Adam (gated by the SUMMED loss word) + the staged scalars' copies.  One memory pool:
                     # what B reads of A (the staged loss values, the words) stays where A left it.
-                    from ..ops import lstm as _lstm
                     # (the words live OUTSIDE the graphs' pool: the collective between the graphs works on ordinary allocations)
                     self._words = torch.zeros(2, dtype=torch.float32, device=self.device)
                     with torch.cuda.graph(graph, capture_error_mode='thread_local'):

@@ -255,6 +255,17 @@ class Trainer:
     def _dp_active():
         return dist.is_available() and dist.is_initialized()
 
+    @staticmethod
+    def backward(loss):
+        """``loss.backward(retain_graph=False)`` (``trainer.py:375``) starting from a cached ``1.`` instead of a ``ones_like`` fill
+        launch per micro-step (``ops.scalars``)."""
+        from ..ops import scalars as _scalars
+        one = _scalars.unit_grad(loss) if loss.is_cuda else None
+        if one is None:
+            loss.backward(retain_graph=False)
+        else:
+            torch.autograd.backward(loss, one, retain_graph=False)
+
     def _time(self, key, t0):
         self.timer[key] = self.timer.get(key, 0.) + time.perf_counter() - t0
 
@@ -372,7 +383,7 @@ class Trainer:
                         self.train_summary.update(review)
                         del example, model_output, review
                         t0 = time.perf_counter()
-                        loss.backward(retain_graph=False)
+                        self.backward(loss)
                         self._time('time_per_backward', t0)
                         del loss
                     elif W > 1 and not self.deferred_checks:
@@ -452,7 +463,7 @@ class Trainer:
             batch = self.graph_prepare(example) if self.graph_prepare is not None else example
             loss, _, _, review = self.train_step(self.model, batch, device)
             self.train_summary.update(review)
-            loss.backward(retain_graph=False)
+            self.backward(loss)
             del loss, review, batch
         summary = self.optimizer_step()
         self.train_summary.update(summary)
@@ -741,16 +752,17 @@ class Trainer:
                     loss = term if (isinstance(loss, float) and loss == 0.) else loss + term
                 review['scalars'][f'{key}_loss_weight'] = weight
             keys = list(losses)
-            vals = torch.stack([losses[k].detach().reshape(()) for k in keys] + [loss.detach().reshape(())])
+            vals, index = self._loss_values(losses, keys, loss)
             if self._deferred(loss):
                 host = self._stage('loss', vals, review)
-                for i, k in enumerate(keys):
+                for i, k in zip(index, keys):
                     review['scalars'][k] = host[i]
-                review['scalars']['loss'] = host[-1]
+                review['scalars']['loss'] = host[index[-1]]
                 del review['losses']
                 assert loss.dim() == 0, loss
                 return loss, review
             host = vals.tolist()
+            host = [host[i] for i in index]
             for k, v in zip(keys, host[:-1]):
                 review['scalars'][k] = v
             loss_value = host[-1]
@@ -777,6 +789,21 @@ class Trainer:
             raise RuntimeError(f'The loss ({loss_value}) is not finite.\n'
                                f'See error states (model, example, model_out and review) in {path}.')
         return loss, review
+
+    @staticmethod
+    def _loss_values(losses, keys, loss):
+        """One tensor with every value the summary wants (each loss and the weighted sum) plus their positions in it - without a
+        ``cat`` launch when the values already lie in one tensor: ``ops.scalars.pick``s of one loss vector whose weighted sum is one
+        of them (weights 0 / 1, ``pit/train.py:68-71``), or a single loss."""
+        from ..ops import scalars as _scalars
+        tensors = [losses[k] for k in keys] + [loss]
+        if all(t is tensors[0] for t in tensors):
+            return tensors[0].detach().reshape(1), [0] * len(tensors)
+        picks = [_scalars.picked_from(t) for t in tensors]
+        # (the weighted sum stays the LAST staged value: what the update is gated on and the host checks read as [-1])
+        if all(p is not None and p[0] is picks[0][0] for p in picks) and picks[-1][1] == picks[0][0].numel() - 1:
+            return picks[0][0].detach(), [p[1] for p in picks]
+        return torch.stack([t.detach().reshape(()) for t in tensors]), list(range(len(tensors)))
 
     # ------------------------------------------------------------------ deferred host checks
     def _deferred(self, t):

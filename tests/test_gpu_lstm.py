@@ -262,6 +262,24 @@ def test_weight_prep_forms(I, H, ndir):
     assert float(got[0]) == float(torch.cat(w_ih, 0).abs().max()) and float(got[1]) == 7.5
 
 
+def test_weight_prep_of_parameters_at_odd_addresses():
+    """Parameters that are views at 4-byte (not 16-byte) aligned addresses of a flat buffer, input width a multiple of 4: the float4
+    copy of the stacked input weights must not be taken (round 6's ``vec_ih``)."""
+    import padertorch_amd.ops.library  # noqa: F401
+    torch.manual_seed(5)
+    I, H, ndir = 8, 20, 2
+    G, KP = 4 * H, 32
+    flat = torch.randn(1 + ndir * (G * I + 3), device='cuda')
+    w_ih = [flat[1 + d * (G * I + 3):1 + d * (G * I + 3) + G * I].view(G, I) for d in range(ndir)]
+    assert all(w.data_ptr() % 16 for w in w_ih)
+    w_hh = [torch.randn(G, H, device='cuda') for _ in range(ndir)]
+    b = [torch.randn(G, device='cuda') for _ in range(ndir)]
+    cat, bias, w_pad, w_t, amax = torch.ops.ptmi.lstm_weight_prep(w_ih, w_hh, b, b, KP)
+    assert torch.equal(cat, torch.cat(w_ih, 0)) and torch.equal(w_t, torch.stack(w_hh).transpose(1, 2))
+    got = amax.view(torch.float32).cpu()
+    assert float(got[0]) == float(torch.cat(w_ih, 0).abs().max()) and float(got[1]) == float(torch.stack(w_hh).abs().max())
+
+
 @pytest.mark.parametrize('lens', [[130] * 32, [200, 180, 180, 131, 77, 64, 3]])
 def test_in_place_weight_gradients_and_time_ranges(lens, monkeypatch):
     """The Trainer's path - weight gradients accumulated in place on the side stream - against autograd through torch's CPU
