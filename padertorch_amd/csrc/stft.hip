@@ -1281,10 +1281,21 @@ static int launch_inv(InvArgs& A, long long batch, hipStream_t st) {
     // would otherwise not fill the chip.
     const long long total = A.cut_left + A.out_samples;                 // OLA samples needed
     const int min_hops = std::max(2 * PL::FPW, 2 * A.halo);
-    int run_hops = std::max(64, min_hops);
-    while (run_hops / 2 >= min_hops &&
-           batch * ((total + (long long)run_hops * shift - 1) / ((long long)run_hops * shift)) < resident_waves)
-        run_hops /= 2;
+    // the run length with the smallest (rounds of the resident wavefronts) x (frames a run walks = its hops + the halo): round 6 -
+    // until then 64 hops unless the call did not fill the chip; 1536 x 64000 samples took 4 rounds of 67 frames where 1 round of
+    // 259 does (-3 %)
+    int run_hops = min_hops;
+    long long best = -1;
+    for (int rh = min_hops; rh <= 1024; rh *= 2) {
+        const long long chunks = (total + (long long)rh * shift - 1) / ((long long)rh * shift);
+        const long long rounds = (batch * chunks + resident_waves - 1) / resident_waves;
+        const long long cost = rounds * (rh + A.halo);
+        if (best < 0 || cost < best) {
+            best = cost;
+            run_hops = rh;
+        }
+        if (chunks == 1) break;
+    }
     A.run_hops = (run_hops + PL::FPW - 1) / PL::FPW * PL::FPW;
     A.groups = (A.halo + A.run_hops + PL::FPW - 1) / PL::FPW;
     const char* dbg_env = getenv("PTMI_STFT_DBG");

@@ -1,6 +1,6 @@
 """1500 replays of ONE captured step over ever-new length patterns (ops.sequence.StaticSlots; 64 examples of 3-6 s in 32 slots, the full
 PIT model): every loss finite, no recurrence watchdog time-out, one capture."""
-import random, sys, time
+import os, random, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import torch
@@ -11,7 +11,7 @@ from padertorch_amd.ops.sequence import SlotLayout, StaticSlots
 from padertorch_amd.train.graphed import GraphedStep
 dev = torch.device('cuda:0')
 torch.manual_seed(0)
-fs, B, S = 8000, 64, 32
+fs, B, S = 8000, int(os.environ.get('SOAK_B', 64)), int(os.environ.get('SOAK_S', 32))     # SOAK_B=32 SOAK_CAP=376 SOAK_N=12: one example per slot, for a rocprofv3 timeline
 model = PermutationInvariantTrainingModel()
 tr = pt.Trainer(model, '/tmp/soak_ragged', pt.optimizer.Adam(gradient_clipping=1.), loss_weights=dict(pit_ips_loss=1., pit_mse_loss=0.), deferred_checks=True)
 tr.to(dev); tr._flat = tr.optimizer.use_flat_grads(); tr.op_context.defer_wgrad = True; L.warm_side_stream(dev); model.train()
@@ -24,7 +24,7 @@ rnd = random.Random(7)
 def pattern():
     lens = sorted((rnd.randint(3 * fs, n_max) for _ in range(B)), reverse=True)
     return lens, [int(stft.samples_to_frames(v)) for v in lens]
-cap = 640
+cap = int(os.environ.get('SOAK_CAP', 640))
 ring = [StaticSlots(B, S, cap, T_max, dev) for _ in range(2)]
 s_dev = wave.to(dev)
 def batch(i):
@@ -41,7 +41,7 @@ def features(src):
     return dict(pt.ops.pit_features(src['y'], src['s'], src['num_samples'], num_frames_dev=src['slots'].frames), slots=src['slots'])
 b0, _ = batch(0)
 step = GraphedStep(tr, [b0], prepare=features, warmup=2, clone_inputs=True)
-N = 1500
+N = int(os.environ.get('SOAK_N', 1500))
 t0 = time.perf_counter(); frames = 0; worst = 0.
 nxt = batch(1)
 step.load([nxt[0]])
