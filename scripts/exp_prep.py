@@ -1,4 +1,6 @@
-"""lstm_weight_prep alone: us per launch for the three layers of the c2 model (PTMI_PREP_DBG ablations: 1 no W_ih job, 2 no W_hh job, 4 no maximum)."""
+"""lstm_weight_prep alone: us per call for the layer shapes of the c2 model (host bound at ~22 us: run it under `rocprofv3 --kernel-trace
+--stats` for the kernel's own duration).  The PTMI_PREP_DBG ablation bits this script sweeps (1 no W_ih job, 2 no W_hh job, 4 no maximum word,
+8 unconditional atomicMax) existed in csrc/lstm_prep.hip while profiles/r6_head_of_step.txt was measured and were removed afterwards."""
 import os
 import sys
 import subprocess

@@ -27,6 +27,12 @@ db=$(find /tmp/kt -name "*.db" 2>/dev/null | head -1)
 ( for cfg in c3 c4 c5; do timeout 900 python $repo/bench.py --config $cfg --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | tail -1; done
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --eager 2>/dev/null | tail -1
   timeout 900 python $repo/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --bf16 2>/dev/null | tail -1 ) > $out/${tag}_configs.jsonl
+# the kernels of the TIMED mode (replays): what bench.py's frac_replay_profile reads
+for cfg in c2 c3; do
+  rm -rf /tmp/ktr; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ktr -o p -- python $repo/bench.py --config $cfg --no-extras --no-kernel-events --no-cpu-baseline > /tmp/ktr.log 2>&1 </dev/null
+  db=$(find /tmp/ktr -name "*.db" 2>/dev/null | head -1)
+  [ -n "$db" ] && python $repo/scripts/profile_summary.py "$db" --top 40 > $out/${tag}_kernel_trace_replay_$cfg.txt 2>&1 </dev/null
+done
 # the captured step's schedule: rocprofv3 kernel trace of graph replays (a replay does not depend on the host), c2 and c3
 cd $repo; bash scripts/timeline_graph.sh > /dev/null 2>&1; cp gpurun_out/timeline_graph.txt $out/${tag}_graph_timeline.txt
 bash scripts/timeline_graph.sh --config c3 > /dev/null 2>&1; cp gpurun_out/timeline_graph.txt $out/${tag}_graph_timeline_c3.txt; cd /tmp
