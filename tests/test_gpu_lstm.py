@@ -269,8 +269,8 @@ def test_weight_prep_of_parameters_at_odd_addresses():
     torch.manual_seed(5)
     I, H, ndir = 8, 20, 2
     G, KP = 4 * H, 32
-    flat = torch.randn(1 + ndir * (G * I + 3), device='cuda')
-    w_ih = [flat[1 + d * (G * I + 3):1 + d * (G * I + 3) + G * I].view(G, I) for d in range(ndir)]
+    flat = torch.randn(1 + ndir * (G * I + 1), device='cuda')
+    w_ih = [flat[1 + d * (G * I + 1):1 + d * (G * I + 1) + G * I].view(G, I) for d in range(ndir)]
     assert all(w.data_ptr() % 16 for w in w_ih)
     w_hh = [torch.randn(G, H, device='cuda') for _ in range(ndir)]
     b = [torch.randn(G, device='cuda') for _ in range(ndir)]
