@@ -22,7 +22,8 @@ g = torch.Generator().manual_seed(1)
 wave = 0.1 * torch.randn(B, 2, n_max, generator=g)
 rnd = random.Random(7)
 def pattern():
-    lens = sorted((rnd.randint(3 * fs, n_max) for _ in range(B)), reverse=True)
+    fixed = float(os.environ.get('SOAK_FIXED', 0))          # SOAK_FIXED=4: every example 4 s (the masked kernels on a uniform batch)
+    lens = [int(fixed * fs)] * B if fixed else sorted((rnd.randint(3 * fs, n_max) for _ in range(B)), reverse=True)
     return lens, [int(stft.samples_to_frames(v)) for v in lens]
 cap = int(os.environ.get('SOAK_CAP', 640))
 ring = [StaticSlots(B, S, cap, T_max, dev) for _ in range(2)]
