@@ -142,9 +142,12 @@ _WGRAD_DONE = {}
 _PENDING_WGRAD = []
 
 
-def flush_pending_wgrad():
+def flush_pending_wgrad(start=None):
+    """Enqueue the deferred weight-gradient launches.  ``start``: an event on the main queue that launches without an event of their own
+    (``ops.linear``: the dense layers' weight gradients) wait for - recorded in FRONT of the recurrence launch they are enqueued behind,
+    i.e. they start beside that recurrence instead of beside the dense layers' input-gradient chain that leads up to it."""
     while _PENDING_WGRAD:
-        _PENDING_WGRAD.pop(0)()
+        _PENDING_WGRAD.pop(0)(start)
 
 
 # (Measured in round 2 and not kept - DESIGN.md sections 3.9 / 4 have the numbers -: the pattern fill ahead of time on a side stream,
@@ -622,6 +625,10 @@ class _LstmLayerFn(torch.autograd.Function):
             gm is not None or _side_stream_safe(meta.rows, x.shape[1], H, ndir, ctx.ext is not None))
         main = torch.cuda.current_stream(x.device) if in_place else None
         side = _wgrad_stream(x.device) if use_side else main
+        before_recurrence = None
+        if _PENDING_WGRAD and dhy.is_cuda:       # (deferred launches of the layers above: they start where this layer's recurrence starts)
+            before_recurrence = torch.cuda.Event()
+            before_recurrence.record(torch.cuda.current_stream(dhy.device))
         operands, xplanes = [None], {}
 
         dgplanes = {}
@@ -819,7 +826,7 @@ class _LstmLayerFn(torch.autograd.Function):
             db_kernel = flags[flags.numel() - nflags - ndir * G:flags.numel() - nflags].view(torch.float32)
             if lib.ptmi_lstm_split_enabled():
                 amax_kernel = flags[flags.numel() - nflags:flags.numel() - nflags + 1]
-        flush_pending_wgrad()          # (captured steps: the layer above's weight gradients, behind this layer's recurrence launch)
+        flush_pending_wgrad(before_recurrence)          # (captured steps: the layer above's weight gradients, behind this layer's recurrence launch)
         amax_dg = None
         if gm is not None:
             amax_x, amax_w = gm
@@ -871,7 +878,7 @@ class _LstmLayerFn(torch.autograd.Function):
                 here.record(main)
             ext_ = ctx.ext
 
-            def accumulate():
+            def accumulate(_start=None):
                 if use_side:
                     if later:
                         side.wait_event(here)
