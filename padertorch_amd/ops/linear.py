@@ -24,6 +24,8 @@ AMAX_ATTR = '_ptmi_amax'
 #: captured steps: a dense layer's weight gradient is enqueued behind - and starts with - the backward recurrence of the BLSTM layer below it
 #: (A/B switch)
 DEFER_TO_RECURRENCE = True
+#: the same in the eager step (experiment switch, see _LinearFn.backward)
+DEFER_IN_EAGER = False
 
 #: ``linear(..., activation='relu')``: the ReLU in the GEMM's epilogue (False: a torch op behind the layer, as before round 4 - A/B switch)
 FUSE_RELU = True
@@ -121,14 +123,15 @@ class _LinearFn(torch.autograd.Function):
                 oc.grad_ready_hook([mod.weight] + ([mod.bias] if has_bias else []))
 
         from . import capture as _capture
-        if DEFER_TO_RECURRENCE and _capture.ACTIVE and side is not main and ctx.needs_input_grad[0]:
+        if DEFER_TO_RECURRENCE and (_capture.ACTIVE or DEFER_IN_EAGER) and side is not main and ctx.needs_input_grad[0]:
             # enqueued behind - and started with - the recurrence launch of the BLSTM layer below (ops.lstm.flush_pending_wgrad;
             # sync_deferred enqueues it when there is none).  Started here, linear2's weight gradient ran beside the input-gradient
             # chain relu' -> pack -> GEMM of linear1 that the top layer's backward recurrence waits for (that chain 151 us instead of
             # ~100 in the replay's timeline); a recurrence gives up ~7 % of the time of what runs beside it.  Round 6, one box,
-            # alternating: captured c2 step 6.581 against 6.616 ms.  Captured steps only: in the eager step it is worth 0.015 ms
-            # (6.741 against 6.755) and the eager bucketed data-parallel run of tests/test_gpu_graphed_dp.py (two ranks, gloo) then ends
-            # 3e-4 away from the captured one - not understood, not shipped.
+            # alternating: captured c2 step 6.581 against 6.616 ms.  Captured steps only (DEFER_IN_EAGER): in the eager step it is worth
+            # 0.015 ms (6.741 against 6.755); gradients bit-identical in one process (scripts/dbg_linear_defer.py) and under a one-rank
+            # RCCL group with layer buckets, but the eager BUCKETED two-rank run over gloo (tests/test_gpu_graphed_dp.py: two processes on
+            # one GPU) then ends 3e-4 away from the captured one - not understood, so not shipped.
             _lstm._PENDING_WGRAD.append(accumulate)
         else:
             accumulate()
