@@ -26,6 +26,10 @@ AMAX_ATTR = '_ptmi_amax'
 DEFER_TO_RECURRENCE = True
 #: the same in the eager step (experiment switch, see _LinearFn.backward)
 DEFER_IN_EAGER = False
+#: ... for weight gradients up to this many flop (2 M N K): a big one beside the recurrence costs more than it frees in front of it
+#: (same box, captured step, deferred against not: c2 - 11.7 and 5 GFLOP - 6.581 / 6.616 ms; c3 - 46 and 20 GFLOP - 21.33 / 21.23;
+#: c5 - one of 397 GFLOP - 18.87 / 18.11)
+DEFER_MAX_FLOP = 15e9
 
 #: ``linear(..., activation='relu')``: the ReLU in the GEMM's epilogue (False: a torch op behind the layer, as before round 4 - A/B switch)
 FUSE_RELU = True
@@ -123,7 +127,8 @@ class _LinearFn(torch.autograd.Function):
                 oc.grad_ready_hook([mod.weight] + ([mod.bias] if has_bias else []))
 
         from . import capture as _capture
-        if DEFER_TO_RECURRENCE and (_capture.ACTIVE or DEFER_IN_EAGER) and side is not main and ctx.needs_input_grad[0]:
+        small = 2. * g.shape[0] * g.shape[1] * x.shape[1] <= DEFER_MAX_FLOP
+        if DEFER_TO_RECURRENCE and small and (_capture.ACTIVE or DEFER_IN_EAGER) and side is not main and ctx.needs_input_grad[0]:
             # enqueued behind - and started with - the recurrence launch of the BLSTM layer below (ops.lstm.flush_pending_wgrad;
             # sync_deferred enqueues it when there is none).  Started here, linear2's weight gradient ran beside the input-gradient
             # chain relu' -> pack -> GEMM of linear1 that the top layer's backward recurrence waits for (that chain 151 us instead of
