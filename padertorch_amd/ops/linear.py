@@ -136,7 +136,8 @@ class _LinearFn(torch.autograd.Function):
             # alternating: captured c2 step 6.581 against 6.616 ms.  Captured steps only (DEFER_IN_EAGER): in the eager step it is worth
             # 0.015 ms (6.741 against 6.755); gradients bit-identical in one process (scripts/dbg_linear_defer.py) and under a one-rank
             # RCCL group with layer buckets, but the eager BUCKETED two-rank run over gloo (tests/test_gpu_graphed_dp.py: two processes on
-            # one GPU) then ends 3e-4 away from the captured one - not understood, so not shipped.
+            # one GPU) then ends 3e-4 away from the captured one - with linear1's deferred, not with linear2's alone; with or without
+            # the start event - not understood, so not shipped.
             _lstm._PENDING_WGRAD.append(accumulate)
         else:
             accumulate()
