@@ -329,7 +329,9 @@ int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_
 /* backward_scratch of ptmi_lstm_forward_persistent (NULL: none): the scratch the caller will hand to this layer's
  * ptmi_lstm_backward_persistent.  When ptmi_lstm_forward_fills(T, ndir, max_batch, H) != 0 the forward launch writes the
  * pattern into its planes itself - an otherwise idle wavefront of every workgroup, a slice per time step, i.e. for free -
- * and the caller passes prefilled = 1 to the backward launch.  Otherwise the pointer is ignored. */
+ * and the caller passes the returned value as `prefilled` to the backward launch: 2 = the planes AND the words behind them
+ * (bias sums, maximum word, arrival slots, error words: zeroed) are ready, the backward call enqueues nothing in front of its
+ * recurrence kernel (round 6; 1, until then: the planes only).  Otherwise the pointer is ignored. */
 int ptmi_lstm_forward_fills(int32_t T, int32_t ndir, int32_t max_batch, int32_t H);
 
 /* ---- (log-)mel features ----------------------------------------------------------------------------

@@ -461,7 +461,7 @@ int ptmi_lstm_forward_fills(int32_t T, int32_t ndir, int32_t max_batch, int32_t 
     fwd_tile_shape(max_batch, H, ndir, true, &jt, &mtl);
     const int ntiles = (max_batch + 16 * mtl - 1) / (16 * mtl);
     const int jx = (H + jt - 1) / jt;
-    return ((long long)jx * ndir * ntiles <= cu_count() && 16 * mtl * jt <= 7 * 64) ? 1 : 0;
+    return ((long long)jx * ndir * ntiles <= cu_count() && 16 * mtl * jt <= 7 * 64) ? 2 : 0;      // 2: planes AND the words behind them
 }
 
 int ptmi_lstm_scratch_prefill(uint32_t* scratch, int32_t T, int32_t ndir, int32_t max_batch, int32_t H, int32_t backward,
@@ -590,6 +590,8 @@ int ptmi_lstm_forward_persistent_slots(float* gates, float* hy, float* c, const 
         const int G32 = (4 * H + 31) / 32 * 32;
         A.fill_ptr = reinterpret_cast<uint4*>(backward_scratch);
         A.fill_n16 = (unsigned long long)lstm_tile_elems(T, ndir, max_batch, G32) / 4;
+        // the words behind the planes: [ndir][4H] bias sums, 8 words, arrival slots + error words - a multiple of 4 words (kSlots is)
+        A.zero_n16 = (unsigned long long)((long long)ndir * 4 * H + 8 + ptmi_lstm_flags_elems(T, ndir, max_batch)) / 4;
     }
     for (int t0 = 0; t0 < ntiles; t0 += per_launch) {
         A.tile0 = t0;
@@ -714,7 +716,7 @@ static int lstm_backward_persistent_impl(const float* gates, const float* c, con
         if (split && bwd_daf_applies() && !prefilled) {       // data-as-flag hand-off: the planes start as the fill pattern (same launch)
             int fe = daf_prefill_and_zero(dgt, (size_t)lstm_tile_elems(T, ndir, max_batch, G32), flags, nz, st);
             if (fe) return fe;
-        } else {
+        } else if (prefilled != 2) {       // (2: the forward launch has zeroed these words with the pattern fill - ptmi_lstm_forward_fills)
             hipError_t e = zero_words_async(flags, nz, st);
             if (e != hipSuccess) return (int)e;
         }

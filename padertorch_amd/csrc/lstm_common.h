@@ -48,6 +48,9 @@ struct LstmPersistArgs {
     // scratch) get the fill pattern from an otherwise idle wavefront, a slice per workgroup and step
     uint4* fill_ptr = nullptr;
     unsigned long long fill_n16 = 0;
+    // ... and the `zero_n16` 16-byte units BEHIND them (the backward scratch's bias sums, maximum word, arrival slots and error words)
+    // get zeros the same way (round 6): the backward launch then has nothing to enqueue in front of its recurrence kernel
+    unsigned long long zero_n16 = 0;
     // Row-slot batches (data-as-flag kernels; layout = uniform [T][max_batch] rows, max_batch <= 64 slots): several sequences lie END TO
     // END in one row slot, so "row b is alive at step t" and "row b has a predecessor" are no prefix rules any more.  masks[3 t + 0]
     // = rows alive at time index t, + 1 = rows whose sequence STARTS at t (no predecessor in the forward direction), + 2 = rows whose

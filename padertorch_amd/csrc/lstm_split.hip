@@ -281,15 +281,17 @@ __global__ __launch_bounds__(NW * 64, 2) void lstm_fwd_daf_kernel(const LstmPers
         }
     }
     // this workgroup's slice of the pattern fill, dealt out over the steps (the last wavefront owns no element here)
-    const unsigned long long fill_share = A.fill_ptr ? (A.fill_n16 + wg_cnt - 1) / wg_cnt : 0ull;
+    const unsigned long long fill_all = A.fill_n16 + A.zero_n16;          // pattern units, then zero units
+    const unsigned long long fill_share = A.fill_ptr ? (fill_all + wg_cnt - 1) / wg_cnt : 0ull;
     unsigned long long fill_pos = fill_share * wg_lin;
-    const unsigned long long fill_end = A.fill_ptr ? (fill_pos + fill_share < A.fill_n16 ? fill_pos + fill_share : A.fill_n16) : 0ull;
+    const unsigned long long fill_end = A.fill_ptr ? (fill_pos + fill_share < fill_all ? fill_pos + fill_share : fill_all) : 0ull;
     const unsigned long long fill_step = (fill_share + (unsigned)A.T - 1) / (unsigned)A.T;
     auto fill_some = [&](bool all) {
         if (ACTW < NW && wave >= ACTW && fill_pos < fill_end) {        // the wavefronts without elements share the step's portion
             const unsigned long long stop = all ? fill_end : (fill_pos + fill_step < fill_end ? fill_pos + fill_step : fill_end);
-            const uint4 v = make_uint4(kFill, kFill, kFill, kFill);
-            for (unsigned long long i = fill_pos + (unsigned)(wave - ACTW) * 64u + lane; i < stop; i += 64u * (NW - ACTW)) A.fill_ptr[i] = v;
+            const uint4 v = make_uint4(kFill, kFill, kFill, kFill), z = make_uint4(0u, 0u, 0u, 0u);
+            for (unsigned long long i = fill_pos + (unsigned)(wave - ACTW) * 64u + lane; i < stop; i += 64u * (NW - ACTW))
+                A.fill_ptr[i] = i < A.fill_n16 ? v : z;
             fill_pos = stop;
         }
     };

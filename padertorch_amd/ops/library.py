@@ -202,20 +202,20 @@ def absmax(x, rows, cols, ld):
 
 @_register('lstm_recurrence_backward_range(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!) dg, '
            'Tensor(b!) scratch, Tensor(c!) dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, int H, '
-           'int ndir, int s_begin, int s_end, bool prefilled=False, Tensor? dc_n=None) -> bool')
+           'int ndir, int s_begin, int s_end, int prefilled=0, Tensor? dc_n=None) -> bool')
 def lstm_recurrence_backward_range(gates, c, c0, dhy, w_hh_t, dg, scratch, dc_carry, bs_dev, offs_dev, T, max_batch, rows, H, ndir,
-                                   s_begin, s_end, prefilled=False, dc_n=None):
+                                   s_begin, s_end, prefilled=0, dc_n=None):
     """The persistent backward recurrence over the processing steps [s_begin, s_end) (``ptmi_lstm_backward_persistent_range``;
     ranges in order, same ``dg`` / ``scratch`` / ``dc_carry``).  False: the launch cannot be resident (nothing was run)."""
     if dc_n is not None:        # + the gradient w.r.t. the final cell state (ptmi_lstm_backward_persistent_states; whole recurrence)
         assert s_begin == 0 and s_end == T and dc_n.shape == (ndir, max_batch, H) and dc_n.is_contiguous(), (s_begin, s_end, dc_n.shape)
         rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_states, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                         dhy.data_ptr(), dc_n.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        scratch.data_ptr(), dc_carry.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled)), _lib.stream(gates.device))
+                        scratch.data_ptr(), dc_carry.data_ptr(), T, max_batch, rows, H, ndir, int(prefilled), _lib.stream(gates.device))
     else:
         rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_range, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                         dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), scratch.data_ptr(),
-                        dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)), _lib.stream(gates.device))
+                        dc_carry.data_ptr(), T, max_batch, rows, H, ndir, s_begin, s_end, int(prefilled), _lib.stream(gates.device))
     if rc == -2:
         return False
     _lib.check(rc, 'ptmi_lstm_backward_persistent_range')
@@ -224,9 +224,9 @@ def lstm_recurrence_backward_range(gates, c, c0, dhy, w_hh_t, dg, scratch, dc_ca
 
 @_register('lstm_recurrence_backward_planes(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor(a!)? dg, '
            'Tensor(b!) dg_t, Tensor(c!) scratch, Tensor(d!)? dc_carry, Tensor bs_dev, Tensor offs_dev, int T, int max_batch, int rows, '
-           'int H, int ndir, int s_begin, int s_end, bool prefilled=False, Tensor? step_masks=None) -> bool')
+           'int H, int ndir, int s_begin, int s_end, int prefilled=0, Tensor? step_masks=None) -> bool')
 def lstm_recurrence_backward_planes(gates, c, c0, dhy, w_hh_t, dg, dg_t, scratch, dc_carry, bs_dev, offs_dev, T, max_batch, rows, H, ndir,
-                                    s_begin, s_end, prefilled=False, step_masks=None):
+                                    s_begin, s_end, prefilled=0, step_masks=None):
     """``ptmi_lstm_backward_persistent_planes``: the persistent backward recurrence over the processing steps [s_begin, s_end) with
     the gate gradients leaving as bf16 planes of ``dgates^T`` (``dg_t``: ``ndir * ptmi_planes_elems(4H, range rows)`` bf16 values, the
     operand of the weight-gradient GEMMs) and, only when ``dg`` is given, as the row-major fp32 tensor too.  False: the launch
@@ -237,11 +237,11 @@ def lstm_recurrence_backward_planes(gates, c, c0, dhy, w_hh_t, dg, dg_t, scratch
         assert c0 is None and s_begin == 0 and s_end == T, 'row-slot batches: no initial states, no step ranges'
         rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_slots, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
                         w_hh_t.data_ptr(), _lib.ptr(dg), dg_t.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
-                        scratch.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled)), _lib.stream(gates.device))
+                        scratch.data_ptr(), T, max_batch, rows, H, ndir, int(prefilled), _lib.stream(gates.device))
     else:
         rc = _lib.timed('lstm_backward', _lib.load().ptmi_lstm_backward_persistent_planes, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                         dhy.data_ptr(), w_hh_t.data_ptr(), _lib.ptr(dg), dg_t.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                        scratch.data_ptr(), _lib.ptr(dc_carry), T, max_batch, rows, H, ndir, s_begin, s_end, int(bool(prefilled)),
+                        scratch.data_ptr(), _lib.ptr(dc_carry), T, max_batch, rows, H, ndir, s_begin, s_end, int(prefilled),
                         _lib.stream(gates.device))
     if rc == -2:
         return False
@@ -496,9 +496,9 @@ def lstm_recurrence_forward(gates, hy, c0, w_hh_pad, w_amax, bs_dev, offs_dev, b
 
 @_register('lstm_recurrence_backward(Tensor gates, Tensor c, Tensor? c0, Tensor dhy, Tensor w_hh_t, Tensor bs_dev, Tensor offs_dev, '
            'int bs_host, int offs_host, int T, int max_batch, int rows, int H, int ndir, bool persistent, Tensor(a!)? scratch=None, '
-           'bool prefilled=False, Tensor? step_masks=None) -> (Tensor, Tensor?)')
+           'int prefilled=0, Tensor? step_masks=None) -> (Tensor, Tensor?)')
 def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_host, offs_host, T, max_batch, rows, H, ndir, persistent,
-                             scratch=None, prefilled=False, step_masks=None):
+                             scratch=None, prefilled=0, step_masks=None):
     """Returns (dgates, scratch): scratch as above; behind its tile-major copy it carries the bias gradient [ndir * 4H]
     and, for the split kernels, the word with max |dgates| (see ``ops.lstm``)."""
     lib = _lib.load()
@@ -515,11 +515,11 @@ def lstm_recurrence_backward(gates, c, c0, dhy, w_hh_t, bs_dev, offs_dev, bs_hos
             assert c0 is None
             rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent_slots, gates.data_ptr(), c.data_ptr(), dhy.data_ptr(),
                             w_hh_t.data_ptr(), dg.data_ptr(), None, bs_dev.data_ptr(), offs_dev.data_ptr(), step_masks.data_ptr(),
-                            flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
+                            flags.data_ptr(), T, max_batch, rows, H, ndir, int(prefilled) if scratch is not None else 0, st)
         else:
             rc = _lib.timed('lstm_backward', lib.ptmi_lstm_backward_persistent, gates.data_ptr(), c.data_ptr(), _lib.ptr(c0),
                             dhy.data_ptr(), w_hh_t.data_ptr(), dg.data_ptr(), bs_dev.data_ptr(), offs_dev.data_ptr(),
-                            flags.data_ptr(), T, max_batch, rows, H, ndir, int(bool(prefilled and scratch is not None)), st)
+                            flags.data_ptr(), T, max_batch, rows, H, ndir, int(prefilled) if scratch is not None else 0, st)
         if rc not in (0, -2) or (step_masks is not None and rc != 0):
             _lib.check(rc, 'ptmi_lstm_backward_persistent')
     if rc == -2:

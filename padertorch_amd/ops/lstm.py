@@ -485,14 +485,15 @@ class _LstmLayerFn(torch.autograd.Function):
         # hand-off scratch of this layer's backward pass when one will come: its data-as-flag pattern is written by the forward
         # recurrence kernel itself (below); the forward scratch is allocated and filled by the op
         scratch_f = scratch_b = None
-        pre_f = pre_b = False
-        if (PERSISTENT and scratch_b is None and x.is_cuda and any(ctx.needs_input_grad)
-                and lib.ptmi_lstm_forward_fills(meta.T, ndir, meta.max_batch, H)):
+        pre_f, pre_b = False, 0
+        fills = int(lib.ptmi_lstm_forward_fills(meta.T, ndir, meta.max_batch, H)) if (
+            PERSISTENT and scratch_b is None and x.is_cuda and any(ctx.needs_input_grad)) else 0
+        if fills:
             # the forward recurrence itself writes the pattern into the planes of this layer's backward scratch (an idle
             # wavefront per workgroup, a slice per time step)
             scratch_b = torch.empty(int(lib.ptmi_lstm_scratch_elems(meta.T, ndir, meta.max_batch, H, 1)), dtype=torch.int32,
                                     device=x.device)
-            pre_b = True
+            pre_b = fills        # (2: the planes' pattern and the zeroed words behind them - the value the backward call takes as `prefilled`)
             fill_b = scratch_b
         else:
             fill_b = None
@@ -577,7 +578,7 @@ class _LstmLayerFn(torch.autograd.Function):
             gates, hy, c0, w_pad, amax_whh, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
             meta.T, meta.max_batch, meta.rows, H, KP, ndir, PERSISTENT, scratch_f, pre_f, fill_b, masks)
         if fill_b is not None and flags is None:        # the persistent launch was refused: nothing was filled
-            pre_b = False
+            pre_b = 0
         # (a row-slot batch's planes are operands as well: its kernels write zeros for the idle slot steps)
         if handoff is not None and flags is not None and not stateful and (meta.equal_lengths or masks is not None) and meta.bs0 % 16 == 0:
             cols_out = int(lib.ptmi_lstm_handoff_cols(H, 0))
@@ -747,7 +748,7 @@ class _LstmLayerFn(torch.autograd.Function):
         if use_tp:
             flags = ctx.scratch_b[0] if ctx.scratch_b[0] is not None else torch.empty(
                 int(lib.ptmi_lstm_scratch_elems(T, ndir, meta.max_batch, H, 1)), dtype=torch.int32, device=dhy.device)
-            pre = bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0])
+            pre = int(ctx.scratch_b[1]) if flags is ctx.scratch_b[0] else 0
             cuts = [T * i // chunks for i in range(chunks + 1)]
             carry = torch.empty((ndir, meta.max_batch, H), dtype=torch.float32, device=dhy.device) if chunks > 1 else None
             B_ = meta.max_batch
@@ -793,7 +794,7 @@ class _LstmLayerFn(torch.autograd.Function):
             def launch(i):
                 return torch.ops.ptmi.lstm_recurrence_backward_range(
                     gates, c, c0, dhy, w_t, dg, flags, carry, meta.bs_dev, meta.offs_dev, T, meta.max_batch, meta.rows, H,
-                    ndir, cuts[i], cuts[i + 1], bool(ctx.scratch_b[1] and flags is ctx.scratch_b[0]), dcn)
+                    ndir, cuts[i], cuts[i + 1], int(ctx.scratch_b[1]) if flags is ctx.scratch_b[0] else 0, dcn)
             if launch(0):
                 for i in range(1, chunks):
                     snap = amax_word.clone()                     # max |dgates| so far: the operand scale of this part
@@ -817,7 +818,7 @@ class _LstmLayerFn(torch.autograd.Function):
         if dg is None and not use_tp:
             dg, flags = torch.ops.ptmi.lstm_recurrence_backward(
                 gates, c, c0, dhy, w_t, meta.bs_dev, meta.offs_dev, meta.bs_host.ctypes.data, meta.offs_host.ctypes.data,
-                T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], ctx.scratch_b[1], masks)
+                T, meta.max_batch, meta.rows, H, ndir, PERSISTENT, ctx.scratch_b[0], int(ctx.scratch_b[1]), masks)
         if flags is not None:
             if CHECK_PERSISTENT_ERRORS:
                 check_errors()
