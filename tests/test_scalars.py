@@ -57,3 +57,18 @@ def test_loss_values_without_a_concatenation():
     total = 0.5 * losses['a'] + losses['b']
     vals, index = pt.Trainer._loss_values(losses, ['a', 'b'], total)
     assert vals.tolist() == [3., 5., 6.5] and index == [0, 1, 2]
+
+
+def test_capture_zero_block_hands_out_its_words_once_and_survives_the_capture():
+    """ops.capture.zero_block: the ONE zero-filled block at the head of a captured step serves every accumulation word of the step, each
+    word once; it stays referenced when the capture ends (its memory belongs to the graph).  (Host logic only: no stream capture on CPU.)"""
+    from padertorch_amd.ops import capture
+    with capture.capture_mode():
+        capture.zero_block(torch.device('cpu'), words=8)
+        words = [capture.zero_word(torch.device('cpu')) for _ in range(8)]
+        block = capture._shared[0]
+        assert all(w.numel() == 1 and int(w) == 0 for w in words)
+        assert sorted(w.data_ptr() for w in words) == [block.data_ptr() + 4 * i for i in range(8)]
+        assert capture._shared[1] == 8
+    assert not capture._shared and any(e[0] is block for e in capture._zero_blocks)
+    assert not capture.ACTIVE
